@@ -1,0 +1,82 @@
+"""ctypes binding of libdcl_hip.so (C ABI: include/dcl_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libdcl_hip.so")
+CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
+
+CP = 256          # DCL_CP
+ROW_TILE = 128    # DCL_ROW_TILE
+SEG = 256         # DCL_SEG
+MAX_CLASSES = 255
+MAX_SLABS = 48
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_f = ctypes.c_float
+
+# name -> argtypes (all return int except where noted); mirrors include/dcl_hip.h one to one
+SIGNATURES = {
+    "dcl_label_hist": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "dcl_rank_select": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "dcl_gather_normalize": [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "dcl_gather_raw": [_vp, _i64, _i64, _i64, _i, _vp, _vp, _i, _i, _vp, _vp],
+    "dcl_infonce_fwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dcl_infonce_prep_stats": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
+    "dcl_infonce_bwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
+    "dcl_normalize_bwd_scatter": [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
+                                  _i64, _i64, _i64, _vp],
+    "dcl_suggest_nsplit": [_i, _i],
+    "dcl_version": [],
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into libdcl_hip.so (in-tree)."""
+    out = subprocess.run(["make", "-C", CSRC_DIR], capture_output=True, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+        print(out.stderr)
+    if out.returncode != 0:
+        raise RuntimeError("building libdcl_hip.so failed:\n" + out.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found. The dense contrastive loss has no fallback path: build the HIP "
+                f"library first (python -c 'import __graft_entry__ as g; g.build()' or make -C {CSRC_DIR}).")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        l.dcl_last_error.restype = ctypes.c_char_p
+        l.dcl_last_error.argtypes = []
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().dcl_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor as c_void_p; None -> NULL."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())

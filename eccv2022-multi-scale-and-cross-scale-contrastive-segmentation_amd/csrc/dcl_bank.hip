@@ -1,0 +1,156 @@
+// dcl_bank.hip -- K3 (gather + L2-normalise into a class-sorted bank) and K6 (slab reduce +
+// normalise-backward + scatter into the dense feature gradient).  HBM-bound: one wave per bank
+// row, 1 KiB coalesced row stores / loads on the bank side.
+#include "dcl_common.h"
+
+// One wave per bank row; 4 rows per workgroup.  Lane l owns channels l, l+64, l+128, l+192 so that
+// for channel-last features (stride_c == 1) the gather reads are 256-B coalesced.
+// Replaces DenseContrastiveLossV2.py:123 (gather), :138 (F.normalize, eps 1e-12), :139-149 (layout).
+__global__ __launch_bounds__(256) void k_gather_normalize(
+    const float *__restrict__ feat, int64_t sn, int64_t sc, int64_t sp, int C,
+    const int32_t *__restrict__ pix, const int32_t *__restrict__ pair_b,
+    const int32_t *__restrict__ slot_pair, int N, int V, int Npad, float *__restrict__ bank,
+    float *__restrict__ nrm)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Npad)
+        return;
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    float ss = 0.f;
+    if (row < N) {
+        const int u = row / V, v = row - u * V;
+        const int t = slot_pair[u];
+        const int64_t base = (int64_t)pair_b[t] * sn + (int64_t)pix[(int64_t)t * V + v] * sp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane + 64 * q;
+            if (c < C)
+                x[q] = feat[base + (int64_t)c * sc];
+            ss += x[q] * x[q];
+        }
+        ss = wave_sum(ss);
+    }
+    const float norm = sqrtf(ss);
+    const float inv = 1.0f / fmaxf(norm, 1e-12f);
+    float *out = bank + (int64_t)row * DCL_CP;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        out[lane + 64 * q] = x[q] * inv;
+    if (lane == 0)
+        nrm[row] = norm;
+}
+
+extern "C" int dcl_gather_normalize(const float *feat, int64_t stride_n, int64_t stride_c,
+                                    int64_t stride_p, int C, const int32_t *pix,
+                                    const int32_t *pair_b, const int32_t *slot_pair, int T, int V,
+                                    float *bank, float *nrm, void *stream)
+{
+    DCL_CHECK_ARG(feat && pix && pair_b && slot_pair && bank && nrm, "null pointer");
+    DCL_CHECK_ARG(C > 0 && C <= DCL_CP, "embedding width must be in [1, 256]");
+    DCL_CHECK_ARG(T > 0 && V > 0, "empty bank");
+    const int N = T * V, Npad = dcl_round_up(N, DCL_ROW_TILE);
+    hipLaunchKernelGGL(k_gather_normalize, dim3(Npad / 4), dim3(256), 0, (hipStream_t)stream, feat,
+                       stride_n, stride_c, stride_p, C, pix, pair_b, slot_pair, N, V, Npad, bank, nrm);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// X[t, c, v] = feat[b_t, c, pix[t, v]] in the reference's own [T, C, V] layout.
+__global__ __launch_bounds__(256) void k_gather_raw(const float *__restrict__ feat, int64_t sn,
+                                                   int64_t sc, int64_t sp, int C,
+                                                   const int32_t *__restrict__ pix,
+                                                   const int32_t *__restrict__ pair_b, int V,
+                                                   int64_t total, float *__restrict__ X)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total)
+        return;
+    const int v = (int)(e % V);
+    const int64_t tc = e / V;
+    const int c = (int)(tc % C);
+    const int t = (int)(tc / C);
+    X[e] = feat[(int64_t)pair_b[t] * sn + (int64_t)c * sc + (int64_t)pix[(int64_t)t * V + v] * sp];
+}
+
+extern "C" int dcl_gather_raw(const float *feat, int64_t stride_n, int64_t stride_c,
+                              int64_t stride_p, int C, const int32_t *pix, const int32_t *pair_b,
+                              int T, int V, float *X, void *stream)
+{
+    DCL_CHECK_ARG(feat && pix && pair_b && X, "null pointer");
+    DCL_CHECK_ARG(C > 0 && T > 0 && V > 0, "bad sizes");
+    const int64_t total = (int64_t)T * C * V;
+    hipLaunchKernelGGL(k_gather_raw, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, feat, stride_n, stride_c, stride_p, C, pix, pair_b, V,
+                       total, X);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+#define DCL_MAX_SLABS 48
+struct SlabList {
+    const float *p[DCL_MAX_SLABS];
+};
+
+// One wave per bank row: dF = sum of slabs (fixed order -> bitwise reproducible), then
+// dx = (dF - f (f . dF)) / max(|x|, eps)   [|x| <= eps: dF / eps], scattered to dfeat[b, :, pix].
+__global__ __launch_bounds__(256) void k_normalize_bwd_scatter(
+    SlabList slabs, int nslab, const float *__restrict__ bank, const float *__restrict__ nrm,
+    const int32_t *__restrict__ pix, const int32_t *__restrict__ pair_b,
+    const int32_t *__restrict__ slot_pair, int N, int V, int C, float *__restrict__ dfeat,
+    int64_t sn, int64_t sc, int64_t sp)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N)
+        return;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nslab; ++s) {
+        const float *src = slabs.p[s] + (int64_t)row * DCL_CP;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            d[q] += src[lane + 64 * q];
+    }
+    float f[4];
+    float inner = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f[q] = bank[(int64_t)row * DCL_CP + lane + 64 * q];
+        inner += f[q] * d[q];
+    }
+    inner = wave_sum(inner);
+    const float norm = nrm[row];
+    const float inv = 1.0f / fmaxf(norm, 1e-12f);
+    const bool clamped = !(norm > 1e-12f);
+    const int u = row / V, v = row - u * V;
+    const int t = slot_pair[u];
+    const int64_t base = (int64_t)pair_b[t] * sn + (int64_t)pix[(int64_t)t * V + v] * sp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        if (c < C) {
+            const float dx = clamped ? d[q] * inv : (d[q] - f[q] * inner) * inv;
+            dfeat[base + (int64_t)c * sc] = dx;
+        }
+    }
+}
+
+extern "C" int dcl_normalize_bwd_scatter(const float *const *slabs_host, int nslab,
+                                         const float *bank, const float *nrm, const int32_t *pix,
+                                         const int32_t *pair_b, const int32_t *slot_pair, int T,
+                                         int V, int C, float *dfeat, int64_t stride_n,
+                                         int64_t stride_c, int64_t stride_p, void *stream)
+{
+    DCL_CHECK_ARG(slabs_host && bank && nrm && pix && pair_b && slot_pair && dfeat, "null pointer");
+    DCL_CHECK_ARG(nslab >= 0 && nslab <= DCL_MAX_SLABS, "too many slabs (max 48)");
+    DCL_CHECK_ARG(C > 0 && C <= DCL_CP && T > 0 && V > 0, "bad sizes");
+    SlabList sl;
+    for (int i = 0; i < DCL_MAX_SLABS; ++i)
+        sl.p[i] = i < nslab ? slabs_host[i] : nullptr;
+    const int N = T * V;
+    hipLaunchKernelGGL(k_normalize_bwd_scatter, dim3((N + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, sl, nslab, bank, nrm, pix, pair_b, slot_pair, N, V, C,
+                       dfeat, stride_n, stride_c, stride_p);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,405 @@
+// dcl_sweep.hip -- K4 / K5: fused similarity + masked InfoNCE forward and backward on the f32
+// matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s dense peak).
+//
+// One kernel template, three modes, one structure:
+//   * a workgroup = 4 waves owns DCL_ROW_TILE = 128 anchor rows; each wave keeps ITS 32 rows of A
+//     (32 x 256 f32) in 128 VGPRs for the whole sweep -- A is read from HBM/L2 exactly once;
+//   * the contrast bank B streams through LDS in chunks of 32 rows (32 x 1 KiB, +16 B row pad so the
+//     ds_read_b128 operand fetch is bank-conflict free), double buffered and filled by LDS-DMA
+//     (global_load_lds_dwordx4: one 1-KiB wave-instruction = one bank row), one barrier per chunk;
+//   * the similarity tile is computed TRANSPOSED, X[j][i] = <B_j, A_i>, so the MFMA result has the
+//     anchor i on the lane and the 32 columns j in the 16 accumulator registers x 2 lane halves:
+//     row reductions over j are in-lane adds (no shuffles), and the accumulator registers are,
+//     as they stand, the A-operand of the second product dA[i][:] += H[j][i] * B[j][:] (backward);
+//   * the N1 x N2 similarity matrix never exists in memory.
+//
+// Replaces (reference, /root/reference): losses/DenseContrastiveLossV2.py:150 (matmul/div),
+// :154-171 (get_masks2), :173-192 (get_loss); losses/DenseContrastiveLossV2_ms.py:114, :118-130,
+// :132-161; and the autograd backward of all of them.
+#include <limits.h>
+
+#include "dcl_common.h"
+
+namespace {
+
+constexpr int CP = DCL_CP;              // 256 channels (padded)
+constexpr int ROWF = CP + 4;            // LDS row stride in floats (1040 B)
+constexpr int CJ = 32;                  // bank rows (similarity columns) per chunk
+constexpr int BM = DCL_ROW_TILE;        // anchor rows per workgroup
+constexpr int BUF_FLOATS = CJ * ROWF;   // 8320 floats = 33,280 B per buffer
+
+enum { MODE_Z = 0, MODE_POS = 1, MODE_BWD = 2 };
+
+struct SweepArgs {
+    const float *A;        // [N1pad, CP]
+    const float *B;        // [N2pad, CP]
+    int N1, N2, V1;
+    const int32_t *rng_lo; // per A slot: positive column range [lo, hi) in B
+    const int32_t *rng_hi;
+    float inv_tau, c1;     // c1 = inv_tau * log2(e)
+    int intra;
+    int nsplit;
+    float *zpart;          // MODE_Z out / MODE_POS in: [nsplit, N1pad]
+    int zsplits;           // MODE_POS: number of zpart slabs to sum
+    float *Z, *rowloss, *W;        // MODE_POS out: [N1pad]
+    const float *rstat, *cstat;    // MODE_BWD in: [N1pad,4], [N2pad,4] = {Z, cW, cZ, 0}
+    int use_row, use_col;
+    float *dpart;          // MODE_BWD out: [nsplit, N1pad, CP]
+};
+
+__device__ __forceinline__ void stage_chunk(float *buf, const float *B, int j0, int wave, int lane)
+{
+    // 32 bank rows per chunk, 8 per wave; one LDS-DMA wave-instruction moves one 1-KiB row:
+    // LDS destination = wave-uniform row base + lane * 16 B, global source is per lane.
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = wave * 8 + r;
+        const float *g = B + (size_t)(j0 + row) * CP + lane * 4;
+        float *l = buf + row * ROWF;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ int jrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int MODE>
+__global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, li = lane & 31;
+    const int rb = blockIdx.x, split = blockIdx.y;
+    const int N1pad = gridDim.x * BM;
+    const int i = rb * BM + wave * 32 + li;     // this lane's anchor row (both lane halves)
+
+    // ---- A panel -> registers.  Lane half h holds k in {8q + 4h .. 8q + 4h + 3}: the MFMA sums over
+    // all k, so any k order works as long as both operands use the same one.
+    float a[128];
+    {
+        const float *arow = p.A + (size_t)i * CP + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const f32x4 v = *(const f32x4 *)(arow + 8 * q);
+            a[4 * q + 0] = v.x;
+            a[4 * q + 1] = v.y;
+            a[4 * q + 2] = v.z;
+            a[4 * q + 3] = v.w;
+        }
+    }
+
+    // ---- positive column range of this anchor, and of the wave / workgroup
+    int lo = 0, hi = 0;
+    if (i < p.N1) {
+        const int u = i / p.V1;
+        lo = p.rng_lo[u];
+        hi = p.rng_hi[u];
+    }
+    const unsigned span = (unsigned)(hi - lo);
+    const int wlo = __builtin_amdgcn_readfirstlane(wave_min_i(hi > lo ? lo : INT_MAX));
+    const int whi = __builtin_amdgcn_readfirstlane(wave_max_i(hi > lo ? hi : 0));
+
+    // ---- chunk range
+    int c0, c1;
+    if (MODE == MODE_POS) {
+        int *red = (int *)lds;
+        if (lane == 0) {
+            red[wave] = wlo;
+            red[4 + wave] = whi;
+        }
+        __syncthreads();
+        const int blo = min(min(red[0], red[1]), min(red[2], red[3]));
+        const int bhi = max(max(red[4], red[5]), max(red[6], red[7]));
+        __syncthreads();
+        if (bhi > blo) {
+            c0 = blo / CJ;
+            c1 = (bhi + CJ - 1) / CJ;
+        } else {
+            c0 = c1 = 0;
+        }
+    } else {
+        const int nchunk = (p.N2 + CJ - 1) / CJ;
+        c0 = (int)((long long)split * nchunk / p.nsplit);
+        c1 = (int)((long long)(split + 1) * nchunk / p.nsplit);
+    }
+
+    // ---- per-mode row state
+    float zi = 0.f;            // MODE_Z accumulator / MODE_POS: Z_i
+    float rl = 0.f, wsum = 0.f;
+    float rZ = 0.f, rcW = 0.f, rcZ = 0.f;
+    f32x16 dacc[MODE == MODE_BWD ? 8 : 1];
+    if (MODE == MODE_POS) {
+        for (int s = 0; s < p.zsplits; ++s)
+            zi += p.zpart[(size_t)s * N1pad + i];
+    }
+    if (MODE == MODE_BWD) {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dacc[ct][r] = 0.f;
+        if (p.use_row) {
+            const f32x4 st = *(const f32x4 *)(p.rstat + (size_t)i * 4);
+            rZ = st.x;
+            rcW = st.y;
+            rcZ = st.z;
+        }
+    }
+
+    // ---- sweep
+    if (c0 < c1)
+        stage_chunk(lds, p.B, c0 * CJ, wave, lane);
+    for (int c = c0; c < c1; ++c) {
+        __syncthreads();       // (drains the LDS-DMA: chunk c has landed; everyone left chunk c-1)
+        const float *buf = lds + ((c - c0) & 1) * BUF_FLOATS;
+        if (c + 1 < c1)
+            stage_chunk(lds + ((c + 1 - c0) & 1) * BUF_FLOATS, p.B, (c + 1) * CJ, wave, lane);
+        const int j0 = c * CJ;
+
+        // column statistics for the backward epilogue: issue early, consume after the MFMA chain
+        float ccw[16];
+        if (MODE == MODE_BWD) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ccw[r] = p.use_col ? p.cstat[(size_t)(j0 + jrow(r, h)) * 4 + 1] : 0.f;
+        }
+
+        // X[j][i] = sum_k B[j0 + j][k] * A[i][k]
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[r] = 0.f;
+        {
+            const float *bt = buf + li * ROWF + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const f32x4 b = *(const f32x4 *)(bt + 8 * q);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[4 * q + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[4 * q + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[4 * q + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[4 * q + 3], acc, 0, 0, 0);
+            }
+        }
+
+        const bool plain = !((j0 < whi) && (j0 + CJ > wlo)) && (j0 + CJ <= p.N2);  // wave-uniform
+        if (MODE == MODE_Z) {
+            if (plain) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    zi += __builtin_amdgcn_exp2f(acc[r] * p.c1);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jj = j0 + jrow(r, h);
+                    const float e = __builtin_amdgcn_exp2f(acc[r] * p.c1);
+                    const bool inr = (unsigned)(jj - lo) < span;
+                    zi += (jj < p.N2 && !inr) ? e : 0.f;
+                }
+            }
+        } else if (MODE == MODE_POS) {
+            if (!plain) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jj = j0 + jrow(r, h);
+                    const float e = __builtin_amdgcn_exp2f(acc[r] * p.c1);
+                    bool pos = ((unsigned)(jj - lo) < span) && (jj < p.N2);
+                    if (p.intra)
+                        pos = pos && (jj != i);
+                    const float t = e + zi;
+                    rl += pos ? (acc[r] * p.inv_tau - logf(t)) : 0.f;
+                    wsum += pos ? __builtin_amdgcn_rcpf(t) : 0.f;
+                }
+            }
+        } else {
+            if (plain) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[r] = __builtin_amdgcn_exp2f(acc[r] * p.c1) * (rcW + ccw[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jj = j0 + jrow(r, h);
+                    const float e = __builtin_amdgcn_exp2f(acc[r] * p.c1);
+                    const bool valid = jj < p.N2;
+                    const bool inr = (unsigned)(jj - lo) < span;
+                    bool pos = inr && valid;
+                    if (p.intra)
+                        pos = pos && (jj != i);
+                    float cZ = 0.f, ccZ = 0.f;
+                    if (p.use_col) {
+                        cZ = p.cstat[(size_t)jj * 4 + 0];
+                        ccZ = p.cstat[(size_t)jj * 4 + 2];
+                    }
+                    const float hn = e * (rcW + ccw[r]);
+                    const float hp = -(rcZ * __builtin_amdgcn_rcpf(e + rZ) +
+                                       ccZ * __builtin_amdgcn_rcpf(e + cZ));
+                    acc[r] = pos ? hp : ((valid && !inr) ? hn : 0.f);
+                }
+            }
+            // dA[i][c] += sum_j H[j][i] * B[j0 + j][c]: acc register r IS the A-operand of k-step r
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *brow = buf + jrow(r, h) * ROWF + li;
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct)
+                    dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], brow[32 * ct], dacc[ct],
+                                                                   0, 0, 0);
+            }
+        }
+    }
+
+    // ---- outputs
+    if (MODE == MODE_Z) {
+        zi += __shfl_xor(zi, 32, 64);
+        if (h == 0)
+            p.zpart[(size_t)split * N1pad + i] = zi;
+    } else if (MODE == MODE_POS) {
+        rl += __shfl_xor(rl, 32, 64);
+        wsum += __shfl_xor(wsum, 32, 64);
+        if (h == 0) {
+            p.Z[i] = zi;
+            p.rowloss[i] = rl;
+            p.W[i] = wsum;
+        }
+    } else {
+        float *out = p.dpart + ((size_t)split * N1pad + (size_t)rb * BM + wave * 32) * CP + li;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(size_t)jrow(r, h) * CP + 32 * ct] = dacc[ct][r];
+    }
+}
+
+// loss = -(1/N1) sum_i rowloss_i / P_i     (DenseContrastiveLossV2.py:188-189; ms:148-156)
+__global__ __launch_bounds__(1024) void k_loss_reduce(const float *__restrict__ rowloss,
+                                                     const int32_t *__restrict__ rng_lo,
+                                                     const int32_t *__restrict__ rng_hi, int N1,
+                                                     int V1, int intra, float *__restrict__ loss)
+{
+    __shared__ float part[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < N1; i += 1024) {
+        const int u = i / V1;
+        const int P = rng_hi[u] - rng_lo[u] - (intra ? 1 : 0);
+        const float Pn = intra ? (float)P : (float)max(P, 1);
+        acc += rowloss[i] / Pn;       // intra with P == 0: 0/0 = NaN, as in the reference
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < 16; ++w)
+            s += part[w];
+        loss[0] = -s / (float)N1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prep_stats(const float *__restrict__ Z,
+                                                   const float *__restrict__ W,
+                                                   const int32_t *__restrict__ rng_lo,
+                                                   const int32_t *__restrict__ rng_hi, int N1,
+                                                   int N1pad, int V1, int intra, float wscale,
+                                                   float inv_tau, const float *__restrict__ grad_out,
+                                                   float *__restrict__ stat)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N1pad)
+        return;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (i < N1) {
+        const float gs = wscale * inv_tau * (grad_out ? grad_out[0] : 1.0f);
+        const int u = i / V1;
+        const int P = rng_hi[u] - rng_lo[u] - (intra ? 1 : 0);
+        const float Pn = intra ? (float)P : (float)max(P, 1);
+        const float coef = gs / ((float)N1 * Pn);
+        o.x = Z[i];
+        o.y = coef * W[i];
+        o.z = coef * Z[i];
+    }
+    *(f32x4 *)(stat + (size_t)i * 4) = o;
+}
+
+int check_common(const float *A, int N1, int V1, const float *B, int N2, const int32_t *lo,
+                 const int32_t *hi, int nsplit)
+{
+    if (!A || !B || !lo || !hi) {
+        dcl_set_error("null pointer");
+        return DCL_EINVAL;
+    }
+    if (N1 <= 0 || N2 <= 0 || V1 <= 0 || nsplit <= 0 || nsplit > 64) {
+        dcl_set_error("bad sizes (N1=%d N2=%d V1=%d nsplit=%d)", N1, N2, V1, nsplit);
+        return DCL_EINVAL;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dcl_infonce_fwd(const float *A, int N1, int V1, const float *B, int N2,
+                               const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau,
+                               int intra, int nsplit, float *zpart, float *Z, float *rowloss,
+                               float *W, float *loss, void *stream)
+{
+    int rc = check_common(A, N1, V1, B, N2, rng_lo, rng_hi, nsplit);
+    if (rc)
+        return rc;
+    DCL_CHECK_ARG(zpart && Z && rowloss && W && loss, "null output pointer");
+    SweepArgs p = {};
+    p.A = A; p.B = B; p.N1 = N1; p.N2 = N2; p.V1 = V1;
+    p.rng_lo = rng_lo; p.rng_hi = rng_hi;
+    p.inv_tau = inv_tau; p.c1 = inv_tau * 1.4426950408889634f;
+    p.intra = intra; p.nsplit = nsplit; p.zpart = zpart; p.zsplits = nsplit;
+    p.Z = Z; p.rowloss = rowloss; p.W = W;
+    const int RB = dcl_round_up(N1, BM) / BM;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sweep<MODE_Z>, dim3(RB, nsplit), dim3(256), 0, st, p);
+    DCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sweep<MODE_POS>, dim3(RB, 1), dim3(256), 0, st, p);
+    DCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, rowloss, rng_lo, rng_hi, N1, V1,
+                       intra, loss);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_infonce_prep_stats(const float *Z, const float *W, const int32_t *rng_lo,
+                                      const int32_t *rng_hi, int N1, int V1, int intra,
+                                      float wscale, float inv_tau, const float *grad_out,
+                                      float *stat, void *stream)
+{
+    DCL_CHECK_ARG(Z && W && rng_lo && rng_hi && stat, "null pointer");
+    DCL_CHECK_ARG(N1 > 0 && V1 > 0, "bad sizes");
+    const int N1pad = dcl_round_up(N1, BM);
+    hipLaunchKernelGGL(k_prep_stats, dim3(N1pad / 256 + 1), dim3(256), 0, (hipStream_t)stream, Z, W,
+                       rng_lo, rng_hi, N1, N1pad, V1, intra, wscale, inv_tau, grad_out, stat);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, int N2,
+                               const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau,
+                               int intra, int use_row, int use_col, const float *rstat,
+                               const float *cstat, int nsplit, float *dpart, void *stream)
+{
+    int rc = check_common(A, N1, V1, B, N2, rng_lo, rng_hi, nsplit);
+    if (rc)
+        return rc;
+    DCL_CHECK_ARG(dpart, "null output pointer");
+    DCL_CHECK_ARG(!use_row || rstat, "use_row needs rstat");
+    DCL_CHECK_ARG(!use_col || cstat, "use_col needs cstat");
+    SweepArgs p = {};
+    p.A = A; p.B = B; p.N1 = N1; p.N2 = N2; p.V1 = V1;
+    p.rng_lo = rng_lo; p.rng_hi = rng_hi;
+    p.inv_tau = inv_tau; p.c1 = inv_tau * 1.4426950408889634f;
+    p.intra = intra; p.nsplit = nsplit;
+    p.rstat = rstat; p.cstat = cstat; p.use_row = use_row; p.use_col = use_col;
+    p.dpart = dpart;
+    const int RB = dcl_round_up(N1, BM) / BM;
+    hipLaunchKernelGGL(k_sweep<MODE_BWD>, dim3(RB, nsplit), dim3(256), 0, (hipStream_t)stream, p);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,96 @@
+"""Single-scale supervised dense pixel-contrastive loss -- drop-in for the reference class of the
+same name (losses/DenseContrastiveLossV2.py:11-206): same constructor (flat ``loss`` config dict),
+same attributes, same forward signature and return arity; the work runs in libdcl_hip.so."""
+import torch
+import torch.nn as nn
+
+from ..utils import DATASETS_INFO, printlog
+from .engine import EngineConfig, dense_contrast_terms
+from .. import _lib
+from .engine import _stream_ptr
+
+
+class _RawBank(torch.autograd.Function):
+    """sampled_features[t, c, v] = features[b_t, c, pix[t, v]] in the reference's [T, C, V] layout
+    (DenseContrastiveLossV2.py:113-123), differentiable (scatter in backward)."""
+
+    @staticmethod
+    def forward(ctx, feat, sc):
+        p = sc.plan
+        X = torch.empty((p.T, sc.C, p.V), dtype=torch.float32, device=feat.device)
+        sn, scs, sp = sc.strides
+        _lib.check(_lib.lib().dcl_gather_raw(_lib.ptr(feat), sn, scs, sp, sc.C, _lib.ptr(sc.pix),
+                                             _lib.ptr(sc.pair_b), p.T, p.V, _lib.ptr(X),
+                                             _stream_ptr()), "dcl_gather_raw")
+        ctx.sc = sc
+        ctx.meta = (tuple(feat.shape), tuple(feat.stride()))
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        sc = ctx.sc
+        shape, strides = ctx.meta
+        n, C, h, w = shape
+        d = torch.zeros((n, C, h * w), dtype=torch.float32, device=dX.device)
+        b = sc.pair_b.long()[:, None, None].expand(-1, C, sc.plan.V)
+        c = torch.arange(C, device=dX.device)[None, :, None].expand(sc.plan.T, -1, sc.plan.V)
+        p = sc.pix.long()[:, None, :].expand(-1, C, -1)
+        d.index_put_((b, c, p), dX.float(), accumulate=True)
+        return d.view(n, C, h, w), None
+
+
+class DenseContrastiveLossV2(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.experiment = config['experiment']
+        self.dataset = config['dataset']
+        names = DATASETS_INFO[self.dataset].CLASS_INFO[self.experiment][1]
+        self.num_all_classes = len(names)                                        # ref :16
+        self.num_real_classes = self.num_all_classes - 1 if 255 in names else self.num_all_classes
+        self.ignore_class = (len(names) - 1) if 255 in names else -1
+        self.temperature = config['temperature'] if 'temperature' in config else 0.5
+        self.base_temperature = 1.0
+        self.min_views_per_class = config['min_views_per_class'] if 'min_views_per_class' in config else 5
+        self.label_scaling_mode = config['label_scaling_mode'] if 'label_scaling_mode' in config else 'nn'
+        self.cross_scale_contrast = config['cross_scale_contrast'] if 'cross_scale_contrast' in config else False
+        self.dominant_mode = 'all'
+        self.eps = torch.tensor(1e-10)
+        self.metadata = {name: (0.0, 0.0) for name in names.values()}
+        self.max_views_per_class = config['max_views_per_class'] if 'max_views_per_class' in config else 2500
+        self.max_features_total = config['max_features_total'] if 'max_features_total' in config else 10000
+        self.log_this_step = False
+        self._scale = None
+        self.last_state = None            # StepState of the most recent forward (plans, banks)
+        if self.label_scaling_mode == 'nn':
+            assert self.dominant_mode == 'all', \
+                'cannot use label_scaling_mode: "{}" with dominant_mode: "{}" - only "all" is allowed'.format(
+                    self.label_scaling_mode, self.dominant_mode)
+
+    def engine_config(self, **over):
+        cfg = dict(num_all_classes=int(self.num_all_classes), temperature=float(self.temperature),
+                   min_views_per_class=int(self.min_views_per_class),
+                   max_views_per_class=int(self.max_views_per_class),
+                   max_features_total=int(self.max_features_total))
+        cfg.update(over)
+        return EngineConfig(**cfg)
+
+    def _note_plan(self, plan, scale):
+        """Mirror the logging side effects of _select_views_per_class (ref :64-84)."""
+        self._scale = scale
+        if plan.log_this_step:
+            self.log_this_step = True
+            printlog(f'capping views: T={plan.T} V={plan.V} (max_views_per_class='
+                     f'{self.max_views_per_class}, max_features_total={self.max_features_total})')
+
+    def forward(self, label: torch.Tensor, features: torch.Tensor):
+        terms, st = dense_contrast_terms(self.engine_config(weights=(1.0,)), label, [features])
+        self.last_state = st
+        sc = st.scales[0]
+        self._note_plan(sc.plan, int(label.shape[-1] // features.shape[-1]))
+        loss = terms[0]
+        if self.cross_scale_contrast:
+            f32 = features if features.dtype == torch.float32 else features.float()
+            sampled_features = _RawBank.apply(f32, sc)
+            sampled_labels = sc.pair_k.to(torch.float32)
+            return loss, sampled_features, sampled_labels, False
+        return loss

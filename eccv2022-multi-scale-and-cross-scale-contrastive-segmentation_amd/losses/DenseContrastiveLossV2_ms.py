@@ -1,0 +1,76 @@
+"""Multi-scale + cross-scale dense contrastive loss -- drop-in for the reference class of the same
+name (losses/DenseContrastiveLossV2_ms.py:12-161).  All scales and cross-scale terms of one step
+run as ONE autograd node over libdcl_hip.so (one host sync for the label histograms)."""
+import torch
+import torch.nn as nn
+
+from ..utils import DATASETS_INFO, is_distributed, printlog
+from .DenseContrastiveLossV2 import DenseContrastiveLossV2 as DCV2
+from .engine import dense_contrast_terms
+
+
+class DenseContrastiveLossV2_ms(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.parallel = is_distributed()
+        self.experiment = config['experiment']
+        self.dataset = config['dataset']
+        names = DATASETS_INFO[self.dataset].CLASS_INFO[self.experiment][1]
+        self.num_all_classes = len(names)
+        self.num_real_classes = self.num_all_classes - 1 if 255 in names else self.num_all_classes
+        self.ignore_class = (len(names) - 1) if 255 in names else -1
+        self.scales = config['scales'] if 'scales' in config else 2
+        self.weights = config['weights'] if 'weights' in config else [1.0] * self.scales
+        assert self.scales == len(self.weights), \
+            f'given dc loss number of scales [{self.scales}] not equal len of weights {self.weights}'
+        self.losses = []
+        self.eps = torch.tensor(1e-10)
+        self.meta = {name: (0.0, 0.0) for name in names.values()}
+        self.cross_scale_contrast = config['cross_scale_contrast'] if 'cross_scale_contrast' in config else False
+        # reference quirk (ms:28): the VALUE of 'cross_scale_temperature' is ignored -- its presence
+        # selects the constant 0.1, its absence selects config['temperature']
+        self.cross_scale_temperature = config['temperature'] if 'cross_scale_temperature' not in config else 0.1
+        self.detach_cs_deepest = config['detach_deepest'] if 'detach_deepest' in config else False
+        self.w_high_low = config['w_high_low'] if 'w_high_low' in config else 1.0
+        self.w_high_mid = config['w_high_mid'] if 'w_high_mid' in config else 1.0
+        self.ms_losses = []
+        self.cs_losses = []
+        self.last_state = None
+        printlog(f'defining dcv2 ms loss with number of scales {self.scales} and weights {self.weights}')
+        printlog(f'using cross scale contrast {self.cross_scale_contrast}')
+        for s in range(self.scales):
+            setattr(self, f'DCV2_scale{s}', DCV2(config))
+        if self.cross_scale_contrast:
+            printlog(f'using cross-scale contrast with detach_cs_deepest set to {self.detach_cs_deepest}, '
+                     f'w_high_low: {self.w_high_low}, w_high_mid: {self.w_high_mid}')
+
+    def forward(self, label: torch.Tensor, features: list, **kwargs):
+        self.cs_losses = []
+        self.ms_losses = []
+        S = self.scales
+        sub0 = self.DCV2_scale0
+        with_cross = bool(self.cross_scale_contrast)
+        if with_cross:
+            assert S > 1 and len(features) > 1
+        cfg = sub0.engine_config(weights=tuple(float(w) for w in self.weights),
+                                 cross_scale_contrast=with_cross,
+                                 cross_scale_temperature=float(self.cross_scale_temperature),
+                                 detach_deepest=bool(self.detach_cs_deepest),
+                                 w_high_low=float(self.w_high_low), w_high_mid=float(self.w_high_mid))
+        feats = [features[s] for s in range(S)]
+        terms, st = dense_contrast_terms(cfg, label, feats)
+        self.last_state = st
+        for s in range(S):
+            getattr(self, f'DCV2_scale{s}')._note_plan(st.scales[s].plan,
+                                                      int(label.shape[-1] // feats[s].shape[-1]))
+        wvec = torch.tensor([t.weight for t in st.terms], dtype=torch.float32, device=terms.device)
+        loss = (terms * wvec).sum()
+        det = terms.detach()
+        self.ms_losses = [det[s] for s in range(S)]
+        if with_cross:
+            # ms:66-80 -- the high->low term is logged only when the deep bank is NOT detached
+            if not self.detach_cs_deepest:
+                self.cs_losses.append(det[S])
+            if S > 2:
+                self.cs_losses.append(det[S + 1])
+        return loss

@@ -1,0 +1,148 @@
+/*
+ * dcl_hip.h -- C ABI of libdcl_hip.so: the MI355X (gfx950) implementation of the
+ * multi-scale / cross-scale dense pixel-contrastive loss hot path.
+ *
+ * The reference (RViMLab/ECCV2022-multi-scale-and-cross-scale-contrastive-segmentation)
+ * is pure Python; it has no FFI.  Its boundary for this path is the Python call
+ * surface losses/LossWrapper.py:40 -> losses/DenseContrastiveLossV2_ms.py:44 ->
+ * losses/DenseContrastiveLossV2.py:44.  The entry points below are the operators
+ * those three functions decompose into; each one cites the reference lines it
+ * replaces.  The host-side mirror of the reference classes (mscs_amd.losses.*)
+ * binds them with ctypes; the signatures use only plain
+ * pointers and sizes -- no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     nothing synchronises the host;
+ *   - return value: 0 on success, otherwise a hipError_t (or a negative DCL_E*
+ *     code for argument errors); dcl_last_error() gives the message of the last
+ *     failure on the calling thread;
+ *   - bank matrices are row-major [Npad, DCL_CP] f32, Npad = N rounded up to
+ *     DCL_ROW_TILE, rows >= N and channels >= C are zero.
+ */
+#ifndef DCL_HIP_H
+#define DCL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCL_CP 256        /* padded embedding width handled by the sweep kernels   */
+#define DCL_ROW_TILE 128  /* bank rows per workgroup; Npad granularity             */
+#define DCL_SEG 256       /* label pixels per histogram segment                    */
+#define DCL_MAX_CLASSES 255
+
+#define DCL_EINVAL (-1)
+#define DCL_EUNSUPPORTED (-2)
+
+const char *dcl_last_error(void);
+int dcl_version(void);
+
+/* ---- K1 ---------------------------------------------------------------------------------
+ * Nearest down-sample of the label map to (h, w) = (H / scale, W / scale) and per-image class
+ * histogram.  Replaces F.interpolate(label.float(), mode='nearest') (DenseContrastiveLossV2.py:205)
+ * and `compare = lbl == arange(K); compare.sum(1)` (:100-103).
+ *   label     int64 [n, H, W] (class ids already remapped to network ids)
+ *   lbl_s     uint8 [n, h*w]           down-sampled ids; ids outside [0,K) -> 255
+ *   seg_hist  int32 [n, nseg, K]       per DCL_SEG-pixel segment histogram, nseg = ceil(h*w/DCL_SEG)
+ *   counts    int32 [n, K]             must be zero on entry; accumulated with integer atomics
+ */
+int dcl_label_hist(const int64_t *label, int n, int H, int W, int scale, int K,
+                   uint8_t *lbl_s, int32_t *seg_hist, int32_t *counts, void *stream);
+
+/* ---- K2 ---------------------------------------------------------------------------------
+ * Rank-select: pix[t, v] = the sel[t, v]-th pixel (ascending flat index) of class pair_k[t] in
+ * image pair_b[t].  Replaces the per-pair `compare[b,:,k].nonzero()` + `idx[perm[:V]]`
+ * (DenseContrastiveLossV2.py:117-122); sel holds the first V entries of the host-drawn
+ * torch.randperm(count) so indices are bit-identical to the reference.
+ *   pair_b, pair_k int32 [T];  sel int32 [T, V];  pix int32 [T, V]
+ */
+int dcl_rank_select(const uint8_t *lbl_s, const int32_t *seg_hist, int n, int hw, int K,
+                    const int32_t *pair_b, const int32_t *pair_k, int T, int V,
+                    const int32_t *sel, int32_t *pix, void *stream);
+
+/* ---- K3 ---------------------------------------------------------------------------------
+ * Gather + L2-normalise into a bank.  Replaces `features[b, :, idx]` (:123),
+ * F.normalize(dim=1) (:138) and the transpose/contiguous/view (:139-149).
+ * Bank row (u*V + v) holds pixel pix[slot_pair[u], v] of image pair_b[slot_pair[u]]; slot order
+ * is chosen by the host (class-major).  feat element (b, c, p) is at
+ * feat[b*stride_n + c*stride_c + p*stride_p] (NCHW: stride_c = h*w, stride_p = 1; NHWC: 1, C).
+ *   bank f32 [Npad, DCL_CP] (fully written, padding zeroed);  nrm f32 [Npad] raw L2 norms
+ */
+int dcl_gather_normalize(const float *feat, int64_t stride_n, int64_t stride_c, int64_t stride_p,
+                         int C, const int32_t *pix, const int32_t *pair_b,
+                         const int32_t *slot_pair, int T, int V, float *bank, float *nrm,
+                         void *stream);
+
+/* Reference-layout raw bank X[t, c, v] = features[b_t, c, pix[t, v]] (the `sampled_features`
+ * member of the 4-tuple returned by DenseContrastiveLossV2.forward, :61). */
+int dcl_gather_raw(const float *feat, int64_t stride_n, int64_t stride_c, int64_t stride_p, int C,
+                   const int32_t *pix, const int32_t *pair_b, int T, int V, float *X,
+                   void *stream);
+
+/* ---- K4 ---------------------------------------------------------------------------------
+ * Fused similarity + masked InfoNCE forward; the N1 x N2 matrix is never materialised.
+ * Replaces matmul/div (:150, ms:114), get_masks2 (:154-171, ms:118-130) and get_loss /
+ * InfoNce_loss (:173-192, ms:132-161).
+ *
+ * Rows of A are anchors, rows of B are contrast samples.  Positives of anchor row i are the
+ * contiguous column range [rng_lo[i / V1], rng_hi[i / V1]) of B (banks are class-sorted), minus
+ * column i itself when `intra` != 0; every other column < N2 is a negative.
+ *
+ * dcl_infonce_fwd runs both forward sweeps:
+ *   Z[i]       = sum_neg exp(s_ij),               s_ij = <A_i, B_j> / tau
+ *   rowloss[i] = sum_pos (s_ij - log(exp(s_ij) + Z[i]))
+ *   W[i]       = sum_pos 1 / (exp(s_ij) + Z[i])
+ * and loss[0] = -(1/N1) sum_i rowloss[i] / P_i with P_i = #positives (intra: 0/0 = NaN like the
+ * reference; cross-scale: P_i -> max(P_i, 1), ms:148-152).
+ *   zpart  f32 workspace [nsplit * N1pad];  Z, rowloss, W  f32 [N1pad];  loss f32 [1]
+ */
+int dcl_infonce_fwd(const float *A, int N1, int V1, const float *B, int N2,
+                    const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int intra,
+                    int nsplit, float *zpart, float *Z, float *rowloss, float *W, float *loss,
+                    void *stream);
+
+/* ---- K5 ---------------------------------------------------------------------------------
+ * InfoNCE backward.  With G_ij = dL/ds_ij:
+ *   dcl_infonce_prep_stats   packs per-row statistics {Z, gs*W/(N1*P), gs*Z/(N1*P), 0} where
+ *                            gs = wscale * (*grad_out) * inv_tau  (grad_out: device scalar, may be NULL = 1)
+ *   dcl_infonce_bwd          dpart[split][a, :] = sum_b H_ab * B_b  over that split's columns, where
+ *                            H_ab = use_row * G(a -> b; rstat[a]) + use_col * G(b -> a; cstat[b]).
+ *      intra-scale:  A = B, rstat = cstat, use_row = use_col = 1      (dF = (G + G^T) F / tau)
+ *      cross, dF1:   A = F1, B = F2, use_row = 1, use_col = 0         (G F2 / tau)
+ *      cross, dF2:   A = F2, B = F1, use_row = 0, use_col = 1, cstat = stats of F1's rows
+ *                    (rng_* are then F2's slot ranges into F1)        (G^T F1 / tau)
+ *   stat  f32 [N1pad, 4];   dpart f32 [nsplit, N1pad, DCL_CP]
+ */
+int dcl_infonce_prep_stats(const float *Z, const float *W, const int32_t *rng_lo,
+                           const int32_t *rng_hi, int N1, int V1, int intra, float wscale,
+                           float inv_tau, const float *grad_out, float *stat, void *stream);
+
+int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, int N2,
+                    const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int intra,
+                    int use_row, int use_col, const float *rstat, const float *cstat, int nsplit,
+                    float *dpart, void *stream);
+
+/* ---- K6 ---------------------------------------------------------------------------------
+ * Sum the partial dF slabs of a bank in a fixed order, apply the VJP of F.normalize
+ * (dx = (dF - f (f.dF)) / max(|x|, 1e-12)) and scatter into the dense feature gradient
+ * (autograd's IndexBackward x T + add_ x T in the reference).  dfeat must be zero on entry; every
+ * sampled pixel is written exactly once (pixels are unique within a scale), so no atomics.
+ *   slabs_host   host array of `nslab` device pointers, each f32 [Npad, DCL_CP]
+ */
+int dcl_normalize_bwd_scatter(const float *const *slabs_host, int nslab, const float *bank,
+                              const float *nrm, const int32_t *pix, const int32_t *pair_b,
+                              const int32_t *slot_pair, int T, int V, int C, float *dfeat,
+                              int64_t stride_n, int64_t stride_c, int64_t stride_p, void *stream);
+
+/* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the
+ * grid fills the 256 CUs evenly (host helper, no device work). */
+int dcl_suggest_nsplit(int N1, int N2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCL_HIP_H */

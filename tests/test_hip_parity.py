@@ -1,0 +1,341 @@
+"""GPU parity tests: the HIP path (through the C ABI of libdcl_hip.so) against
+  * the golden vectors produced by running the reference (tests/golden),
+  * the oracle on seeded inputs,
+  * size-independent properties at BASELINE config-2 size.
+Tolerances (fp32 path): loss rtol 1e-5; gradients atol 1e-4 * max|grad| (summation order differs);
+sampled pixel indices bit-exact."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, num_classes_for
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-5
+GRAD_ATOL_REL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import mscs_amd  # noqa: F401
+    from mscs_amd import _lib
+    _lib.lib()                                   # fails loudly if libdcl_hip.so is missing
+    return torch.device("cuda:0")
+
+
+def _module_cfg(c):
+    cfg = {k: v for k, v in c.items() if not k.startswith("_override_")}
+    return cfg
+
+
+def _apply_overrides(mod, c):
+    for k in ("num_all_classes", "ignore_class"):
+        if "_override_" + k in c:
+            setattr(mod, k, c["_override_" + k])
+            for s in range(getattr(mod, "scales", 0)):
+                setattr(getattr(mod, f"DCV2_scale{s}"), k, c["_override_" + k])
+
+
+def _check_plans(g, st):
+    for s, sc in enumerate(st.scales):
+        assert sc.plan.V == int(g[f"s{s}_V"])
+        np.testing.assert_array_equal(sc.plan.pair_b, g[f"s{s}_pair_b"])
+        np.testing.assert_array_equal(sc.plan.pair_k, g[f"s{s}_pair_k"])
+        np.testing.assert_array_equal(sc.pix.cpu().numpy(), g[f"s{s}_pix"])      # bit-exact
+
+
+def _check_grad(got, ref):
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    np.testing.assert_allclose(got, ref, atol=GRAD_ATOL_REL * scale, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", golden_names(["G1", "G3"]))
+def test_single_scale_vs_reference(dev, name):
+    from mscs_amd.losses import DenseContrastiveLossV2
+    g = load_golden(name)
+    c = g["config"]
+    mod = DenseContrastiveLossV2(_module_cfg(c))
+    _apply_overrides(mod, c)
+    feat = torch.from_numpy(g["feat0"]).to(dev).requires_grad_(True)
+    label = torch.from_numpy(g["label"].astype(np.int64)).to(dev)
+    torch.manual_seed(int(g["seed"]))
+    out = mod(label, feat)
+    loss = out[0] if isinstance(out, tuple) else out
+    loss.backward()
+    _check_plans(g, mod.last_state)
+    assert mod.log_this_step == bool(g["s0_log_this_step"])
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=LOSS_RTOL)
+    _check_grad(feat.grad.cpu().numpy(), g["s0_grad"])
+    if isinstance(out, tuple):
+        np.testing.assert_array_equal(out[1].detach().cpu().numpy(), g["sampled_features"])
+        np.testing.assert_array_equal(out[2].cpu().numpy(), g["sampled_labels"])
+        assert out[3] is False
+
+
+@pytest.mark.parametrize("name", golden_names(["G2", "G4", "G5", "G9"]))
+def test_multi_scale_vs_reference(dev, name):
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    g = load_golden(name)
+    c = g["config"]
+    mod = DenseContrastiveLossV2_ms(_module_cfg(c))
+    _apply_overrides(mod, c)
+    S = mod.scales
+    feats = [torch.from_numpy(g[f"feat{s}"]).to(dev).requires_grad_(True) for s in range(S)]
+    label = torch.from_numpy(g["label"].astype(np.int64)).to(dev)
+    torch.manual_seed(int(g["seed"]))
+    loss = mod(label, feats)
+    loss.backward()
+    _check_plans(g, mod.last_state)
+    np.testing.assert_allclose([x.item() for x in mod.ms_losses], g["ms_losses"], rtol=LOSS_RTOL)
+    assert len(mod.cs_losses) == len(g["cs_losses"])
+    np.testing.assert_allclose([x.item() for x in mod.cs_losses], g["cs_losses"], rtol=LOSS_RTOL)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=LOSS_RTOL)
+    for s in range(S):
+        got = feats[s].grad
+        got = np.zeros_like(g[f"s{s}_grad"]) if got is None else got.cpu().numpy()
+        _check_grad(got, g[f"s{s}_grad"])
+
+
+def test_losswrapper_vs_reference(dev):
+    from mscs_amd.losses import LossWrapper
+    g = load_golden("G6_losswrapper")
+    c = dict(g["config"], device=str(dev))
+    lw = LossWrapper(c)
+    logits = torch.from_numpy(g["logits_f16"].astype(np.float32)).to(dev).requires_grad_(True)
+    feats = [torch.from_numpy(g[f"feat{s}"]).to(dev).requires_grad_(True) for s in range(2)]
+    label = torch.from_numpy(g["label"].astype(np.int64)).to(dev)
+    torch.manual_seed(int(g["seed"]))
+    total = lw(logits, label, deep_features=feats)
+    total.backward()
+    np.testing.assert_allclose(total.item(), g["total"], rtol=LOSS_RTOL)
+    keys = sorted(k[5:] for k in g if k.startswith("val__"))
+    assert sorted(lw.loss_vals.keys()) == keys
+    for k in keys:
+        np.testing.assert_allclose(float(lw.loss_vals[k]), g["val__" + k], rtol=LOSS_RTOL)
+    _check_grad(logits.grad[:, :, ::4, ::4].cpu().numpy(), g["logits_grad_sample"])
+    for s in range(2):
+        _check_grad(feats[s].grad.cpu().numpy(), g[f"s{s}_grad"])
+    # TwoScaleLoss through the wrapper
+    c2 = dict(json.loads(str(g["twoscale_config_json"])), device=str(dev))
+    lw2 = LossWrapper(c2)
+    interm = torch.from_numpy(g["interm_f16"].astype(np.float32)).to(dev)
+    t2 = lw2(logits.detach(), label, interm_prediction=interm)
+    np.testing.assert_allclose(t2.item(), g["twoscale_total"], rtol=LOSS_RTOL)
+
+
+def _random_case(seed, n, H, W, K, C, strides, classes=None):
+    gen = torch.Generator().manual_seed(seed)
+    if classes is None:
+        label = torch.randint(0, K, (n, H, W), generator=gen)
+    else:
+        idx = torch.randint(0, len(classes), (n, H // 8, W // 8), generator=gen)
+        label = torch.tensor(classes)[idx].repeat_interleave(8, 1).repeat_interleave(8, 2)
+    feats = [torch.randn(n, C, H // s, W // s, generator=gen) for s in strides]
+    return label, feats
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_vs_oracle_c256_three_scales(dev, oracle, channels_last):
+    """C = 256 (the production width), 3 scales + cross-scale, against the fp64 oracle."""
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    label, feats = _random_case(5, 2, 128, 256, 20, 256, (4, 8, 16), classes=[0, 3, 5, 7, 11, 19])
+    cfg = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": 3,
+           "weights": [1.0, 0.7, 0.4], "cross_scale_contrast": True, "max_features_total": 3000}
+    mod = DenseContrastiveLossV2_ms(cfg)
+    ocfg = oracle.LossConfig(num_all_classes=20, temperature=0.1, max_features_total=3000, scales=3,
+                             weights=[1.0, 0.7, 0.4], cross_scale_contrast=True)
+    res = oracle.dcv2_ms(label.numpy(), [f.numpy() for f in feats], ocfg, rng=oracle.MT19937(77))
+    dfeats = []
+    for f in feats:
+        f = f.to(dev)
+        if channels_last:
+            f = f.contiguous(memory_format=torch.channels_last)
+        dfeats.append(f.requires_grad_(True))
+    torch.manual_seed(77)
+    loss = mod(label.to(dev), dfeats)
+    loss.backward()
+    for s, sc in enumerate(mod.last_state.scales):
+        np.testing.assert_array_equal(sc.pix.cpu().numpy(), res.plans[s].pix)
+    np.testing.assert_allclose(loss.item(), res.loss, rtol=LOSS_RTOL)
+    np.testing.assert_allclose([x.item() for x in mod.ms_losses], res.ms_losses, rtol=LOSS_RTOL)
+    np.testing.assert_allclose([x.item() for x in mod.cs_losses], res.cs_losses, rtol=LOSS_RTOL)
+    for s in range(3):
+        _check_grad(dfeats[s].grad.cpu().numpy(), res.grads[s])
+        if channels_last:
+            assert dfeats[s].grad.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_deterministic_bitwise(dev):
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    label, feats = _random_case(9, 2, 128, 256, 20, 64, (4, 8))
+    cfg = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": 2,
+           "weights": [1.0, 0.5], "cross_scale_contrast": True}
+    mod = DenseContrastiveLossV2_ms(cfg)
+    outs = []
+    for _ in range(2):
+        fs = [f.to(dev).requires_grad_(True) for f in feats]
+        torch.manual_seed(1)
+        loss = mod(label.to(dev), fs)
+        loss.backward()
+        outs.append((loss.item(), [f.grad.clone() for f in fs]))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+
+
+def test_properties_at_baseline_config2_size(dev):
+    """BASELINE config 2 (n=12, 512x1024, K=20, C=256, 3 scales + cross-scale), size-independent checks:
+    sampled pixels have the pair's class and are unique; the gradient lives only on sampled pixels
+    and is orthogonal to the feature vector there (VJP of the L2 normalisation); scaling the features
+    leaves the loss unchanged; the loss equals a dense fp32 torch evaluation of the same banks."""
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    gen = torch.Generator().manual_seed(0)
+    n, H, W, K, C = 12, 512, 1024, 20, 256
+    label = torch.randint(0, K, (n, H, W), generator=gen).to(dev)
+    feats = [torch.randn(n, C, H // s, W // s, generator=gen).to(dev).requires_grad_(True)
+             for s in (4, 8, 16)]
+    cfg = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": 3,
+           "weights": [1.0, 0.7, 0.4], "cross_scale_contrast": True}
+    mod = DenseContrastiveLossV2_ms(cfg)
+    torch.manual_seed(0)
+    loss = mod(label, feats)
+    loss.backward()
+    st = mod.last_state
+    assert [(sc.plan.T, sc.plan.V) for sc in st.scales] == [(228, 43)] * 3
+    for s, sc in enumerate(st.scales):
+        stride = 4 * 2 ** s
+        lbl_s = label[:, ::stride, ::stride].reshape(n, -1)
+        pix = sc.pix.long()
+        b = sc.pair_b.long()[:, None].expand_as(pix)
+        assert torch.equal(lbl_s[b, pix], sc.pair_k.long()[:, None].expand_as(pix))
+        key = (b * lbl_s.shape[1] + pix).flatten()
+        assert key.unique().numel() == key.numel()
+        g = feats[s].grad.reshape(n, C, -1)
+        nz = (g.abs().sum(1) > 0)
+        touched = torch.zeros_like(nz)
+        touched[b.flatten(), pix.flatten()] = True
+        assert torch.equal(nz & ~touched, torch.zeros_like(nz))
+        x = feats[s].detach().reshape(n, C, -1)[b.flatten(), :, pix.flatten()]
+        gx = g[b.flatten(), :, pix.flatten()]
+        cos = (x * gx).sum(1).abs() / (x.norm(dim=1) * gx.norm(dim=1) + 1e-30)
+        assert cos.max().item() < 1e-3
+    # dense torch fp32 evaluation of the same banks (reference formulas on the device)
+    total = 0.0
+    for t, term in enumerate(st.terms):
+        A, B = st.scales[term.a], st.scales[term.b]
+        Fa, Fb = A.bank[:A.plan.N], B.bank[:B.plan.N]
+        ca = torch.from_numpy(np.repeat(A.plan.pair_k[A.plan.slot_pair], A.plan.V)).to(dev)
+        cb = torch.from_numpy(np.repeat(B.plan.pair_k[B.plan.slot_pair], B.plan.V)).to(dev)
+        Smat = (Fa @ Fb.T) / term.tau
+        pos = (ca[:, None] == cb[None, :]).float()
+        neg = 1 - pos
+        if term.intra:
+            pos.fill_diagonal_(0)
+        E = torch.exp(Smat)
+        Z = (E * neg).sum(1, keepdim=True)
+        logp = Smat - torch.log(E + Z)
+        P = pos.sum(1)
+        Pn = P if term.intra else torch.where(P > 0, P, torch.ones_like(P))
+        ref = -((pos * logp).sum(1) / Pn).mean()
+        np.testing.assert_allclose(st.loss_buf[t].item(), ref.item(), rtol=LOSS_RTOL)
+        total += term.weight * ref.item()
+    np.testing.assert_allclose(loss.item(), total, rtol=LOSS_RTOL)
+    # scale invariance (features are L2-normalised before use)
+    feats2 = [(f.detach() * 3.0) for f in feats]
+    torch.manual_seed(0)
+    loss2 = mod(label, feats2)
+    np.testing.assert_allclose(loss2.item(), loss.item(), rtol=1e-5)
+
+
+def test_c_abi_direct_infonce_cross(dev, oracle):
+    """dcl_infonce_fwd / _prep_stats / _bwd called through ctypes on hand-made banks (ragged sizes,
+    a class missing from the contrast bank) against the oracle's cross_loss."""
+    from mscs_amd import _lib
+    import ctypes
+    L = _lib.lib()
+    rs = np.random.RandomState(3)
+    V1, V2 = 7, 5
+    cls1 = np.array([0, 0, 2, 5, 5, 5, 9])          # slots, class-sorted
+    cls2 = np.array([0, 2, 2, 9, 9, 11])            # class 5 absent -> rows with P = 0
+    N1, N2 = len(cls1) * V1, len(cls2) * V2
+    F1 = rs.randn(N1, 256).astype(np.float32); F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+    F2 = rs.randn(N2, 256).astype(np.float32); F2 /= np.linalg.norm(F2, axis=1, keepdims=True)
+    r1, r2 = np.repeat(cls1, V1), np.repeat(cls2, V2)
+    tau = 0.1
+    ref_loss, d1, d2 = oracle.cross_loss(F1.astype(np.float64), r1, F2.astype(np.float64), r2, tau)
+
+    def ranges(ca, cb, Vb):
+        lo = np.array([np.flatnonzero(cb == c)[0] * Vb if (cb == c).any() else 0 for c in ca], np.int32)
+        hi = np.array([(np.flatnonzero(cb == c)[-1] + 1) * Vb if (cb == c).any() else 0 for c in ca], np.int32)
+        return lo, hi
+    lo, hi = ranges(cls1, cls2, V2)
+    rlo, rhi = ranges(cls2, cls1, V1)
+
+    def bank(F):
+        pad = (-F.shape[0]) % 128
+        return torch.from_numpy(np.concatenate([F, np.zeros((pad, 256), np.float32)])).to(dev)
+    A, B = bank(F1), bank(F2)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    lo_d, hi_d, rlo_d, rhi_d = t(lo), t(hi), t(rlo), t(rhi)
+    ns = 2
+    N1pad, N2pad = A.shape[0], B.shape[0]
+    zpart = torch.empty(ns * N1pad, device=dev); Z = torch.empty(N1pad, device=dev)
+    rl = torch.empty(N1pad, device=dev); Wt = torch.empty(N1pad, device=dev); loss = torch.empty(1, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = _lib.ptr
+    _lib.check(L.dcl_infonce_fwd(p(A), N1, V1, p(B), N2, p(lo_d), p(hi_d), 1 / tau, 0, ns, p(zpart), p(Z),
+                                 p(rl), p(Wt), p(loss), st), "fwd")
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=LOSS_RTOL)
+    stat = torch.empty(N1pad, 4, device=dev)
+    _lib.check(L.dcl_infonce_prep_stats(p(Z), p(Wt), p(lo_d), p(hi_d), N1, V1, 0, 1.0, 1 / tau, None,
+                                        p(stat), st), "prep")
+    dp1 = torch.empty(ns, N1pad, 256, device=dev)
+    _lib.check(L.dcl_infonce_bwd(p(A), N1, V1, p(B), N2, p(lo_d), p(hi_d), 1 / tau, 0, 1, 0, p(stat), None,
+                                 ns, p(dp1), st), "bwd1")
+    dp2 = torch.empty(ns, N2pad, 256, device=dev)
+    _lib.check(L.dcl_infonce_bwd(p(B), N2, V2, p(A), N1, p(rlo_d), p(rhi_d), 1 / tau, 0, 0, 1, None, p(stat),
+                                 ns, p(dp2), st), "bwd2")
+    _check_grad(dp1.sum(0)[:N1].cpu().numpy(), d1)
+    _check_grad(dp2.sum(0)[:N2].cpu().numpy(), d2)
+
+
+def test_k1_k2_direct_odd_sizes(dev, oracle):
+    """K1/K2 through ctypes at sizes that are not multiples of the stride or the segment length."""
+    from mscs_amd import _lib
+    import ctypes
+    L = _lib.lib()
+    rs = np.random.RandomState(11)
+    n, H, W, K, scale = 3, 101, 203, 7, 3
+    label = rs.randint(0, K + 2, size=(n, H, W)).astype(np.int64)      # ids >= K are out of range
+    label[0, :5, :5] = -1
+    lbl_ref = oracle.downsample_labels(label, scale)
+    h, w = lbl_ref.shape[1:]
+    counts_ref = oracle.class_counts(lbl_ref, K)
+    nseg = (h * w + 255) // 256
+    lab_d = torch.from_numpy(label).to(dev)
+    lbl_s = torch.empty(n, h * w, dtype=torch.uint8, device=dev)
+    seg = torch.empty(n, nseg, K, dtype=torch.int32, device=dev)
+    counts = torch.zeros(n, K, dtype=torch.int32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = _lib.ptr
+    _lib.check(L.dcl_label_hist(p(lab_d), n, H, W, scale, K, p(lbl_s), p(seg), p(counts), st), "k1")
+    np.testing.assert_array_equal(counts.cpu().numpy(), counts_ref)
+    exp = lbl_ref.reshape(n, -1).copy(); exp[(exp < 0) | (exp >= K)] = 255
+    np.testing.assert_array_equal(lbl_s.cpu().numpy(), exp.astype(np.uint8))
+    np.testing.assert_array_equal(seg.sum(1).cpu().numpy(), counts_ref)
+    # every rank of a few pairs
+    pairs = [(0, 1), (2, 6), (1, 0)]
+    V = int(min(counts_ref[b, k] for b, k in pairs))
+    sel = np.stack([rs.permutation(counts_ref[b, k])[:V] for b, k in pairs]).astype(np.int32)
+    pix = torch.empty(len(pairs), V, dtype=torch.int32, device=dev)
+    pb = torch.tensor([b for b, _ in pairs], dtype=torch.int32, device=dev)
+    pk = torch.tensor([k for _, k in pairs], dtype=torch.int32, device=dev)
+    _lib.check(L.dcl_rank_select(p(lbl_s), p(seg), n, h * w, K, p(pb), p(pk), len(pairs), V,
+                                 p(torch.from_numpy(sel).to(dev)), p(pix), st), "k2")
+    flat = lbl_ref.reshape(n, -1)
+    want = np.stack([np.flatnonzero(flat[b] == k)[sel[t]] for t, (b, k) in enumerate(pairs)])
+    np.testing.assert_array_equal(pix.cpu().numpy(), want)
