@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native dense contrastive segmentation hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload step|loss]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).  Rank 0
+prints ONE JSON line.  `value` is the whole-job rate; the timed region is bracketed by a barrier and
+torch.cuda.synchronize() on both sides and the maximum over ranks is taken.
+
+Workloads (BASELINE.json configs[1]: HRNet-W48 + DenseContrastiveLossV2_ms (3 scales), synthetic
+Cityscapes 512x1024, batch 12 per GPU):
+  step  one training step: model forward, LossWrapper(CE + 0.1 * DCV2_ms), backward, SGD update
+  loss  the contrastive loss alone (forward + backward) on synthetic 256-d projector outputs
+Extra keys: `roofline` (dominant kernel = InfoNCE backward sweep, algorithmic FLOPs over HIP-event
+time), `cpu_baseline` (oracle/eager_torch.py on the host cores, bounded sample), and
+`contrastive_loss_fwd_bwd_ms`.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=["step", "loss"])
+    ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--scales", type=int, default=3)
+    ap.add_argument("--no-cross", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-baseline", action="store_true",
+                    help="also time the eager-structure restatement of the loss on the GPU")
+    return ap.parse_args()
+
+
+def loss_config(S, cross):
+    weights = [1.0, 0.7, 0.4, 0.1][:S]
+    return {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": S,
+            "weights": weights, "cross_scale_contrast": cross, "min_views_per_class": 5,
+            "max_views_per_class": 2500, "max_features_total": 10000, "label_scaling_mode": "nn"}
+
+
+def synth_loss_inputs(args, dev, rank):
+    gen = torch.Generator().manual_seed(1000 * rank)
+    n, H, W = args.batch, args.height, args.width
+    label = torch.randint(0, 20, (n, H, W), generator=gen).to(dev)          # iid: worst-case load (N at the cap)
+    feats = [torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).to(dev).requires_grad_(True)
+             for s in range(args.scales)]
+    return label, feats
+
+
+def time_loss_only(args, dev, rank, world):
+    import mscs_amd  # noqa: F401
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    from mscs_amd.utils import set_verbosity
+    set_verbosity(40)
+    cross = not args.no_cross
+    mod = DenseContrastiveLossV2_ms(loss_config(args.scales, cross))
+    label, feats = synth_loss_inputs(args, dev, rank)
+    torch.manual_seed(0)
+
+    def step():
+        for f in feats:
+            f.grad = None
+        loss = mod(label, feats)
+        loss.backward()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync(world)
+    dt = time.perf_counter() - t0
+    return dt, mod
+
+
+def sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def roofline_bwd_kernel(mod, iters=10):
+    """Average launch duration of the dominant kernel (InfoNCE backward sweep, intra-scale term 0),
+    HIP events on the launch stream; algorithmic FLOPs = 4 * N1 * N2 * C (S = A B^T recompute + H B)."""
+    from mscs_amd import _lib
+    L = _lib.lib()
+    st = mod.last_state
+    t = st.terms[0]
+    A = st.scales[t.a]
+    N = A.plan.N
+    Npad = A.bank.shape[0]
+    dev = A.bank.device
+    stat = torch.empty((Npad, 4), device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = _lib.ptr
+    _lib.check(L.dcl_infonce_prep_stats(p(t.Z), p(t.W), p(t.rng_lo), p(t.rng_hi), N, A.plan.V, 1, 1.0,
+                                        1.0 / t.tau, None, p(stat), stream), "prep")
+    ns = int(L.dcl_suggest_nsplit(N, N))
+    dpart = torch.empty((ns, Npad, 256), device=dev)
+
+    def launch():
+        _lib.check(L.dcl_infonce_bwd(p(A.bank), N, A.plan.V, p(A.bank), N, p(t.rng_lo), p(t.rng_hi),
+                                     1.0 / t.tau, 1, 1, 1, p(stat), p(stat), ns, p(dpart), stream), "bwd")
+    launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 4.0 * N * N * 256
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_sweep<MODE_BWD> (dcl_infonce_bwd)", "achieved": round(achieved, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": None, "launch_ms": round(ms, 4), "N1": N, "N2": N, "C": 256, "nsplit": ns}
+
+
+def cpu_baseline_loss(args, n_terms):
+    """oracle/eager_torch.py on the host cores.  Bounded sample: ONE intra-scale term (scale index 2,
+    the cheapest label scan) forward + backward; every term of this workload is a ~9804 x 9804
+    evaluation, so a full loss evaluation is n_terms such terms."""
+    from oracle import eager_torch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(0)
+    n, H, W = args.batch, args.height, args.width
+    label = torch.randint(0, 20, (n, H, W), generator=gen)
+    s = min(2, args.scales - 1)
+    feat = torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).requires_grad_(True)
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    bank, classes = eager_torch.sample_bank(label, feat, 20, 5, 2500, 10000)
+    l = eager_torch.intra_loss(bank, classes, 0.1)
+    l.backward()
+    dt = time.perf_counter() - t0
+    return dt, cores, f"1 of {n_terms} loss terms (intra-scale, stride {4 << s}, N={bank.shape[0] * bank.shape[2]}) " \
+                      f"fwd+bwd, eager torch fp32 on {cores} host threads, scaled by {n_terms}"
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    workload = args.workload or "loss"
+
+    if workload == "loss":
+        dt, mod = time_loss_only(args, dev, rank, world)
+        unit_per_step = 1.0
+        metric, unit = "contrastive_loss_fwd_bwd_per_sec", "loss evals/s"
+    else:
+        raise SystemExit("workload 'step' lands with the HRNet-W48 model")
+
+    tmax = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * unit_per_step * args.steps / dt
+
+    out = None
+    if rank == 0:
+        n_terms = len(mod.last_state.terms)
+        out = {
+            "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"DenseContrastiveLossV2_ms fwd+bwd, {args.scales} scales"
+                                   f"{'' if args.no_cross else ' + cross-scale'}, n={args.batch} "
+                                   f"{args.height}x{args.width} iid labels K=20, C=256, per GPU",
+                       "terms": [[t.a, t.b, st_n(mod, t.a), st_n(mod, t.b)] for t in mod.last_state.terms]},
+            "contrastive_loss_fwd_bwd_ms": round(ms_per_step, 3),
+        }
+        out["roofline"] = roofline_bwd_kernel(mod)
+        if not args.no_cpu_baseline:
+            cdt, cores, sample = cpu_baseline_loss(args, n_terms)
+            out["cpu_baseline"] = {"value": round(1.0 / (cdt * n_terms), 5), "unit": unit, "cores": cores,
+                                   "kind": "port", "sample": sample, "sample_seconds": round(cdt, 2)}
+        if args.eager_baseline:
+            out["eager_gpu_loss_ms"] = round(eager_gpu_loss_ms(args, dev), 2)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def st_n(mod, s):
+    return mod.last_state.scales[s].plan.N
+
+
+def eager_gpu_loss_ms(args, dev):
+    """The eager-structure restatement of the loss (oracle/eager_torch.py) on the MI355X."""
+    from oracle import eager_torch
+    gen = torch.Generator().manual_seed(0)
+    n, H, W = args.batch, args.height, args.width
+    label = torch.randint(0, 20, (n, H, W), generator=gen).to(dev)
+    feats = [torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).to(dev).requires_grad_(True)
+             for s in range(args.scales)]
+    w = [1.0, 0.7, 0.4, 0.1][:args.scales]
+
+    def step():
+        for f in feats:
+            f.grad = None
+        total, _, _ = eager_torch.dcv2_ms(label, feats, 20, 0.1, w, cross=not args.no_cross)
+        total.backward()
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / 2 * 1e3
+
+
+if __name__ == "__main__":
+    main()

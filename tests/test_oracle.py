@@ -123,3 +123,27 @@ def test_no_pairs_raises(oracle):
     lab = np.full((1, 16, 16), 19, dtype=np.int64)     # only the (dropped) last class present
     with pytest.raises(RuntimeError):
         oracle.make_plan(lab, 4, 20, 5, 2500, 10000, rng=oracle.MT19937(0))
+
+
+@pytest.mark.parametrize("name", ["G2_ms4_cross", "G5a_detach", "G5e_S3", "G4_cross_zero_pos"])
+def test_eager_torch_restatement_matches_reference(name):
+    """oracle/eager_torch.py (the eager-structure comparator used by bench.py) against the goldens."""
+    from oracle import eager_torch
+    g = load_golden(name)
+    c = g["config"]
+    S = c["scales"]
+    feats = [torch.from_numpy(g[f"feat{s}"]).requires_grad_(True) for s in range(S)]
+    label = torch.from_numpy(g["label"].astype(np.int64))
+    torch.manual_seed(int(g["seed"]))
+    total, ms, cs = eager_torch.dcv2_ms(
+        label, feats, 20, c["temperature"], c["weights"], cross=c.get("cross_scale_contrast", False),
+        cross_tau=0.1 if "cross_scale_temperature" in c else None,
+        detach_deepest=c.get("detach_deepest", False), w_high_low=c.get("w_high_low", 1.0),
+        w_high_mid=c.get("w_high_mid", 1.0))
+    total.backward()
+    np.testing.assert_allclose(total.item(), g["loss"], rtol=1e-6)
+    np.testing.assert_allclose([x.item() for x in ms], g["ms_losses"], rtol=1e-6)
+    np.testing.assert_allclose([x.item() for x in cs], g["cs_losses"], rtol=1e-6)
+    for s in range(S):
+        got = feats[s].grad.numpy() if feats[s].grad is not None else np.zeros_like(g[f"s{s}_grad"])
+        np.testing.assert_allclose(got, g[f"s{s}_grad"], atol=1e-6 * np.abs(g[f"s{s}_grad"]).max() + 1e-12)
