@@ -1,0 +1,368 @@
+"""HRNetV2 backbone (W18 / W32 / W48) + segmentation head + (multi-scale) projector.
+
+Drop-in for the reference (models/HRNet.py:56-705, models/hrnet_config.py): same constructor
+``HRNet(config=graph_dict, experiment=int)``, same attributes (``out_stride``, ``projector_model``,
+``return_features``, ``align_corners``, ``num_classes``), same forward return arity, and the same
+module tree, so state_dict keys match the reference's 1,870 entries (``backbone.*``,
+``cls_head.{0,1,2}.*``, ``projector_model.project{s}.{0,2,3}.*``) and its checkpoints load.
+
+Architecture (HRNetV2, Sun et al. 2019): a stem of two stride-2 3x3 convs, a bottleneck stage, then
+three multi-resolution stages.  Each stage is a chain of exchange modules: every branch runs 4 basic
+residual blocks at its own resolution, then every output resolution sums contributions from all
+branches (1x1 conv + bilinear up-sampling from coarser branches, strided 3x3 conv chains from finer
+ones).  Convolutions run through MIOpen (dense contractions on the matrix cores); ``memory_format``
+channels_last is supported end to end so the projector output feeds the loss's gather as contiguous
+1-KiB rows.
+
+Reference quirks kept on purpose: exchange modules interpolate with
+``align_corners=False`` (they are constructed without the flag, HRNet.py:486-493) while the final
+concat and the logits up-sampling use the configured value; ``HRNet`` always builds the W48 backbone
+unless ``config['backbone']`` names another factory (an extension: the reference hard-codes it).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..utils import DATASETS_INFO, printlog
+from .Projector import Projector
+
+__all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _stage(modules, branches, block, channels):
+    return _Cfg(NUM_MODULES=modules, NUM_BRANCHES=branches, NUM_BLOCKS=[4] * branches,
+                NUM_CHANNELS=channels, BLOCK=block, FUSE_METHOD='SUM')
+
+
+def _arch(w):
+    return _Cfg(FINAL_CONV_KERNEL=1,
+                STAGE1=_stage(1, 1, 'BOTTLENECK', [64]),
+                STAGE2=_stage(1, 2, 'BASIC', [w, 2 * w]),
+                STAGE3=_stage(4, 3, 'BASIC', [w, 2 * w, 4 * w]),
+                STAGE4=_stage(3, 4, 'BASIC', [w, 2 * w, 4 * w, 8 * w]))
+
+
+MODEL_CONFIGS = {'hrnet18': _arch(18), 'hrnet32': _arch(32), 'hrnet48': _arch(48)}
+
+
+def _conv_bn(cin, cout, k, stride=1, relu=False, norm=nn.BatchNorm2d):
+    layers = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False), norm(cout)]
+    if relu:
+        layers.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*layers)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        out = out + (x if self.downsample is None else self.downsample(x))
+        return self.relu(out)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = norm_layer(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        out = out + (x if self.downsample is None else self.downsample(x))
+        return self.relu(out)
+
+
+blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck}
+
+
+def _residual_chain(block, inplanes, planes, n_blocks, norm, stride=1):
+    down = None
+    if stride != 1 or inplanes != planes * block.expansion:
+        down = _conv_bn(inplanes, planes * block.expansion, 1, stride, norm=norm)
+    layers = [block(inplanes, planes, stride, down, norm_layer=norm)]
+    layers += [block(planes * block.expansion, planes, norm_layer=norm) for _ in range(1, n_blocks)]
+    return nn.Sequential(*layers)
+
+
+class HighResolutionModule(nn.Module):
+    """One exchange module: parallel residual branches followed by all-to-all fusion."""
+
+    def __init__(self, num_branches, block, num_blocks, num_inchannels, num_channels, fuse_method,
+                 multi_scale_output=True, norm_layer=None, align_corners=False):
+        super().__init__()
+        if not (num_branches == len(num_blocks) == len(num_channels) == len(num_inchannels)):
+            raise ValueError(f'NUM_BRANCHES({num_branches}) must match NUM_BLOCKS({len(num_blocks)}), '
+                             f'NUM_CHANNELS({len(num_channels)}) and NUM_INCHANNELS({len(num_inchannels)})')
+        self.norm_layer = norm_layer or nn.BatchNorm2d
+        self.align_corners = align_corners
+        self.num_inchannels = list(num_inchannels)
+        self.fuse_method = fuse_method
+        self.num_branches = num_branches
+        self.multi_scale_output = multi_scale_output
+        branches = []
+        for b in range(num_branches):
+            branches.append(_residual_chain(block, self.num_inchannels[b], num_channels[b], num_blocks[b],
+                                            self.norm_layer))
+            self.num_inchannels[b] = num_channels[b] * block.expansion
+        self.branches = nn.ModuleList(branches)
+        self.fuse_layers = self._fusion()
+        self.relu = nn.ReLU(inplace=True)
+
+    def _fusion(self):
+        if self.num_branches == 1:
+            return None
+        ch = self.num_inchannels
+        rows = []
+        for i in range(self.num_branches if self.multi_scale_output else 1):
+            row = []
+            for j in range(self.num_branches):
+                if j > i:       # coarser -> finer: 1x1 conv + BN (bilinear up-sampling in forward)
+                    row.append(_conv_bn(ch[j], ch[i], 1, norm=self.norm_layer))
+                elif j == i:
+                    row.append(None)
+                else:           # finer -> coarser: (i - j) stride-2 3x3 convs, ReLU between them
+                    steps = [_conv_bn(ch[j], ch[j], 3, 2, relu=True, norm=self.norm_layer)
+                             for _ in range(i - j - 1)]
+                    steps.append(_conv_bn(ch[j], ch[i], 3, 2, norm=self.norm_layer))
+                    row.append(nn.Sequential(*steps))
+            rows.append(nn.ModuleList(row))
+        return nn.ModuleList(rows)
+
+    def get_num_inchannels(self):
+        return self.num_inchannels
+
+    def forward(self, x):
+        if self.num_branches == 1:
+            return [self.branches[0](x[0])]
+        x = [branch(xi) for branch, xi in zip(self.branches, x)]
+        fused = []
+        for i, row in enumerate(self.fuse_layers):
+            y = x[0] if i == 0 else row[0](x[0])
+            for j in range(1, self.num_branches):
+                if j == i:
+                    y = y + x[j]
+                elif j > i:
+                    y = y + F.interpolate(row[j](x[j]), size=x[i].shape[-2:], mode='bilinear',
+                                          align_corners=self.align_corners)
+                else:
+                    y = y + row[j](x[j])
+            fused.append(self.relu(y))
+        return fused
+
+
+class HighResolutionNet(nn.Module):
+    def __init__(self, cfg, norm_layer=None, mixing_layer=False, use_as_backbone=False,
+                 return_all_scales=False, align_corners=False, dataset='CITYSCAPES', experiment=1):
+        super().__init__()
+        self.norm_layer = norm_layer or nn.BatchNorm2d
+        self.use_mxing_layer = mixing_layer
+        self.dataset = dataset
+        self.experiment = experiment
+        self.use_as_backbone = use_as_backbone
+        self.return_all_scales = return_all_scales
+        self.align_corners = align_corners
+        self.out_stride = 4
+        self.projector_model = None
+        if use_as_backbone and mixing_layer:
+            self.num_classes = 0
+        else:
+            names = DATASETS_INFO[dataset].CLASS_INFO[experiment][1]
+            self.num_classes = len(names) - 1 if 255 in names.keys() else len(names)
+
+        self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
+        self.bn1 = self.norm_layer(64)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = self.norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+
+        self.stage1_cfg = cfg['STAGE1']
+        block = blocks_dict[self.stage1_cfg['BLOCK']]
+        self.layer1 = _residual_chain(block, 64, self.stage1_cfg['NUM_CHANNELS'][0],
+                                      self.stage1_cfg['NUM_BLOCKS'][0], self.norm_layer)
+        pre = [block.expansion * self.stage1_cfg['NUM_CHANNELS'][0]]
+
+        self.stage2_cfg = cfg['STAGE2']
+        self.stage3_cfg = cfg['STAGE3']
+        self.stage4_cfg = cfg['STAGE4']
+        for idx, scfg in ((2, self.stage2_cfg), (3, self.stage3_cfg), (4, self.stage4_cfg)):
+            blk = blocks_dict[scfg['BLOCK']]
+            cur = [c * blk.expansion for c in scfg['NUM_CHANNELS']]
+            setattr(self, f'transition{idx - 1}', self._transition(pre, cur))
+            stage, pre = self._make_stage(scfg, cur)
+            setattr(self, f'stage{idx}', stage)
+
+    def _transition(self, pre, cur):
+        layers = []
+        for i, c in enumerate(cur):
+            if i < len(pre):
+                layers.append(_conv_bn(pre[i], c, 3, relu=True, norm=self.norm_layer) if c != pre[i] else None)
+            else:   # new, coarser branch: stride-2 3x3 convs from the coarsest existing branch
+                n_new = i + 1 - len(pre)
+                steps = [_conv_bn(pre[-1], c if s == n_new - 1 else pre[-1], 3, 2, relu=True,
+                                  norm=self.norm_layer) for s in range(n_new)]
+                layers.append(nn.Sequential(*steps))
+        return nn.ModuleList(layers)
+
+    def _make_stage(self, scfg, num_inchannels, multi_scale_output=True):
+        block = blocks_dict[scfg['BLOCK']]
+        modules = []
+        for m in range(scfg['NUM_MODULES']):
+            ms_out = multi_scale_output or m < scfg['NUM_MODULES'] - 1
+            modules.append(HighResolutionModule(scfg['NUM_BRANCHES'], block, scfg['NUM_BLOCKS'],
+                                                num_inchannels, scfg['NUM_CHANNELS'], scfg['FUSE_METHOD'],
+                                                ms_out, norm_layer=self.norm_layer))
+            num_inchannels = modules[-1].get_num_inchannels()
+        return nn.Sequential(*modules), num_inchannels
+
+    @staticmethod
+    def _enter_stage(transition, prev, n_prev):
+        out = []
+        for i, t in enumerate(transition):
+            src = prev[i] if i < n_prev else prev[-1]
+            out.append(src if t is None else t(src))
+        return out
+
+    def forward(self, x):
+        x = self.relu(self.bn1(self.conv1(x)))
+        x = self.relu(self.bn2(self.conv2(x)))
+        x = self.layer1(x)
+        y = self.stage2(self._enter_stage(self.transition1, [x], 1))
+        y = self.stage3(self._enter_stage(self.transition2, y, self.stage2_cfg['NUM_BRANCHES']))
+        y = self.stage4(self._enter_stage(self.transition3, y, self.stage3_cfg['NUM_BRANCHES']))
+        assert self.use_as_backbone
+        size = y[0].shape[-2:]
+        ups = [y[0]] + [F.interpolate(t, size=size, mode='bilinear', align_corners=self.align_corners)
+                        for t in y[1:]]
+        cat = torch.cat(ups, 1)
+        if self.return_all_scales:
+            return cat, [y[0], y[1], y[2], y[3]]
+        return cat
+
+
+def _hrnet(arch, pretrained, progress, **kwargs):
+    model = HighResolutionNet(MODEL_CONFIGS[arch], **kwargs)
+    if pretrained:
+        import os
+        path = os.environ.get('HRNET_PRETRAINED', 'hrnetv2_w48_imagenet_pretrained.pth')
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f'pretrained HRNet weights not found at {path} (no network on this box; '
+                                    'set HRNET_PRETRAINED or use pretrained=False)')
+        state = torch.load(path, map_location='cpu')
+        missing = model.load_state_dict(state, strict=False)
+        printlog(f'loaded pretrained {arch} from {path}; missing keys: {len(missing.missing_keys)}')
+    return model
+
+
+def hrnet18(pretrained=False, progress=True, **kwargs):
+    return _hrnet('hrnet18', pretrained, progress, **kwargs)
+
+
+def hrnet32(pretrained=False, progress=True, **kwargs):
+    return _hrnet('hrnet32', pretrained, progress, **kwargs)
+
+
+def hrnet48(pretrained=False, progress=True, **kwargs):
+    return _hrnet('hrnet48', pretrained, progress, **kwargs)
+
+
+_FACTORIES = {'hrnet18': hrnet18, 'hrnet32': hrnet32, 'hrnet48': hrnet48}
+
+
+class HRNet(nn.Module):
+    eligible_backbones = ['hrnet48', 'hrnet32', 'hrnet18']
+
+    def __init__(self, config, experiment):
+        super().__init__()
+        self.config = config
+        # the reference ignores config['backbone'] and always builds W48 (HRNet.py:567, 590);
+        # honouring 'hrnet18'/'hrnet32' is an extension needed by BASELINE config 1
+        name = config.get('backbone', 'hrnet48')
+        self.backbone_name = name if name in _FACTORIES else 'hrnet48'
+        self.out_stride = 4
+        self.dataset = config['dataset']
+        self.norm = nn.BatchNorm2d
+        names = DATASETS_INFO[self.dataset].CLASS_INFO[experiment][1]
+        self.num_classes = len(names) - 1 if 255 in names.keys() else len(names)
+        self.align_corners = config['align_corners'] if 'align_corners' in config else True
+        self.use_ms_projector = False
+        self.projector_before_context = None
+        self.backbone_cutoff = {'layer4': 'C5'}
+        self.return_backbone_feats = False
+        return_all_scales = 'ms_projector' in config
+        if 'return_all_scales' in config:
+            return_all_scales = config['return_all_scales']
+            self.return_backbone_feats = True
+            self.return_features = True
+
+        self.backbone = _FACTORIES[self.backbone_name](
+            self.config['pretrained'], mixing_layer=True, use_as_backbone=True,
+            return_all_scales=return_all_scales, align_corners=self.align_corners,
+            dataset=self.dataset, experiment=experiment)
+        self.backbone_out_channels = sum(self.backbone.stage4_cfg.NUM_CHANNELS)
+        c = self.backbone_out_channels
+        self.cls_head = nn.Sequential(
+            nn.Conv2d(c, c, kernel_size=3, stride=1, padding=1),
+            self.norm(c),
+            nn.Conv2d(c, self.num_classes, kernel_size=1, stride=1, padding=0, bias=False))
+
+        if 'projector' in config:
+            self.return_features = True
+            self.config['projector']['c_in'] = c
+            self.projector_model = Projector(config=self.config['projector'])
+        elif 'ms_projector' in config:
+            self.return_features = True
+            self.use_ms_projector = True
+            mp = self.config['ms_projector']
+            self.ms_projector_scales = mp['scales'] if 'scales' in mp else 4
+            assert self.ms_projector_scales in [2, 3, 4], \
+                f'HRNet scales must be in [2,3,4] instead got {self.ms_projector_scales}'
+            mp['c_in'] = self.backbone.stage4_cfg.NUM_CHANNELS[:self.ms_projector_scales]
+            self.projector_model = Projector(config=mp)
+        else:
+            self.projector_model = None
+            self.return_features = False
+        if 'return_all_scales' in config:
+            self.return_features = True
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        feats = self.backbone(x)
+        multi = self.use_ms_projector or self.return_backbone_feats
+        logits = self.cls_head(feats[0] if multi else feats)
+        logits = F.interpolate(logits, size=size, mode='bilinear', align_corners=self.align_corners)
+        if self.projector_model is not None:
+            if self.use_ms_projector:
+                proj = self.projector_model(feats[1][:self.ms_projector_scales])
+            else:
+                proj = self.projector_model(feats)
+            return (logits, proj) if self.return_features else logits
+        return (logits, feats) if self.return_features else logits

@@ -1,0 +1,64 @@
+"""Per-scale projection head: 1x1-conv MLP from backbone features to the d-dimensional embedding
+the contrastive loss samples from.  Drop-in for the reference class (models/Projector.py:7-91):
+same config keys (``d``, ``c_in`` int | list, ``mlp`` [[k, c, s], ...] with c = -1 meaning c_in,
+``use_bn``), same sub-module names (``project`` / ``project{s}``) and Sequential indices, hence the
+same state_dict keys; list in -> list out."""
+from typing import Union
+
+import torch
+from torch import nn
+
+from ..utils import printlog
+
+
+class Projector(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.d = config['d'] if 'd' in config else 128
+        self.c_in = config['c_in']
+        assert isinstance(self.c_in, (list, int))
+        self.mlp = config['mlp'] if 'mlp' in config else []
+        self.use_bn = config['use_bn'] if 'use_bn' in config else False
+        self.transformer = config['trans'] if 'trans' in config else False
+        if self.transformer:
+            raise NotImplementedError("Projector(trans=True) is not part of the MI355X hot path "
+                                      "(no shipped config uses it; reference: models/Transformers.py)")
+        assert isinstance(self.mlp, list), 'config["mlp"] must be [[k_1, c_1, s_1], ..., [k_n, c_n, s_n]] or []'
+        for layer in self.mlp:
+            assert isinstance(layer, list) and len(layer) == 3 and layer[2] in [1, 2], \
+                f'mlp layers are [kernel, channels, stride], got {layer}'
+            if layer[1] > 0:
+                assert layer[0] < layer[1], f'kernel size is the first element, got {layer}'
+        self.is_ms = isinstance(self.c_in, list)
+        if self.is_ms:
+            for feat_id, c_in in enumerate(self.c_in):
+                setattr(self, f'project{feat_id}', self._head(c_in))
+        else:
+            self.project = self._head(self.c_in)
+
+    def _head(self, c_in: int) -> nn.Sequential:
+        layers = []
+        c_prev = c_in
+        for layer_id, (k, c_out, s) in enumerate(self.mlp):
+            if layer_id == 0 and c_out == -1:
+                c_out = c_prev
+            p = (k - s + 1) // 2
+            layers.append(nn.Conv2d(c_prev, c_out, kernel_size=k, stride=s, padding=p, bias=not self.use_bn))
+            layers.append(nn.ReLU(inplace=True))
+            if self.use_bn:
+                layers.append(nn.BatchNorm2d(c_out, momentum=0.0003))
+            c_prev = c_out
+        layers.append(nn.Conv2d(c_prev, self.d, kernel_size=1, stride=1))
+        printlog(f'Projector head {c_in} -> {self.d} ({len(self.mlp)} hidden layer(s), bn={self.use_bn})')
+        return nn.Sequential(*layers)
+
+    def forward(self, x: Union[list, torch.Tensor]):
+        if self.is_ms:
+            assert isinstance(x, (list, tuple)), \
+                f'if multiscale projector is used a list is expected as input instead got {type(x)}'
+            return [getattr(self, f'project{i}')(x_i) for i, x_i in enumerate(x)]
+        if isinstance(x, list):
+            if len(x) != 1:
+                raise ValueError(f'x is {type(x)}, of length {len(x)}')
+            x = x[0]
+        return self.project(x)

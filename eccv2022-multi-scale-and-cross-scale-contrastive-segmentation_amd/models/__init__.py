@@ -1,0 +1,2 @@
+from .Projector import Projector
+from .HRNet import hrnet48, hrnet32, hrnet18, HRNet
