@@ -16,6 +16,7 @@ time), `cpu_baseline` (oracle/eager_torch.py on the host cores, bounded sample),
 `contrastive_loss_fwd_bwd_ms`.
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -44,6 +45,8 @@ def parse():
     ap.add_argument("--scales", type=int, default=3)
     ap.add_argument("--no-cross", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--amp", action="store_true", help="bf16 autocast for the model (loss stays fp32)")
+    ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--eager-baseline", action="store_true",
                     help="also time the eager-structure restatement of the loss on the GPU")
     return ap.parse_args()
@@ -139,12 +142,14 @@ def roofline_bwd_kernel(mod, iters=10):
 
 
 def cpu_baseline_loss(args, n_terms):
-    """oracle/eager_torch.py on the host cores.  Bounded sample: ONE intra-scale term (scale index 2,
-    the cheapest label scan) forward + backward; every term of this workload is a ~9804 x 9804
-    evaluation, so a full loss evaluation is n_terms such terms."""
+    """oracle/eager_torch.py on the host cores.  Bounded sample: ONE intra-scale term with
+    max_features_total = 2500 (N ~ 2.4k instead of ~9.8k); every term of the workload is an
+    N x N evaluation with N ~ 9.8k, so one loss evaluation costs n_terms * (9804 / N_sample)^2 samples.
+    Returns (scale_factor, sample_seconds, threads, description)."""
     from oracle import eager_torch
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
     gen = torch.Generator().manual_seed(0)
     n, H, W = args.batch, args.height, args.width
     label = torch.randint(0, 20, (n, H, W), generator=gen)
@@ -152,12 +157,126 @@ def cpu_baseline_loss(args, n_terms):
     feat = torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).requires_grad_(True)
     torch.manual_seed(0)
     t0 = time.perf_counter()
-    bank, classes = eager_torch.sample_bank(label, feat, 20, 5, 2500, 10000)
+    bank, classes = eager_torch.sample_bank(label, feat, 20, 5, 2500, 2500)
     l = eager_torch.intra_loss(bank, classes, 0.1)
     l.backward()
     dt = time.perf_counter() - t0
-    return dt, cores, f"1 of {n_terms} loss terms (intra-scale, stride {4 << s}, N={bank.shape[0] * bank.shape[2]}) " \
-                      f"fwd+bwd, eager torch fp32 on {cores} host threads, scaled by {n_terms}"
+    N = bank.shape[0] * bank.shape[2]
+    scale = n_terms * (9804.0 / N) ** 2
+    return scale, dt, threads, (f"loss: 1 intra-scale term at N={N} (max_features_total=2500) fwd+bwd, eager torch "
+                                f"fp32 on {threads} host threads, scaled by {n_terms} terms x (9804/{N})^2")
+
+
+def cpu_baseline_model(args):
+    """HRNet-W48 + projector + CE forward/backward/SGD for ONE image of the benchmark size on the host
+    cores (stock PyTorch CPU, fp32); per-step model time = batch x this."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import HRNet
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    graph = {"backbone": "hrnet48", "pretrained": False, "dataset": "CITYSCAPES", "align_corners": True,
+             "ms_projector": {"mlp": [[1, -1, 1]], "scales": args.scales, "d": 256, "use_bn": True}}
+    model = HRNet(graph, 1)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    gen = torch.Generator().manual_seed(0)
+    img = torch.randn(1, 3, args.height, args.width, generator=gen)
+    lbl = torch.randint(0, 20, (1, args.height, args.width), generator=gen)
+    ce = torch.nn.CrossEntropyLoss(ignore_index=19)
+    t0 = time.perf_counter()
+    out, proj = model(img)
+    loss = ce(out, lbl) + sum(p.mean() for p in proj) * 0.0
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return dt, (f"model: HRNet-W48 + projector + CE fwd+bwd+SGD on 1 image {args.height}x{args.width}, torch CPU "
+                f"fp32 on {threads} threads, scaled by batch {args.batch}")
+
+
+def workload_name(args, workload):
+    cross = "" if args.no_cross else " + cross-scale"
+    if workload == "loss":
+        return (f"DenseContrastiveLossV2_ms fwd+bwd, {args.scales} scales{cross}, n={args.batch} "
+                f"{args.height}x{args.width} iid labels K=20, C=256, per GPU")
+    return (f"HRNet-W48 + LossWrapper(CE + 0.1*DenseContrastiveLossV2_ms, {args.scales} scales{cross}) train step "
+            f"(fwd+bwd+SGD), synthetic Cityscapes {args.height}x{args.width}, batch {args.batch} per GPU, iid labels")
+
+
+def step_config(args, world):
+    S = args.scales
+    return {
+        "name": "bench", "mode": "training", "manager": "HRNet", "cuda": True, "seed": 0,
+        "parallel": world > 1, "batch_is_global": False, "channels_last": args.channels_last,
+        "graph": {"model": "HRNet", "backbone": "hrnet48", "sync_bn": True, "out_stride": 4, "pretrained": False,
+                  "align_corners": True,
+                  "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "before_context": True}},
+        "data": {"dataset": "CITYSCAPES", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
+                 "synthetic": True, "synthetic_length": args.batch * 2,
+                 "transform_values": {"crop_shape": [args.height, args.width]}},
+        "loss": dict(loss_config(S, not args.no_cross), name="LossWrapper",
+                     losses={"CrossEntropyLoss": 1, "DenseContrastiveLossV2_ms": 0.1}),
+        "train": {"learning_rate": 0.01, "lr_fct": "polynomial", "optim": "SGD", "lr_batchwise": True,
+                  "epochs": 484, "momentum": 0.9, "weight_decay": 0.0005},
+    }
+
+
+def time_train_step(args, dev, rank, world):
+    """K training steps of HRNetManager on one resident synthetic batch per rank."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.managers import HRNetManager
+    from mscs_amd.utils import set_verbosity
+    set_verbosity(40)
+    mgr = HRNetManager(step_config(args, world), autostart=False)
+    mgr.setup()
+    mgr.model.train()
+    gen = torch.Generator().manual_seed(1000 * rank)
+    img = torch.randn(args.batch, 3, args.height, args.width, generator=gen).to(dev)
+    lbl = torch.randint(0, 20, (args.batch, args.height, args.width), generator=gen, dtype=torch.int32).to(dev)
+    if args.channels_last:
+        img = img.contiguous(memory_format=torch.channels_last)
+    amp = torch.autocast("cuda", dtype=torch.bfloat16) if args.amp else contextlib.nullcontext()
+    loss_ms = []
+
+    def step(measure_loss=False):
+        mgr.optimiser.zero_grad(set_to_none=True)
+        with amp:
+            ret = mgr.forward_step(img, lbl)
+        ret["loss"].backward()
+        mgr.optimiser.step()
+        mgr.scheduler.step()
+        return ret
+
+    for _ in range(args.warmup):
+        step()
+    sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync(world)
+    dt = time.perf_counter() - t0
+    mod = mgr.loss.loss_classes["DenseContrastiveLossV2_ms"]
+    extra = {"contrastive_loss_fwd_bwd_ms": round(loss_only_ms(mod, dev, args), 3),
+             "model_dtype": "bf16-autocast" if args.amp else "f32",
+             "memory_format": "channels_last" if args.channels_last else "contiguous",
+             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    return dt, mod, extra
+
+
+def loss_only_ms(mod, dev, args, iters=5):
+    """Contrastive-loss fwd+bwd alone on projector-shaped synthetic features (same labels/config as the
+    step), wall time per evaluation including its host-side planning."""
+    label, feats = synth_loss_inputs(args, dev, 0)
+    def run():
+        for f in feats:
+            f.grad = None
+        mod(label, feats).backward()
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
 
 
 def main():
@@ -171,14 +290,17 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    workload = args.workload or "loss"
+    workload = args.workload or "step"
 
+    extra = {}
     if workload == "loss":
         dt, mod = time_loss_only(args, dev, rank, world)
         unit_per_step = 1.0
         metric, unit = "contrastive_loss_fwd_bwd_per_sec", "loss evals/s"
     else:
-        raise SystemExit("workload 'step' lands with the HRNet-W48 model")
+        dt, mod, extra = time_train_step(args, dev, rank, world)
+        unit_per_step = float(args.batch)
+        metric, unit = "train_images_per_sec", "images/s"
 
     tmax = torch.tensor([dt], device=dev)
     if world > 1:
@@ -195,17 +317,25 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"DenseContrastiveLossV2_ms fwd+bwd, {args.scales} scales"
-                                   f"{'' if args.no_cross else ' + cross-scale'}, n={args.batch} "
-                                   f"{args.height}x{args.width} iid labels K=20, C=256, per GPU",
+            "config": {"workload": workload_name(args, workload),
                        "terms": [[t.a, t.b, st_n(mod, t.a), st_n(mod, t.b)] for t in mod.last_state.terms]},
-            "contrastive_loss_fwd_bwd_ms": round(ms_per_step, 3),
         }
+        out.update(extra)
+        if workload == "loss":
+            out["contrastive_loss_fwd_bwd_ms"] = round(ms_per_step, 3)
         out["roofline"] = roofline_bwd_kernel(mod)
         if not args.no_cpu_baseline:
-            cdt, cores, sample = cpu_baseline_loss(args, n_terms)
-            out["cpu_baseline"] = {"value": round(1.0 / (cdt * n_terms), 5), "unit": unit, "cores": cores,
-                                   "kind": "port", "sample": sample, "sample_seconds": round(cdt, 2)}
+            scale, lsec, cores, lsample = cpu_baseline_loss(args, n_terms)
+            loss_sec = lsec * scale
+            if workload == "loss":
+                out["cpu_baseline"] = {"value": round(1.0 / loss_sec, 5), "unit": unit, "cores": cores,
+                                       "kind": "port", "sample": lsample, "sample_seconds": round(lsec, 2)}
+            else:
+                msec, msample = cpu_baseline_model(args)
+                step_sec = msec * args.batch + loss_sec
+                out["cpu_baseline"] = {"value": round(args.batch / step_sec, 5), "unit": unit, "cores": cores,
+                                       "kind": "port", "sample": msample + "; " + lsample,
+                                       "sample_seconds": round(msec + lsec, 2)}
         if args.eager_baseline:
             out["eager_gpu_loss_ms"] = round(eager_gpu_loss_ms(args, dev), 2)
         print(json.dumps(out), flush=True)
