@@ -1,0 +1,192 @@
+"""UPerNet decoder (PPM + FPN) over a Swin backbone, auxiliary head and projector placement
+``backbone`` / ``fpn`` / ``fused_feats`` -- drop-in for the reference (models/UPerNet.py:14-261):
+constructor ``UPerNet(config=graph_dict, experiment=int)``, attributes ``out_stride``,
+``projector_model``, ``return_features``, ``align_corners``, ``num_classes``, ``get_intermediate``;
+forward returns ``(interm_logits, logits, proj_feats)`` / ``(logits, proj_feats)`` / ... exactly as
+the reference does; state_dict keys identical (``backbone.*``, ``fpn.{ppm_conv,ppm_last_conv,fpn_in,
+fpn_out,conv_last}.*``, ``aux_head.*``, ``projector_model.project{s}.*``).
+
+Reference quirks kept: the PPM up-sampling always uses ``align_corners=False`` (UPerNet.py:78) while
+the FPN top-down path and the logits use the configured value; only Swin backbones are available
+(the reference's torchvision ResNet backbones are outside the BASELINE path)."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..utils import DATASETS_INFO, printlog
+from .Projector import Projector
+from .Swin import SwinTransformer
+from .Swin import backbone_config as backbone_config_swin
+
+
+def conv3x3(in_planes, out_planes, batch_norm, relu, stride=1):
+    """conv3x3 (+BN) (+ReLU) builder with the reference's Sequential layout (utils/torch_utils.py:107-123)."""
+    layers = [nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)]
+    if batch_norm:
+        layers.append(nn.BatchNorm2d(out_planes))
+    if relu:
+        layers.append(nn.ReLU(inplace=True))
+    return layers[0] if len(layers) == 1 else nn.Sequential(*layers)
+
+
+def _num_classes(dataset, experiment):
+    names = DATASETS_INFO[dataset].CLASS_INFO[experiment][1]
+    return len(names) - 1 if 255 in names.keys() else len(names)
+
+
+def _conv1x1_bn_relu(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class FPN(nn.Module):
+    def __init__(self, config, experiment):
+        super().__init__()
+        self.dropout = config.get('dropout_rate', 0.0)
+        self.align_corners = config.get('align_corners', True)
+        self.dataset = config['dataset']
+        self.num_classes = _num_classes(self.dataset, experiment)
+        self.pool_scales = config.get('pool_scales', [1, 2, 3, 6])
+        self.in_channels = config['input_channels']
+        self.in_scales = config['input_scales']
+        self.ppm_num_ch = config.get('ppm_num_ch', 512)
+        self.fpn_num_ch = config.get('fpn_num_ch', 512)
+        self.fpn_num_lvl = min(max(config.get('fpn_num_lvl', len(self.in_scales)), 1), len(self.in_scales))
+        self.interpolate_result_up = config.get('interpolate_result_up', True)
+        self.return_features = True
+        top = self.in_channels[-1]
+        self.ppm_pooling = nn.ModuleList([nn.AdaptiveAvgPool2d(s) for s in self.pool_scales])
+        self.ppm_conv = nn.ModuleList([_conv1x1_bn_relu(top, self.ppm_num_ch) for _ in self.pool_scales])
+        self.ppm_last_conv = conv3x3(top + len(self.pool_scales) * self.ppm_num_ch, self.fpn_num_ch,
+                                     batch_norm=True, relu=True)
+        self.fpn_in = nn.ModuleList([_conv1x1_bn_relu(c, self.fpn_num_ch)
+                                     for c in self.in_channels[-self.fpn_num_lvl:-1]])
+        self.fpn_out = nn.ModuleList([nn.Sequential(conv3x3(self.fpn_num_ch, self.fpn_num_ch, True, True))
+                                      for _ in range(self.fpn_num_lvl - 1)])
+        self.conv_last = nn.Sequential(
+            conv3x3(self.fpn_num_lvl * self.fpn_num_ch, self.fpn_num_ch, batch_norm=True, relu=True),
+            nn.Dropout2d(self.dropout),
+            nn.Conv2d(self.fpn_num_ch, self.num_classes, kernel_size=1))
+
+    def forward(self, conv_out):
+        c5 = conv_out[-1]
+        size5 = c5.shape[2:]
+        ppm = [c5] + [conv(F.interpolate(pool(c5), size5, mode='bilinear', align_corners=False))
+                      for pool, conv in zip(self.ppm_pooling, self.ppm_conv)]
+        feature = self.ppm_last_conv(torch.cat(ppm, 1))
+        pyramid = [feature]
+        for i in range(2, self.fpn_num_lvl + 1):
+            lateral = self.fpn_in[-i + 1](conv_out[-i])
+            feature = lateral + F.interpolate(feature, size=lateral.shape[2:], mode='bilinear',
+                                              align_corners=self.align_corners)
+            pyramid.append(self.fpn_out[-i + 1](feature))
+        pyramid.reverse()                                       # [P2 .. P5]
+        out_size = pyramid[0].shape[2:]
+        # concat order is [P2, P5, P4, P3]: the reference walks the reversed list from its END
+        # (UPerNet.py:96-101), and conv_last's input channels are laid out accordingly
+        fused = torch.cat([pyramid[0]] + [F.interpolate(pyramid[-i + 1], out_size, mode='bilinear',
+                                                        align_corners=self.align_corners)
+                                          for i in range(2, self.fpn_num_lvl + 1)], 1)
+        x = self.conv_last(fused)
+        if self.return_features:
+            return x, pyramid, fused
+        return x
+
+
+class UPerNet(nn.Module):
+    eligible_backbones = ['swinT', 'swinS', 'swinB', 'swinL']
+    valid_projector_positions = ['fpn', 'backbone', 'fused_feats']
+
+    def __init__(self, config, experiment):
+        super().__init__()
+        self.config = config
+        self.experiment = experiment
+        self.out_stride = 32
+        self.dataset = config['dataset']
+        self.backbone_name = config['backbone']
+        self.norm = nn.BatchNorm2d
+        assert self.backbone_name in self.eligible_backbones, \
+            f'backbone must be in {self.eligible_backbones} (torchvision ResNets of the reference are not built here)'
+        self.num_classes = _num_classes(self.dataset, experiment)
+        self.align_corners = config.get('align_corners', True)
+        self.return_backbone_feats = False
+        if 'return_all_scales' in config:
+            self.return_backbone_feats = config['return_all_scales']
+            self.return_features = True
+        settings = dict(backbone_config_swin[self.backbone_name])
+        settings['pretrained'] = config.get('pretrained', True)
+        self.backbone = SwinTransformer(**settings)
+        self.config['input_channels'] = settings['out_channels']
+        self.config['input_scales'] = [4, 8, 16, 32]
+        self.fpn = FPN(config=self.config, experiment=experiment)
+        self._get_aux_head()
+        self._get_projector()
+
+    def _get_aux_head(self):
+        if 'aux_head' in self.config:
+            ah = self.config['aux_head']
+            self.aux_in_index = ah['in_index']
+            self.aux_in_channels = self.config['input_channels'][self.aux_in_index]
+            self.aux_out_channels = ah.get('out_channels', 256)
+            self.aux_dropout = ah.get('dropout_rate', 0.0)
+            self.aux_head = nn.Sequential(
+                nn.Conv2d(self.aux_in_channels, self.aux_out_channels, kernel_size=3, stride=1, padding=1),
+                self.norm(self.aux_out_channels), nn.ReLU(inplace=True), nn.Dropout2d(self.aux_dropout),
+                nn.Conv2d(self.aux_out_channels, self.num_classes, kernel_size=1, stride=1, padding=0, bias=True))
+            self.get_intermediate = True
+        else:
+            self.in_index = None
+            self.aux_head = None
+            self.get_intermediate = False
+
+    def _get_projector(self):
+        self.projector_position = None
+        self.projector_model = None
+        self.return_features = False
+        self.use_ms_projector = False
+        if 'projector' in self.config:
+            # the reference reads self.backbone_out_channels here, which only its ResNet branches set
+            # (UPerNet.py:194 would raise AttributeError for Swin); the fused FPN map has
+            # fpn_num_lvl * fpn_num_ch channels, which is what this position actually needs
+            self.return_features = True
+            self.projector_position = 'fused_feats'
+            self.config['projector']['c_in'] = self.fpn.fpn_num_lvl * self.fpn.fpn_num_ch
+            self.projector_model = Projector(config=self.config['projector'])
+        elif 'ms_projector' in self.config:
+            mp = self.config['ms_projector']
+            self.ms_projector_scales = mp['scales'] if 'scales' in mp else self.fpn.fpn_num_lvl
+            self.return_features = True
+            self.use_ms_projector = True
+            self.projector_position = mp['position']
+            if self.projector_position == 'backbone':
+                mp['c_in'] = self.config['input_channels'][:self.ms_projector_scales]
+            elif self.projector_position == 'fpn':
+                mp['c_in'] = [self.fpn.fpn_num_ch] * self.ms_projector_scales
+            else:
+                raise ValueError(f"ms_projector position must be 'backbone' or 'fpn', got {self.projector_position}")
+            self.projector_model = Projector(config=mp)
+        if self.projector_model is not None:
+            printlog(f'added projector(s) {self.projector_model.c_in} -> {self.projector_model.d} | '
+                     f'position {self.projector_position}')
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        feats = self.backbone(x)
+        logits, fpn_feats, fused = self.fpn(feats)
+        up = dict(size=size, mode='bilinear', align_corners=self.align_corners)
+        logits = F.interpolate(logits, **up)
+        interm = None
+        if self.get_intermediate and self.aux_head is not None:
+            interm = F.interpolate(self.aux_head(feats[self.aux_in_index]), **up)
+        if self.projector_model is not None:
+            if self.use_ms_projector:
+                if self.projector_position == 'backbone':
+                    proj = self.projector_model(feats[:self.ms_projector_scales])
+                else:
+                    proj = self.projector_model(fpn_feats)
+            else:
+                proj = self.projector_model(fused)
+            if self.return_features:
+                return (interm, logits, proj) if self.get_intermediate else (logits, proj)
+        if self.get_intermediate:
+            return (interm, logits, list(feats)) if self.return_backbone_feats else (interm, logits)
+        return (logits, list(feats)[::-1]) if self.return_backbone_feats else logits
