@@ -114,12 +114,17 @@ class BaseManager:
     def _worker_setup(self, device_index, rank, split_batch=True):
         set_seeds(self.config['seed'])
         self.rank = rank
-        self.device = torch.device(f'cuda:{device_index}')
-        torch.cuda.set_device(self.device)
+        use_cuda = self.config['cuda'] and torch.cuda.is_available()
+        if use_cuda:
+            self.device = torch.device(f'cuda:{device_index}')
+            torch.cuda.set_device(self.device)
+        else:                                   # CPU ranks (gloo) -- used by the multi-process tests
+            self.device = torch.device('cpu')
         if split_batch:
             self.batch_size = int(self.batch_size) // self.n_gpus    # global batch -> per rank (:128)
         if not dist.is_initialized():
-            dist.init_process_group(backend='nccl', world_size=self.world_size, rank=self.rank)
+            backend = self.config.get('dist_backend', 'nccl' if use_cuda else 'gloo')   # 'nccl' == RCCL on ROCm
+            dist.init_process_group(backend=backend, world_size=self.world_size, rank=self.rank)
         self.load_model()
         self.load_loss()
         self.load_data()
@@ -137,9 +142,14 @@ class BaseManager:
             self.model = self.model.to(memory_format=torch.channels_last)
         if self.parallel:
             if graph.get('sync_bn', False):
-                self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model)
+                if self.device.type == 'cuda':
+                    self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model)
+                else:
+                    printlog('sync_bn requested but ranks are on CPU: SyncBatchNorm needs GPU modules, '
+                             'keeping per-rank BatchNorm statistics')
             self.model = torch.nn.parallel.DistributedDataParallel(
-                self.model, device_ids=[self.device], gradient_as_bucket_view=True)
+                self.model, device_ids=[self.device] if self.device.type == 'cuda' else None,
+                gradient_as_bucket_view=True)
         n_params = sum(p.numel() for p in self.model.parameters() if p.requires_grad)
         printlog(f"Using model '{graph['model']}' with backbone '{graph.get('backbone')}' : "
                  f"trainable parameters {n_params}")
