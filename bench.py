@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--amp", action="store_true", help="bf16 autocast for the model (loss stays fp32)")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--miopen-benchmark", action="store_true",
+                    help="cudnn.benchmark=True like the reference (BaseManager.py:122). OFF by default: on a fresh box "
+                         "MIOpen's exhaustive fp32 solver search for HRNet-W48's ~300 conv shapes takes > 20 minutes")
     ap.add_argument("--eager-baseline", action="store_true",
                     help="also time the eager-structure restatement of the loss on the GPU")
     return ap.parse_args()
@@ -226,6 +229,7 @@ def time_train_step(args, dev, rank, world):
     from mscs_amd.managers import HRNetManager
     from mscs_amd.utils import set_verbosity
     set_verbosity(40)
+    torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
     mgr = HRNetManager(step_config(args, world), autostart=False)
     mgr.setup()
     mgr.model.train()
