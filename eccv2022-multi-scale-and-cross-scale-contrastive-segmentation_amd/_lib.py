@@ -34,6 +34,7 @@ SIGNATURES = {
     "dcl_infonce_bwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
     "dcl_normalize_bwd_scatter": [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
                                   _i64, _i64, _i64, _vp],
+    "dcl_host_randperm_select": [_vp, _i64, _vp, _i, _i, _vp],
     "dcl_suggest_nsplit": [_i, _i],
     "dcl_version": [],
 }

@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from ..utils import DATASETS_INFO, is_distributed, printlog
 from .DenseContrastiveLossV2 import DenseContrastiveLossV2 as DCV2
-from .engine import dense_contrast_terms
+from .engine import dense_contrast_terms, stage_labels
 
 
 class DenseContrastiveLossV2_ms(nn.Module):
@@ -36,6 +36,9 @@ class DenseContrastiveLossV2_ms(nn.Module):
         self.ms_losses = []
         self.cs_losses = []
         self.last_state = None
+        self._geoms = {}                  # label shape -> [(scale, h, w)] seen in earlier steps
+        self._staged = None
+        self._side_stream = None
         printlog(f'defining dcv2 ms loss with number of scales {self.scales} and weights {self.weights}')
         printlog(f'using cross scale contrast {self.cross_scale_contrast}')
         for s in range(self.scales):
@@ -43,6 +46,21 @@ class DenseContrastiveLossV2_ms(nn.Module):
         if self.cross_scale_contrast:
             printlog(f'using cross-scale contrast with detach_cs_deepest set to {self.detach_cs_deepest}, '
                      f'w_high_low: {self.w_high_low}, w_high_mid: {self.w_high_mid}')
+
+    def prepare(self, label: torch.Tensor):
+        """Optional, call BEFORE the model forward is enqueued: runs the label stage (stride-sample +
+        class histograms of every scale, 960-byte D2H) on a side stream so that it -- and the host-side
+        sampling plan that needs its result -- overlap the model forward instead of waiting behind it.
+        A no-op until one forward has been seen for this label shape (the strides come from the feature
+        maps).  Does not touch the RNG; forward() ignores the staged result if the label changed."""
+        geoms = self._geoms.get(tuple(label.shape))
+        if geoms is None or not label.is_cuda:
+            return False
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=label.device)
+        self._staged = stage_labels(int(self.DCV2_scale0.num_all_classes), label, geoms,
+                                    side_stream=self._side_stream)
+        return True
 
     def forward(self, label: torch.Tensor, features: list, **kwargs):
         self.cs_losses = []
@@ -58,8 +76,11 @@ class DenseContrastiveLossV2_ms(nn.Module):
                                  detach_deepest=bool(self.detach_cs_deepest),
                                  w_high_low=float(self.w_high_low), w_high_mid=float(self.w_high_mid))
         feats = [features[s] for s in range(S)]
-        terms, st = dense_contrast_terms(cfg, label, feats)
+        staged, self._staged = self._staged, None
+        terms, st = dense_contrast_terms(cfg, label, feats, staged=staged)
         self.last_state = st
+        self._geoms[tuple(label.shape)] = [(int(label.shape[-1] // f.shape[-1]), f.shape[2], f.shape[3])
+                                           for f in feats]
         for s in range(S):
             getattr(self, f'DCV2_scale{s}')._note_plan(st.scales[s].plan,
                                                       int(label.shape[-1] // feats[s].shape[-1]))

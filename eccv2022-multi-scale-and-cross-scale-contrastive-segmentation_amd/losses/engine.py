@@ -104,36 +104,43 @@ def _npad(N: int) -> int:
     return (N + _lib.ROW_TILE - 1) // _lib.ROW_TILE * _lib.ROW_TILE
 
 
-def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torch.Tensor],
-                    with_cross: bool) -> StepState:
-    """K1 -> host plan -> K2 for every scale; builds the term list with its positive ranges."""
-    L = _lib.lib()
-    dev = feats[0].device
-    if dev.type != "cuda":
-        raise RuntimeError("mscs_amd dense contrastive loss runs on the MI355X only: features are on "
-                           f"{dev}; there is no CPU fallback")
+class StagedLabels:
+    """Result of the label stage (K1 on every scale + D2H of the histogram), possibly produced ahead
+    of time on a side stream while the model forward runs (DenseContrastiveLossV2_ms.prepare)."""
+
+    def __init__(self):
+        self.key = None                 # (data_ptr, shape, version) of the label tensor it was made from
+        self.geoms = None               # [(scale, h, w)] per feature map
+        self.lbl_s: List[torch.Tensor] = []
+        self.seg_hists: List[torch.Tensor] = []
+        self.counts = None              # device int32 [S, n, K]
+        self.counts_host = None         # pinned int32 [S, n, K]
+        self.event = None               # recorded after the D2H copy
+        self.stream = None              # stream the stage ran on
+        self.label = None               # keeps the (int64, contiguous) label alive
+
+
+def _label_key(label: torch.Tensor):
+    return (label.data_ptr(), tuple(label.shape), label.dtype, label._version)
+
+
+def _canon_label(label: torch.Tensor, dev):
     if label.device != dev:
         label = label.to(dev)
     if label.dtype != torch.int64:
         label = label.long()
-    label = label.contiguous()
-    n, H, W = label.shape
-    K = cfg.num_all_classes
-    if not 0 < K <= _lib.MAX_CLASSES:
-        raise RuntimeError(f"num_all_classes={K} outside the supported range [1, 255]")
-    S = len(feats)
-    st = StepState()
-    stream = _stream_ptr()
+    return label.contiguous()
 
-    # ---- K1 (all scales), one D2H of the [S, n, K] histogram
-    counts = torch.zeros((S, n, K), dtype=torch.int32, device=dev)
-    seg_hists = []
+
+def feature_geometry(label_shape, feats: Sequence[torch.Tensor]):
+    """[(scale, h, w)] with scale = W_label // W_feat (DenseContrastiveLossV2.py:46) and the checks the
+    reference leaves to an IndexError."""
+    n, H, W = label_shape
+    geoms = []
     for s, f in enumerate(feats):
         if f.dim() != 4 or f.shape[0] != n:
             raise RuntimeError(f"features[{s}] must be [n, C, h, w] with n={n}, got {tuple(f.shape)}")
-        if f.dtype != torch.float32:
-            raise RuntimeError(f"features[{s}] must be float32, got {f.dtype}")
-        scale = int(W // f.shape[-1])                      # DenseContrastiveLossV2.py:46
+        scale = int(W // f.shape[-1])
         if scale < 1:
             raise RuntimeError(f"features[{s}] is wider than the label map")
         h, w = H // scale, W // scale
@@ -142,22 +149,89 @@ def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torc
                 f"features[{s}] is {f.shape[2]}x{f.shape[3]} but the label map down-sampled by "
                 f"{scale} is {h}x{w}; the reference indexes features with label-grid positions "
                 "(DenseContrastiveLossV2.py:97,123), so the two grids must coincide")
+        geoms.append((scale, h, w))
+    return geoms
+
+
+def stage_labels(K: int, label: torch.Tensor, geoms, side_stream=None) -> StagedLabels:
+    """K1 for every scale + asynchronous D2H of the [S, n, K] histogram into pinned memory.
+    With ``side_stream`` the work is enqueued there (after everything already queued on the current
+    stream), so it overlaps whatever the caller enqueues next on the current stream."""
+    L = _lib.lib()
+    if not 0 < K <= _lib.MAX_CLASSES:
+        raise RuntimeError(f"num_all_classes={K} outside the supported range [1, 255]")
+    dev = label.device
+    st = StagedLabels()
+    st.key = _label_key(label)
+    label = _canon_label(label, dev)
+    st.label, st.geoms = label, list(geoms)
+    n, H, W = label.shape
+    S = len(geoms)
+    cur = torch.cuda.current_stream()
+    run = side_stream if side_stream is not None else cur
+    if side_stream is not None:
+        side_stream.wait_stream(cur)                # label is produced on the current stream
+        label.record_stream(side_stream)
+    with torch.cuda.stream(run):
+        stream = ctypes.c_void_p(run.cuda_stream)
+        st.counts = torch.zeros((S, n, K), dtype=torch.int32, device=dev)
+        for s, (scale, h, w) in enumerate(geoms):
+            nseg = (h * w + _lib.SEG - 1) // _lib.SEG
+            lbl_s = torch.empty((n, h * w), dtype=torch.uint8, device=dev)
+            seg_hist = torch.empty((n, nseg, K), dtype=torch.int32, device=dev)
+            _lib.check(L.dcl_label_hist(_lib.ptr(label), n, H, W, scale, K, _lib.ptr(lbl_s),
+                                        _lib.ptr(seg_hist), _lib.ptr(st.counts[s]), stream),
+                       "dcl_label_hist")
+            st.lbl_s.append(lbl_s)
+            st.seg_hists.append(seg_hist)
+        st.counts_host = torch.empty((S, n, K), dtype=torch.int32, pin_memory=True)
+        st.counts_host.copy_(st.counts, non_blocking=True)
+        st.event = torch.cuda.Event()
+        st.event.record(run)
+    st.stream = run
+    return st
+
+
+def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torch.Tensor],
+                    with_cross: bool, staged: Optional[StagedLabels] = None) -> StepState:
+    """label stage (or a pre-staged one) -> host plan -> K2 for every scale; builds the term list with
+    its positive ranges."""
+    L = _lib.lib()
+    dev = feats[0].device
+    if dev.type != "cuda":
+        raise RuntimeError("mscs_amd dense contrastive loss runs on the MI355X only: features are on "
+                           f"{dev}; there is no CPU fallback")
+    n, H, W = label.shape
+    K = cfg.num_all_classes
+    S = len(feats)
+    geoms = feature_geometry((n, H, W), feats)
+    if staged is not None and (staged.key != _label_key(label) or staged.geoms != geoms
+                               or staged.counts.shape[-1] != K):
+        staged = None                               # stale: made from another label / geometry
+    if staged is None:
+        staged = stage_labels(K, label.to(dev) if label.device != dev else label, geoms)
+    st = StepState()
+    stream = _stream_ptr()
+    for s, f in enumerate(feats):
+        if f.dtype != torch.float32:
+            raise RuntimeError(f"features[{s}] must be float32, got {f.dtype}")
         C = f.shape[1]
         if C > _lib.CP:
             raise RuntimeError(f"embedding width {C} > {_lib.CP} is not supported by the sweep kernels")
         strides = _feature_strides(f)
         if strides is None:
             raise RuntimeError(f"features[{s}] has a non-collapsible (h, w) layout; call .contiguous()")
-        nseg = (h * w + _lib.SEG - 1) // _lib.SEG
-        lbl_s = torch.empty((n, h * w), dtype=torch.uint8, device=dev)
-        seg_hist = torch.empty((n, nseg, K), dtype=torch.int32, device=dev)
-        _lib.check(L.dcl_label_hist(_lib.ptr(label), n, H, W, scale, K, _lib.ptr(lbl_s),
-                                    _lib.ptr(seg_hist), _lib.ptr(counts[s]), stream),
-                   "dcl_label_hist")
-        sc = _Scale(plan=None, h=h, w=w, C=C, strides=strides, lbl_s=lbl_s)
-        st.scales.append(sc)
-        seg_hists.append(seg_hist)
-    counts_host = counts.cpu().numpy()                      # the one host sync of the forward
+        _, h, w = geoms[s]
+        st.scales.append(_Scale(plan=None, h=h, w=w, C=C, strides=strides, lbl_s=staged.lbl_s[s]))
+    seg_hists = staged.seg_hists
+    staged.event.synchronize()                      # the one host wait of the forward (K1 + 960-B D2H)
+    counts_host = staged.counts_host.numpy()
+    cur = torch.cuda.current_stream()
+    if staged.stream is not cur:
+        cur.wait_event(staged.event)
+        for t in staged.lbl_s + staged.seg_hists:
+            t.record_stream(cur)
+    st.keepalive.append(staged)
 
     # ---- host: plans in scale order (this is the RNG consumption order of the reference)
     for s in range(S):
@@ -269,7 +343,7 @@ class DenseContrastFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: EngineConfig, label: torch.Tensor, holder: dict, *feats):
         with_cross = bool(cfg.cross_scale_contrast) and len(feats) > 1
-        st = plan_and_sample(cfg, label, feats, with_cross)
+        st = plan_and_sample(cfg, label, feats, with_cross, staged=holder.get("staged"))
         build_banks(st, feats)
         run_forward_terms(st)
         ctx.st = st
@@ -346,10 +420,12 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
     return grads
 
 
-def dense_contrast_terms(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torch.Tensor]):
+def dense_contrast_terms(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torch.Tensor],
+                         staged: Optional[StagedLabels] = None):
     """Returns (term_losses f32 [n_terms] with grad, StepState).  Term order: intra scale 0..S-1,
-    then cross (0, S-1), then cross (0, S-2) if S > 2."""
-    holder = {}
+    then cross (0, S-1), then cross (0, S-2) if S > 2.  ``staged``: result of an earlier
+    ``stage_labels`` call on the same label tensor (ignored if stale)."""
+    holder = {"staged": staged}
     feats = [f if f.dtype == torch.float32 else f.float() for f in feats]
     out = DenseContrastFunction.apply(cfg, label, holder, *feats)
     return out, holder["state"]

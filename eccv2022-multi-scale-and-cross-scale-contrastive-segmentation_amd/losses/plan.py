@@ -51,16 +51,35 @@ def select_views_per_class(min_views: int, total_cls: int, max_views_per_class: 
     return int(v), log
 
 
+def _native_randperm_select(cnt: np.ndarray, V: int) -> np.ndarray:
+    """First V entries of torch.randperm(cnt[t]) for every pair, drawn from torch's global CPU
+    generator by the native MT19937 stepper (csrc/dcl_host_rng.cpp): same values, same final
+    generator state as T separate torch.randperm calls."""
+    import ctypes
+    from .. import _lib
+    L = _lib.lib()
+    T = int(cnt.shape[0])
+    counts32 = np.ascontiguousarray(cnt, dtype=np.int32)
+    sel = np.empty((T, V), dtype=np.int32)
+    state = torch.get_rng_state()
+    _lib.check(L.dcl_host_randperm_select(ctypes.c_void_p(state.data_ptr()), state.numel(),
+                                          counts32.ctypes.data_as(ctypes.c_void_p), T, V,
+                                          sel.ctypes.data_as(ctypes.c_void_p)),
+               "dcl_host_randperm_select")
+    torch.set_rng_state(state)
+    return sel
+
+
 def build_host_plan(counts: np.ndarray, min_views_per_class: int, max_views_per_class: int,
                     max_features_total: int,
-                    randperm: Optional[Callable[[int], torch.Tensor]] = None) -> HostPlan:
+                    randperm: Optional[Callable[[int], torch.Tensor]] = None,
+                    native_rng: bool = True) -> HostPlan:
     """counts: int [n, K] per-image class histogram of the down-sampled label map.
 
     Follows sample_anchors_fast (DenseContrastiveLossV2.py:100-124): pairs = where(counts[:, :-1]
     >= min_views) in row-major order (the last class column is ALWAYS dropped), V from the minimum
-    count over pairs, one randperm per pair in pair order."""
-    if randperm is None:
-        randperm = torch.randperm
+    count over pairs, one randperm per pair in pair order.  Draws: ``randperm`` callable if given,
+    else the native stepper of torch's global generator (``native_rng``), else torch.randperm."""
     counts = np.asarray(counts)
     n, K = counts.shape
     pb, pk = np.nonzero(counts[:, :-1] >= min_views_per_class)      # row-major, like torch.where
@@ -73,10 +92,13 @@ def build_host_plan(counts: np.ndarray, min_views_per_class: int, max_views_per_
             "losses/DenseContrastiveLossV2.py:110)")
     cnt = counts[pb, pk].astype(np.int64)
     V, log = select_views_per_class(int(cnt.min()), T, max_views_per_class, max_features_total)
-    sel = np.empty((T, V), dtype=np.int32)
-    for t in range(T):
-        perm = randperm(int(cnt[t]))
-        sel[t] = perm[:V].numpy()
+    if randperm is None and native_rng:
+        sel = _native_randperm_select(cnt, V)
+    else:
+        draw = randperm or torch.randperm
+        sel = np.empty((T, V), dtype=np.int32)
+        for t in range(T):
+            sel[t] = draw(int(cnt[t]))[:V].numpy()
     pk32 = pk.astype(np.int32)
     slot_pair = np.argsort(pk32, kind="stable").astype(np.int32)     # class-major bank order
     per_cls = np.bincount(pk32, minlength=K).astype(np.int32)

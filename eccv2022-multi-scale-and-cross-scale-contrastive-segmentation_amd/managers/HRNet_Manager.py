@@ -12,6 +12,9 @@ class HRNetManager(BaseManager):
         skip_mem_update = kwargs.get('skip_mem_update', False)
         proj_features = None
         if isinstance(self.loss, LossWrapper):
+            lbl = lbl.long()                      # converted once so that prepare() and forward() see one tensor
+            if self.return_features and self.model.training:
+                self.loss.prepare(lbl)            # label stage on a side stream, overlaps the model forward
             if self.return_features:
                 output, proj_features = self.model(img.float())
                 loss = self.loss(output, lbl.long(), deep_features=proj_features, epoch=self.epoch,

@@ -13,6 +13,9 @@ class OCRNetManager(BaseManager):
         skip_mem_update = kwargs.get('skip_mem_update', False)
         proj_features, interm_output = None, None
         if isinstance(self.loss, LossWrapper):
+            lbl = lbl.long()                      # converted once so that prepare() and forward() see one tensor
+            if self.return_features and self.model.training:
+                self.loss.prepare(lbl)            # label stage on a side stream, overlaps the model forward
             if self.return_features:
                 out = self.model(img.float())
                 if len(out) == 3:

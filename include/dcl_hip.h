@@ -53,6 +53,17 @@ int dcl_version(void);
 int dcl_label_hist(const int64_t *label, int n, int H, int W, int scale, int K,
                    uint8_t *lbl_s, int32_t *seg_hist, int32_t *counts, void *stream);
 
+/* ---- host: permutation draws -------------------------------------------------------------
+ * Native replacement of the T host-side `torch.randperm(count)[:V]` calls
+ * (DenseContrastiveLossV2.py:121-122).  `rng_state_host` is the byte image of PyTorch's CPU
+ * generator (torch.get_rng_state(), 5056 bytes, at::mt19937): it is advanced IN PLACE by exactly the
+ * draws the reference would consume (count - 1 per pair, pairs in order), so writing it back with
+ * torch.set_rng_state() leaves the global RNG stream identical to the reference's.
+ *   counts_host int32 [T] (HOST), sel_host int32 [T, V] (HOST, out)
+ */
+int dcl_host_randperm_select(uint8_t *rng_state_host, int64_t state_bytes,
+                             const int32_t *counts_host, int T, int V, int32_t *sel_host);
+
 /* ---- K2 ---------------------------------------------------------------------------------
  * Rank-select: pix[t, v] = the sel[t, v]-th pixel (ascending flat index) of class pair_k[t] in
  * image pair_b[t].  Replaces the per-pair `compare[b,:,k].nonzero()` + `idx[perm[:V]]`

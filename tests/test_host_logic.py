@@ -110,3 +110,28 @@ def test_loss_modules_fail_loudly_without_gpu():
     m = DenseContrastiveLossV2({"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1})
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 16, 16, dtype=torch.long), torch.randn(1, 8, 4, 4))
+
+
+@pytest.mark.parametrize("seed", [0, 7, 2 ** 31 + 5])
+def test_native_rng_equals_torch_randperm_and_keeps_stream(seed):
+    """csrc/dcl_host_rng.cpp: same sel as T torch.randperm calls AND the same generator state after."""
+    rs = np.random.RandomState(seed % 1000)
+    counts = rs.randint(0, 3000, size=(4, 20)).astype(np.int64)
+    counts[0, 3] = 5                                   # the minimum -> V = 5
+    torch.manual_seed(seed)
+    torch.rand(7)                                      # arbitrary stream position (mid-block)
+    st = torch.get_rng_state()
+    a = build_host_plan(counts, 5, 2500, 10000, native_rng=False)
+    after_a = torch.rand(5)
+    torch.set_rng_state(st)
+    b = build_host_plan(counts, 5, 2500, 10000, native_rng=True)
+    after_b = torch.rand(5)
+    np.testing.assert_array_equal(a.sel, b.sel)
+    assert torch.equal(after_a, after_b)
+    # crossing several MT19937 block boundaries (624 draws per block)
+    torch.set_rng_state(st)
+    big = np.zeros((1, 3), dtype=np.int64); big[0, 0] = 40000; big[0, 1] = 1300
+    c = build_host_plan(big, 5, 2500, 10000, native_rng=False)
+    torch.set_rng_state(st)
+    d = build_host_plan(big, 5, 2500, 10000, native_rng=True)
+    np.testing.assert_array_equal(c.sel, d.sel)
