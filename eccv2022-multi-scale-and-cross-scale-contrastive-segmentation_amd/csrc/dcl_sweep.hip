@@ -63,7 +63,17 @@ __device__ __forceinline__ void stage_chunk(float *buf, const float *B, int j0, 
 
 __device__ __forceinline__ int jrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <int MODE>
+// LDS operand fetch, software-pipelined by hand: the reads for step q+1 are issued right after the
+// FIRST MFMA of step q, so they land under the remaining MFMAs of that step (sched_group_barrier pins
+// "1 MFMA, n DS reads, rest of the MFMAs").  Left to itself hipcc emits read -> s_waitcnt lgkmcnt(0)
+// -> MFMAs, which at one wave per SIMD (backward) exposes the LDS latency in every group (measured:
+// 67-71 % of the f32 MFMA peak before this change).
+#define DCL_SCHED_MFMA_DS_MFMA(n_ds, n_mfma)                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x100, (n_ds), 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x008, (n_mfma) - 1, 0)
+
+template <int MODE, bool USE_COL>
 __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepArgs p)
 {
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
         if (MODE == MODE_BWD) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                ccw[r] = p.use_col ? p.cstat[(size_t)(j0 + jrow(r, h)) * 4 + 1] : 0.f;
+                ccw[r] = USE_COL ? p.cstat[(size_t)(j0 + jrow(r, h)) * 4 + 1] : 0.f;
         }
 
         // X[j][i] = sum_k B[j0 + j][k] * A[i][k]
@@ -172,13 +182,17 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             acc[r] = 0.f;
         {
             const float *bt = buf + li * ROWF + 4 * h;
+            f32x4 b = *(const f32x4 *)bt;
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // prologue read of step 0
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
-                const f32x4 b = *(const f32x4 *)(bt + 8 * q);
+                const f32x4 bn = *(const f32x4 *)(bt + 8 * (q < 31 ? q + 1 : 31));
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[4 * q + 0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[4 * q + 1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[4 * q + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[4 * q + 3], acc, 0, 0, 0);
+                DCL_SCHED_MFMA_DS_MFMA(1, 4);
+                b = bn;
             }
         }
 
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                     if (p.intra)
                         pos = pos && (jj != i);
                     float cZ = 0.f, ccZ = 0.f;
-                    if (p.use_col) {
+                    if (USE_COL) {
                         cZ = p.cstat[(size_t)jj * 4 + 0];
                         ccZ = p.cstat[(size_t)jj * 4 + 2];
                     }
@@ -237,14 +251,31 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                     acc[r] = pos ? hp : ((valid && !inr) ? hn : 0.f);
                 }
             }
-            // dA[i][c] += sum_j H[j][i] * B[j0 + j][c]: acc register r IS the A-operand of k-step r
+            // dA[i][c] += sum_j H[j][i] * B[j0 + j][c]: acc register r IS the A-operand of k-step r.
+            // Column permutation: MFMA (g, e) writes column li <-> channel c = 128 g + 4 li + e, so one
+            // ds_read_b128 per (r, g) feeds four MFMAs and the final store is 16 B per lane.
+            {
+                const float *b0 = buf + 4 * li;
+                f32x4 u0 = *(const f32x4 *)(b0 + jrow(0, h) * ROWF);
+                f32x4 u1 = *(const f32x4 *)(b0 + jrow(0, h) * ROWF + 128);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // prologue reads of step 0
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float *brow = buf + jrow(r, h) * ROWF + li;
-#pragma unroll
-                for (int ct = 0; ct < 8; ++ct)
-                    dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], brow[32 * ct], dacc[ct],
-                                                                   0, 0, 0);
+                for (int r = 0; r < 16; ++r) {
+                    const int rn = r < 15 ? r + 1 : 15;
+                    const f32x4 n0 = *(const f32x4 *)(b0 + jrow(rn, h) * ROWF);
+                    const f32x4 n1 = *(const f32x4 *)(b0 + jrow(rn, h) * ROWF + 128);
+                    dacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u0.x, dacc[0], 0, 0, 0);
+                    dacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u0.y, dacc[1], 0, 0, 0);
+                    dacc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u0.z, dacc[2], 0, 0, 0);
+                    dacc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u0.w, dacc[3], 0, 0, 0);
+                    dacc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u1.x, dacc[4], 0, 0, 0);
+                    dacc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u1.y, dacc[5], 0, 0, 0);
+                    dacc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u1.z, dacc[6], 0, 0, 0);
+                    dacc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u1.w, dacc[7], 0, 0, 0);
+                    DCL_SCHED_MFMA_DS_MFMA(2, 8);
+                    u0 = n0;
+                    u1 = n1;
+                }
             }
         }
     }
@@ -263,12 +294,18 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             p.W[i] = wsum;
         }
     } else {
-        float *out = p.dpart + ((size_t)split * N1pad + (size_t)rb * BM + wave * 32) * CP + li;
+        float *out = p.dpart + ((size_t)split * N1pad + (size_t)rb * BM + wave * 32) * CP + 4 * li;
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                out[(size_t)jrow(r, h) * CP + 32 * ct] = dacc[ct][r];
+            for (int r = 0; r < 16; ++r) {
+                f32x4 v;
+                v.x = dacc[4 * g + 0][r];
+                v.y = dacc[4 * g + 1][r];
+                v.z = dacc[4 * g + 2][r];
+                v.w = dacc[4 * g + 3][r];
+                *(f32x4 *)(out + (size_t)jrow(r, h) * CP + 128 * g) = v;
+            }
     }
 }
 
@@ -356,9 +393,9 @@ extern "C" int dcl_infonce_fwd(const float *A, int N1, int V1, const float *B, i
     p.Z = Z; p.rowloss = rowloss; p.W = W;
     const int RB = dcl_round_up(N1, BM) / BM;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sweep<MODE_Z>, dim3(RB, nsplit), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((k_sweep<MODE_Z, false>), dim3(RB, nsplit), dim3(256), 0, st, p);
     DCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sweep<MODE_POS>, dim3(RB, 1), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((k_sweep<MODE_POS, false>), dim3(RB, 1), dim3(256), 0, st, p);
     DCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, rowloss, rng_lo, rng_hi, N1, V1,
                        intra, loss);
@@ -399,7 +436,10 @@ extern "C" int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, i
     p.rstat = rstat; p.cstat = cstat; p.use_row = use_row; p.use_col = use_col;
     p.dpart = dpart;
     const int RB = dcl_round_up(N1, BM) / BM;
-    hipLaunchKernelGGL(k_sweep<MODE_BWD>, dim3(RB, nsplit), dim3(256), 0, (hipStream_t)stream, p);
+    if (use_col)
+        hipLaunchKernelGGL((k_sweep<MODE_BWD, true>), dim3(RB, nsplit), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((k_sweep<MODE_BWD, false>), dim3(RB, nsplit), dim3(256), 0, (hipStream_t)stream, p);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -84,8 +84,11 @@ class DenseContrastiveLossV2_ms(nn.Module):
         for s in range(S):
             getattr(self, f'DCV2_scale{s}')._note_plan(st.scales[s].plan,
                                                       int(label.shape[-1] // feats[s].shape[-1]))
-        wvec = torch.tensor([t.weight for t in st.terms], dtype=torch.float32, device=terms.device)
-        loss = (terms * wvec).sum()
+        wkey = (tuple(t.weight for t in st.terms), terms.device)
+        if getattr(self, '_wvec_key', None) != wkey:      # static per config: upload once, not per step
+            self._wvec = torch.tensor(wkey[0], dtype=torch.float32, device=terms.device)
+            self._wvec_key = wkey
+        loss = (terms * self._wvec).sum()
         det = terms.detach()
         self.ms_losses = [det[s] for s in range(S)]
         if with_cross:

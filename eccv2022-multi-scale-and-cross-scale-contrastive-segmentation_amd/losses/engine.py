@@ -87,6 +87,31 @@ class StepState:
         self.keepalive: list = []
 
 
+class _PinnedRing:
+    """Persistent pinned host staging buffers.  Allocating pinned memory per step (hipHostMalloc) costs
+    tens of milliseconds whenever the host allocator cannot recycle a block that is still in flight,
+    so the loss keeps a small ring of grow-only buffers instead.  A slot is reused every ``depth``
+    uses; every use is followed (stream-ordered) by the next step's label stage, whose completion the
+    host waits for before it writes the following slot."""
+
+    def __init__(self, dtype, depth=3):
+        self.dtype, self.depth = dtype, depth
+        self.slots = [None] * depth
+        self.i = 0
+
+    def get(self, numel: int) -> torch.Tensor:
+        self.i = (self.i + 1) % self.depth
+        buf = self.slots[self.i]
+        if buf is None or buf.numel() < numel:
+            buf = torch.empty((max(numel, 1) * 3 // 2 + 64,), dtype=self.dtype, pin_memory=True)
+            self.slots[self.i] = buf
+        return buf[:numel]
+
+
+_PACK_RING = _PinnedRing(torch.int32)
+_COUNTS_RING = _PinnedRing(torch.int32)
+
+
 def _stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -184,7 +209,7 @@ def stage_labels(K: int, label: torch.Tensor, geoms, side_stream=None) -> Staged
                        "dcl_label_hist")
             st.lbl_s.append(lbl_s)
             st.seg_hists.append(seg_hist)
-        st.counts_host = torch.empty((S, n, K), dtype=torch.int32, pin_memory=True)
+        st.counts_host = _COUNTS_RING.get(S * n * K).view(S, n, K)
         st.counts_host.copy_(st.counts, non_blocking=True)
         st.event = torch.cuda.Event()
         st.event.record(run)
@@ -273,7 +298,9 @@ def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torc
             rlo, rhi = positive_ranges(pb, pa)
             ids += [add(rlo), add(rhi)]
         term_slots.append(ids)
-    pack_host = torch.from_numpy(np.concatenate(chunks)).pin_memory()
+    total = sum(c.size for c in chunks)
+    pack_host = _PACK_RING.get(total)
+    np.concatenate(chunks, out=pack_host.numpy())
     pack = pack_host.to(dev, non_blocking=True)
     st.keepalive += [pack_host, pack]
 
