@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
+from .ops import conv3x3_gemm_wrw
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
 
@@ -352,12 +353,22 @@ class HRNet(nn.Module):
             self.return_features = False
         if 'return_all_scales' in config:
             self.return_features = True
+        # weight gradient of the head's big 3x3 conv as im2col + rocBLAS GEMM (2.4x MIOpen's default
+        # fp32 solver on MI355X, models/ops.py); same forward, same state_dict
+        self.gemm_wrw_head = bool(config.get('gemm_wrw_head', True))
+
+    def _head(self, x):
+        if self.gemm_wrw_head and self.training and x.is_cuda and x.dtype == torch.float32 \
+                and torch.is_grad_enabled() and not torch.is_autocast_enabled():
+            x = conv3x3_gemm_wrw(x, self.cls_head[0])
+            return self.cls_head[2](self.cls_head[1](x))
+        return self.cls_head(x)
 
     def forward(self, x):
         size = x.shape[-2:]
         feats = self.backbone(x)
         multi = self.use_ms_projector or self.return_backbone_feats
-        logits = self.cls_head(feats[0] if multi else feats)
+        logits = self._head(feats[0] if multi else feats)
         logits = F.interpolate(logits, size=size, mode='bilinear', align_corners=self.align_corners)
         if self.projector_model is not None:
             if self.use_ms_projector:

@@ -1,0 +1,47 @@
+"""Operator-level replacements inside the models where the library's default kernel is far from the
+hardware roofline on MI355X (measured, see profiles/)."""
+import torch
+import torch.nn.functional as F
+
+
+class _Conv3x3GemmWrw(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 convolution whose WEIGHT gradient is computed as im2col + batched GEMM.
+
+    HRNet's segmentation head (models/HRNet.py:596-600 in the reference: conv3x3 720 -> 720 at 1/4
+    resolution) holds 47 % of the model's FLOPs.  For its weight gradient (a 720 x 6480 x 393,216 GEMM
+    at batch 12, 512x1024) MIOpen's default fp32 solver runs at 44 TFLOP/s (83.7 ms); unfolding the
+    input and calling rocBLAS' batched SGEMM runs the same contraction at 113 TFLOP/s (32-35 ms
+    including the im2col), bit-compatible up to fp32 summation order (2.5e-5 of max).  Forward and
+    input-gradient stay on MIOpen (they already run at ~110 TFLOP/s)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, chunk):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.chunk = chunk
+        return F.conv2d(x, weight, bias, stride=1, padding=1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.nn.grad.conv2d_input(x.shape, weight, gy, stride=1, padding=1)
+        if ctx.needs_input_grad[1]:
+            n = x.shape[0]
+            gyf = gy.flatten(2)                                        # [N, Cout, HW]
+            for i in range(0, n, ctx.chunk):
+                cols = F.unfold(x[i:i + ctx.chunk], 3, padding=1)      # [n, Cin*9, HW]
+                part = torch.bmm(gyf[i:i + ctx.chunk], cols.transpose(1, 2)).sum(0)
+                gw = part if gw is None else gw + part
+            gw = gw.view_as(weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb, None
+
+
+def conv3x3_gemm_wrw(x, conv: torch.nn.Conv2d, chunk: int = 4):
+    """Apply ``conv`` (3x3, stride 1, padding 1, groups 1) with the GEMM weight-gradient path."""
+    assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) \
+        and conv.groups == 1 and conv.dilation == (1, 1)
+    return _Conv3x3GemmWrw.apply(x, conv.weight, conv.bias, chunk)

@@ -339,3 +339,21 @@ def test_k1_k2_direct_odd_sizes(dev, oracle):
     flat = lbl_ref.reshape(n, -1)
     want = np.stack([np.flatnonzero(flat[b] == k)[sel[t]] for t, (b, k) in enumerate(pairs)])
     np.testing.assert_array_equal(pix.cpu().numpy(), want)
+
+
+def test_head_conv_gemm_wrw_matches_default_backward(dev):
+    """models/ops.py: im2col + GEMM weight gradient == the library conv backward (fp32, 1e-4 of max)."""
+    from mscs_amd.models.ops import conv3x3_gemm_wrw
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(48, 40, 3, padding=1).to(dev)
+    x = torch.randn(5, 48, 33, 47, device=dev, requires_grad=True)
+    gy = torch.randn(5, 40, 33, 47, device=dev)
+    ref = conv(x)
+    ref.backward(gy)
+    g_ref = (x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    x.grad = None; conv.weight.grad = None; conv.bias.grad = None
+    out = conv3x3_gemm_wrw(x, conv, chunk=2)
+    assert torch.allclose(out, ref, atol=1e-5)
+    out.backward(gy)
+    for got, want in zip((x.grad, conv.weight.grad, conv.bias.grad), g_ref):
+        assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
