@@ -120,7 +120,7 @@ def roofline_bwd_kernel(mod, iters=10):
     stat = torch.empty((Npad, 4), device=dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = _lib.ptr
-    _lib.check(L.dcl_infonce_prep_stats(p(t.Z), p(t.W), p(t.rng_lo), p(t.rng_hi), N, A.plan.V, 1, 1.0,
+    _lib.check(L.dcl_infonce_prep_stats(p(t.Z), p(t.W), p(t.rng_lo), p(t.rng_hi), None, N, A.plan.V, 1, 1.0,
                                         1.0 / t.tau, None, p(stat), stream), "prep")
     ns = int(L.dcl_suggest_nsplit(N, N))
     dpart = torch.empty((ns, Npad, 256), device=dev)

@@ -14,7 +14,7 @@ CP = 256          # DCL_CP
 ROW_TILE = 128    # DCL_ROW_TILE
 SEG = 256         # DCL_SEG
 MAX_CLASSES = 255
-MAX_SLABS = 48
+MAX_SLABS = 64
 
 _lib = None
 
@@ -30,7 +30,10 @@ SIGNATURES = {
     "dcl_gather_normalize": [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "dcl_gather_raw": [_vp, _i64, _i64, _i64, _i, _vp, _vp, _i, _i, _vp, _vp],
     "dcl_infonce_fwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "dcl_infonce_prep_stats": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
+    "dcl_infonce_zsweep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _vp],
+    "dcl_infonce_possweep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "dcl_infonce_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "dcl_infonce_prep_stats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
     "dcl_infonce_bwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
     "dcl_normalize_bwd_scatter": [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
                                   _i64, _i64, _i64, _vp],

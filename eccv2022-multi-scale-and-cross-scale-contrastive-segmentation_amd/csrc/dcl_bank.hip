@@ -87,7 +87,7 @@ extern "C" int dcl_gather_raw(const float *feat, int64_t stride_n, int64_t strid
     return 0;
 }
 
-#define DCL_MAX_SLABS 48
+#define DCL_MAX_SLABS 64
 struct SlabList {
     const float *p[DCL_MAX_SLABS];
 };
@@ -142,7 +142,7 @@ extern "C" int dcl_normalize_bwd_scatter(const float *const *slabs_host, int nsl
                                          int64_t stride_c, int64_t stride_p, void *stream)
 {
     DCL_CHECK_ARG(slabs_host && bank && nrm && pix && pair_b && slot_pair && dfeat, "null pointer");
-    DCL_CHECK_ARG(nslab >= 0 && nslab <= DCL_MAX_SLABS, "too many slabs (max 48)");
+    DCL_CHECK_ARG(nslab >= 0 && nslab <= DCL_MAX_SLABS, "too many slabs (max 64)");
     DCL_CHECK_ARG(C > 0 && C <= DCL_CP && T > 0 && V > 0, "bad sizes");
     SlabList sl;
     for (int i = 0; i < DCL_MAX_SLABS; ++i)

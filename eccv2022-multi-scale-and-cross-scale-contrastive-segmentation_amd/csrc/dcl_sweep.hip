@@ -41,6 +41,7 @@ struct SweepArgs {
     int nsplit;
     float *zpart;          // MODE_Z out / MODE_POS in: [nsplit, N1pad]
     int zsplits;           // MODE_POS: number of zpart slabs to sum
+    int accumulate;        // MODE_POS: add to rowloss / W instead of overwriting (multi-segment banks)
     float *Z, *rowloss, *W;        // MODE_POS out: [N1pad]
     const float *rstat, *cstat;    // MODE_BWD in: [N1pad,4], [N2pad,4] = {Z, cW, cZ, 0}
     int use_row, use_col;
@@ -290,6 +291,10 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
         wsum += __shfl_xor(wsum, 32, 64);
         if (h == 0) {
             p.Z[i] = zi;
+            if (p.accumulate) {
+                rl += p.rowloss[i];
+                wsum += p.W[i];
+            }
             p.rowloss[i] = rl;
             p.W[i] = wsum;
         }
@@ -310,17 +315,24 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
 }
 
 // loss = -(1/N1) sum_i rowloss_i / P_i     (DenseContrastiveLossV2.py:188-189; ms:148-156)
+__device__ __forceinline__ float positives_of(const int32_t *pcount, const int32_t *rng_lo,
+                                              const int32_t *rng_hi, int u, int intra)
+{
+    // explicit per-slot count (multi-segment banks) or derived from the single positive range
+    const int P = pcount ? pcount[u] : (rng_hi[u] - rng_lo[u] - (intra ? 1 : 0));
+    return intra ? (float)P : (float)max(P, 1);      // cross-scale: where(P > 0, P, 1)  (ms:148-152)
+}
+
 __global__ __launch_bounds__(1024) void k_loss_reduce(const float *__restrict__ rowloss,
                                                      const int32_t *__restrict__ rng_lo,
-                                                     const int32_t *__restrict__ rng_hi, int N1,
+                                                     const int32_t *__restrict__ rng_hi,
+                                                     const int32_t *__restrict__ pcount, int N1,
                                                      int V1, int intra, float *__restrict__ loss)
 {
     __shared__ float part[16];
     float acc = 0.f;
     for (int i = threadIdx.x; i < N1; i += 1024) {
-        const int u = i / V1;
-        const int P = rng_hi[u] - rng_lo[u] - (intra ? 1 : 0);
-        const float Pn = intra ? (float)P : (float)max(P, 1);
+        const float Pn = positives_of(pcount, rng_lo, rng_hi, i / V1, intra);
         acc += rowloss[i] / Pn;       // intra with P == 0: 0/0 = NaN, as in the reference
     }
     acc = wave_sum(acc);
@@ -338,7 +350,8 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(const float *__restrict__ 
 __global__ __launch_bounds__(256) void k_prep_stats(const float *__restrict__ Z,
                                                    const float *__restrict__ W,
                                                    const int32_t *__restrict__ rng_lo,
-                                                   const int32_t *__restrict__ rng_hi, int N1,
+                                                   const int32_t *__restrict__ rng_hi,
+                                                   const int32_t *__restrict__ pcount, int N1,
                                                    int N1pad, int V1, int intra, float wscale,
                                                    float inv_tau, const float *__restrict__ grad_out,
                                                    float *__restrict__ stat)
@@ -349,9 +362,7 @@ __global__ __launch_bounds__(256) void k_prep_stats(const float *__restrict__ Z,
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (i < N1) {
         const float gs = wscale * inv_tau * (grad_out ? grad_out[0] : 1.0f);
-        const int u = i / V1;
-        const int P = rng_hi[u] - rng_lo[u] - (intra ? 1 : 0);
-        const float Pn = intra ? (float)P : (float)max(P, 1);
+        const float Pn = positives_of(pcount, rng_lo, rng_hi, i / V1, intra);
         const float coef = gs / ((float)N1 * Pn);
         o.x = Z[i];
         o.y = coef * W[i];
@@ -376,43 +387,88 @@ int check_common(const float *A, int N1, int V1, const float *B, int N2, const i
 
 }  // namespace
 
+static SweepArgs fwd_args(const float *A, int N1, int V1, const float *B, int N2,
+                          const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int intra)
+{
+    SweepArgs p = {};
+    p.A = A; p.B = B; p.N1 = N1; p.N2 = N2; p.V1 = V1;
+    p.rng_lo = rng_lo; p.rng_hi = rng_hi;
+    p.inv_tau = inv_tau; p.c1 = inv_tau * 1.4426950408889634f;
+    p.intra = intra;
+    return p;
+}
+
+extern "C" int dcl_infonce_zsweep(const float *A, int N1, int V1, const float *B, int N2,
+                                  const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau,
+                                  int nsplit, float *zpart, void *stream)
+{
+    int rc = check_common(A, N1, V1, B, N2, rng_lo, rng_hi, nsplit);
+    if (rc)
+        return rc;
+    DCL_CHECK_ARG(zpart, "null output pointer");
+    SweepArgs p = fwd_args(A, N1, V1, B, N2, rng_lo, rng_hi, inv_tau, 0);
+    p.nsplit = nsplit; p.zpart = zpart;
+    const int RB = dcl_round_up(N1, BM) / BM;
+    hipLaunchKernelGGL((k_sweep<MODE_Z, false>), dim3(RB, nsplit), dim3(256), 0, (hipStream_t)stream, p);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_infonce_possweep(const float *A, int N1, int V1, const float *B, int N2,
+                                    const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau,
+                                    int intra, const float *zpart, int zsplits, int accumulate,
+                                    float *Z, float *rowloss, float *W, void *stream)
+{
+    int rc = check_common(A, N1, V1, B, N2, rng_lo, rng_hi, 1);
+    if (rc)
+        return rc;
+    DCL_CHECK_ARG(zpart && Z && rowloss && W && zsplits > 0, "bad arguments");
+    SweepArgs p = fwd_args(A, N1, V1, B, N2, rng_lo, rng_hi, inv_tau, intra);
+    p.nsplit = 1; p.zpart = const_cast<float *>(zpart); p.zsplits = zsplits; p.accumulate = accumulate;
+    p.Z = Z; p.rowloss = rowloss; p.W = W;
+    const int RB = dcl_round_up(N1, BM) / BM;
+    hipLaunchKernelGGL((k_sweep<MODE_POS, false>), dim3(RB, 1), dim3(256), 0, (hipStream_t)stream, p);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_infonce_loss(const float *rowloss, const int32_t *rng_lo, const int32_t *rng_hi,
+                                const int32_t *pcount, int N1, int V1, int intra, float *loss,
+                                void *stream)
+{
+    DCL_CHECK_ARG(rowloss && loss && (pcount || (rng_lo && rng_hi)) && N1 > 0 && V1 > 0, "bad arguments");
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, (hipStream_t)stream, rowloss, rng_lo,
+                       rng_hi, pcount, N1, V1, intra, loss);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dcl_infonce_fwd(const float *A, int N1, int V1, const float *B, int N2,
                                const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau,
                                int intra, int nsplit, float *zpart, float *Z, float *rowloss,
                                float *W, float *loss, void *stream)
 {
-    int rc = check_common(A, N1, V1, B, N2, rng_lo, rng_hi, nsplit);
+    int rc = dcl_infonce_zsweep(A, N1, V1, B, N2, rng_lo, rng_hi, inv_tau, nsplit, zpart, stream);
     if (rc)
         return rc;
-    DCL_CHECK_ARG(zpart && Z && rowloss && W && loss, "null output pointer");
-    SweepArgs p = {};
-    p.A = A; p.B = B; p.N1 = N1; p.N2 = N2; p.V1 = V1;
-    p.rng_lo = rng_lo; p.rng_hi = rng_hi;
-    p.inv_tau = inv_tau; p.c1 = inv_tau * 1.4426950408889634f;
-    p.intra = intra; p.nsplit = nsplit; p.zpart = zpart; p.zsplits = nsplit;
-    p.Z = Z; p.rowloss = rowloss; p.W = W;
-    const int RB = dcl_round_up(N1, BM) / BM;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((k_sweep<MODE_Z, false>), dim3(RB, nsplit), dim3(256), 0, st, p);
-    DCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_sweep<MODE_POS, false>), dim3(RB, 1), dim3(256), 0, st, p);
-    DCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(1024), 0, st, rowloss, rng_lo, rng_hi, N1, V1,
-                       intra, loss);
-    DCL_LAUNCH_CHECK();
-    return 0;
+    rc = dcl_infonce_possweep(A, N1, V1, B, N2, rng_lo, rng_hi, inv_tau, intra, zpart, nsplit, 0, Z,
+                              rowloss, W, stream);
+    if (rc)
+        return rc;
+    DCL_CHECK_ARG(loss, "null output pointer");
+    return dcl_infonce_loss(rowloss, rng_lo, rng_hi, nullptr, N1, V1, intra, loss, stream);
 }
 
 extern "C" int dcl_infonce_prep_stats(const float *Z, const float *W, const int32_t *rng_lo,
-                                      const int32_t *rng_hi, int N1, int V1, int intra,
-                                      float wscale, float inv_tau, const float *grad_out,
-                                      float *stat, void *stream)
+                                      const int32_t *rng_hi, const int32_t *pcount, int N1, int V1,
+                                      int intra, float wscale, float inv_tau,
+                                      const float *grad_out, float *stat, void *stream)
 {
-    DCL_CHECK_ARG(Z && W && rng_lo && rng_hi && stat, "null pointer");
+    DCL_CHECK_ARG(Z && W && stat && (pcount || (rng_lo && rng_hi)), "null pointer");
     DCL_CHECK_ARG(N1 > 0 && V1 > 0, "bad sizes");
     const int N1pad = dcl_round_up(N1, BM);
     hipLaunchKernelGGL(k_prep_stats, dim3(N1pad / 256 + 1), dim3(256), 0, (hipStream_t)stream, Z, W,
-                       rng_lo, rng_hi, N1, N1pad, V1, intra, wscale, inv_tau, grad_out, stat);
+                       rng_lo, rng_hi, pcount, N1, N1pad, V1, intra, wscale, inv_tau, grad_out, stat);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -61,6 +61,9 @@ class DenseContrastiveLossV2(nn.Module):
         self.log_this_step = False
         self._scale = None
         self.last_state = None            # StepState of the most recent forward (plans, banks)
+        # extension, default off = reference semantics: contrast against the banks of ALL ranks
+        # (RCCL all-gather of the sampled embeddings; gradients stay rank-local)
+        self.global_negatives = bool(config.get('global_negatives', False))
         if self.label_scaling_mode == 'nn':
             assert self.dominant_mode == 'all', \
                 'cannot use label_scaling_mode: "{}" with dominant_mode: "{}" - only "all" is allowed'.format(
@@ -70,7 +73,8 @@ class DenseContrastiveLossV2(nn.Module):
         cfg = dict(num_all_classes=int(self.num_all_classes), temperature=float(self.temperature),
                    min_views_per_class=int(self.min_views_per_class),
                    max_views_per_class=int(self.max_views_per_class),
-                   max_features_total=int(self.max_features_total))
+                   max_features_total=int(self.max_features_total),
+                   global_negatives=bool(self.global_negatives))
         cfg.update(over)
         return EngineConfig(**cfg)
 

@@ -39,6 +39,7 @@ class DenseContrastiveLossV2_ms(nn.Module):
         self._geoms = {}                  # label shape -> [(scale, h, w)] seen in earlier steps
         self._staged = None
         self._side_stream = None
+        self._emulated_peers = None       # test hook: (rank, peer_banks, peer_layouts) of virtual ranks
         printlog(f'defining dcv2 ms loss with number of scales {self.scales} and weights {self.weights}')
         printlog(f'using cross scale contrast {self.cross_scale_contrast}')
         for s in range(self.scales):
@@ -77,7 +78,8 @@ class DenseContrastiveLossV2_ms(nn.Module):
                                  w_high_low=float(self.w_high_low), w_high_mid=float(self.w_high_mid))
         feats = [features[s] for s in range(S)]
         staged, self._staged = self._staged, None
-        terms, st = dense_contrast_terms(cfg, label, feats, staged=staged)
+        terms, st = dense_contrast_terms(cfg, label, feats, staged=staged,
+                                         emulated_peers=self._emulated_peers)
         self.last_state = st
         self._geoms[tuple(label.shape)] = [(int(label.shape[-1] // f.shape[-1]), f.shape[2], f.shape[3])
                                            for f in feats]

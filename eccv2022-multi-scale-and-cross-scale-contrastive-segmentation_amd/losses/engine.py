@@ -40,6 +40,9 @@ class EngineConfig:
     detach_deepest: bool = False
     w_high_low: float = 1.0
     w_high_mid: float = 1.0
+    # extension (not in the reference, SURVEY.md section 8 row e): contrast against the all-gathered
+    # banks of every rank instead of the rank-local bank only.  Off = reference semantics.
+    global_negatives: bool = False
 
 
 @dataclass
@@ -74,6 +77,19 @@ class _Term:
     rev_hi: torch.Tensor = None
     Z: torch.Tensor = None
     W: torch.Tensor = None
+    nsplit: int = 1
+    segs: list = None                    # contrast-bank segments (own bank first unless gathered)
+    pcount: torch.Tensor = None          # int32 [T_a] positives per anchor slot over ALL segments
+
+
+@dataclass
+class _Seg:
+    """One segment of a term's contrast bank: the rank-local bank or one remote rank's bank."""
+    bank: torch.Tensor                   # f32 [>= N rows, 256]
+    N: int
+    rng_lo: torch.Tensor                 # int32 [T_a] positive range of each anchor slot in this segment
+    rng_hi: torch.Tensor
+    own: bool                            # rows of this segment are this rank's own bank rows
     nsplit: int = 1
 
 
@@ -110,6 +126,11 @@ class _PinnedRing:
 
 _PACK_RING = _PinnedRing(torch.int32)
 _COUNTS_RING = _PinnedRing(torch.int32)
+
+
+def _dist_world() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def _stream_ptr():
@@ -341,26 +362,148 @@ def build_banks(st: StepState, feats: Sequence[torch.Tensor]):
                    "dcl_gather_normalize")
 
 
+def _own_segments(st: StepState):
+    """Default (reference) contrast banks: every term contrasts against the rank-local bank only."""
+    L = _lib.lib()
+    for t in st.terms:
+        B = st.scales[t.b]
+        t.segs = [_Seg(bank=B.bank, N=B.plan.N, rng_lo=t.rng_lo, rng_hi=t.rng_hi, own=True,
+                       nsplit=int(L.dcl_suggest_nsplit(st.scales[t.a].plan.N, B.plan.N)))]
+        t.pcount = None
+
+
+def class_layout(plan: HostPlan) -> np.ndarray:
+    """[V, pairs of class 0, ..., pairs of class K-1]: all a peer needs to address a class-sorted bank."""
+    return np.concatenate([[plan.V], plan.cls_hi - plan.cls_lo]).astype(np.int32)
+
+
+def attach_global_segments(st: StepState, rank: int, peer_banks, peer_layouts):
+    """Replace every term's contrast bank by the concatenation of all ranks' banks.
+
+    peer_banks[q][s]: f32 [>= N_q, 256] bank of rank q at scale s (entry ``rank`` is ignored: the local
+    bank is used); peer_layouts[q][s]: ``class_layout`` of that bank (host int32 [K + 1]).
+    Positives of a local anchor = rows of its class in EVERY segment (minus itself), negatives = all
+    other rows of every segment; gradients flow to the local bank only (all_gather has no gradient,
+    the convention of the reference's unused concat_all_gather, utils/distributed.py:50-55)."""
+    L = _lib.lib()
+    dev = st.scales[0].bank.device
+    world = len(peer_layouts)
+    chunks, where = [], []
+
+    def add(arr):
+        arr = np.ascontiguousarray(arr, dtype=np.int32).reshape(-1)
+        where.append((sum(c.size for c in chunks), arr.size))
+        chunks.append(arr)
+        return len(where) - 1
+
+    todo = []
+    for t in st.terms:
+        pa = st.scales[t.a].plan
+        cls = pa.pair_k[pa.slot_pair]
+        total_rows = 0
+        pc = np.zeros(pa.T, dtype=np.int64)
+        seg_ids = []
+        for q in range(world):
+            lay = np.asarray(peer_layouts[q][t.b])
+            Vq, per_cls = int(lay[0]), lay[1:].astype(np.int64)
+            hi = np.cumsum(per_cls)
+            lo = hi - per_cls
+            Nq = int(per_cls.sum()) * Vq
+            total_rows += Nq
+            pc += per_cls[cls] * Vq
+            seg_ids.append((q, Nq, add(lo[cls] * Vq), add(hi[cls] * Vq)))
+        if t.intra:
+            pc -= 1                                   # the anchor itself is not its own positive
+        todo.append((t, seg_ids, add(pc), total_rows))
+    pack_host = _PACK_RING.get(sum(c.size for c in chunks))
+    np.concatenate(chunks, out=pack_host.numpy())
+    pack = pack_host.to(dev, non_blocking=True)
+    st.keepalive += [pack_host, pack]
+
+    def view(idx):
+        off, size = where[idx]
+        return pack[off:off + size]
+
+    for t, seg_ids, pc_id, total_rows in todo:
+        N1 = st.scales[t.a].plan.N
+        per_seg = max(1, int(L.dcl_suggest_nsplit(N1, total_rows)) // world)
+        t.segs = []
+        for q, Nq, lo_id, hi_id in seg_ids:
+            if Nq == 0:
+                continue
+            own = q == rank
+            bank = st.scales[t.b].bank if own else peer_banks[q][t.b]
+            t.segs.append(_Seg(bank=bank, N=Nq, rng_lo=view(lo_id), rng_hi=view(hi_id), own=own,
+                               nsplit=min(per_seg, max(1, (Nq + 31) // 32))))
+        t.pcount = view(pc_id)
+
+
+def gather_peer_banks(st: StepState, max_features_total: int, group=None):
+    """RCCL all-gather of every scale's bank (padded to a fixed row count) and class layout.
+    Returns (rank, peer_banks, peer_layouts) for ``attach_global_segments``.  The bank gathers are
+    issued asynchronously, one per scale, and awaited together; the layout gather is a few hundred
+    bytes followed by the only extra host sync of this extension."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = st.scales[0].bank.device
+    cap = _npad(max(max_features_total, max(sc.plan.N for sc in st.scales)))
+    K = st.scales[0].plan.K
+    lay = torch.from_numpy(np.stack([class_layout(sc.plan) for sc in st.scales])).to(dev)
+    # outputs are laid out [world * rows, ...] (concatenation along dim 0) and viewed per rank afterwards
+    lay_all = torch.empty((world * lay.shape[0], lay.shape[1]), dtype=torch.int32, device=dev)
+    work = [dist.all_gather_into_tensor(lay_all, lay, group=group, async_op=True)]
+    gathered = []
+    for sc in st.scales:
+        src = sc.bank
+        if src.shape[0] != cap:
+            pad = torch.zeros((cap, _lib.CP), dtype=torch.float32, device=dev)
+            pad[:src.shape[0]] = src
+            src = pad
+        out = torch.empty((world * cap, _lib.CP), dtype=torch.float32, device=dev)
+        work.append(dist.all_gather_into_tensor(out, src, group=group, async_op=True))
+        gathered.append(out.view(world, cap, _lib.CP))
+    for w in work:
+        w.wait()
+    layouts = lay_all.view(world, len(st.scales), -1).cpu().numpy()   # [world, S, K + 1]
+    peer_banks = [[gathered[s][q] for s in range(len(st.scales))] for q in range(world)]
+    peer_layouts = [[layouts[q, s] for s in range(len(st.scales))] for q in range(world)]
+    st.keepalive += gathered
+    return rank, peer_banks, peer_layouts
+
+
 def run_forward_terms(st: StepState):
-    """K4 for every term; raw term losses land in st.loss_buf[idx]."""
+    """K4 for every term over its contrast segments; raw term losses land in st.loss_buf[idx]."""
     L = _lib.lib()
     stream = _stream_ptr()
     dev = st.scales[0].bank.device
     st.loss_buf = torch.empty((len(st.terms),), dtype=torch.float32, device=dev)
     for idx, t in enumerate(st.terms):
-        A, B = st.scales[t.a], st.scales[t.b]
-        N1, N2 = A.plan.N, B.plan.N
+        A = st.scales[t.a]
+        N1, V1 = A.plan.N, A.plan.V
         N1pad = _npad(N1)
-        t.nsplit = int(L.dcl_suggest_nsplit(N1, N2))
-        zpart = torch.empty((t.nsplit * N1pad,), dtype=torch.float32, device=dev)
+        zs_total = sum(sg.nsplit for sg in t.segs)
+        t.nsplit = zs_total
+        zpart = torch.empty((zs_total * N1pad,), dtype=torch.float32, device=dev)
         t.Z = torch.empty((N1pad,), dtype=torch.float32, device=dev)
         t.W = torch.empty((N1pad,), dtype=torch.float32, device=dev)
         rowloss = torch.empty((N1pad,), dtype=torch.float32, device=dev)
-        _lib.check(L.dcl_infonce_fwd(_lib.ptr(A.bank), N1, A.plan.V, _lib.ptr(B.bank), N2,
-                                     _lib.ptr(t.rng_lo), _lib.ptr(t.rng_hi), 1.0 / t.tau,
-                                     1 if t.intra else 0, t.nsplit, _lib.ptr(zpart), _lib.ptr(t.Z),
-                                     _lib.ptr(rowloss), _lib.ptr(t.W), _lib.ptr(st.loss_buf[idx:]),
-                                     stream), "dcl_infonce_fwd")
+        inv_tau = 1.0 / t.tau
+        off = 0
+        for sg in t.segs:
+            _lib.check(L.dcl_infonce_zsweep(_lib.ptr(A.bank), N1, V1, _lib.ptr(sg.bank), sg.N,
+                                            _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi), inv_tau, sg.nsplit,
+                                            _lib.ptr(zpart[off * N1pad:]), stream), "dcl_infonce_zsweep")
+            off += sg.nsplit
+        for k, sg in enumerate(t.segs):
+            _lib.check(L.dcl_infonce_possweep(_lib.ptr(A.bank), N1, V1, _lib.ptr(sg.bank), sg.N,
+                                              _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi), inv_tau,
+                                              1 if (t.intra and sg.own) else 0, _lib.ptr(zpart), zs_total,
+                                              0 if k == 0 else 1, _lib.ptr(t.Z), _lib.ptr(rowloss),
+                                              _lib.ptr(t.W), stream), "dcl_infonce_possweep")
+        first = t.segs[0]
+        _lib.check(L.dcl_infonce_loss(_lib.ptr(rowloss), _lib.ptr(first.rng_lo), _lib.ptr(first.rng_hi),
+                                      _lib.ptr(t.pcount), N1, V1, 1 if t.intra else 0,
+                                      _lib.ptr(st.loss_buf[idx:]), stream), "dcl_infonce_loss")
         st.keepalive += [zpart, rowloss]
 
 
@@ -372,6 +515,16 @@ class DenseContrastFunction(torch.autograd.Function):
         with_cross = bool(cfg.cross_scale_contrast) and len(feats) > 1
         st = plan_and_sample(cfg, label, feats, with_cross, staged=holder.get("staged"))
         build_banks(st, feats)
+        peers = holder.get("emulated_peers")
+        if peers is not None:                       # single-process emulation of other ranks (tests)
+            rank, peer_banks, peer_layouts = peers
+            peer_layouts = list(peer_layouts)
+            peer_layouts[rank] = [class_layout(sc.plan) for sc in st.scales]
+            attach_global_segments(st, rank, peer_banks, peer_layouts)
+        elif cfg.global_negatives and _dist_world() > 1:
+            attach_global_segments(st, *gather_peer_banks(st, cfg.max_features_total))
+        else:
+            _own_segments(st)
         run_forward_terms(st)
         ctx.st = st
         ctx.feats_meta = [(tuple(f.shape), tuple(f.stride()), f.dtype) for f in feats]
@@ -403,25 +556,29 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
         want_b = (not t.intra) and need[t.b] and not t.detach_b
         if not (want_a or want_b):
             continue
+        inv_tau = 1.0 / t.tau
+        first = t.segs[0]
         stat = torch.empty((N1pad, 4), dtype=torch.float32, device=dev)
-        _lib.check(L.dcl_infonce_prep_stats(_lib.ptr(t.Z), _lib.ptr(t.W), _lib.ptr(t.rng_lo),
-                                            _lib.ptr(t.rng_hi), N1, A.plan.V, 1 if t.intra else 0,
-                                            1.0, 1.0 / t.tau, _lib.ptr(g[idx:]), _lib.ptr(stat),
-                                            stream), "dcl_infonce_prep_stats")
+        _lib.check(L.dcl_infonce_prep_stats(_lib.ptr(t.Z), _lib.ptr(t.W), _lib.ptr(first.rng_lo),
+                                            _lib.ptr(first.rng_hi), _lib.ptr(t.pcount), N1, A.plan.V,
+                                            1 if t.intra else 0, 1.0, inv_tau, _lib.ptr(g[idx:]),
+                                            _lib.ptr(stat), stream), "dcl_infonce_prep_stats")
         if want_a:
-            ns = int(L.dcl_suggest_nsplit(N1, N2))
-            dpart = torch.empty((ns, N1pad, _lib.CP), dtype=torch.float32, device=dev)
-            _lib.check(L.dcl_infonce_bwd(_lib.ptr(A.bank), N1, A.plan.V, _lib.ptr(B.bank), N2,
-                                         _lib.ptr(t.rng_lo), _lib.ptr(t.rng_hi), 1.0 / t.tau,
-                                         1 if t.intra else 0, 1, 1 if t.intra else 0,
-                                         _lib.ptr(stat), _lib.ptr(stat) if t.intra else None, ns,
-                                         _lib.ptr(dpart), stream), "dcl_infonce_bwd")
-            slabs[t.a] += [dpart[i] for i in range(ns)]
+            for sg in t.segs:
+                sym = t.intra and sg.own            # own rows are anchors AND contrast columns
+                dpart = torch.empty((sg.nsplit, N1pad, _lib.CP), dtype=torch.float32, device=dev)
+                _lib.check(L.dcl_infonce_bwd(_lib.ptr(A.bank), N1, A.plan.V, _lib.ptr(sg.bank), sg.N,
+                                             _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi), inv_tau,
+                                             1 if sym else 0, 1, 1 if sym else 0, _lib.ptr(stat),
+                                             _lib.ptr(stat) if sym else None, sg.nsplit,
+                                             _lib.ptr(dpart), stream), "dcl_infonce_bwd")
+                slabs[t.a] += [dpart[i] for i in range(sg.nsplit)]
         if want_b:
+            # G^T F1 restricted to this rank's rows of bank b (they are columns of the own segment)
             ns = int(L.dcl_suggest_nsplit(N2, N1))
             dpart = torch.empty((ns, N2pad, _lib.CP), dtype=torch.float32, device=dev)
             _lib.check(L.dcl_infonce_bwd(_lib.ptr(B.bank), N2, B.plan.V, _lib.ptr(A.bank), N1,
-                                         _lib.ptr(t.rev_lo), _lib.ptr(t.rev_hi), 1.0 / t.tau, 0, 0, 1,
+                                         _lib.ptr(t.rev_lo), _lib.ptr(t.rev_hi), inv_tau, 0, 0, 1,
                                          None, _lib.ptr(stat), ns, _lib.ptr(dpart), stream),
                        "dcl_infonce_bwd")
             slabs[t.b] += [dpart[i] for i in range(ns)]
@@ -448,11 +605,11 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
 
 
 def dense_contrast_terms(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torch.Tensor],
-                         staged: Optional[StagedLabels] = None):
+                         staged: Optional[StagedLabels] = None, emulated_peers=None):
     """Returns (term_losses f32 [n_terms] with grad, StepState).  Term order: intra scale 0..S-1,
     then cross (0, S-1), then cross (0, S-2) if S > 2.  ``staged``: result of an earlier
     ``stage_labels`` call on the same label tensor (ignored if stale)."""
-    holder = {"staged": staged}
+    holder = {"staged": staged, "emulated_peers": emulated_peers}
     feats = [f if f.dtype == torch.float32 else f.float() for f in feats]
     out = DenseContrastFunction.apply(cfg, label, holder, *feats)
     return out, holder["state"]

@@ -116,6 +116,24 @@ int dcl_infonce_fwd(const float *A, int N1, int V1, const float *B, int N2,
                     int nsplit, float *zpart, float *Z, float *rowloss, float *W, float *loss,
                     void *stream);
 
+/* The three stages of dcl_infonce_fwd, exposed separately so that the contrast bank may consist of
+ * several SEGMENTS (the per-rank banks of the all-gathered negative bank, SURVEY.md section 8 row e):
+ *   zsweep    one segment's negatives: zpart slice [nsplit * N1pad] (slices of all segments are summed)
+ *   possweep  one segment's positives; reduces ALL zsplits slices into Z, then writes (accumulate = 0)
+ *             or adds (accumulate = 1) rowloss / W.  Call in a fixed segment order.
+ *   loss      -(1/N1) sum_i rowloss_i / P_i with P_i = pcount[i / V1] if pcount != NULL (positives over
+ *             all segments, self already excluded), else derived from rng_lo/hi as in dcl_infonce_fwd.
+ */
+int dcl_infonce_zsweep(const float *A, int N1, int V1, const float *B, int N2,
+                       const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int nsplit,
+                       float *zpart, void *stream);
+int dcl_infonce_possweep(const float *A, int N1, int V1, const float *B, int N2,
+                         const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int intra,
+                         const float *zpart, int zsplits, int accumulate, float *Z, float *rowloss,
+                         float *W, void *stream);
+int dcl_infonce_loss(const float *rowloss, const int32_t *rng_lo, const int32_t *rng_hi,
+                     const int32_t *pcount, int N1, int V1, int intra, float *loss, void *stream);
+
 /* ---- K5 ---------------------------------------------------------------------------------
  * InfoNCE backward.  With G_ij = dL/ds_ij:
  *   dcl_infonce_prep_stats   packs per-row statistics {Z, gs*W/(N1*P), gs*Z/(N1*P), 0} where
@@ -129,8 +147,9 @@ int dcl_infonce_fwd(const float *A, int N1, int V1, const float *B, int N2,
  *   stat  f32 [N1pad, 4];   dpart f32 [nsplit, N1pad, DCL_CP]
  */
 int dcl_infonce_prep_stats(const float *Z, const float *W, const int32_t *rng_lo,
-                           const int32_t *rng_hi, int N1, int V1, int intra, float wscale,
-                           float inv_tau, const float *grad_out, float *stat, void *stream);
+                           const int32_t *rng_hi, const int32_t *pcount /* may be NULL */, int N1,
+                           int V1, int intra, float wscale, float inv_tau, const float *grad_out,
+                           float *stat, void *stream);
 
 int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, int N2,
                     const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int intra,

@@ -365,3 +365,84 @@ def dcv2_ms(label: np.ndarray, features: Sequence[np.ndarray], cfg: LossConfig,
             dX = normalize_backward(Xs[s], dFhs[s])
             grads.append(scatter_grad(dX, plans[s], features[s].shape))
     return Result(float(total), ms, cs, plans, grads, [p.log_this_step for p in plans])
+
+
+# --------------------------------------------------------------------------
+# Extension without a reference oracle (SURVEY.md section 8 row e): shared negative bank.
+# Pinned by (1) world_size = 1 == the reference exactly (all tests above) and (2) this single-process
+# emulation: the reference-style InfoNCE with self-mask evaluated on the CONCATENATION of the per-rank
+# banks, anchors = the local rows, gradient w.r.t. the local features only (remote banks constant).
+# --------------------------------------------------------------------------
+def _global_term(Fa, ra, banks_b, rows_b, rank, tau, intra):
+    """Anchors Fa (local) vs concat(banks_b).  Returns (loss, dFa, dFb_local)."""
+    dt = Fa.dtype.type
+    Fcat = np.concatenate(banks_b, axis=0)
+    rcat = np.concatenate(rows_b, axis=0)
+    off = int(sum(b.shape[0] for b in banks_b[:rank]))
+    nb = banks_b[rank].shape[0]
+    N1 = Fa.shape[0]
+    S = (Fa @ Fcat.T) / dt(tau)
+    same = ra[:, None] == rcat[None, :]
+    pos = same.astype(Fa.dtype)
+    neg = (~same).astype(Fa.dtype)
+    if intra:
+        pos[np.arange(N1), off + np.arange(N1)] = 0          # self
+    E = np.exp(S)
+    Z = (E * neg).sum(1, keepdims=True)
+    logp = S - np.log(E + Z)
+    P = pos.sum(1)
+    Pn = P if intra else np.where(P > 0, P, 1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        loss = -((pos * logp).sum(1) / Pn).mean()
+        inv = 1.0 / (E + Z)
+        W = (pos * inv).sum(1, keepdims=True)
+        G = (1.0 / (N1 * Pn))[:, None] * (-pos * Z * inv + neg * E * W)
+    dFa = (G @ Fcat) / dt(tau)
+    Gown = G[:, off:off + nb]
+    if intra:
+        dFa = dFa + (Gown.T @ Fa) / dt(tau)
+        return float(loss), dFa, None
+    return float(loss), dFa, (Gown.T @ Fa) / dt(tau)
+
+
+def dcv2_ms_global(labels, features, cfg: LossConfig, seeds, rank: int, dtype=np.float64) -> Result:
+    """Loss and gradients of ``rank`` when every term contrasts against the banks of all ranks.
+    labels[q], features[q][s]: inputs of rank q; seeds[q]: that rank's torch seed."""
+    world = len(labels)
+    S = cfg.scales
+    weights = list(cfg.weights) if cfg.weights is not None else [1.0] * S
+    plans, Xs, Fhs, rows = [], [], [], []
+    for q in range(world):
+        rng = MT19937(seeds[q])
+        pq, xq, fq, rq = [], [], [], []
+        for s in range(S):
+            f = features[q][s].astype(dtype)
+            scale = int(labels[q].shape[-1] // f.shape[-1])
+            plan = make_plan(labels[q], scale, cfg.num_all_classes, cfg.min_views_per_class,
+                             cfg.max_views_per_class, cfg.max_features_total, rng=rng)
+            X = gather_bank(f, plan)
+            Fh, _ = normalize_bank(X)
+            pq.append(plan); xq.append(X); fq.append(Fh); rq.append(_row_labels(plan.pair_k, plan.V))
+        plans.append(pq); Xs.append(xq); Fhs.append(fq); rows.append(rq)
+    total, ms, cs = 0.0, [], []
+    dF = [np.zeros_like(Fhs[rank][s]) for s in range(S)]
+    for s in range(S):
+        l, da, _ = _global_term(Fhs[rank][s], rows[rank][s], [Fhs[q][s] for q in range(world)],
+                                [rows[q][s] for q in range(world)], rank, cfg.temperature, True)
+        total += weights[s] * l
+        ms.append(l)
+        dF[s] += weights[s] * da
+    if cfg.cross_scale_contrast:
+        terms = [(S - 1, cfg.w_high_low)] + ([(S - 2, cfg.w_high_mid)] if S > 2 else [])
+        for k, wgt in terms:
+            l, da, db = _global_term(Fhs[rank][0], rows[rank][0], [Fhs[q][k] for q in range(world)],
+                                     [rows[q][k] for q in range(world)], rank,
+                                     cfg.cross_scale_temperature, False)
+            total += wgt * l
+            cs.append(l)
+            dF[0] += wgt * da
+            if not cfg.detach_deepest:
+                dF[k] += wgt * db
+    grads = [scatter_grad(normalize_backward(Xs[rank][s], dF[s]), plans[rank][s], features[rank][s].shape)
+             for s in range(S)]
+    return Result(float(total), ms, cs, plans[rank], grads, [p.log_this_step for p in plans[rank]])

@@ -73,3 +73,45 @@ def test_single_process_helpers():
     assert not is_distributed() and get_rank() == 0 and get_world_size() == 1
     t = torch.arange(4.0)
     assert torch.equal(concat_all_gather(t), t) and torch.equal(reduce_tensor(t), t)
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    import numpy as np
+    from mscs_amd.losses.engine import StepState, _Scale, gather_peer_banks, class_layout, _npad
+    from mscs_amd.losses.plan import build_host_plan
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rs = np.random.RandomState(10 + rank)
+    st = StepState()
+    for s in range(2):
+        counts = rs.randint(0, 60, size=(2, 6)).astype(np.int64)
+        counts[:, -1] = 99
+        counts[0, rank] = 30                          # at least one qualifying pair
+        plan = build_host_plan(counts, 5, 2500, 200, native_rng=False)
+        bank = torch.zeros(_npad(plan.N), 256)
+        bank[:plan.N] = float(rank + 1) + 0.01 * s
+        st.scales.append(_Scale(plan=plan, h=1, w=1, C=256, strides=(1, 1, 1), bank=bank))
+    r, banks, layouts = gather_peer_banks(st, max_features_total=200)
+    assert r == rank and len(banks) == world and len(layouts) == world
+    for q in range(world):
+        for s in range(2):
+            assert banks[q][s].shape == (_npad(200), 256)
+            assert torch.all(banks[q][s][0] == float(q + 1) + 0.01 * s)
+    for s in range(2):
+        np.testing.assert_array_equal(layouts[rank][s], class_layout(st.scales[s].plan))
+    torch.save([[l.tolist() for l in lq] for lq in layouts], os.path.join(out_dir, f"lay{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_negative_bank_all_gather_two_ranks_gloo(tmp_path):
+    """The exchange step of the shared-negative-bank extension: fixed-size padded bank gather + class
+    layouts, identical on every rank."""
+    port = _free_port()
+    mp.spawn(_gather_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), "lay0.pt"))
+    b = torch.load(os.path.join(str(tmp_path), "lay1.pt"))
+    assert a == b

@@ -291,7 +291,7 @@ def test_c_abi_direct_infonce_cross(dev, oracle):
                                  p(rl), p(Wt), p(loss), st), "fwd")
     np.testing.assert_allclose(loss.item(), ref_loss, rtol=LOSS_RTOL)
     stat = torch.empty(N1pad, 4, device=dev)
-    _lib.check(L.dcl_infonce_prep_stats(p(Z), p(Wt), p(lo_d), p(hi_d), N1, V1, 0, 1.0, 1 / tau, None,
+    _lib.check(L.dcl_infonce_prep_stats(p(Z), p(Wt), p(lo_d), p(hi_d), None, N1, V1, 0, 1.0, 1 / tau, None,
                                         p(stat), st), "prep")
     dp1 = torch.empty(ns, N1pad, 256, device=dev)
     _lib.check(L.dcl_infonce_bwd(p(A), N1, V1, p(B), N2, p(lo_d), p(hi_d), 1 / tau, 0, 1, 0, p(stat), None,
@@ -357,3 +357,40 @@ def test_head_conv_gemm_wrw_matches_default_backward(dev):
     out.backward(gy)
     for got, want in zip((x.grad, conv.weight.grad, conv.bias.grad), g_ref):
         assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+def test_global_negative_bank_two_virtual_ranks(dev, oracle):
+    """Extension (no reference oracle, SURVEY section 8 row e): every term contrasts against the banks of
+    all ranks.  Two virtual ranks on one GPU (the peer's banks are injected where the RCCL all-gather
+    would deliver them) against the oracle's single-process emulation on the concatenated banks."""
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    from mscs_amd.losses.engine import class_layout
+    cfg = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": 2, "weights": [1.0, 0.6],
+           "cross_scale_contrast": True, "max_features_total": 1500, "global_negatives": True}
+    data = [_random_case(21 + q, 2, 64, 128, 20, 32, (4, 8), classes=[[0, 3, 5, 7], [3, 5, 9, 19]][q])
+            for q in range(2)]
+    seeds = [100, 200]
+    ocfg = oracle.LossConfig(num_all_classes=20, temperature=0.1, max_features_total=1500, scales=2,
+                             weights=[1.0, 0.6], cross_scale_contrast=True)
+    # virtual rank 1 first: its banks are what the all-gather would hand to rank 0
+    mods = [DenseContrastiveLossV2_ms(cfg) for _ in range(2)]
+    torch.manual_seed(seeds[1])
+    f1 = [f.to(dev) for f in data[1][1]]
+    mods[1](data[1][0].to(dev), f1)
+    st1 = mods[1].last_state
+    peer_banks = [None, [sc.bank for sc in st1.scales]]
+    peer_layouts = [None, [class_layout(sc.plan) for sc in st1.scales]]
+    mods[0]._emulated_peers = (0, peer_banks, peer_layouts)
+    f0 = [f.to(dev).requires_grad_(True) for f in data[0][1]]
+    torch.manual_seed(seeds[0])
+    loss = mods[0](data[0][0].to(dev), f0)
+    loss.backward()
+    ref = oracle.dcv2_ms_global([d[0].numpy() for d in data], [[f.numpy() for f in d[1]] for d in data],
+                                ocfg, seeds, rank=0)
+    np.testing.assert_allclose(loss.item(), ref.loss, rtol=LOSS_RTOL)
+    np.testing.assert_allclose([x.item() for x in mods[0].ms_losses], ref.ms_losses, rtol=LOSS_RTOL)
+    np.testing.assert_allclose([x.item() for x in mods[0].cs_losses], ref.cs_losses, rtol=LOSS_RTOL)
+    for s in range(2):
+        _check_grad(f0[s].grad.cpu().numpy(), ref.grads[s])
+    # class 19 / 9 exist on rank 1 only, class 0 / 7 on rank 0 only: segments with empty positive ranges
+    assert len(mods[0].last_state.terms[0].segs) == 2

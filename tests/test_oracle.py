@@ -147,3 +147,18 @@ def test_eager_torch_restatement_matches_reference(name):
     for s in range(S):
         got = feats[s].grad.numpy() if feats[s].grad is not None else np.zeros_like(g[f"s{s}_grad"])
         np.testing.assert_allclose(got, g[f"s{s}_grad"], atol=1e-6 * np.abs(g[f"s{s}_grad"]).max() + 1e-12)
+
+
+def test_global_bank_emulation_reduces_to_reference_at_world_1(oracle):
+    """dcv2_ms_global with one rank == the reference-pinned dcv2_ms (pin (1) of SURVEY section 8 row e)."""
+    g = load_golden("G2_ms4_cross")
+    c = g["config"]
+    cfg = _cfg(oracle, c, 20)
+    feats = [g[f"feat{s}"] for s in range(cfg.scales)]
+    lab = g["label"].astype(np.int64)
+    a = oracle.dcv2_ms(lab, feats, cfg, rng=oracle.MT19937(int(g["seed"])))
+    b = oracle.dcv2_ms_global([lab], [feats], cfg, [int(g["seed"])], rank=0)
+    np.testing.assert_allclose(b.loss, a.loss, rtol=1e-12)
+    for x, y in zip(a.grads, b.grads):
+        np.testing.assert_allclose(y, x, atol=1e-12 * max(1.0, np.abs(x).max()))
+    np.testing.assert_allclose(b.loss, g["loss"], rtol=2e-6)
