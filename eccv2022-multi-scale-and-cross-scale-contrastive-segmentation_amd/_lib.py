@@ -38,6 +38,12 @@ SIGNATURES = {
     "dcl_normalize_bwd_scatter": [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
                                   _i64, _i64, _i64, _vp],
     "dcl_host_randperm_select": [_vp, _i64, _vp, _i, _i, _vp],
+    "dcl_bn_num_slices": [_i, _i],
+    "dcl_bn_stats": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "dcl_bn_finalize": [_vp, _i, ctypes.c_double, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "dcl_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "dcl_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "dcl_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp],
     "dcl_suggest_nsplit": [_i, _i],
     "dcl_version": [],
 }

@@ -1,0 +1,319 @@
+// dcl_bn.hip -- fused training-mode BatchNorm2d (+ residual add) (+ ReLU) for NCHW f32 tensors.
+//
+// HRNet-W48 has 310 BatchNorm layers, almost all followed by ReLU and a third of them by a residual
+// add (reference models/HRNet.py:77-93, 118-137, 270-285).  In the reference each of these is 2-4
+// separate HBM-bound kernels (batch_norm, add_, relu_ and their backwards).  Here one statistics pass
+// and one apply pass per direction do all of it:
+//   forward : stats (sum, sumsq per channel) -> finalize (mean, invstd, running stats) ->
+//             y = relu(gamma * (x - mean) * invstd + beta + residual)
+//   backward: g = dy * (y > 0);  reduce (sum g, sum g*xhat) -> dx = gamma*invstd*(g - mean_g - xhat*mean_gx),
+//             d_residual = g, dgamma, dbeta
+// All kernels are HBM-bound streaming kernels (16-B accesses, one (n, c) plane per workgroup row).
+// The statistics are exchanged between ranks by the caller (SyncBatchNorm semantics) between the
+// stats/reduce kernel and the finalize/apply kernel.
+#include "dcl_common.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+
+__device__ inline void block_reduce2(float &a, float &b, float *sh)
+{
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[w] = a;
+        sh[4 + w] = b;
+    }
+    __syncthreads();
+    a = sh[0] + sh[1] + sh[2] + sh[3];
+    b = sh[4] + sh[5] + sh[6] + sh[7];
+}
+
+// grid (C, nslice): workgroup (c, s) reduces planes n = s, s + nslice, ... of channel c.
+// part[(c * nslice + s) * 2 + {0,1}] = {sum x, sum x^2}
+__global__ __launch_bounds__(BN_THREADS) void k_bn_stats(const float *__restrict__ x, int N, int C,
+                                                        int HW, int nslice, float *__restrict__ part)
+{
+    __shared__ float sh[8];
+    const int c = blockIdx.x, s = blockIdx.y;
+    float a = 0.f, b = 0.f;
+    const int hw4 = HW >> 2;
+    for (int n = s; n < N; n += nslice) {
+        const float *p = x + ((size_t)n * C + c) * HW;
+        const f32x4 *p4 = (const f32x4 *)p;
+        for (int i = threadIdx.x; i < hw4; i += BN_THREADS) {
+            const f32x4 v = p4[i];
+            a += (v.x + v.y) + (v.z + v.w);
+            b += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        for (int i = (hw4 << 2) + threadIdx.x; i < HW; i += BN_THREADS) {
+            const float v = p[i];
+            a += v;
+            b += v * v;
+        }
+    }
+    block_reduce2(a, b, sh);
+    if (threadIdx.x == 0) {
+        part[((size_t)c * nslice + s) * 2 + 0] = a;
+        part[((size_t)c * nslice + s) * 2 + 1] = b;
+    }
+}
+
+// sums[c*2 + {0,1}] = fixed-order sum of the slices (double accumulation)
+__global__ void k_bn_combine(const float *__restrict__ part, int C, int nslice, float *__restrict__ sums)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C)
+        return;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < nslice; ++s) {
+        a += part[((size_t)c * nslice + s) * 2 + 0];
+        b += part[((size_t)c * nslice + s) * 2 + 1];
+    }
+    sums[c * 2 + 0] = (float)a;
+    sums[c * 2 + 1] = (float)b;
+}
+
+// mean / invstd from (possibly all-reduced) sums over `count` elements; running-stat update with
+// PyTorch's convention (unbiased variance, momentum m: r = (1 - m) r + m s).
+__global__ void k_bn_finalize(const float *__restrict__ sums, int C, double count, float eps,
+                              float momentum, float *__restrict__ mean, float *__restrict__ invstd,
+                              float *__restrict__ running_mean, float *__restrict__ running_var)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C)
+        return;
+    const double m = (double)sums[c * 2] / count;
+    double var = (double)sums[c * 2 + 1] / count - m * m;
+    var = var > 0.0 ? var : 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+// grid (ceil(HW/1024), N*C)
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict__ x,
+                                                        const float *__restrict__ res,
+                                                        const float *__restrict__ mean,
+                                                        const float *__restrict__ invstd,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, int C, int HW,
+                                                        float *__restrict__ y)
+{
+    const int plane = blockIdx.y, c = plane % C;
+    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
+    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    const size_t base = (size_t)plane * HW;
+    const int i4 = blockIdx.x * BN_THREADS + threadIdx.x;
+    const int i = i4 << 2;
+    if (i + 3 < HW && (HW & 3) == 0) {
+        f32x4 v = *(const f32x4 *)(x + base + i);
+        v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+        if (RES) {
+            const f32x4 r = *(const f32x4 *)(res + base + i);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *(f32x4 *)(y + base + i) = v;
+    } else {
+        for (int k = i; k < HW && k < i + 4; ++k) {
+            float v = x[base + k] * sc + sh;
+            if (RES)
+                v += res[base + k];
+            if (RELU)
+                v = fmaxf(v, 0.f);
+            y[base + k] = v;
+        }
+    }
+}
+
+// part[(c*nslice + s)*2 + {0,1}] = {sum g, sum g * xhat},  g = dy * (y > 0 if RELU)
+template <bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__restrict__ dy,
+                                                             const float *__restrict__ x,
+                                                             const float *__restrict__ y,
+                                                             const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, int N,
+                                                             int C, int HW, int nslice,
+                                                             float *__restrict__ part)
+{
+    __shared__ float sh[8];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const float m = mean[c], is = invstd[c];
+    float a = 0.f, b = 0.f;
+    const int hw4 = HW >> 2;
+    for (int n = s; n < N; n += nslice) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        const f32x4 *d4 = (const f32x4 *)(dy + base), *x4 = (const f32x4 *)(x + base),
+                    *y4 = (const f32x4 *)(y + base);
+        for (int i = threadIdx.x; i < hw4; i += BN_THREADS) {
+            f32x4 g = d4[i];
+            const f32x4 xv = x4[i];
+            if (RELU) {
+                const f32x4 yv = y4[i];
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            }
+            a += (g.x + g.y) + (g.z + g.w);
+            b += (g.x * (xv.x - m) + g.y * (xv.y - m)) + (g.z * (xv.z - m) + g.w * (xv.w - m));
+        }
+        for (int i = (hw4 << 2) + threadIdx.x; i < HW; i += BN_THREADS) {
+            float g = dy[base + i];
+            if (RELU)
+                g = y[base + i] > 0.f ? g : 0.f;
+            a += g;
+            b += g * (x[base + i] - m);
+        }
+    }
+    b *= is;
+    block_reduce2(a, b, sh);
+    if (threadIdx.x == 0) {
+        part[((size_t)c * nslice + s) * 2 + 0] = a;
+        part[((size_t)c * nslice + s) * 2 + 1] = b;
+    }
+}
+
+// dx = gamma * invstd * (g - sum_g / count - xhat * sum_gx / count);  dres = g (optional)
+template <bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__restrict__ dy,
+                                                            const float *__restrict__ x,
+                                                            const float *__restrict__ y,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ sums,
+                                                            float inv_count, int C, int HW,
+                                                            float *__restrict__ dx,
+                                                            float *__restrict__ dres)
+{
+    const int plane = blockIdx.y, c = plane % C;
+    const float m = mean[c], is = invstd[c];
+    const float k = is * (gamma ? gamma[c] : 1.f);
+    const float mg = sums[c * 2] * inv_count, mgx = sums[c * 2 + 1] * inv_count;
+    const size_t base = (size_t)plane * HW;
+    const int i = (blockIdx.x * BN_THREADS + threadIdx.x) << 2;
+    if (i + 3 < HW && (HW & 3) == 0) {
+        f32x4 g = *(const f32x4 *)(dy + base + i);
+        const f32x4 xv = *(const f32x4 *)(x + base + i);
+        if (RELU) {
+            const f32x4 yv = *(const f32x4 *)(y + base + i);
+            g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+            g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        }
+        if (dres)
+            *(f32x4 *)(dres + base + i) = g;
+        f32x4 o;
+        o.x = k * (g.x - mg - (xv.x - m) * is * mgx);
+        o.y = k * (g.y - mg - (xv.y - m) * is * mgx);
+        o.z = k * (g.z - mg - (xv.z - m) * is * mgx);
+        o.w = k * (g.w - mg - (xv.w - m) * is * mgx);
+        *(f32x4 *)(dx + base + i) = o;
+    } else {
+        for (int q = i; q < HW && q < i + 4; ++q) {
+            float g = dy[base + q];
+            if (RELU)
+                g = y[base + q] > 0.f ? g : 0.f;
+            if (dres)
+                dres[base + q] = g;
+            dx[base + q] = k * (g - mg - (x[base + q] - m) * is * mgx);
+        }
+    }
+}
+
+int pick_slices(int N, int C)
+{
+    // enough workgroups to fill 256 CUs several times over, at most one slice per image
+    int s = (2048 + C - 1) / C;
+    if (s > N)
+        s = N;
+    return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+extern "C" int dcl_bn_num_slices(int N, int C) { return pick_slices(N, C); }
+
+// sums f32 [C, 2] = per-channel {sum x, sum x^2} over this rank's N*HW elements; part = workspace
+// f32 [C * dcl_bn_num_slices(N, C) * 2].
+extern "C" int dcl_bn_stats(const float *x, int N, int C, int HW, float *part, float *sums, void *stream)
+{
+    DCL_CHECK_ARG(x && part && sums && N > 0 && C > 0 && HW > 0, "bad arguments");
+    const int ns = pick_slices(N, C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_stats, dim3(C, ns), dim3(BN_THREADS), 0, st, x, N, C, HW, ns, part);
+    DCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_bn_finalize(const float *sums, int C, double count, float eps, float momentum,
+                               float *mean, float *invstd, float *running_mean, float *running_var,
+                               void *stream)
+{
+    DCL_CHECK_ARG(sums && mean && invstd && C > 0 && count > 0, "bad arguments");
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C,
+                       count, eps, momentum, mean, invstd, running_mean, running_var);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_bn_apply(const float *x, const float *res, const float *mean, const float *invstd,
+                            const float *gamma, const float *beta, int N, int C, int HW, int relu,
+                            float *y, void *stream)
+{
+    DCL_CHECK_ARG(x && mean && invstd && y && N > 0 && C > 0 && HW > 0, "bad arguments");
+    dim3 grid((HW + BN_THREADS * 4 - 1) / (BN_THREADS * 4), N * C);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, mean, invstd, gamma, beta, C, HW, y)
+    if (relu && res) LAUNCH(true, true);
+    else if (relu) LAUNCH(true, false);
+    else if (res) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y, const float *mean,
+                                 const float *invstd, int N, int C, int HW, int relu, float *part,
+                                 float *sums, void *stream)
+{
+    DCL_CHECK_ARG(dy && x && mean && invstd && part && sums && (!relu || y), "bad arguments");
+    const int ns = pick_slices(N, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu)
+        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, N, C, HW, ns, part);
+    else
+        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, N, C, HW, ns, part);
+    DCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y, const float *mean,
+                                const float *invstd, const float *gamma, const float *sums,
+                                double count, int N, int C, int HW, int relu, float *dx, float *dres,
+                                void *stream)
+{
+    DCL_CHECK_ARG(dy && x && mean && invstd && sums && dx && (!relu || y) && count > 0, "bad arguments");
+    dim3 grid((HW + BN_THREADS * 4 - 1) / (BN_THREADS * 4), N * C);
+    hipStream_t st = (hipStream_t)stream;
+    const float inv = (float)(1.0 / count);
+    if (relu)
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, sums, inv, C, HW, dx, dres);
+    else
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, sums, inv, C, HW, dx, dres);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}

@@ -143,7 +143,8 @@ class BaseManager:
         if self.parallel:
             if graph.get('sync_bn', False):
                 if self.device.type == 'cuda':
-                    self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model)
+                    from ..models.fused_bn import convert_sync_batchnorm
+                    self.model = convert_sync_batchnorm(self.model)
                 else:
                     printlog('sync_bn requested but ranks are on CPU: SyncBatchNorm needs GPU modules, '
                              'keeping per-rank BatchNorm statistics')

@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
 from .ops import conv3x3_gemm_wrw
+from .fused_bn import FusedBatchNorm2d, bn_act
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
 
@@ -50,11 +51,19 @@ def _arch(w):
 MODEL_CONFIGS = {'hrnet18': _arch(18), 'hrnet32': _arch(32), 'hrnet48': _arch(48)}
 
 
+class _ConvBN(nn.Sequential):
+    """Sequential(conv, norm[, ReLU]) -- same indices / state_dict keys as the reference's Sequentials --
+    whose forward hands the ReLU (and an optional residual) to the norm layer when it can fuse them."""
+
+    def forward(self, x, residual=None):
+        return bn_act(self[1], self[0](x), residual=residual, relu=len(self) == 3)
+
+
 def _conv_bn(cin, cout, k, stride=1, relu=False, norm=nn.BatchNorm2d):
     layers = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False), norm(cout)]
     if relu:
         layers.append(nn.ReLU(inplace=True))
-    return nn.Sequential(*layers)
+    return _ConvBN(*layers)
 
 
 class BasicBlock(nn.Module):
@@ -72,10 +81,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return self.relu(out)
+        identity = x if self.downsample is None else self.downsample(x)
+        out = bn_act(self.bn1, self.conv1(x))
+        return bn_act(self.bn2, self.conv2(out), residual=identity)
 
 
 class Bottleneck(nn.Module):
@@ -95,11 +103,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return self.relu(out)
+        identity = x if self.downsample is None else self.downsample(x)
+        out = bn_act(self.bn1, self.conv1(x))
+        out = bn_act(self.bn2, self.conv2(out))
+        return bn_act(self.bn3, self.conv3(out), residual=identity)
 
 
 blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck}
@@ -175,7 +182,11 @@ class HighResolutionModule(nn.Module):
                     y = y + F.interpolate(row[j](x[j]), size=x[i].shape[-2:], mode='bilinear',
                                           align_corners=self.align_corners)
                 else:
-                    y = y + row[j](x[j])
+                    chain = row[j]                  # stride-2 conv chain; its last norm absorbs "+ y"
+                    t = x[j]
+                    for step in list(chain)[:-1]:
+                        t = step(t)
+                    y = chain[-1](t, residual=y)
             fused.append(self.relu(y))
         return fused
 
@@ -253,8 +264,8 @@ class HighResolutionNet(nn.Module):
         return out
 
     def forward(self, x):
-        x = self.relu(self.bn1(self.conv1(x)))
-        x = self.relu(self.bn2(self.conv2(x)))
+        x = bn_act(self.bn1, self.conv1(x))
+        x = bn_act(self.bn2, self.conv2(x))
         x = self.layer1(x)
         y = self.stage2(self._enter_stage(self.transition1, [x], 1))
         y = self.stage3(self._enter_stage(self.transition2, y, self.stage2_cfg['NUM_BRANCHES']))
@@ -310,7 +321,8 @@ class HRNet(nn.Module):
         self.backbone_name = name if name in _FACTORIES else 'hrnet48'
         self.out_stride = 4
         self.dataset = config['dataset']
-        self.norm = nn.BatchNorm2d
+        # fused BN(+add)(+ReLU) kernels (models/fused_bn.py); same parameters / state_dict as nn.BatchNorm2d
+        self.norm = FusedBatchNorm2d if config.get('fused_bn', True) else nn.BatchNorm2d
         names = DATASETS_INFO[self.dataset].CLASS_INFO[experiment][1]
         self.num_classes = len(names) - 1 if 255 in names.keys() else len(names)
         self.align_corners = config['align_corners'] if 'align_corners' in config else True
@@ -327,7 +339,7 @@ class HRNet(nn.Module):
         self.backbone = _FACTORIES[self.backbone_name](
             self.config['pretrained'], mixing_layer=True, use_as_backbone=True,
             return_all_scales=return_all_scales, align_corners=self.align_corners,
-            dataset=self.dataset, experiment=experiment)
+            dataset=self.dataset, experiment=experiment, norm_layer=self.norm)
         self.backbone_out_channels = sum(self.backbone.stage4_cfg.NUM_CHANNELS)
         c = self.backbone_out_channels
         self.cls_head = nn.Sequential(

@@ -1,0 +1,138 @@
+"""Fused training-mode BatchNorm2d (+ residual add) (+ ReLU) on the HIP kernels of csrc/dcl_bn.hip.
+
+``FusedBatchNorm2d`` IS an ``nn.BatchNorm2d`` (same parameters, buffers and state_dict keys, so
+reference checkpoints load); called as ``bn(x)`` it behaves exactly like one.  Called as
+``bn(x, residual=r, relu=True)`` it additionally folds the residual add and the ReLU that follow it in
+the reference's blocks (models/HRNet.py:77-93, 118-137; Projector / transition / fuse layers) into the
+same two HBM passes, forward and backward.  With ``sync=True`` the per-channel sums are all-reduced
+across ranks between the statistics and the apply kernel (SyncBatchNorm semantics over RCCL).
+
+The fused path runs for CUDA / float32 / contiguous NCHW tensors in training mode; evaluation mode and
+CPU tensors use PyTorch's own batch_norm (running statistics, no batch reduction)."""
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class _FusedBNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync):
+        L = _lib.lib()
+        N, C, H, W = x.shape
+        HW = H * W
+        dev = x.device
+        ns = L.dcl_bn_num_slices(N, C)
+        part = torch.empty((C * ns * 2,), dtype=torch.float32, device=dev)
+        sums = torch.empty((C, 2), dtype=torch.float32, device=dev)
+        st = _stream()
+        _lib.check(L.dcl_bn_stats(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(sums), st), "dcl_bn_stats")
+        world = _world() if sync else 1
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(sums)
+        count = float(N * HW * world)
+        mean = torch.empty((C,), dtype=torch.float32, device=dev)
+        invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+        _lib.check(L.dcl_bn_finalize(_lib.ptr(sums), C, count, eps, momentum, _lib.ptr(mean),
+                                     _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), st),
+                   "dcl_bn_finalize")
+        y = torch.empty_like(x)
+        _lib.check(L.dcl_bn_apply(_lib.ptr(x), _lib.ptr(res), _lib.ptr(mean), _lib.ptr(invstd),
+                                  _lib.ptr(weight), _lib.ptr(bias), N, C, HW, 1 if relu else 0, _lib.ptr(y),
+                                  st), "dcl_bn_apply")
+        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        ctx.relu, ctx.world, ctx.count = relu, world, count
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        HW = H * W
+        dev = x.device
+        dy = dy.contiguous()
+        ns = L.dcl_bn_num_slices(N, C)
+        part = torch.empty((C * ns * 2,), dtype=torch.float32, device=dev)
+        sums = torch.empty((C, 2), dtype=torch.float32, device=dev)
+        st = _stream()
+        relu = 1 if ctx.relu else 0
+        _lib.check(L.dcl_bn_bwd_reduce(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
+                                       _lib.ptr(invstd), N, C, HW, relu, _lib.ptr(part), _lib.ptr(sums), st),
+                   "dcl_bn_bwd_reduce")
+        dbeta = sums[:, 0].clone() if ctx.needs_input_grad[3] else None     # local sums: DDP averages them
+        dgamma = sums[:, 1].clone() if ctx.needs_input_grad[2] else None
+        if ctx.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(sums)
+        dx = torch.empty_like(x)
+        want_res = ctx.has_res and ctx.needs_input_grad[1]
+        dres = torch.empty_like(x) if want_res else None
+        _lib.check(L.dcl_bn_bwd_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
+                                      _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(sums), ctx.count, N, C,
+                                      HW, relu, _lib.ptr(dx), _lib.ptr(dres), st), "dcl_bn_bwd_apply")
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+class FusedBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d with an optional fused (residual add, ReLU) epilogue; see module docstring."""
+    sync = False
+
+    def _fusable(self, x, residual):
+        return (self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and x.is_contiguous() and self.affine and self.track_running_stats
+                and self.momentum is not None and not torch.is_autocast_enabled()
+                and (residual is None or (residual.shape == x.shape and residual.is_contiguous()
+                                          and residual.dtype == torch.float32)))
+
+    def forward(self, x, residual=None, relu=False):
+        if self._fusable(x, residual):
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return _FusedBNFunction.apply(x, residual, self.weight, self.bias, self.running_mean,
+                                          self.running_var, float(self.eps), float(self.momentum), bool(relu),
+                                          bool(self.sync))
+        y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y, inplace=True) if relu else y
+
+
+def bn_act(bn, x, residual=None, relu=True):
+    """norm (+ residual) (+ ReLU) for any norm layer; one fused call when ``bn`` supports it."""
+    if isinstance(bn, FusedBatchNorm2d):
+        return bn(x, residual=residual, relu=relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y, inplace=True) if relu else y
+
+
+def convert_sync_batchnorm(module: nn.Module) -> nn.Module:
+    """SyncBatchNorm conversion that keeps ``FusedBatchNorm2d`` modules (it switches their ``sync`` flag
+    on: statistics are all-reduced inside the fused op) and converts every other BatchNorm through
+    torch.nn.SyncBatchNorm.convert_sync_batchnorm (reference: BaseManager.py:450-451)."""
+    if isinstance(module, FusedBatchNorm2d):
+        module.sync = True
+        return module
+    if isinstance(module, nn.modules.batchnorm._BatchNorm):
+        return nn.SyncBatchNorm.convert_sync_batchnorm(module)
+    for name, child in module.named_children():
+        new = convert_sync_batchnorm(child)
+        if new is not child:
+            setattr(module, name, new)
+    return module

@@ -168,6 +168,30 @@ int dcl_normalize_bwd_scatter(const float *const *slabs_host, int nslab, const f
                               const int32_t *slot_pair, int T, int V, int C, float *dfeat,
                               int64_t stride_n, int64_t stride_c, int64_t stride_p, void *stream);
 
+/* ---- fused BatchNorm2d (+ residual) (+ ReLU), training mode, NCHW f32 ----
+ * Replaces nn.BatchNorm2d -> (out += identity) -> nn.ReLU chains of the models (reference
+ * models/HRNet.py:77-93, 118-137, 270-285; models/Projector.py:59-63) and their autograd backward.
+ *   forward : dcl_bn_stats -> [all-reduce of sums across ranks = SyncBatchNorm] -> dcl_bn_finalize ->
+ *             dcl_bn_apply:      y = relu(gamma * (x - mean) * invstd + beta + res)
+ *   backward: dcl_bn_bwd_reduce -> [all-reduce of sums] -> dcl_bn_bwd_apply:
+ *             g = dy * (y > 0),  dx = gamma * invstd * (g - sum_g/count - xhat * sum_gx/count),  dres = g
+ *   sums f32 [C, 2];  part f32 workspace [C * dcl_bn_num_slices(N, C) * 2];  count = elements per channel
+ *   over ALL ranks;  res / dres / gamma / beta / running_* may be NULL.  dgamma = sums[:,1], dbeta = sums[:,0].
+ */
+int dcl_bn_num_slices(int N, int C);
+int dcl_bn_stats(const float *x, int N, int C, int HW, float *part, float *sums, void *stream);
+int dcl_bn_finalize(const float *sums, int C, double count, float eps, float momentum, float *mean,
+                    float *invstd, float *running_mean, float *running_var, void *stream);
+int dcl_bn_apply(const float *x, const float *res, const float *mean, const float *invstd,
+                 const float *gamma, const float *beta, int N, int C, int HW, int relu, float *y,
+                 void *stream);
+int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y, const float *mean,
+                      const float *invstd, int N, int C, int HW, int relu, float *part, float *sums,
+                      void *stream);
+int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y, const float *mean,
+                     const float *invstd, const float *gamma, const float *sums, double count, int N,
+                     int C, int HW, int relu, float *dx, float *dres, void *stream);
+
 /* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the
  * grid fills the 256 CUs evenly (host helper, no device work). */
 int dcl_suggest_nsplit(int N1, int N2);

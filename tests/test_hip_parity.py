@@ -394,3 +394,44 @@ def test_global_negative_bank_two_virtual_ranks(dev, oracle):
         _check_grad(f0[s].grad.cpu().numpy(), ref.grads[s])
     # class 19 / 9 exist on rank 1 only, class 0 / 7 on rank 0 only: segments with empty positive ranges
     assert len(mods[0].last_state.terms[0].segs) == 2
+
+
+@pytest.mark.parametrize("relu,use_res,shape", [(True, True, (3, 48, 33, 47)), (True, False, (4, 18, 16, 24)),
+                                                (False, False, (2, 720, 8, 12)), (False, True, (5, 7, 5, 3))])
+def test_fused_batchnorm_matches_torch(dev, relu, use_res, shape):
+    """csrc/dcl_bn.hip through FusedBatchNorm2d against nn.BatchNorm2d (+ add) (+ ReLU) in training mode."""
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d
+    torch.manual_seed(3)
+    C = shape[1]
+    ref = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev)
+    fus = FusedBatchNorm2d(C, momentum=0.1).to(dev)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5); ref.bias.uniform_(-0.5, 0.5)
+        ref.running_mean.normal_(); ref.running_var.uniform_(0.5, 2.0)
+    fus.load_state_dict(ref.state_dict())
+    x = (torch.randn(shape, device=dev) * 2 + 0.7)
+    r = torch.randn(shape, device=dev) if use_res else None
+    gy = torch.randn(shape, device=dev)
+    outs = []
+    for m in (ref, fus):
+        xi = x.clone().requires_grad_(True)
+        ri = r.clone().requires_grad_(True) if use_res else None
+        if m is fus:
+            y = m(xi, residual=ri, relu=relu)
+        else:
+            y = m(xi)
+            if use_res:
+                y = y + ri
+            if relu:
+                y = torch.relu(y)
+        y.backward(gy)
+        outs.append((y.detach(), xi.grad, ri.grad if use_res else None, m.weight.grad, m.bias.grad,
+                     m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        if a is None:
+            continue
+        scale = max(a.abs().max().item(), 1e-6)
+        assert (a.float() - b.float()).abs().max().item() <= 2e-5 * scale + 1e-6, (relu, use_res, shape)
+    # eval mode = PyTorch's own path on running stats
+    fus.eval(); ref.eval()
+    assert torch.allclose(fus(x), ref(x), atol=1e-6)
