@@ -39,7 +39,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_stats(const float *__restrict
     __shared__ float sh[8];
     const int c = blockIdx.x, s = blockIdx.y;
     float a = 0.f, b = 0.f;
-    const int hw4 = HW >> 2;
+    const int hw4 = (HW & 3) ? 0 : (HW >> 2);      // 16-B loads only when every plane base is 16-B aligned
     for (int n = s; n < N; n += nslice) {
         const float *p = x + ((size_t)n * C + c) * HW;
         const f32x4 *p4 = (const f32x4 *)p;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__res
     const int c = blockIdx.x, s = blockIdx.y;
     const float m = mean[c], is = invstd[c];
     float a = 0.f, b = 0.f;
-    const int hw4 = HW >> 2;
+    const int hw4 = (HW & 3) ? 0 : (HW >> 2);      // see k_bn_stats
     for (int n = s; n < N; n += nslice) {
         const size_t base = ((size_t)n * C + c) * HW;
         const f32x4 *d4 = (const f32x4 *)(dy + base), *x4 = (const f32x4 *)(x + base),

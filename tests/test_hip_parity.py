@@ -398,40 +398,43 @@ def test_global_negative_bank_two_virtual_ranks(dev, oracle):
 
 @pytest.mark.parametrize("relu,use_res,shape", [(True, True, (3, 48, 33, 47)), (True, False, (4, 18, 16, 24)),
                                                 (False, False, (2, 720, 8, 12)), (False, True, (5, 7, 5, 3))])
-def test_fused_batchnorm_matches_torch(dev, relu, use_res, shape):
-    """csrc/dcl_bn.hip through FusedBatchNorm2d against nn.BatchNorm2d (+ add) (+ ReLU) in training mode."""
+def test_fused_batchnorm_matches_fp64_reference(dev, relu, use_res, shape):
+    """csrc/dcl_bn.hip through FusedBatchNorm2d against nn.BatchNorm2d (+ add) (+ ReLU) evaluated on the
+    CPU in float64.  (Not against the GPU library: PyTorch-ROCm 2.10's MIOpen batch-norm BACKWARD returns
+    wrong dx / dweight when H*W is not a multiple of 4 -- 3e-3 / 6.4 absolute error at 3x48x33x47,
+    tools/debug_bn.py -- while the fused kernels stay at 4e-7.)"""
     from mscs_amd.models.fused_bn import FusedBatchNorm2d
     torch.manual_seed(3)
     C = shape[1]
-    ref = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev)
+    ref = torch.nn.BatchNorm2d(C, momentum=0.1).double()
     fus = FusedBatchNorm2d(C, momentum=0.1).to(dev)
     with torch.no_grad():
         ref.weight.uniform_(0.5, 1.5); ref.bias.uniform_(-0.5, 0.5)
         ref.running_mean.normal_(); ref.running_var.uniform_(0.5, 2.0)
-    fus.load_state_dict(ref.state_dict())
-    x = (torch.randn(shape, device=dev) * 2 + 0.7)
-    r = torch.randn(shape, device=dev) if use_res else None
-    gy = torch.randn(shape, device=dev)
-    outs = []
-    for m in (ref, fus):
-        xi = x.clone().requires_grad_(True)
-        ri = r.clone().requires_grad_(True) if use_res else None
-        if m is fus:
-            y = m(xi, residual=ri, relu=relu)
-        else:
-            y = m(xi)
-            if use_res:
-                y = y + ri
-            if relu:
-                y = torch.relu(y)
-        y.backward(gy)
-        outs.append((y.detach(), xi.grad, ri.grad if use_res else None, m.weight.grad, m.bias.grad,
-                     m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone()))
-    for a, b in zip(outs[0], outs[1]):
+    fus.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in ref.state_dict().items()})
+    x = (torch.randn(shape) * 2 + 0.7)
+    r = torch.randn(shape) if use_res else None
+    gy = torch.randn(shape)
+    xr = x.double().requires_grad_(True)
+    rr = r.double().requires_grad_(True) if use_res else None
+    y = ref(xr)
+    if use_res:
+        y = y + rr
+    if relu:
+        y = torch.relu(y)
+    y.backward(gy.double())
+    want = (y.detach(), xr.grad, rr.grad if use_res else None, ref.weight.grad, ref.bias.grad,
+            ref.running_mean, ref.running_var, ref.num_batches_tracked)
+    xf = x.to(dev).requires_grad_(True)
+    rf = r.to(dev).requires_grad_(True) if use_res else None
+    yf = fus(xf, residual=rf, relu=relu)
+    yf.backward(gy.to(dev))
+    got = (yf.detach(), xf.grad, rf.grad if use_res else None, fus.weight.grad, fus.bias.grad,
+           fus.running_mean, fus.running_var, fus.num_batches_tracked)
+    for a, b in zip(want, got):
         if a is None:
             continue
         scale = max(a.abs().max().item(), 1e-6)
-        assert (a.float() - b.float()).abs().max().item() <= 2e-5 * scale + 1e-6, (relu, use_res, shape)
-    # eval mode = PyTorch's own path on running stats
+        assert (a.double() - b.double().cpu()).abs().max().item() <= 2e-5 * scale + 1e-6, (relu, use_res, shape)
     fus.eval(); ref.eval()
-    assert torch.allclose(fus(x), ref(x), atol=1e-6)
+    assert torch.allclose(fus(x.to(dev)).cpu().double(), ref(x.double()), atol=1e-5)
