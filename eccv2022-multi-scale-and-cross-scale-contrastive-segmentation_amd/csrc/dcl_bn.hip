@@ -61,8 +61,15 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_stats(const float *__restrict
     }
 }
 
-// sums[c*2 + {0,1}] = fixed-order sum of the slices (double accumulation)
-__global__ void k_bn_combine(const float *__restrict__ part, int C, int nslice, float *__restrict__ sums)
+// sums[c*2 + {0,1}] = fixed-order sum of the slices (double accumulation).  Optional extras, so that the
+// single-rank path needs no further tiny launches: o0/o1 receive the two sums as separate [C] vectors
+// (dbeta / dgamma of the backward), and with `finalize` the forward statistics are turned into
+// mean / invstd (+ running-stat update, PyTorch's convention: unbiased variance, r = (1-m) r + m s).
+__global__ void k_bn_combine(const float *__restrict__ part, int C, int nslice, float *__restrict__ sums,
+                             float *__restrict__ o0, float *__restrict__ o1, int finalize, double count,
+                             float eps, float momentum, float *__restrict__ mean,
+                             float *__restrict__ invstd, float *__restrict__ running_mean,
+                             float *__restrict__ running_var)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C)
@@ -74,10 +81,25 @@ __global__ void k_bn_combine(const float *__restrict__ part, int C, int nslice, 
     }
     sums[c * 2 + 0] = (float)a;
     sums[c * 2 + 1] = (float)b;
+    if (o0)
+        o0[c] = (float)a;
+    if (o1)
+        o1[c] = (float)b;
+    if (finalize) {
+        const double m = (double)(float)a / count;
+        double var = (double)(float)b / count - m * m;
+        var = var > 0.0 ? var : 0.0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+    }
 }
 
-// mean / invstd from (possibly all-reduced) sums over `count` elements; running-stat update with
-// PyTorch's convention (unbiased variance, momentum m: r = (1 - m) r + m s).
+// mean / invstd from all-reduced sums over `count` elements (multi-rank path).
 __global__ void k_bn_finalize(const float *__restrict__ sums, int C, double count, float eps,
                               float momentum, float *__restrict__ mean, float *__restrict__ invstd,
                               float *__restrict__ running_mean, float *__restrict__ running_var)
@@ -251,7 +273,26 @@ extern "C" int dcl_bn_stats(const float *x, int N, int C, int HW, float *part, f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_bn_stats, dim3(C, ns), dim3(BN_THREADS), 0, st, x, N, C, HW, ns, part);
     DCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums);
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums,
+                       (float *)nullptr, (float *)nullptr, 0, 1.0, 0.f, 0.f, (float *)nullptr,
+                       (float *)nullptr, (float *)nullptr, (float *)nullptr);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// Single-rank forward statistics: dcl_bn_stats + dcl_bn_finalize in two launches instead of three.
+extern "C" int dcl_bn_stats_finalize(const float *x, int N, int C, int HW, float eps, float momentum,
+                                     float *part, float *sums, float *mean, float *invstd,
+                                     float *running_mean, float *running_var, void *stream)
+{
+    DCL_CHECK_ARG(x && part && sums && mean && invstd && N > 0 && C > 0 && HW > 0, "bad arguments");
+    const int ns = pick_slices(N, C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_stats, dim3(C, ns), dim3(BN_THREADS), 0, st, x, N, C, HW, ns, part);
+    DCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums,
+                       (float *)nullptr, (float *)nullptr, 1, (double)N * HW, eps, momentum, mean, invstd,
+                       running_mean, running_var);
     DCL_LAUNCH_CHECK();
     return 0;
 }
@@ -286,7 +327,7 @@ extern "C" int dcl_bn_apply(const float *x, const float *res, const float *mean,
 
 extern "C" int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y, const float *mean,
                                  const float *invstd, int N, int C, int HW, int relu, float *part,
-                                 float *sums, void *stream)
+                                 float *sums, float *dbeta, float *dgamma, void *stream)
 {
     DCL_CHECK_ARG(dy && x && mean && invstd && part && sums && (!relu || y), "bad arguments");
     const int ns = pick_slices(N, C);
@@ -296,7 +337,9 @@ extern "C" int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y
     else
         hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, N, C, HW, ns, part);
     DCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums);
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums, dbeta,
+                       dgamma, 0, 1.0, 0.f, 0.f, (float *)nullptr, (float *)nullptr, (float *)nullptr,
+                       (float *)nullptr);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,168 @@
+// dcl_resize.hip -- bilinear up-sampling of NCHW f32 maps, forward and (gather-form, deterministic)
+// backward.  HRNet performs 35 of these per step (exchange-module fusions models/HRNet.py:279-282, the
+// 720-channel concat :549-551 and the logits up-sampling :638 in the reference); 3.3 GB of output per
+// step at BASELINE config 2.  PyTorch's kernel reaches ~270 GB/s there (one thread per output element,
+// scalar stores) and its backward uses float atomics; this one writes 16 B per lane and gathers.
+//
+// Index arithmetic restates ATen's (UpSample.h: area_pixel_compute_scale / _source_index, f32):
+//   align_corners: scale = (in-1)/(out-1) (0 if out == 1), src = scale * dst
+//   otherwise    : scale = in/out,                         src = max(scale * (dst + 0.5) - 0.5, 0)
+//   i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1
+#include "dcl_common.h"
+
+namespace {
+
+struct Axis {
+    float scale;
+    int align;
+};
+
+__device__ __forceinline__ void src_index(const Axis a, int dst, int in_size, int &i0, int &i1, float &l0,
+                                          float &l1)
+{
+    float s = a.align ? a.scale * (float)dst : fmaxf(a.scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+    i0 = (int)s;
+    if (i0 > in_size - 1)
+        i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+
+// one workgroup per output row (n, c, oy); each thread produces 4 consecutive ox
+__global__ __launch_bounds__(256) void k_upsample_fwd(const float *__restrict__ x, int h, int w, int H,
+                                                     int W, Axis ay, Axis ax, float *__restrict__ y)
+{
+    const int row = blockIdx.x;              // (n*C + c) * H + oy
+    const int oy = row % H;
+    const size_t plane = row / H;
+    int y0, y1;
+    float ly0, ly1;
+    src_index(ay, oy, h, y0, y1, ly0, ly1);
+    const float *r0 = x + (plane * h + y0) * (size_t)w;
+    const float *r1 = x + (plane * h + y1) * (size_t)w;
+    float *out = y + (size_t)row * W;
+    const bool vec = (W & 3) == 0;
+    for (int ox4 = threadIdx.x * 4; ox4 < W; ox4 += 256 * 4) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ox = ox4 + k;
+            if (ox < W) {
+                int x0, x1;
+                float lx0, lx1;
+                src_index(ax, ox, w, x0, x1, lx0, lx1);
+                v[k] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+            } else {
+                v[k] = 0.f;
+            }
+        }
+        if (vec) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *(f32x4 *)(out + ox4) = o;
+        } else {
+            for (int k = 0; k < 4 && ox4 + k < W; ++k)
+                out[ox4 + k] = v[k];
+        }
+    }
+}
+
+// weight of input index `i` in output index `o` along one axis
+__device__ __forceinline__ float axis_weight(const Axis a, int o, int in_size, int i)
+{
+    int i0, i1;
+    float l0, l1;
+    src_index(a, o, in_size, i0, i1, l0, l1);
+    return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+// candidate output range touching input index i (conservative; weights decide)
+__device__ __forceinline__ void out_range(const Axis a, int i, int in_size, int out_size, int &lo, int &hi)
+{
+    // src(o) is non-decreasing in o; input i is touched when src(o) in (i-1, i+1)
+    const float inv = a.scale > 0.f ? 1.f / a.scale : 0.f;
+    float flo, fhi;
+    if (a.align) {
+        flo = ((float)i - 1.f) * inv;
+        fhi = ((float)i + 1.f) * inv;
+    } else {
+        flo = ((float)i - 1.f + 0.5f) * inv - 0.5f;
+        fhi = ((float)i + 1.f + 0.5f) * inv - 0.5f;
+    }
+    lo = (int)floorf(flo) - 1;
+    hi = (int)ceilf(fhi) + 1;
+    if (a.scale <= 0.f) {
+        lo = 0;
+        hi = out_size - 1;
+    }
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > out_size - 1 ? out_size - 1 : hi;
+}
+
+// one thread per input element: dx[n,c,iy,ix] = sum_{oy,ox} wy(iy,oy) * wx(ix,ox) * dy[n,c,oy,ox]
+__global__ __launch_bounds__(256) void k_upsample_bwd(const float *__restrict__ dy, int h, int w, int H,
+                                                     int W, Axis ay, Axis ax, size_t total,
+                                                     float *__restrict__ dx)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total)
+        return;
+    const int ix = (int)(e % w);
+    const size_t t = e / w;
+    const int iy = (int)(t % h);
+    const size_t plane = t / h;
+    int oy_lo, oy_hi, ox_lo, ox_hi;
+    out_range(ay, iy, h, H, oy_lo, oy_hi);
+    out_range(ax, ix, w, W, ox_lo, ox_hi);
+    const float *g = dy + plane * (size_t)H * W;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const float wy = axis_weight(ay, oy, h, iy);
+        if (wy == 0.f)
+            continue;
+        float rowacc = 0.f;
+        const float *gr = g + (size_t)oy * W;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const float wx = axis_weight(ax, ox, w, ix);
+            rowacc += wx * gr[ox];
+        }
+        acc += wy * rowacc;
+    }
+    dx[e] = acc;
+}
+
+Axis make_axis(int in_size, int out_size, int align)
+{
+    Axis a;
+    a.align = align;
+    if (align)
+        a.scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    else
+        a.scale = (float)in_size / (float)out_size;
+    return a;
+}
+
+}  // namespace
+
+extern "C" int dcl_upsample_bilinear_fwd(const float *x, int planes, int h, int w, int H, int W,
+                                         int align_corners, float *y, void *stream)
+{
+    DCL_CHECK_ARG(x && y && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad arguments");
+    DCL_CHECK_ARG((long long)planes * H < 2147483647LL, "too many output rows");
+    hipLaunchKernelGGL(k_upsample_fwd, dim3((unsigned)(planes * H)), dim3(256), 0, (hipStream_t)stream, x,
+                       h, w, H, W, make_axis(h, H, align_corners), make_axis(w, W, align_corners), y);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int w, int H, int W,
+                                         int align_corners, float *dx, void *stream)
+{
+    DCL_CHECK_ARG(dy && dx && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad arguments");
+    const size_t total = (size_t)planes * h * w;
+    hipLaunchKernelGGL(k_upsample_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dy, h, w, H, W, make_axis(h, H, align_corners),
+                       make_axis(w, W, align_corners), total, dx);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
-from .ops import conv3x3_gemm_wrw
+from .ops import conv3x3_gemm_wrw, upsample_bilinear
 from .fused_bn import FusedBatchNorm2d, bn_act
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
@@ -179,8 +179,7 @@ class HighResolutionModule(nn.Module):
                 if j == i:
                     y = y + x[j]
                 elif j > i:
-                    y = y + F.interpolate(row[j](x[j]), size=x[i].shape[-2:], mode='bilinear',
-                                          align_corners=self.align_corners)
+                    y = y + upsample_bilinear(row[j](x[j]), x[i].shape[-2:], self.align_corners)
                 else:
                     chain = row[j]                  # stride-2 conv chain; its last norm absorbs "+ y"
                     t = x[j]
@@ -272,8 +271,7 @@ class HighResolutionNet(nn.Module):
         y = self.stage4(self._enter_stage(self.transition3, y, self.stage3_cfg['NUM_BRANCHES']))
         assert self.use_as_backbone
         size = y[0].shape[-2:]
-        ups = [y[0]] + [F.interpolate(t, size=size, mode='bilinear', align_corners=self.align_corners)
-                        for t in y[1:]]
+        ups = [y[0]] + [upsample_bilinear(t, size, self.align_corners) for t in y[1:]]
         cat = torch.cat(ups, 1)
         if self.return_all_scales:
             return cat, [y[0], y[1], y[2], y[3]]
@@ -381,7 +379,7 @@ class HRNet(nn.Module):
         feats = self.backbone(x)
         multi = self.use_ms_projector or self.return_backbone_feats
         logits = self._head(feats[0] if multi else feats)
-        logits = F.interpolate(logits, size=size, mode='bilinear', align_corners=self.align_corners)
+        logits = upsample_bilinear(logits, size, self.align_corners)
         if self.projector_model is not None:
             if self.use_ms_projector:
                 proj = self.projector_model(feats[1][:self.ms_projector_scales])

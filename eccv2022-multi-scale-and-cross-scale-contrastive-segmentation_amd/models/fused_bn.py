@@ -38,17 +38,22 @@ class _FusedBNFunction(torch.autograd.Function):
         part = torch.empty((C * ns * 2,), dtype=torch.float32, device=dev)
         sums = torch.empty((C, 2), dtype=torch.float32, device=dev)
         st = _stream()
-        _lib.check(L.dcl_bn_stats(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(sums), st), "dcl_bn_stats")
         world = _world() if sync else 1
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(sums)
         count = float(N * HW * world)
         mean = torch.empty((C,), dtype=torch.float32, device=dev)
         invstd = torch.empty((C,), dtype=torch.float32, device=dev)
-        _lib.check(L.dcl_bn_finalize(_lib.ptr(sums), C, count, eps, momentum, _lib.ptr(mean),
-                                     _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), st),
-                   "dcl_bn_finalize")
+        if world == 1:
+            _lib.check(L.dcl_bn_stats_finalize(_lib.ptr(x), N, C, HW, eps, momentum, _lib.ptr(part),
+                                               _lib.ptr(sums), _lib.ptr(mean), _lib.ptr(invstd),
+                                               _lib.ptr(running_mean), _lib.ptr(running_var), st),
+                       "dcl_bn_stats_finalize")
+        else:
+            import torch.distributed as dist
+            _lib.check(L.dcl_bn_stats(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(sums), st), "dcl_bn_stats")
+            dist.all_reduce(sums)
+            _lib.check(L.dcl_bn_finalize(_lib.ptr(sums), C, count, eps, momentum, _lib.ptr(mean),
+                                         _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), st),
+                       "dcl_bn_finalize")
         y = torch.empty_like(x)
         _lib.check(L.dcl_bn_apply(_lib.ptr(x), _lib.ptr(res), _lib.ptr(mean), _lib.ptr(invstd),
                                   _lib.ptr(weight), _lib.ptr(bias), N, C, HW, 1 if relu else 0, _lib.ptr(y),
@@ -71,11 +76,12 @@ class _FusedBNFunction(torch.autograd.Function):
         sums = torch.empty((C, 2), dtype=torch.float32, device=dev)
         st = _stream()
         relu = 1 if ctx.relu else 0
+        dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
+        dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         _lib.check(L.dcl_bn_bwd_reduce(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
-                                       _lib.ptr(invstd), N, C, HW, relu, _lib.ptr(part), _lib.ptr(sums), st),
-                   "dcl_bn_bwd_reduce")
-        dbeta = sums[:, 0].clone() if ctx.needs_input_grad[3] else None     # local sums: DDP averages them
-        dgamma = sums[:, 1].clone() if ctx.needs_input_grad[2] else None
+                                       _lib.ptr(invstd), N, C, HW, relu, _lib.ptr(part), _lib.ptr(sums),
+                                       _lib.ptr(dbeta), _lib.ptr(dgamma), st), "dcl_bn_bwd_reduce")
+        # dbeta / dgamma are the LOCAL sums (written before the all-reduce): DDP averages them
         if ctx.world > 1:
             import torch.distributed as dist
             dist.all_reduce(sums)

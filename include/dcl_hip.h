@@ -180,6 +180,9 @@ int dcl_normalize_bwd_scatter(const float *const *slabs_host, int nslab, const f
  */
 int dcl_bn_num_slices(int N, int C);
 int dcl_bn_stats(const float *x, int N, int C, int HW, float *part, float *sums, void *stream);
+int dcl_bn_stats_finalize(const float *x, int N, int C, int HW, float eps, float momentum, float *part,
+                          float *sums, float *mean, float *invstd, float *running_mean,
+                          float *running_var, void *stream);   /* single-rank: stats + finalize */
 int dcl_bn_finalize(const float *sums, int C, double count, float eps, float momentum, float *mean,
                     float *invstd, float *running_mean, float *running_var, void *stream);
 int dcl_bn_apply(const float *x, const float *res, const float *mean, const float *invstd,
@@ -187,10 +190,18 @@ int dcl_bn_apply(const float *x, const float *res, const float *mean, const floa
                  void *stream);
 int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y, const float *mean,
                       const float *invstd, int N, int C, int HW, int relu, float *part, float *sums,
-                      void *stream);
+                      float *dbeta /* [C] or NULL */, float *dgamma /* [C] or NULL */, void *stream);
 int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y, const float *mean,
                      const float *invstd, const float *gamma, const float *sums, double count, int N,
                      int C, int HW, int relu, float *dx, float *dres, void *stream);
+
+/* ---- bilinear up-sampling, NCHW f32 (planes = N * C), ATen index arithmetic ----------------------------
+ * Replaces F.interpolate(mode='bilinear') in the models (reference models/HRNet.py:279-282, 549-551, 638)
+ * and its autograd backward (gather form: deterministic, no atomics). */
+int dcl_upsample_bilinear_fwd(const float *x, int planes, int h, int w, int H, int W, int align_corners,
+                              float *y, void *stream);
+int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int w, int H, int W, int align_corners,
+                              float *dx, void *stream);
 
 /* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the
  * grid fills the 256 CUs evenly (host helper, no device work). */

@@ -438,3 +438,23 @@ def test_fused_batchnorm_matches_fp64_reference(dev, relu, use_res, shape):
         assert (a.double() - b.double().cpu()).abs().max().item() <= 2e-5 * scale + 1e-6, (relu, use_res, shape)
     fus.eval(); ref.eval()
     assert torch.allclose(fus(x.to(dev)).cpu().double(), ref(x.double()), atol=1e-5)
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("shape,size", [((2, 5, 16, 32), (64, 128)), ((3, 7, 9, 13), (36, 52)),
+                                        ((1, 4, 8, 8), (30, 33)), ((2, 3, 1, 5), (4, 20)),
+                                        ((2, 19, 32, 64), (128, 256))])
+def test_upsample_bilinear_matches_torch(dev, align, shape, size):
+    """csrc/dcl_resize.hip against F.interpolate(mode='bilinear') forward and backward (fp32, 1e-5)."""
+    from mscs_amd.models.ops import upsample_bilinear
+    torch.manual_seed(1)
+    x = torch.randn(shape, device=dev)
+    gy = torch.randn(shape[:2] + size, device=dev)
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ya = torch.nn.functional.interpolate(xa, size=size, mode="bilinear", align_corners=align)
+    yb = upsample_bilinear(xb, size, align)
+    ya.backward(gy)
+    yb.backward(gy)
+    assert (ya - yb).abs().max().item() <= 1e-5 * max(1.0, ya.abs().max().item())
+    assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * max(1.0, xa.grad.abs().max().item())
