@@ -1,0 +1,121 @@
+"""Two ranks on ONE GPU (gloo backend moving CUDA tensors through the host) -- exercises the multi-rank
+code paths that a single-GPU box can reach: SyncBatchNorm semantics of FusedBatchNorm2d, the DDP training
+step of the manager with the HIP loss, and the shared-negative-bank all-gather."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _bn_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    shape = (4, 24, 12, 20)
+    x = torch.randn(shape, generator=g) * 1.5 + 0.3
+    r = torch.randn(shape, generator=g)
+    gy = torch.randn(shape, generator=g)
+    w = torch.rand(24, generator=g) + 0.5
+    b = torch.rand(24, generator=g) - 0.5
+    half = slice(2 * rank, 2 * rank + 2)
+    bn = FusedBatchNorm2d(24).to(dev)
+    bn.sync = True
+    with torch.no_grad():
+        bn.weight.copy_(w); bn.bias.copy_(b)
+    xi = x[half].to(dev).requires_grad_(True)
+    ri = r[half].to(dev).requires_grad_(True)
+    y = bn(xi, residual=ri, relu=True)
+    y.backward(gy[half].to(dev))
+    torch.save({"y": y.detach().cpu(), "dx": xi.grad.cpu(), "dr": ri.grad.cpu(), "dw": bn.weight.grad.cpu(),
+                "db": bn.bias.grad.cpu(), "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu()},
+               os.path.join(out_dir, f"bn{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_fused_bn_sync_two_ranks_one_gpu(tmp_path):
+    port = _free_port()
+    mp.spawn(_bn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(5)
+    shape = (4, 24, 12, 20)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
+    r = torch.randn(shape, generator=g).double().requires_grad_(True)
+    gy = torch.randn(shape, generator=g).double()
+    w = torch.rand(24, generator=g) + 0.5
+    b = torch.rand(24, generator=g) - 0.5
+    ref = torch.nn.BatchNorm2d(24).double()
+    with torch.no_grad():
+        ref.weight.copy_(w); ref.bias.copy_(b)
+    y = torch.relu(ref(x) + r)
+    y.backward(gy)
+    outs = [torch.load(os.path.join(str(tmp_path), f"bn{q}.pt")) for q in range(2)]
+    for q in range(2):
+        half = slice(2 * q, 2 * q + 2)
+        for key, want in (("y", y.detach()[half]), ("dx", x.grad[half]), ("dr", r.grad[half])):
+            assert (outs[q][key].double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), key
+        assert torch.allclose(outs[q]["rm"].double(), ref.running_mean, atol=1e-5)
+        assert torch.allclose(outs[q]["rv"].double(), ref.running_var, atol=1e-5)
+    # weight / bias grads are per-rank partial sums (DDP averages them): they add up to the full-batch grads
+    assert torch.allclose((outs[0]["dw"] + outs[1]["dw"]).double(), ref.weight.grad, atol=2e-4)
+    assert torch.allclose((outs[0]["db"] + outs[1]["db"]).double(), ref.bias.grad, atol=2e-4)
+
+
+def _train_worker(rank, world, port, out_dir, global_negatives):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import mscs_amd  # noqa: F401
+    from mscs_amd.managers import HRNetManager
+    from mscs_amd.utils import set_verbosity
+    set_verbosity(40)
+    cfg = {"name": "t", "mode": "training", "manager": "HRNet", "cuda": True, "parallel": True,
+           "gpu_device": [0, 0], "seed": 3, "log_every_n_steps": 1000, "dist_backend": "gloo",
+           "graph": {"model": "HRNet", "backbone": "hrnet18", "sync_bn": True, "pretrained": False,
+                     "align_corners": True,
+                     "ms_projector": {"mlp": [[1, -1, 1]], "scales": 2, "d": 64, "use_bn": True}},
+           "data": {"dataset": "CITYSCAPES", "experiment": 1, "batch_size": 4, "synthetic": True,
+                    "synthetic_length": 8, "synthetic_mode": "blocky",
+                    "transform_values": {"crop_shape": [64, 128]}},
+           "loss": {"name": "LossWrapper", "losses": {"CrossEntropyLoss": 1, "DenseContrastiveLossV2_ms": 0.1},
+                    "temperature": 0.1, "scales": 2, "weights": [1.0, 0.5], "cross_scale_contrast": True,
+                    "min_views_per_class": 2, "max_features_total": 600, "global_negatives": global_negatives},
+           "train": {"learning_rate": 0.01, "lr_fct": "polynomial", "optim": "SGD", "lr_batchwise": True,
+                     "epochs": 1}}
+    mgr = HRNetManager(cfg, autostart=False)
+    mgr.world_size = mgr.n_gpus = world
+    mgr._worker_setup(0, rank)
+    mgr.train_one_epoch()
+    flat = torch.cat([p.detach().flatten() for p in mgr.model.parameters()]).cpu()
+    torch.save({"params": flat, "metrics": mgr.metrics,
+                "segs": [len(t.segs) for t in mgr.loss.loss_classes["DenseContrastiveLossV2_ms"].last_state.terms]},
+               os.path.join(out_dir, f"train{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("global_negatives", [False, True])
+def test_ddp_training_step_two_ranks_one_gpu(tmp_path, global_negatives):
+    port = _free_port()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path), global_negatives), nprocs=2, join=True)
+    a, b = [torch.load(os.path.join(str(tmp_path), f"train{q}.pt")) for q in range(2)]
+    assert torch.equal(a["params"], b["params"]), "parameters diverged across ranks"
+    assert np.isfinite(a["metrics"]["loss"]) and np.isfinite(b["metrics"]["loss"])
+    assert a["segs"] == ([2, 2, 2] if global_negatives else [1, 1, 1])
