@@ -139,9 +139,15 @@ def roofline_bwd_kernel(mod, iters=10):
     ms = e0.elapsed_time(e1) / iters
     flops = 4.0 * N * N * 256
     achieved = flops / (ms * 1e-3) / 1e12
+    # HBM traffic per launch of this kernel at N = 9804 from the committed PMC passes
+    # (profiles/r01_loss_pmc_fetch.csv / _write.csv): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the
+    # gfx950 correction in MI355X_MICROARCH.md; only valid for the benchmark shape, else null
+    traffic = (2 * 102168.7 + 128128.0) * 1024 if (N == 9804 and ns == 13) else None
     return {"bound": "mfma", "kernel": "k_sweep<MODE_BWD> (dcl_infonce_bwd)", "achieved": round(achieved, 2),
             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-            "traffic": None, "launch_ms": round(ms, 4), "N1": N, "N2": N, "C": 256, "nsplit": ns}
+            "traffic": traffic, "traffic_source": "profiles/r01_loss_pmc_fetch.csv, r01_loss_pmc_write.csv",
+            "algorithmic_bytes": 3 * N * 256 * 4, "launch_ms": round(ms, 4), "N1": N, "N2": N, "C": 256,
+            "nsplit": ns}
 
 
 def cpu_baseline_loss(args, n_terms):
