@@ -458,3 +458,45 @@ def test_upsample_bilinear_matches_torch(dev, align, shape, size):
     yb.backward(gy)
     assert (ya - yb).abs().max().item() <= 1e-5 * max(1.0, ya.abs().max().item())
     assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * max(1.0, xa.grad.abs().max().item())
+
+
+def test_upernet_swin_training_step_with_twoscale_and_contrastive_loss(dev):
+    """BASELINE configs[3] plumbing at toy size: UPerNet + Swin-T through OCRNetManager.forward_step with
+    TwoScaleLoss (aux + main CE) and the HIP DCV2_ms on the four FPN projector maps; one SGD step."""
+    from mscs_amd.managers import OCRNetManager
+    from mscs_amd.utils import set_verbosity
+    set_verbosity(40)
+    cfg = {"name": "t", "mode": "training", "manager": "OCRNet", "cuda": True, "seed": 1,
+           "graph": {"model": "UPerNet", "backbone": "swinT", "sync_bn": False, "pretrained": False,
+                     "align_corners": False, "aux_head": {"in_index": 3, "dropout_rate": 0.1}, "dropout_rate": 0.1,
+                     "ms_projector": {"mlp": [[1, -1, 1]], "scales": 4, "d": 256, "use_bn": True, "position": "fpn"}},
+           "data": {"dataset": "ADE20K", "experiment": 1, "batch_size": 2, "synthetic": True, "synthetic_length": 2,
+                    "synthetic_mode": "blocky", "transform_values": {"crop_shape": [128, 128]}},
+           "loss": {"name": "LossWrapper", "losses": {"TwoScaleLoss": 1, "DenseContrastiveLossV2_ms": 0.1},
+                    "interm": {"name": "CrossEntropyLoss", "weight": 0.4, "args": []},
+                    "final": {"name": "CrossEntropyLoss", "weight": 1.0, "args": []},
+                    "temperature": 0.1, "scales": 4, "weights": [1, 0.7, 0.4, 0.1], "cross_scale_contrast": True,
+                    "min_views_per_class": 2, "max_views_per_class": 2500, "max_features_total": 2000},
+           "train": {"learning_rate": 1e-4, "lr_fct": "polynomial", "optim": "AdamW", "lr_batchwise": True,
+                     "epochs": 1, "weight_decay": 0.01}}
+    mgr = OCRNetManager(cfg)
+    mgr.model.train()
+    img, _, _ = next(iter(mgr.data_loaders["train_loader"]))
+    # four classes in 32x32 blocks: every scale down to stride 32 keeps >= 2 pixels for some (image, class)
+    # pairs (V >= 2, so every anchor has a positive; V = 1 would give the reference's 0/0 = NaN)
+    g = torch.Generator().manual_seed(4)
+    lbl = torch.randint(0, 4, (2, 4, 4), generator=g).repeat_interleave(32, 1).repeat_interleave(32, 2).int()
+    before = torch.cat([p.detach().flatten() for p in mgr.model.parameters()]).clone()
+    mgr.optimiser.zero_grad()
+    ret = mgr.forward_step(img.to(dev), lbl.to(dev))
+    assert ret["interm_output"].shape == ret["output"].shape == (2, 150, 128, 128)
+    assert [tuple(f.shape) for f in ret["feats"]] == [(2, 256, 32, 32), (2, 256, 16, 16), (2, 256, 8, 8), (2, 256, 4, 4)]
+    ret["loss"].backward()
+    mgr.optimiser.step()
+    assert torch.isfinite(ret["loss"]).item()
+    vals = mgr.loss.loss_vals
+    assert {"TwoScaleLoss", "DenseContrastiveLossV2_ms", "DenseContrastiveLossV2_ms_ms0", "DenseContrastiveLossV2_ms_ms3",
+            "DenseContrastiveLossV2_ms_cs0", "DenseContrastiveLossV2_ms_cs1"} <= set(vals)
+    after = torch.cat([p.detach().flatten() for p in mgr.model.parameters()])
+    assert not torch.equal(before, after)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mgr.model.parameters() if p.requires_grad)
