@@ -30,8 +30,9 @@ __device__ __forceinline__ void src_index(const Axis a, int dst, int in_size, in
 }
 
 // one workgroup per output row (n, c, oy); each thread produces 4 consecutive ox
-__global__ __launch_bounds__(256) void k_upsample_fwd(const float *__restrict__ x, int h, int w, int H,
-                                                     int W, Axis ay, Axis ax, float *__restrict__ y)
+__global__ __launch_bounds__(256) void k_upsample_fwd(const float *__restrict__ x,
+                                                     const float *__restrict__ addend, int h, int w,
+                                                     int H, int W, Axis ay, Axis ax, float *__restrict__ y)
 {
     const int row = blockIdx.x;              // (n*C + c) * H + oy
     const int oy = row % H;
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void k_upsample_fwd(const float *__restrict__ 
     const float *r0 = x + (plane * h + y0) * (size_t)w;
     const float *r1 = x + (plane * h + y1) * (size_t)w;
     float *out = y + (size_t)row * W;
+    const float *add = addend ? addend + (size_t)row * W : nullptr;     // y = addend + upsample(x)
     const bool vec = (W & 3) == 0;
     for (int ox4 = threadIdx.x * 4; ox4 < W; ox4 += 256 * 4) {
         float v[4];
@@ -59,10 +61,14 @@ __global__ __launch_bounds__(256) void k_upsample_fwd(const float *__restrict__ 
         }
         if (vec) {
             f32x4 o = {v[0], v[1], v[2], v[3]};
+            if (add) {
+                const f32x4 a = *(const f32x4 *)(add + ox4);
+                o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+            }
             *(f32x4 *)(out + ox4) = o;
         } else {
             for (int k = 0; k < 4 && ox4 + k < W; ++k)
-                out[ox4 + k] = v[k];
+                out[ox4 + k] = v[k] + (add ? add[ox4 + k] : 0.f);
         }
     }
 }
@@ -115,16 +121,30 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float *__restrict__ 
     out_range(ay, iy, h, H, oy_lo, oy_hi);
     out_range(ax, ix, w, W, ox_lo, ox_hi);
     const float *g = dy + plane * (size_t)H * W;
+    // separable: the x-weights of this input column are evaluated once, not once per output row
+    constexpr int MAXC = 16;
+    float wxs[MAXC];
+    const int nx = ox_hi - ox_lo + 1;
+    if (nx <= MAXC) {
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k)
+            wxs[k] = k < nx ? axis_weight(ax, ox_lo + k, w, ix) : 0.f;
+    }
     float acc = 0.f;
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
         const float wy = axis_weight(ay, oy, h, iy);
         if (wy == 0.f)
             continue;
         float rowacc = 0.f;
-        const float *gr = g + (size_t)oy * W;
-        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-            const float wx = axis_weight(ax, ox, w, ix);
-            rowacc += wx * gr[ox];
+        const float *gr = g + (size_t)oy * W + ox_lo;
+        if (nx <= MAXC) {
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k)
+                if (k < nx)
+                    rowacc += wxs[k] * gr[k];
+        } else {                                   // down-scaling or huge factors: generic path
+            for (int k = 0; k < nx; ++k)
+                rowacc += axis_weight(ax, ox_lo + k, w, ix) * gr[k];
         }
         acc += wy * rowacc;
     }
@@ -144,13 +164,13 @@ Axis make_axis(int in_size, int out_size, int align)
 
 }  // namespace
 
-extern "C" int dcl_upsample_bilinear_fwd(const float *x, int planes, int h, int w, int H, int W,
-                                         int align_corners, float *y, void *stream)
+extern "C" int dcl_upsample_bilinear_fwd(const float *x, const float *addend, int planes, int h, int w,
+                                         int H, int W, int align_corners, float *y, void *stream)
 {
     DCL_CHECK_ARG(x && y && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad arguments");
     DCL_CHECK_ARG((long long)planes * H < 2147483647LL, "too many output rows");
     hipLaunchKernelGGL(k_upsample_fwd, dim3((unsigned)(planes * H)), dim3(256), 0, (hipStream_t)stream, x,
-                       h, w, H, W, make_axis(h, H, align_corners), make_axis(w, W, align_corners), y);
+                       addend, h, w, H, W, make_axis(h, H, align_corners), make_axis(w, W, align_corners), y);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -179,7 +179,7 @@ class HighResolutionModule(nn.Module):
                 if j == i:
                     y = y + x[j]
                 elif j > i:
-                    y = y + upsample_bilinear(row[j](x[j]), x[i].shape[-2:], self.align_corners)
+                    y = upsample_bilinear(row[j](x[j]), x[i].shape[-2:], self.align_corners, add=y)
                 else:
                     chain = row[j]                  # stride-2 conv chain; its last norm absorbs "+ y"
                     t = x[j]

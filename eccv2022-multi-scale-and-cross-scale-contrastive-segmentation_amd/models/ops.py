@@ -49,15 +49,16 @@ def conv3x3_gemm_wrw(x, conv: torch.nn.Conv2d, chunk: int = 4):
 
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, H, W, align_corners):
+    def forward(ctx, x, addend, H, W, align_corners):
         import ctypes
         from .. import _lib
         L = _lib.lib()
         n, c, h, w = x.shape
         y = torch.empty((n, c, H, W), dtype=torch.float32, device=x.device)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(L.dcl_upsample_bilinear_fwd(_lib.ptr(x), n * c, h, w, H, W, 1 if align_corners else 0,
-                                               _lib.ptr(y), st), "dcl_upsample_bilinear_fwd")
+        _lib.check(L.dcl_upsample_bilinear_fwd(_lib.ptr(x), _lib.ptr(addend), n * c, h, w, H, W,
+                                               1 if align_corners else 0, _lib.ptr(y), st),
+                   "dcl_upsample_bilinear_fwd")
         ctx.shape, ctx.align = (n, c, h, w), bool(align_corners)
         return y
 
@@ -69,21 +70,25 @@ class _UpsampleBilinear(torch.autograd.Function):
         n, c, h, w = ctx.shape
         dy = dy.contiguous()
         H, W = dy.shape[-2:]
-        dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.check(L.dcl_upsample_bilinear_bwd(_lib.ptr(dy), n * c, h, w, H, W, 1 if ctx.align else 0,
-                                               _lib.ptr(dx), st), "dcl_upsample_bilinear_bwd")
-        return dx, None, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(L.dcl_upsample_bilinear_bwd(_lib.ptr(dy), n * c, h, w, H, W, 1 if ctx.align else 0,
+                                                   _lib.ptr(dx), st), "dcl_upsample_bilinear_bwd")
+        return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None
 
 
-def upsample_bilinear(x, size, align_corners):
-    """F.interpolate(x, size, mode='bilinear', align_corners=...) on the HIP kernels of csrc/dcl_resize.hip
-    for CUDA / float32 / contiguous NCHW inputs (16-B stores forward, deterministic gather backward);
-    PyTorch's own kernel otherwise (CPU, other dtypes / layouts, autocast)."""
+def upsample_bilinear(x, size, align_corners, add=None):
+    """``add + F.interpolate(x, size, mode='bilinear', align_corners=...)`` (``add`` optional) on the HIP
+    kernels of csrc/dcl_resize.hip for CUDA / float32 / contiguous NCHW inputs (16-B stores forward with the
+    addend folded in, deterministic gather backward); PyTorch's own kernels otherwise."""
     H, W = int(size[0]), int(size[1])
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() \
-            and not torch.is_autocast_enabled():
-        if (H, W) == tuple(x.shape[-2:]):
-            return x
-        return _UpsampleBilinear.apply(x, H, W, bool(align_corners))
-    return F.interpolate(x, size=(H, W), mode='bilinear', align_corners=align_corners)
+            and not torch.is_autocast_enabled() and (H, W) != tuple(x.shape[-2:]) \
+            and (add is None or (add.is_contiguous() and add.dtype == torch.float32
+                                 and tuple(add.shape) == tuple(x.shape[:2]) + (H, W))):
+        return _UpsampleBilinear.apply(x, add, H, W, bool(align_corners))
+    y = x if (H, W) == tuple(x.shape[-2:]) else F.interpolate(x, size=(H, W), mode='bilinear',
+                                                              align_corners=align_corners)
+    return y if add is None else add + y

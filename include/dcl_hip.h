@@ -198,8 +198,9 @@ int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y, const floa
 /* ---- bilinear up-sampling, NCHW f32 (planes = N * C), ATen index arithmetic ----------------------------
  * Replaces F.interpolate(mode='bilinear') in the models (reference models/HRNet.py:279-282, 549-551, 638)
  * and its autograd backward (gather form: deterministic, no atomics). */
-int dcl_upsample_bilinear_fwd(const float *x, int planes, int h, int w, int H, int W, int align_corners,
-                              float *y, void *stream);
+int dcl_upsample_bilinear_fwd(const float *x, const float *addend /* [planes,H,W] or NULL: y = addend + up(x) */,
+                              int planes, int h, int w, int H, int W, int align_corners, float *y,
+                              void *stream);
 int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int w, int H, int W, int align_corners,
                               float *dx, void *stream);
 

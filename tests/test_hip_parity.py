@@ -452,12 +452,17 @@ def test_upsample_bilinear_matches_torch(dev, align, shape, size):
     gy = torch.randn(shape[:2] + size, device=dev)
     xa = x.clone().requires_grad_(True)
     xb = x.clone().requires_grad_(True)
-    ya = torch.nn.functional.interpolate(xa, size=size, mode="bilinear", align_corners=align)
-    yb = upsample_bilinear(xb, size, align)
+    add_a = torch.randn_like(gy).requires_grad_(True)
+    add_b = add_a.detach().clone().requires_grad_(True)
+    ya = add_a + torch.nn.functional.interpolate(xa, size=size, mode="bilinear", align_corners=align)
+    yb = upsample_bilinear(xb, size, align, add=add_b)
     ya.backward(gy)
     yb.backward(gy)
     assert (ya - yb).abs().max().item() <= 1e-5 * max(1.0, ya.abs().max().item())
     assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * max(1.0, xa.grad.abs().max().item())
+    assert torch.equal(add_a.grad, add_b.grad)
+    yc = upsample_bilinear(x, size, align)                       # without addend
+    assert (yc - (ya - add_a).detach()).abs().max().item() <= 1e-5 * max(1.0, yc.abs().max().item())
 
 
 def test_upernet_swin_training_step_with_twoscale_and_contrastive_loss(dev):
