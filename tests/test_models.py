@@ -75,3 +75,15 @@ def test_hrnet_train_mode_backward_runs():
     assert out.shape == (2, 19, 64, 64) and proj.shape == (2, 64, 16, 16)
     (out.mean() + proj.mean()).backward()
     assert all(p.grad is not None for p in m.parameters())
+
+
+def test_lovasz_softmax_matches_reference():
+    from mscs_amd.losses import LovaszSoftmax
+    z = np.load(os.path.join(GOLDEN, "G10_lovasz.npz"))
+    for name in ("default", "per_image", "all"):
+        m = LovaszSoftmax(json.loads(str(z[name + "_cfg"])))
+        x = torch.from_numpy(z["logits"]).requires_grad_(True)
+        loss = m(x, torch.from_numpy(z["label"].astype(np.int64)))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), z[name + "_loss"], rtol=1e-5)
+        np.testing.assert_allclose(x.grad.numpy(), z[name + "_grad"], atol=1e-6 * np.abs(z[name + "_grad"]).max() + 1e-9)
