@@ -505,3 +505,62 @@ def test_upernet_swin_training_step_with_twoscale_and_contrastive_loss(dev):
     after = torch.cat([p.detach().flatten() for p in mgr.model.parameters()])
     assert not torch.equal(before, after)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mgr.model.parameters() if p.requires_grad)
+
+
+def test_single_view_gives_nan_like_the_reference(dev, oracle):
+    """V = 1 and a class present in one image only -> that anchor has no positive: the reference divides 0/0
+    (DenseContrastiveLossV2.py:188) and returns NaN; so do the oracle and the HIP path (no silent clamp)."""
+    from mscs_amd.losses import DenseContrastiveLossV2
+    label = torch.zeros(1, 16, 16, dtype=torch.long)
+    label[0, :8] = 1
+    label[0, 0, 0] = 2                      # one pixel of class 2 -> min count 1 -> V = 1
+    feat = torch.randn(1, 8, 16, 16, generator=torch.Generator().manual_seed(0))
+    cfg = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "min_views_per_class": 1}
+    mod = DenseContrastiveLossV2(cfg)
+    torch.manual_seed(0)
+    loss = mod(label.to(dev), feat.to(dev))
+    ocfg = oracle.LossConfig(num_all_classes=20, temperature=0.1, min_views_per_class=1, scales=1)
+    ref, plan, _ = oracle.dcv2_single(label.numpy(), feat.numpy(), ocfg, rng=oracle.MT19937(0), want_grad=False)
+    assert plan.V == 1 and np.isnan(ref)
+    assert torch.isnan(loss).item()
+
+
+def test_ade20k_class_count_and_mixed_input_dtypes(dev):
+    """K = 151 (ADE20K): 600 (image, class) pairs, V cut by max_features_total; int32 labels; the loss equals a
+    dense fp32 torch evaluation of the same banks; features arriving as bf16 are promoted."""
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    gen = torch.Generator().manual_seed(2)
+    n, H, W, K = 4, 256, 256, 151
+    label = torch.randint(0, K, (n, H, W), generator=gen, dtype=torch.int32).to(dev)
+    feats = [torch.randn(n, 256, H // s, W // s, generator=gen).to(dev).requires_grad_(True) for s in (4, 8)]
+    cfg = {"dataset": "ADE20K", "experiment": 1, "temperature": 0.1, "scales": 2, "weights": [1.0, 0.7],
+           "cross_scale_contrast": True}
+    mod = DenseContrastiveLossV2_ms(cfg)
+    torch.manual_seed(0)
+    loss = mod(label, feats)
+    loss.backward()
+    st = mod.last_state
+    p0 = st.scales[0].plan
+    assert p0.T == 600 and p0.V == min(int(p0.pair_cnt.min()), 10000 // 600)
+    total = 0.0
+    for t, term in enumerate(st.terms):
+        A, B = st.scales[term.a], st.scales[term.b]
+        Fa, Fb = A.bank[:A.plan.N], B.bank[:B.plan.N]
+        ca = torch.from_numpy(np.repeat(A.plan.pair_k[A.plan.slot_pair], A.plan.V)).to(dev)
+        cb = torch.from_numpy(np.repeat(B.plan.pair_k[B.plan.slot_pair], B.plan.V)).to(dev)
+        Smat = (Fa @ Fb.T) / term.tau
+        pos = (ca[:, None] == cb[None, :]).float()
+        neg = 1 - pos
+        if term.intra:
+            pos.fill_diagonal_(0)
+        E = torch.exp(Smat)
+        Z = (E * neg).sum(1, keepdim=True)
+        P = pos.sum(1)
+        Pn = P if term.intra else torch.where(P > 0, P, torch.ones_like(P))
+        ref = -((pos * (Smat - torch.log(E + Z))).sum(1) / Pn).mean()
+        np.testing.assert_allclose(st.loss_buf[t].item(), ref.item(), rtol=LOSS_RTOL)
+        total += term.weight * ref.item()
+    np.testing.assert_allclose(loss.item(), total, rtol=LOSS_RTOL)
+    torch.manual_seed(0)
+    loss_bf16 = mod(label, [f.detach().bfloat16() for f in feats])
+    assert torch.isfinite(loss_bf16).item() and abs(loss_bf16.item() - loss.item()) < 0.05 * abs(loss.item())
