@@ -53,7 +53,7 @@ def _check_grad(got, ref):
     np.testing.assert_allclose(got, ref, atol=GRAD_ATOL_REL * scale, rtol=1e-3)
 
 
-@pytest.mark.parametrize("name", golden_names(["G1", "G3"]))
+@pytest.mark.parametrize("name", golden_names(["G1_", "G1b_", "G3"]))
 def test_single_scale_vs_reference(dev, name):
     from mscs_amd.losses import DenseContrastiveLossV2
     g = load_golden(name)

@@ -7,7 +7,7 @@ import torch
 from conftest import golden_names, load_golden, num_classes_for
 
 MS_CASES = golden_names(["G2", "G4", "G5", "G9"])
-SINGLE_CASES = golden_names(["G1", "G3"])
+SINGLE_CASES = golden_names(["G1_", "G1b_", "G3"])
 
 
 def _cfg(orc, c, K):
