@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--scales", type=int, default=3)
     ap.add_argument("--no-cross", action="store_true")
+    ap.add_argument("--mfma", default=None, choices=["f32", "f16x3"],
+                    help="similarity-product arithmetic of the loss kernels (default: the library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--amp", action="store_true", help="bf16 autocast for the model (loss stays fp32)")
     ap.add_argument("--channels-last", action="store_true")
@@ -55,9 +57,13 @@ def parse():
     return ap.parse_args()
 
 
+MFMA_MODE = None
+
+
 def loss_config(S, cross):
     weights = [1.0, 0.7, 0.4, 0.1][:S]
-    return {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": S,
+    extra = {"mfma_mode": MFMA_MODE} if MFMA_MODE else {}
+    return {**extra, "dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": S,
             "weights": weights, "cross_scale_contrast": cross, "min_views_per_class": 5,
             "max_views_per_class": 2500, "max_features_total": 10000, "label_scaling_mode": "nn"}
 
@@ -127,7 +133,7 @@ def roofline_bwd_kernel(mod, iters=10):
 
     def launch():
         _lib.check(L.dcl_infonce_bwd(p(A.bank), N, A.plan.V, p(A.bank), N, p(t.rng_lo), p(t.rng_hi),
-                                     1.0 / t.tau, 1, 1, 1, p(stat), p(stat), ns, p(dpart), stream), "bwd")
+                                     1.0 / t.tau, 1, 1, 1, p(stat), p(stat), ns, p(dpart), p(A.bank_h), p(A.bank_h), stream), "bwd")
     launch()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -291,6 +297,8 @@ def loss_only_ms(mod, dev, args, iters=5):
 
 def main():
     args = parse()
+    global MFMA_MODE
+    MFMA_MODE = args.mfma
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

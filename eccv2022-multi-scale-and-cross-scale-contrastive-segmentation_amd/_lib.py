@@ -27,14 +27,14 @@ _f = ctypes.c_float
 SIGNATURES = {
     "dcl_label_hist": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "dcl_rank_select": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp],
-    "dcl_gather_normalize": [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "dcl_gather_normalize": [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "dcl_gather_raw": [_vp, _i64, _i64, _i64, _i, _vp, _vp, _i, _i, _vp, _vp],
     "dcl_infonce_fwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "dcl_infonce_zsweep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _vp],
-    "dcl_infonce_possweep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "dcl_infonce_zsweep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp],
+    "dcl_infonce_possweep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_infonce_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "dcl_infonce_prep_stats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
-    "dcl_infonce_bwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
+    "dcl_infonce_bwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "dcl_normalize_bwd_scatter": [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
                                   _i64, _i64, _i64, _vp],
     "dcl_host_randperm_select": [_vp, _i64, _vp, _i, _i, _vp],

@@ -10,7 +10,7 @@ __global__ __launch_bounds__(256) void k_gather_normalize(
     const float *__restrict__ feat, int64_t sn, int64_t sc, int64_t sp, int C,
     const int32_t *__restrict__ pix, const int32_t *__restrict__ pair_b,
     const int32_t *__restrict__ slot_pair, int N, int V, int Npad, float *__restrict__ bank,
-    float *__restrict__ nrm)
+    float *__restrict__ nrm, _Float16 *__restrict__ bank_h)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -37,6 +37,17 @@ __global__ __launch_bounds__(256) void k_gather_normalize(
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         out[lane + 64 * q] = x[q] * inv;
+    if (bank_h) {
+        // f16x3 format of the same row: [256 hi | 256 lo] halves, hi = f16(f * 2^10), lo = f16(f * 2^10 - hi)
+        _Float16 *oh = bank_h + (int64_t)row * (2 * DCL_CP);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = x[q] * inv * 1024.0f;
+            const _Float16 hi = (_Float16)v;
+            oh[lane + 64 * q] = hi;
+            oh[DCL_CP + lane + 64 * q] = (_Float16)(v - (float)hi);
+        }
+    }
     if (lane == 0)
         nrm[row] = norm;
 }
@@ -44,14 +55,15 @@ __global__ __launch_bounds__(256) void k_gather_normalize(
 extern "C" int dcl_gather_normalize(const float *feat, int64_t stride_n, int64_t stride_c,
                                     int64_t stride_p, int C, const int32_t *pix,
                                     const int32_t *pair_b, const int32_t *slot_pair, int T, int V,
-                                    float *bank, float *nrm, void *stream)
+                                    float *bank, float *nrm, void *bank_h, void *stream)
 {
     DCL_CHECK_ARG(feat && pix && pair_b && slot_pair && bank && nrm, "null pointer");
     DCL_CHECK_ARG(C > 0 && C <= DCL_CP, "embedding width must be in [1, 256]");
     DCL_CHECK_ARG(T > 0 && V > 0, "empty bank");
     const int N = T * V, Npad = dcl_round_up(N, DCL_ROW_TILE);
     hipLaunchKernelGGL(k_gather_normalize, dim3(Npad / 4), dim3(256), 0, (hipStream_t)stream, feat,
-                       stride_n, stride_c, stride_p, C, pix, pair_b, slot_pair, N, V, Npad, bank, nrm);
+                       stride_n, stride_c, stride_p, C, pix, pair_b, slot_pair, N, V, Npad, bank, nrm,
+                       (_Float16 *)bank_h);
     DCL_LAUNCH_CHECK();
     return 0;
 }

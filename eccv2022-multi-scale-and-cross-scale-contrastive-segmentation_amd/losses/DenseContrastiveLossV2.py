@@ -64,6 +64,11 @@ class DenseContrastiveLossV2(nn.Module):
         # extension, default off = reference semantics: contrast against the banks of ALL ranks
         # (RCCL all-gather of the sampled embeddings; gradients stay rank-local)
         self.global_negatives = bool(config.get('global_negatives', False))
+        # similarity-product arithmetic: 'f32' (exact fp32 MFMA) or 'f16x3' (split-f16 MFMA, fp32-equivalent);
+        # config key 'mfma_mode', overridable with the DCL_MFMA environment variable
+        import os
+        self.mfma_mode = os.environ.get('DCL_MFMA', config.get('mfma_mode', 'f32'))
+        assert self.mfma_mode in ('f32', 'f16x3'), f"mfma_mode must be 'f32' or 'f16x3', got {self.mfma_mode}"
         if self.label_scaling_mode == 'nn':
             assert self.dominant_mode == 'all', \
                 'cannot use label_scaling_mode: "{}" with dominant_mode: "{}" - only "all" is allowed'.format(
@@ -74,7 +79,7 @@ class DenseContrastiveLossV2(nn.Module):
                    min_views_per_class=int(self.min_views_per_class),
                    max_views_per_class=int(self.max_views_per_class),
                    max_features_total=int(self.max_features_total),
-                   global_negatives=bool(self.global_negatives))
+                   global_negatives=bool(self.global_negatives), mfma=self.mfma_mode)
         cfg.update(over)
         return EngineConfig(**cfg)
 

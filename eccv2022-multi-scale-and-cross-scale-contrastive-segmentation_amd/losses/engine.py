@@ -43,6 +43,9 @@ class EngineConfig:
     # extension (not in the reference, SURVEY.md section 8 row e): contrast against the all-gathered
     # banks of every rank instead of the rank-local bank only.  Off = reference semantics.
     global_negatives: bool = False
+    # similarity-product arithmetic of the sweep kernels: "f32" = v_mfma_f32_32x32x2_f32 (exact fp32),
+    # "f16x3" = three f16 MFMA passes on (hi, lo)-split operands, fp32-equivalent accuracy (csrc/dcl_sweep.hip)
+    mfma: str = "f32"
 
 
 @dataclass
@@ -58,6 +61,7 @@ class _Scale:
     sel: torch.Tensor = None
     pix: torch.Tensor = None             # int32 [T, V]
     bank: torch.Tensor = None            # f32 [Npad, 256]
+    bank_h: torch.Tensor = None          # f16 [Npad, 512] = (hi | lo) halves of bank * 2^10 (f16x3 mode)
     nrm: torch.Tensor = None             # f32 [Npad]
     lbl_s: torch.Tensor = None
 
@@ -91,6 +95,7 @@ class _Seg:
     rng_hi: torch.Tensor
     own: bool                            # rows of this segment are this rank's own bank rows
     nsplit: int = 1
+    bank_h: torch.Tensor = None          # f16x3 copy of ``bank`` (own segments only; None -> f32 product)
 
 
 class StepState:
@@ -346,8 +351,8 @@ def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torc
     return st
 
 
-def build_banks(st: StepState, feats: Sequence[torch.Tensor]):
-    """K3 for every scale."""
+def build_banks(st: StepState, feats: Sequence[torch.Tensor], f16x3: bool = False):
+    """K3 for every scale (optionally also the f16x3 copy of each bank)."""
     L = _lib.lib()
     stream = _stream_ptr()
     for sc, f in zip(st.scales, feats):
@@ -355,10 +360,11 @@ def build_banks(st: StepState, feats: Sequence[torch.Tensor]):
         Npad = _npad(p.N)
         sc.bank = torch.empty((Npad, _lib.CP), dtype=torch.float32, device=f.device)
         sc.nrm = torch.empty((Npad,), dtype=torch.float32, device=f.device)
+        sc.bank_h = torch.empty((Npad, 2 * _lib.CP), dtype=torch.float16, device=f.device) if f16x3 else None
         sn, scs, sp = sc.strides
         _lib.check(L.dcl_gather_normalize(_lib.ptr(f), sn, scs, sp, sc.C, _lib.ptr(sc.pix),
                                           _lib.ptr(sc.pair_b), _lib.ptr(sc.slot_pair), p.T, p.V,
-                                          _lib.ptr(sc.bank), _lib.ptr(sc.nrm), stream),
+                                          _lib.ptr(sc.bank), _lib.ptr(sc.nrm), _lib.ptr(sc.bank_h), stream),
                    "dcl_gather_normalize")
 
 
@@ -368,7 +374,7 @@ def _own_segments(st: StepState):
     for t in st.terms:
         B = st.scales[t.b]
         t.segs = [_Seg(bank=B.bank, N=B.plan.N, rng_lo=t.rng_lo, rng_hi=t.rng_hi, own=True,
-                       nsplit=int(L.dcl_suggest_nsplit(st.scales[t.a].plan.N, B.plan.N)))]
+                       nsplit=int(L.dcl_suggest_nsplit(st.scales[t.a].plan.N, B.plan.N)), bank_h=B.bank_h)]
         t.pcount = None
 
 
@@ -434,7 +440,8 @@ def attach_global_segments(st: StepState, rank: int, peer_banks, peer_layouts):
             own = q == rank
             bank = st.scales[t.b].bank if own else peer_banks[q][t.b]
             t.segs.append(_Seg(bank=bank, N=Nq, rng_lo=view(lo_id), rng_hi=view(hi_id), own=own,
-                               nsplit=min(per_seg, max(1, (Nq + 31) // 32))))
+                               nsplit=min(per_seg, max(1, (Nq + 31) // 32)),
+                               bank_h=st.scales[t.b].bank_h if own else None))   # peers: f32 product
         t.pcount = view(pc_id)
 
 
@@ -490,16 +497,20 @@ def run_forward_terms(st: StepState):
         inv_tau = 1.0 / t.tau
         off = 0
         for sg in t.segs:
+            ah = A.bank_h if sg.bank_h is not None else None
             _lib.check(L.dcl_infonce_zsweep(_lib.ptr(A.bank), N1, V1, _lib.ptr(sg.bank), sg.N,
                                             _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi), inv_tau, sg.nsplit,
-                                            _lib.ptr(zpart[off * N1pad:]), stream), "dcl_infonce_zsweep")
+                                            _lib.ptr(zpart[off * N1pad:]), _lib.ptr(ah), _lib.ptr(sg.bank_h),
+                                            stream), "dcl_infonce_zsweep")
             off += sg.nsplit
         for k, sg in enumerate(t.segs):
             _lib.check(L.dcl_infonce_possweep(_lib.ptr(A.bank), N1, V1, _lib.ptr(sg.bank), sg.N,
                                               _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi), inv_tau,
                                               1 if (t.intra and sg.own) else 0, _lib.ptr(zpart), zs_total,
                                               0 if k == 0 else 1, _lib.ptr(t.Z), _lib.ptr(rowloss),
-                                              _lib.ptr(t.W), stream), "dcl_infonce_possweep")
+                                              _lib.ptr(t.W),
+                                              _lib.ptr(A.bank_h if sg.bank_h is not None else None),
+                                              _lib.ptr(sg.bank_h), stream), "dcl_infonce_possweep")
         first = t.segs[0]
         _lib.check(L.dcl_infonce_loss(_lib.ptr(rowloss), _lib.ptr(first.rng_lo), _lib.ptr(first.rng_hi),
                                       _lib.ptr(t.pcount), N1, V1, 1 if t.intra else 0,
@@ -514,7 +525,7 @@ class DenseContrastFunction(torch.autograd.Function):
     def forward(ctx, cfg: EngineConfig, label: torch.Tensor, holder: dict, *feats):
         with_cross = bool(cfg.cross_scale_contrast) and len(feats) > 1
         st = plan_and_sample(cfg, label, feats, with_cross, staged=holder.get("staged"))
-        build_banks(st, feats)
+        build_banks(st, feats, f16x3=(cfg.mfma == "f16x3"))
         peers = holder.get("emulated_peers")
         if peers is not None:                       # single-process emulation of other ranks (tests)
             rank, peer_banks, peer_layouts = peers
@@ -571,7 +582,9 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
                                              _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi), inv_tau,
                                              1 if sym else 0, 1, 1 if sym else 0, _lib.ptr(stat),
                                              _lib.ptr(stat) if sym else None, sg.nsplit,
-                                             _lib.ptr(dpart), stream), "dcl_infonce_bwd")
+                                             _lib.ptr(dpart),
+                                             _lib.ptr(A.bank_h if sg.bank_h is not None else None),
+                                             _lib.ptr(sg.bank_h), stream), "dcl_infonce_bwd")
                 slabs[t.a] += [dpart[i] for i in range(sg.nsplit)]
         if want_b:
             # G^T F1 restricted to this rank's rows of bank b (they are columns of the own segment)
@@ -579,7 +592,8 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
             dpart = torch.empty((ns, N2pad, _lib.CP), dtype=torch.float32, device=dev)
             _lib.check(L.dcl_infonce_bwd(_lib.ptr(B.bank), N2, B.plan.V, _lib.ptr(A.bank), N1,
                                          _lib.ptr(t.rev_lo), _lib.ptr(t.rev_hi), inv_tau, 0, 0, 1,
-                                         None, _lib.ptr(stat), ns, _lib.ptr(dpart), stream),
+                                         None, _lib.ptr(stat), ns, _lib.ptr(dpart), _lib.ptr(B.bank_h),
+                                         _lib.ptr(A.bank_h if B.bank_h is not None else None), stream),
                        "dcl_infonce_bwd")
             slabs[t.b] += [dpart[i] for i in range(ns)]
     grads = []

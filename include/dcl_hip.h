@@ -86,6 +86,7 @@ int dcl_rank_select(const uint8_t *lbl_s, const int32_t *seg_hist, int n, int hw
 int dcl_gather_normalize(const float *feat, int64_t stride_n, int64_t stride_c, int64_t stride_p,
                          int C, const int32_t *pix, const int32_t *pair_b,
                          const int32_t *slot_pair, int T, int V, float *bank, float *nrm,
+                         void *bank_h /* f16 [Npad, 2*DCL_CP] = (hi | lo) halves of bank * 2^10, or NULL */,
                          void *stream);
 
 /* Reference-layout raw bank X[t, c, v] = features[b_t, c, pix[t, v]] (the `sampled_features`
@@ -123,14 +124,18 @@ int dcl_infonce_fwd(const float *A, int N1, int V1, const float *B, int N2,
  *             or adds (accumulate = 1) rowloss / W.  Call in a fixed segment order.
  *   loss      -(1/N1) sum_i rowloss_i / P_i with P_i = pcount[i / V1] if pcount != NULL (positives over
  *             all segments, self already excluded), else derived from rng_lo/hi as in dcl_infonce_fwd.
+ *
+ * Ah / Bh (both or neither): the banks in f16x3 format (dcl_gather_normalize's bank_h).  When given, the
+ * similarity product <A_i, B_j> runs as three f16 MFMA passes (hi.hi + hi.lo + lo.hi, f32 accumulation,
+ * fp32-equivalent accuracy) instead of f32 MFMA; everything downstream is unchanged.
  */
 int dcl_infonce_zsweep(const float *A, int N1, int V1, const float *B, int N2,
                        const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int nsplit,
-                       float *zpart, void *stream);
+                       float *zpart, const void *Ah, const void *Bh, void *stream);
 int dcl_infonce_possweep(const float *A, int N1, int V1, const float *B, int N2,
                          const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int intra,
                          const float *zpart, int zsplits, int accumulate, float *Z, float *rowloss,
-                         float *W, void *stream);
+                         float *W, const void *Ah, const void *Bh, void *stream);
 int dcl_infonce_loss(const float *rowloss, const int32_t *rng_lo, const int32_t *rng_hi,
                      const int32_t *pcount, int N1, int V1, int intra, float *loss, void *stream);
 
@@ -154,7 +159,8 @@ int dcl_infonce_prep_stats(const float *Z, const float *W, const int32_t *rng_lo
 int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, int N2,
                     const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int intra,
                     int use_row, int use_col, const float *rstat, const float *cstat, int nsplit,
-                    float *dpart, void *stream);
+                    float *dpart, const void *Ah /* f16x3 banks, see dcl_infonce_zsweep */,
+                    const void *Bh, void *stream);
 
 /* ---- K6 ---------------------------------------------------------------------------------
  * Sum the partial dF slabs of a bank in a fixed order, apply the VJP of F.normalize

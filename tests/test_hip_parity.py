@@ -295,10 +295,10 @@ def test_c_abi_direct_infonce_cross(dev, oracle):
                                         p(stat), st), "prep")
     dp1 = torch.empty(ns, N1pad, 256, device=dev)
     _lib.check(L.dcl_infonce_bwd(p(A), N1, V1, p(B), N2, p(lo_d), p(hi_d), 1 / tau, 0, 1, 0, p(stat), None,
-                                 ns, p(dp1), st), "bwd1")
+                                 ns, p(dp1), None, None, st), "bwd1")
     dp2 = torch.empty(ns, N2pad, 256, device=dev)
     _lib.check(L.dcl_infonce_bwd(p(B), N2, V2, p(A), N1, p(rlo_d), p(rhi_d), 1 / tau, 0, 0, 1, None, p(stat),
-                                 ns, p(dp2), st), "bwd2")
+                                 ns, p(dp2), None, None, st), "bwd2")
     _check_grad(dp1.sum(0)[:N1].cpu().numpy(), d1)
     _check_grad(dp2.sum(0)[:N2].cpu().numpy(), d2)
 
