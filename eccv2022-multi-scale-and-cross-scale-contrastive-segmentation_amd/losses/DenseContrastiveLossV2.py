@@ -67,7 +67,7 @@ class DenseContrastiveLossV2(nn.Module):
         # similarity-product arithmetic: 'f32' (exact fp32 MFMA) or 'f16x3' (split-f16 MFMA, fp32-equivalent);
         # config key 'mfma_mode', overridable with the DCL_MFMA environment variable
         import os
-        self.mfma_mode = os.environ.get('DCL_MFMA', config.get('mfma_mode', 'f32'))
+        self.mfma_mode = os.environ.get('DCL_MFMA', config.get('mfma_mode', 'f16x3'))
         assert self.mfma_mode in ('f32', 'f16x3'), f"mfma_mode must be 'f32' or 'f16x3', got {self.mfma_mode}"
         if self.label_scaling_mode == 'nn':
             assert self.dominant_mode == 'all', \

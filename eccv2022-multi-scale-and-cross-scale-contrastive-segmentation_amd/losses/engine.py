@@ -45,7 +45,7 @@ class EngineConfig:
     global_negatives: bool = False
     # similarity-product arithmetic of the sweep kernels: "f32" = v_mfma_f32_32x32x2_f32 (exact fp32),
     # "f16x3" = three f16 MFMA passes on (hi, lo)-split operands, fp32-equivalent accuracy (csrc/dcl_sweep.hip)
-    mfma: str = "f32"
+    mfma: str = "f16x3"
 
 
 @dataclass

@@ -76,12 +76,16 @@ def test_single_scale_vs_reference(dev, name):
         assert out[3] is False
 
 
+@pytest.mark.parametrize("mfma", ["f16x3", "f32"])
 @pytest.mark.parametrize("name", golden_names(["G2", "G4", "G5", "G9"]))
-def test_multi_scale_vs_reference(dev, name):
+def test_multi_scale_vs_reference(dev, name, mfma, monkeypatch):
+    """Both similarity-product arithmetics (split-f16 MFMA and exact-f32 MFMA) against the reference."""
     from mscs_amd.losses import DenseContrastiveLossV2_ms
+    monkeypatch.delenv("DCL_MFMA", raising=False)
     g = load_golden(name)
     c = g["config"]
-    mod = DenseContrastiveLossV2_ms(_module_cfg(c))
+    mod = DenseContrastiveLossV2_ms(dict(_module_cfg(c), mfma_mode=mfma))
+    assert mod.DCV2_scale0.mfma_mode == mfma
     _apply_overrides(mod, c)
     S = mod.scales
     feats = [torch.from_numpy(g[f"feat{s}"]).to(dev).requires_grad_(True) for s in range(S)]
@@ -187,7 +191,8 @@ def test_deterministic_bitwise(dev):
         assert torch.equal(a, b)
 
 
-def test_properties_at_baseline_config2_size(dev):
+@pytest.mark.parametrize("mfma", ["f16x3", "f32"])
+def test_properties_at_baseline_config2_size(dev, mfma, monkeypatch):
     """BASELINE config 2 (n=12, 512x1024, K=20, C=256, 3 scales + cross-scale), size-independent checks:
     sampled pixels have the pair's class and are unique; the gradient lives only on sampled pixels
     and is orthogonal to the feature vector there (VJP of the L2 normalisation); scaling the features
@@ -198,8 +203,9 @@ def test_properties_at_baseline_config2_size(dev):
     label = torch.randint(0, K, (n, H, W), generator=gen).to(dev)
     feats = [torch.randn(n, C, H // s, W // s, generator=gen).to(dev).requires_grad_(True)
              for s in (4, 8, 16)]
+    monkeypatch.delenv("DCL_MFMA", raising=False)
     cfg = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": 3,
-           "weights": [1.0, 0.7, 0.4], "cross_scale_contrast": True}
+           "weights": [1.0, 0.7, 0.4], "cross_scale_contrast": True, "mfma_mode": mfma}
     mod = DenseContrastiveLossV2_ms(cfg)
     torch.manual_seed(0)
     loss = mod(label, feats)
