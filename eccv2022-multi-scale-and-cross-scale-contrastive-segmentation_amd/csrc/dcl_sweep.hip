@@ -292,10 +292,14 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                 }
             }
         } else {
-            // Tiles without positives (the common case) defer their epilogue H = e * (cW_i + cW_j) into the
-            // second product's loop, one register ahead of its use, so the exp/mul VALU work issues between
-            // MFMAs instead of stalling the matrix pipe for a whole tile.  Mixed tiles take the full formula.
-            if (!plain) {
+            // Tiles without positives (the common case): H = e * (cW_i + cW_j), no masks.
+            // (Folding this epilogue into the second product's loop was tried: the VALU ops then sit right in
+            // front of the MFMA that consumes them and cost 3-5 % -- kept as one block per tile.)
+            if (plain) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[r] = __builtin_amdgcn_exp2f(acc[r] * p.c1) * (rcW + ccw[r]);
+            } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int jj = j0 + jrow(r, h);
@@ -324,26 +328,22 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                 f32x4 u0 = *(const f32x4 *)(b0 + jrow(0, h) * ROWF);
                 f32x4 u1 = *(const f32x4 *)(b0 + jrow(0, h) * ROWF + 128);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // prologue reads of step 0
-                float hcur = plain ? __builtin_amdgcn_exp2f(acc[0] * p.c1) * (rcW + ccw[0]) : acc[0];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rn = r < 15 ? r + 1 : 15;
                     const f32x4 n0 = *(const f32x4 *)(b0 + jrow(rn, h) * ROWF);
                     const f32x4 n1 = *(const f32x4 *)(b0 + jrow(rn, h) * ROWF + 128);
-                    const float hnext =
-                        plain ? __builtin_amdgcn_exp2f(acc[rn] * p.c1) * (rcW + ccw[rn]) : acc[rn];
-                    dacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(hcur, u0.x, dacc[0], 0, 0, 0);
-                    dacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(hcur, u0.y, dacc[1], 0, 0, 0);
-                    dacc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(hcur, u0.z, dacc[2], 0, 0, 0);
-                    dacc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(hcur, u0.w, dacc[3], 0, 0, 0);
-                    dacc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(hcur, u1.x, dacc[4], 0, 0, 0);
-                    dacc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(hcur, u1.y, dacc[5], 0, 0, 0);
-                    dacc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(hcur, u1.z, dacc[6], 0, 0, 0);
-                    dacc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(hcur, u1.w, dacc[7], 0, 0, 0);
+                    dacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u0.x, dacc[0], 0, 0, 0);
+                    dacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u0.y, dacc[1], 0, 0, 0);
+                    dacc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u0.z, dacc[2], 0, 0, 0);
+                    dacc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u0.w, dacc[3], 0, 0, 0);
+                    dacc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u1.x, dacc[4], 0, 0, 0);
+                    dacc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u1.y, dacc[5], 0, 0, 0);
+                    dacc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u1.z, dacc[6], 0, 0, 0);
+                    dacc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], u1.w, dacc[7], 0, 0, 0);
                     DCL_SCHED_MFMA_DS_MFMA(2, 8);
                     u0 = n0;
                     u1 = n1;
-                    hcur = hnext;
                 }
             }
         }
