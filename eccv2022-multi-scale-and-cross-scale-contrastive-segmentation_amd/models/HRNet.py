@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
-from .ops import conv3x3_gemm_wrw, upsample_bilinear
+from .ops import conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear
 from .fused_bn import FusedBatchNorm2d, bn_act
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
@@ -366,11 +366,17 @@ class HRNet(nn.Module):
         # weight gradient of the head's big 3x3 conv as im2col + rocBLAS GEMM (2.4x MIOpen's default
         # fp32 solver on MI355X, models/ops.py); same forward, same state_dict
         self.gemm_wrw_head = bool(config.get('gemm_wrw_head', True))
+        # 'f16x3': all three directions of that conv as split-f16 GEMMs at fp32-equivalent accuracy (models/ops.py);
+        # 'gemm_wrw': only the weight gradient as an f32 GEMM; 'library': MIOpen for everything
+        self.head_conv = config.get('head_conv', 'f16x3' if self.gemm_wrw_head else 'library')
 
     def _head(self, x):
-        if self.gemm_wrw_head and self.training and x.is_cuda and x.dtype == torch.float32 \
+        if self.head_conv != 'library' and self.training and x.is_cuda and x.dtype == torch.float32 \
                 and torch.is_grad_enabled() and not torch.is_autocast_enabled():
-            x = conv3x3_gemm_wrw(x, self.cls_head[0])
+            if self.head_conv == 'f16x3' and x.shape[-1] % 8 == 0:
+                x = conv3x3_f16x3(x, self.cls_head[0])
+            else:
+                x = conv3x3_gemm_wrw(x, self.cls_head[0])
             return self.cls_head[2](self.cls_head[1](x))
         return self.cls_head(x)
 
