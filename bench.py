@@ -31,6 +31,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+MFMA_F16_PEAK_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+# f16x3 backward sweep: the S recompute (2NMC algorithmic FLOP) is issued as 3 f16 MFMA passes, the H.B product
+# (2NMC) as f32 MFMA.  Its matrix-pipe roofline for the 4NMC algorithmic FLOP is therefore
+# 4 / (3*2/2500 + 2/157.3) = 264.6 TFLOP/s.
+MFMA_F16X3_BWD_PEAK_TFLOPS = 4.0 / (3 * 2.0 / MFMA_F16_PEAK_TFLOPS + 2.0 / MFMA_F32_PEAK_TFLOPS)
 
 
 def parse():
@@ -145,15 +150,25 @@ def roofline_bwd_kernel(mod, iters=10):
     ms = e0.elapsed_time(e1) / iters
     flops = 4.0 * N * N * 256
     achieved = flops / (ms * 1e-3) / 1e12
-    # HBM traffic per launch of this kernel at N = 9804 from the committed PMC passes
-    # (profiles/r01_loss_pmc_fetch.csv / _write.csv): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the
-    # gfx950 correction in MI355X_MICROARCH.md; only valid for the benchmark shape, else null
-    traffic = (2 * 102168.7 + 128128.0) * 1024 if (N == 9804 and ns == 13) else None
-    return {"bound": "mfma", "kernel": "k_sweep<MODE_BWD> (dcl_infonce_bwd)", "achieved": round(achieved, 2),
-            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+    mode = mod.DCV2_scale0.mfma_mode
+    peak = MFMA_F16X3_BWD_PEAK_TFLOPS if mode == "f16x3" else MFMA_F32_PEAK_TFLOPS
+    # HBM traffic per launch of this kernel at N = 9804 from the committed PMC passes (profiles/README.md):
+    # (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the gfx950 correction in MI355X_MICROARCH.md;
+    # only valid for the benchmark shape, else null
+    pmc = {"f32": (102168.7, 128128.0), "f16x3": PMC_F16X3}.get(mode)
+    traffic = (2 * pmc[0] + pmc[1]) * 1024 if (pmc and N == 9804 and ns == 13) else None
+    return {"bound": "mfma", "kernel": f"k_sweep<MODE_BWD> (dcl_infonce_bwd), similarity product in {mode}",
+            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "peak_note": ("f32 MFMA 157.3 TFLOP/s" if mode == "f32" else
+                          "mixed matrix-pipe roofline of the 4NMC algorithmic FLOP: S recompute as 3 f16 MFMA passes "
+                          "(2.5 PFLOP/s) + H.B in f32 MFMA (157.3 TFLOP/s) = 264.6 TFLOP/s"),
             "traffic": traffic, "traffic_source": "profiles/r01_loss_pmc_fetch.csv, r01_loss_pmc_write.csv",
             "algorithmic_bytes": 3 * N * 256 * 4, "launch_ms": round(ms, 4), "N1": N, "N2": N, "C": 256,
             "nsplit": ns}
+
+
+PMC_F16X3 = None      # filled from profiles/ once the f16x3 PMC passes are committed
 
 
 def cpu_baseline_loss(args, n_terms):

@@ -69,9 +69,11 @@ __global__ void k_bn_combine(const float *__restrict__ part, int C, int nslice, 
                              float *__restrict__ o0, float *__restrict__ o1, int finalize, double count,
                              float eps, float momentum, float *__restrict__ mean,
                              float *__restrict__ invstd, float *__restrict__ running_mean,
-                             float *__restrict__ running_var)
+                             float *__restrict__ running_var, long long *__restrict__ batches_tracked)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && batches_tracked)
+        batches_tracked[0] += 1;                 // nn.BatchNorm2d.num_batches_tracked, without its own launch
     if (c >= C)
         return;
     double a = 0.0, b = 0.0;
@@ -275,7 +277,7 @@ extern "C" int dcl_bn_stats(const float *x, int N, int C, int HW, float *part, f
     DCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums,
                        (float *)nullptr, (float *)nullptr, 0, 1.0, 0.f, 0.f, (float *)nullptr,
-                       (float *)nullptr, (float *)nullptr, (float *)nullptr);
+                       (float *)nullptr, (float *)nullptr, (float *)nullptr, (long long *)nullptr);
     DCL_LAUNCH_CHECK();
     return 0;
 }
@@ -283,7 +285,8 @@ extern "C" int dcl_bn_stats(const float *x, int N, int C, int HW, float *part, f
 // Single-rank forward statistics: dcl_bn_stats + dcl_bn_finalize in two launches instead of three.
 extern "C" int dcl_bn_stats_finalize(const float *x, int N, int C, int HW, float eps, float momentum,
                                      float *part, float *sums, float *mean, float *invstd,
-                                     float *running_mean, float *running_var, void *stream)
+                                     float *running_mean, float *running_var, int64_t *batches_tracked,
+                                     void *stream)
 {
     DCL_CHECK_ARG(x && part && sums && mean && invstd && N > 0 && C > 0 && HW > 0, "bad arguments");
     const int ns = pick_slices(N, C);
@@ -292,7 +295,7 @@ extern "C" int dcl_bn_stats_finalize(const float *x, int N, int C, int HW, float
     DCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums,
                        (float *)nullptr, (float *)nullptr, 1, (double)N * HW, eps, momentum, mean, invstd,
-                       running_mean, running_var);
+                       running_mean, running_var, (long long *)batches_tracked);
     DCL_LAUNCH_CHECK();
     return 0;
 }
@@ -339,7 +342,7 @@ extern "C" int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y
     DCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums, dbeta,
                        dgamma, 0, 1.0, 0.f, 0.f, (float *)nullptr, (float *)nullptr, (float *)nullptr,
-                       (float *)nullptr);
+                       (float *)nullptr, (long long *)nullptr);
     DCL_LAUNCH_CHECK();
     return 0;
 }

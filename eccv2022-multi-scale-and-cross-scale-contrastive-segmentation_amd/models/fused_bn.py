@@ -29,7 +29,7 @@ def _world():
 
 class _FusedBNFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, eps, momentum, relu, sync):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, sync):
         L = _lib.lib()
         N, C, H, W = x.shape
         HW = H * W
@@ -45,10 +45,12 @@ class _FusedBNFunction(torch.autograd.Function):
         if world == 1:
             _lib.check(L.dcl_bn_stats_finalize(_lib.ptr(x), N, C, HW, eps, momentum, _lib.ptr(part),
                                                _lib.ptr(sums), _lib.ptr(mean), _lib.ptr(invstd),
-                                               _lib.ptr(running_mean), _lib.ptr(running_var), st),
+                                               _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(nbt), st),
                        "dcl_bn_stats_finalize")
         else:
             import torch.distributed as dist
+            if nbt is not None:
+                nbt.add_(1)
             _lib.check(L.dcl_bn_stats(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(sums), st), "dcl_bn_stats")
             dist.all_reduce(sums)
             _lib.check(L.dcl_bn_finalize(_lib.ptr(sums), C, count, eps, momentum, _lib.ptr(mean),
@@ -91,7 +93,7 @@ class _FusedBNFunction(torch.autograd.Function):
         _lib.check(L.dcl_bn_bwd_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
                                       _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(sums), ctx.count, N, C,
                                       HW, relu, _lib.ptr(dx), _lib.ptr(dres), st), "dcl_bn_bwd_apply")
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class FusedBatchNorm2d(nn.BatchNorm2d):
@@ -107,11 +109,9 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
 
     def forward(self, x, residual=None, relu=False):
         if self._fusable(x, residual):
-            if self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
             return _FusedBNFunction.apply(x, residual, self.weight, self.bias, self.running_mean,
-                                          self.running_var, float(self.eps), float(self.momentum), bool(relu),
-                                          bool(self.sync))
+                                          self.running_var, self.num_batches_tracked, float(self.eps),
+                                          float(self.momentum), bool(relu), bool(self.sync))
         y = super().forward(x)
         if residual is not None:
             y = y + residual

@@ -188,7 +188,8 @@ int dcl_bn_num_slices(int N, int C);
 int dcl_bn_stats(const float *x, int N, int C, int HW, float *part, float *sums, void *stream);
 int dcl_bn_stats_finalize(const float *x, int N, int C, int HW, float eps, float momentum, float *part,
                           float *sums, float *mean, float *invstd, float *running_mean,
-                          float *running_var, void *stream);   /* single-rank: stats + finalize */
+                          float *running_var, int64_t *batches_tracked /* += 1, or NULL */,
+                          void *stream);   /* single-rank: stats + finalize */
 int dcl_bn_finalize(const float *sums, int C, double count, float eps, float momentum, float *mean,
                     float *invstd, float *running_mean, float *running_var, void *stream);
 int dcl_bn_apply(const float *x, const float *res, const float *mean, const float *invstd,
