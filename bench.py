@@ -155,7 +155,7 @@ def roofline_bwd_kernel(mod, iters=10):
     # HBM traffic per launch of this kernel at N = 9804 from the committed PMC passes (profiles/README.md):
     # (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the gfx950 correction in MI355X_MICROARCH.md;
     # only valid for the benchmark shape, else null
-    pmc = {"f32": (102168.7, 128128.0), "f16x3": PMC_F16X3}.get(mode)
+    pmc = {"f32": (102168.7, 128128.0), "f16x3": PMC_F16X3}.get(mode)       # f32 pair: round-1 f32 passes (README)
     traffic = (2 * pmc[0] + pmc[1]) * 1024 if (pmc and N == 9804 and ns == 13) else None
     return {"bound": "mfma", "kernel": f"k_sweep<MODE_BWD> (dcl_infonce_bwd), similarity product in {mode}",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -168,7 +168,7 @@ def roofline_bwd_kernel(mod, iters=10):
             "nsplit": ns}
 
 
-PMC_F16X3 = None      # filled from profiles/ once the f16x3 PMC passes are committed
+PMC_F16X3 = (160553.9, 128128.0)      # KiB per launch (FETCH_SIZE, WRITE_SIZE), profiles/r01_loss_pmc_*.csv
 
 
 def cpu_baseline_loss(args, n_terms):
