@@ -11,9 +11,12 @@ Workloads (BASELINE.json configs[1]: HRNet-W48 + DenseContrastiveLossV2_ms (3 sc
 Cityscapes 512x1024, batch 12 per GPU):
   step  one training step: model forward, LossWrapper(CE + 0.1 * DCV2_ms), backward, SGD update
   loss  the contrastive loss alone (forward + backward) on synthetic 256-d projector outputs
-Extra keys: `roofline` (dominant kernel = InfoNCE backward sweep, algorithmic FLOPs over HIP-event
-time), `cpu_baseline` (oracle/eager_torch.py on the host cores, bounded sample), and
-`contrastive_loss_fwd_bwd_ms`.
+Extra keys: `roofline` (dominant hot-path kernel = InfoNCE backward sweep, algorithmic FLOPs over HIP-event
+time, peak per arithmetic mode), `cpu_baseline` (oracle/eager_torch.py + the same model code on the host cores,
+bounded sample), `contrastive_loss_fwd_bwd_ms`, and with --eager-baseline the eager-structure torch loss on the
+GPU.  `dtype` "f32" = fp32-equivalent arithmetic: fp32 storage and accumulation everywhere; the loss's similarity
+product and the head convolution run as split-f16 (hi, lo) MFMA passes whose results match fp32 to round-off
+(DESIGN.md section 3); `--mfma f32` and graph key head_conv='library' select plain f32 MFMA / MIOpen instead.
 """
 import argparse
 import contextlib
@@ -266,9 +269,8 @@ def time_train_step(args, dev, rank, world):
     if args.channels_last:
         img = img.contiguous(memory_format=torch.channels_last)
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if args.amp else contextlib.nullcontext()
-    loss_ms = []
 
-    def step(measure_loss=False):
+    def step():
         mgr.optimiser.zero_grad(set_to_none=True)
         with amp:
             ret = mgr.forward_step(img, lbl)
