@@ -38,6 +38,8 @@ enum { MODE_Z = 0, MODE_POS = 1, MODE_BWD = 2 };
 // The dropped lo.lo term is 2^-22 relative.  A bank row in this format is [256 hi | 256 lo] halves = 1 KiB,
 // the same size as the f32 row, so staging and LDS geometry are unchanged.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4 LDS_FP16X4;
 constexpr int ROWH = 2 * ROWF;          // LDS row stride in halves (1040 B)
 constexpr float F16_SCALE_SQ_INV = 1.0f / 1048576.0f;   // 2^-20
 
@@ -103,9 +105,9 @@ __device__ __forceinline__ int jrow(int r, int h) { return (r & 3) + 8 * (r >> 2
 template <int MODE, bool USE_COL, bool F16>
 __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepArgs p)
 {
-    // per buffer: the chunk in the similarity product's format; f16x3 backward also needs the f32 rows for
-    // the second product (dA += H * B), stored behind the half rows
-    constexpr int BUF = (F16 && MODE == MODE_BWD) ? 2 * BUF_FLOATS : BUF_FLOATS;
+    // per buffer: one 32-row chunk of the contrast bank, f32 rows or (hi | lo) half rows (same 1040-B stride);
+    // in f16x3 mode both products of the backward read the half rows
+    constexpr int BUF = BUF_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -195,13 +197,25 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             rcZ = st.z;
         }
     }
+    // f16x3 second product: H is scaled by one power of two G for the whole launch so that |H * G| <= 2^14.
+    // The bound max|H| <= 2 * max_rows max(e^{1/tau} |cW|, |coef|) comes from dcl_infonce_prep_stats (extra row
+    // of the stat arrays); within it every |H| down to 2^-28 of the bound keeps a normal f16 hi part, which
+    // covers the whole range of e^{s}, s in [-1/tau, 1/tau], at tau = 0.1.
+    float hG = 1.f, hInv = 1.f;
+    if (F16 && MODE == MODE_BWD) {
+        float mmax = 0.f;
+        if (p.use_row)
+            mmax = p.rstat[(size_t)N1pad * 4];
+        if (USE_COL)
+            mmax = fmaxf(mmax, p.cstat[(size_t)((p.N2 + BM - 1) / BM * BM) * 4]);
+        hG = (mmax == 0.f) ? 1.f : exp2f(fminf(floorf(log2f(8192.0f / mmax)), 100.f));
+        hInv = 1.0f / (hG * 1024.0f);
+    }
 
     // ---- sweep
     auto stage = [&](float *dst, int j0s) {
         if (F16) {
             stage_chunk_h(dst, p.Bh, j0s, wave, lane);
-            if (MODE == MODE_BWD)
-                stage_chunk(dst + BUF_FLOATS, p.B, j0s, wave, lane);
         } else {
             stage_chunk(dst, p.B, j0s, wave, lane);
         }
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
     for (int c = c0; c < c1; ++c) {
         __syncthreads();       // (drains the LDS-DMA: chunk c has landed; everyone left chunk c-1)
         const float *cur = lds + ((c - c0) & 1) * BUF;
-        const float *buf = (F16 && MODE == MODE_BWD) ? cur + BUF_FLOATS : cur;    // f32 rows (second product)
+        const float *buf = cur;
         if (c + 1 < c1)
             stage(lds + ((c + 1 - c0) & 1) * BUF, (c + 1) * CJ);
         const int j0 = c * CJ;
@@ -320,6 +334,41 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                     acc[r] = pos ? hp : ((valid && !inr) ? hn : 0.f);
                 }
             }
+            if (F16) {
+                // dA[i][c] += sum_j H[j][i] * B[j0 + j][c] as f16x3: the accumulator registers 8kb .. 8kb+7 of
+                // this lane ARE, in order, the 8 k-slots of the A operand of k-block kb (k-slot (h, e) <-> chunk
+                // row 16 kb + 4 h + (e & 3) + 8 (e >> 2)); the matching B operand -- 4 consecutive chunk rows at
+                // one channel per lane -- comes straight out of the row-major half rows with the transposing LDS
+                // read ds_read_b64_tr_b16 (lane 4q+p of a 16-lane group supplies &tile[row q][col 4p] and
+                // receives column (lane % 16), rows 0..3; probed in tools/probes/tr_probe.hip).
+                const _Float16 *hb = (const _Float16 *)cur;
+                const int trq = (lane & 15) >> 2, trp = lane & 3;
+                const int colb = 16 * ((lane >> 4) & 1) + 4 * trp;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    half8 hh, hl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = acc[8 * kb + e] * hG;
+                        const _Float16 t = (_Float16)v;
+                        hh[e] = t;
+                        hl[e] = (_Float16)(v - (float)t);
+                    }
+                    const _Float16 *pa = hb + (16 * kb + 4 * h + trq) * ROWH + colb;
+                    const _Float16 *pb = pa + 8 * ROWH;
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) {
+                        union { half8 v; fp16x4 q[2]; } bh, bl;
+                        bh.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_FP16X4 *)(pa + 32 * ct));
+                        bh.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_FP16X4 *)(pb + 32 * ct));
+                        bl.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_FP16X4 *)(pa + CP + 32 * ct));
+                        bl.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_FP16X4 *)(pb + CP + 32 * ct));
+                        dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh, bh.v, dacc[ct], 0, 0, 0);
+                        dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh, bl.v, dacc[ct], 0, 0, 0);
+                        dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl, bh.v, dacc[ct], 0, 0, 0);
+                    }
+                }
+            } else {
             // dA[i][c] += sum_j H[j][i] * B[j0 + j][c]: acc register r IS the A-operand of k-step r.
             // Column permutation: MFMA (g, e) writes column li <-> channel c = 128 g + 4 li + e, so one
             // ds_read_b128 per (r, g) feeds four MFMAs and the final store is 16 B per lane.
@@ -346,6 +395,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                     u1 = n1;
                 }
             }
+            }
         }
     }
 
@@ -367,18 +417,28 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             p.W[i] = wsum;
         }
     } else {
-        float *out = p.dpart + ((size_t)split * N1pad + (size_t)rb * BM + wave * 32) * CP + 4 * li;
+        if (F16) {
+            // natural channel order (column li of MFMA ct <-> channel 32 ct + li), unscaled by 1 / (G * 2^10)
+            float *out = p.dpart + ((size_t)split * N1pad + (size_t)rb * BM + wave * 32) * CP + li;
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+            for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                f32x4 v;
-                v.x = dacc[4 * g + 0][r];
-                v.y = dacc[4 * g + 1][r];
-                v.z = dacc[4 * g + 2][r];
-                v.w = dacc[4 * g + 3][r];
-                *(f32x4 *)(out + (size_t)jrow(r, h) * CP + 128 * g) = v;
-            }
+                for (int r = 0; r < 16; ++r)
+                    out[(size_t)jrow(r, h) * CP + 32 * ct] = dacc[ct][r] * hInv;
+        } else {
+            float *out = p.dpart + ((size_t)split * N1pad + (size_t)rb * BM + wave * 32) * CP + 4 * li;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    f32x4 v;
+                    v.x = dacc[4 * g + 0][r];
+                    v.y = dacc[4 * g + 1][r];
+                    v.z = dacc[4 * g + 2][r];
+                    v.w = dacc[4 * g + 3][r];
+                    *(f32x4 *)(out + (size_t)jrow(r, h) * CP + 128 * g) = v;
+                }
+        }
     }
 }
 
@@ -435,6 +495,9 @@ __global__ __launch_bounds__(256) void k_prep_stats(const float *__restrict__ Z,
         o.x = Z[i];
         o.y = coef * W[i];
         o.z = coef * Z[i];
+        // bound of |dL/ds| terms this row can produce: negatives e^{s} |cW| <= e^{1/tau} |cW|, positives <= |coef|
+        const float m = fmaxf(expf(inv_tau) * fabsf(o.y), fabsf(coef));
+        atomicMax((unsigned int *)(stat + (size_t)N1pad * 4), __float_as_uint(m));    // m >= 0: uint order
     }
     *(f32x4 *)(stat + (size_t)i * 4) = o;
 }
@@ -549,6 +612,11 @@ extern "C" int dcl_infonce_prep_stats(const float *Z, const float *W, const int3
     DCL_CHECK_ARG(Z && W && stat && (pcount || (rng_lo && rng_hi)), "null pointer");
     DCL_CHECK_ARG(N1 > 0 && V1 > 0, "bad sizes");
     const int N1pad = dcl_round_up(N1, BM);
+    hipError_t e = hipMemsetAsync(stat + (size_t)N1pad * 4, 0, 4 * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) {
+        dcl_set_error("dcl_infonce_prep_stats: memset failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
     hipLaunchKernelGGL(k_prep_stats, dim3(N1pad / 256 + 1), dim3(256), 0, (hipStream_t)stream, Z, W,
                        rng_lo, rng_hi, pcount, N1, N1pad, V1, intra, wscale, inv_tau, grad_out, stat);
     DCL_LAUNCH_CHECK();

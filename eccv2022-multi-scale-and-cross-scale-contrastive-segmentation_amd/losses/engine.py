@@ -569,7 +569,7 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
             continue
         inv_tau = 1.0 / t.tau
         first = t.segs[0]
-        stat = torch.empty((N1pad, 4), dtype=torch.float32, device=dev)
+        stat = torch.empty((N1pad + 1, 4), dtype=torch.float32, device=dev)  # + bound row (dcl_hip.h)
         _lib.check(L.dcl_infonce_prep_stats(_lib.ptr(t.Z), _lib.ptr(t.W), _lib.ptr(first.rng_lo),
                                             _lib.ptr(first.rng_hi), _lib.ptr(t.pcount), N1, A.plan.V,
                                             1 if t.intra else 0, 1.0, inv_tau, _lib.ptr(g[idx:]),

@@ -149,7 +149,8 @@ int dcl_infonce_loss(const float *rowloss, const int32_t *rng_lo, const int32_t 
  *      cross, dF1:   A = F1, B = F2, use_row = 1, use_col = 0         (G F2 / tau)
  *      cross, dF2:   A = F2, B = F1, use_row = 0, use_col = 1, cstat = stats of F1's rows
  *                    (rng_* are then F2's slot ranges into F1)        (G^T F1 / tau)
- *   stat  f32 [N1pad, 4];   dpart f32 [nsplit, N1pad, DCL_CP]
+ *   stat  f32 [N1pad + 1, 4]: rows 0..N1pad-1 as above, row N1pad = {max_i max(e^{1/tau} |cW_i|, |coef_i|), 0, 0, 0}
+ *         (the bound the f16x3 backward uses to scale dL/ds into f16 range);   dpart f32 [nsplit, N1pad, DCL_CP]
  */
 int dcl_infonce_prep_stats(const float *Z, const float *W, const int32_t *rng_lo,
                            const int32_t *rng_hi, const int32_t *pcount /* may be NULL */, int N1,

@@ -296,7 +296,7 @@ def test_c_abi_direct_infonce_cross(dev, oracle):
     _lib.check(L.dcl_infonce_fwd(p(A), N1, V1, p(B), N2, p(lo_d), p(hi_d), 1 / tau, 0, ns, p(zpart), p(Z),
                                  p(rl), p(Wt), p(loss), st), "fwd")
     np.testing.assert_allclose(loss.item(), ref_loss, rtol=LOSS_RTOL)
-    stat = torch.empty(N1pad, 4, device=dev)
+    stat = torch.empty(N1pad + 1, 4, device=dev)
     _lib.check(L.dcl_infonce_prep_stats(p(Z), p(Wt), p(lo_d), p(hi_d), None, N1, V1, 0, 1.0, 1 / tau, None,
                                         p(stat), st), "prep")
     dp1 = torch.empty(ns, N1pad, 256, device=dev)
