@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cross", action="store_true")
     ap.add_argument("--mfma", default=None, choices=["f32", "f16x3"],
                     help="similarity-product arithmetic of the loss kernels (default: the library default)")
+    ap.add_argument("--branch-conv", default="f16x3", choices=["f16x3", "library"],
+                    help="backbone 3x3 convolutions: direct split-f16 kernel (fp32-equivalent) or MIOpen f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--amp", action="store_true", help="bf16 autocast for the model (loss stays fp32)")
     ap.add_argument("--channels-last", action="store_true")
@@ -240,7 +242,7 @@ def step_config(args, world):
         "name": "bench", "mode": "training", "manager": "HRNet", "cuda": True, "seed": 0,
         "parallel": world > 1, "batch_is_global": False, "channels_last": args.channels_last,
         "graph": {"model": "HRNet", "backbone": "hrnet48", "sync_bn": True, "out_stride": 4, "pretrained": False,
-                  "align_corners": True,
+                  "align_corners": True, "branch_conv": args.branch_conv,
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "before_context": True}},
         "data": {"dataset": "CITYSCAPES", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
                  "synthetic": True, "synthetic_length": args.batch * 2,

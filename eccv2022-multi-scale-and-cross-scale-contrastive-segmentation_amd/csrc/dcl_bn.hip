@@ -122,6 +122,26 @@ __global__ void k_bn_finalize(const float *__restrict__ sums, int C, double coun
 }
 
 // grid (ceil(HW/1024), N*C)
+// per-channel absmax side output (consumed by the f16x3 convolution to pick its power-of-two operand scale):
+// block maximum -> one integer atomicMax on the float bits (values are >= 0, so uint order == float order and
+// the result does not depend on arrival order).  All threads of a block work on the same channel.
+__device__ __forceinline__ void block_amax(float m, float *dst)
+{
+    __shared__ float wmax[BN_THREADS / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0)
+        wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < BN_THREADS / 64; ++w)
+            m = fmaxf(m, wmax[w]);
+        atomicMax((unsigned int *)dst, __float_as_uint(m));
+    }
+}
+
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict__ x,
                                                         const float *__restrict__ res,
@@ -129,9 +149,10 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
                                                         const float *__restrict__ invstd,
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, int C, int HW,
-                                                        float *__restrict__ y)
+                                                        float *__restrict__ y, float *__restrict__ amax)
 {
     const int plane = blockIdx.y, c = plane % C;
+    float am = 0.f;
     const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
     const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
     const size_t base = (size_t)plane * HW;
@@ -148,6 +169,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         *(f32x4 *)(y + base + i) = v;
+        am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     } else {
         for (int k = i; k < HW && k < i + 4; ++k) {
             float v = x[base + k] * sc + sh;
@@ -156,8 +178,11 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
             if (RELU)
                 v = fmaxf(v, 0.f);
             y[base + k] = v;
+            am = fmaxf(am, fabsf(v));
         }
     }
+    if (amax)
+        block_amax(am, amax + c);
 }
 
 // part[(c*nslice + s)*2 + {0,1}] = {sum g, sum g * xhat},  g = dy * (y > 0 if RELU)
@@ -217,9 +242,11 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                                                             const float *__restrict__ sums,
                                                             float inv_count, int C, int HW,
                                                             float *__restrict__ dx,
-                                                            float *__restrict__ dres)
+                                                            float *__restrict__ dres,
+                                                            float *__restrict__ amax)
 {
     const int plane = blockIdx.y, c = plane % C;
+    float am = 0.f;
     const float m = mean[c], is = invstd[c];
     const float k = is * (gamma ? gamma[c] : 1.f);
     const float mg = sums[c * 2] * inv_count, mgx = sums[c * 2 + 1] * inv_count;
@@ -241,6 +268,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
         o.z = k * (g.z - mg - (xv.z - m) * is * mgx);
         o.w = k * (g.w - mg - (xv.w - m) * is * mgx);
         *(f32x4 *)(dx + base + i) = o;
+        am = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
     } else {
         for (int q = i; q < HW && q < i + 4; ++q) {
             float g = dy[base + q];
@@ -248,9 +276,13 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                 g = y[base + q] > 0.f ? g : 0.f;
             if (dres)
                 dres[base + q] = g;
-            dx[base + q] = k * (g - mg - (x[base + q] - m) * is * mgx);
+            const float o = k * (g - mg - (x[base + q] - m) * is * mgx);
+            dx[base + q] = o;
+            am = fmaxf(am, fabsf(o));
         }
     }
+    if (amax)
+        block_amax(am, amax + c);
 }
 
 int pick_slices(int N, int C)
@@ -313,12 +345,12 @@ extern "C" int dcl_bn_finalize(const float *sums, int C, double count, float eps
 
 extern "C" int dcl_bn_apply(const float *x, const float *res, const float *mean, const float *invstd,
                             const float *gamma, const float *beta, int N, int C, int HW, int relu,
-                            float *y, void *stream)
+                            float *y, float *amax, void *stream)
 {
     DCL_CHECK_ARG(x && mean && invstd && y && N > 0 && C > 0 && HW > 0, "bad arguments");
     dim3 grid((HW + BN_THREADS * 4 - 1) / (BN_THREADS * 4), N * C);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, mean, invstd, gamma, beta, C, HW, y)
+#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, mean, invstd, gamma, beta, C, HW, y, amax)
     if (relu && res) LAUNCH(true, true);
     else if (relu) LAUNCH(true, false);
     else if (res) LAUNCH(false, true);
@@ -350,16 +382,16 @@ extern "C" int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y
 extern "C" int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y, const float *mean,
                                 const float *invstd, const float *gamma, const float *sums,
                                 double count, int N, int C, int HW, int relu, float *dx, float *dres,
-                                void *stream)
+                                float *amax, void *stream)
 {
     DCL_CHECK_ARG(dy && x && mean && invstd && sums && dx && (!relu || y) && count > 0, "bad arguments");
     dim3 grid((HW + BN_THREADS * 4 - 1) / (BN_THREADS * 4), N * C);
     hipStream_t st = (hipStream_t)stream;
     const float inv = (float)(1.0 / count);
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, sums, inv, C, HW, dx, dres);
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, sums, inv, C, HW, dx, dres, amax);
     else
-        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, sums, inv, C, HW, dx, dres);
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, sums, inv, C, HW, dx, dres, amax);
     DCL_LAUNCH_CHECK();
     return 0;
 }

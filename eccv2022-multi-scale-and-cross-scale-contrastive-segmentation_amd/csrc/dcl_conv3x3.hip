@@ -1,0 +1,405 @@
+// dcl_conv3x3.hip -- direct (implicit-GEMM) 3x3 / stride 1 / pad 1 convolution on the f16 matrix pipe with
+// fp32-equivalent arithmetic ("f16x3"), for the BasicBlock convolutions that carry ~80 % of HRNet-W48's FLOPs
+// (reference models/HRNet.py:32-60 builds them as nn.Conv2d(C, C, 3, 1, 1, bias=False), C in {48, 96, 192, 384}).
+//
+//   y[n, co, y, x] = sum_{ci, ky, kx} w[co, ci, ky, kx] * x[n, ci, y + ky - 1, x + kx - 1]
+//
+// GEMM view per tap: D[co][pixel] += W_tap[co][ci] * X_tap[ci][pixel]; both operands are split on the fly into
+// hi = f16(v * s), lo = f16(v * s - hi) (s: a power of two from the tensor's absmax, read on the device) and every
+// product is issued as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with f32 accumulation.
+//
+// Work decomposition (one workgroup = 4 waves):
+//   * output tile: 4P rows x 32 columns of one image x R*32 output channels; wave w owns rows [P w, P w + P)
+//     (P MFMA pixel tiles of 1 row x 32 columns) for all R channel tiles -> R*P accumulators of 16 registers.
+//   * K loop over chunks of 16 input channels.  The (4P+2) x 34 input patch of a chunk is loaded from NCHW f32
+//     with coalesced 4-byte loads (8 channels of one pixel per work item), split, and written to LDS as one
+//     80-byte record per pixel: [16 hi | 16 lo | pad] -- channel-innermost, so the B operand of a tap (8
+//     consecutive channels of the lane's shifted pixel) is ONE ds_read_b128, conflict-free (80 B = 5 x 16 B).
+//     Double buffered, one barrier per chunk; the next chunk's global loads are in flight during the MFMAs.
+//   * a B fragment depends on (tile row rr = p + ky, kx) only, so the (P+2) x 3 fragments of a chunk are read
+//     once and used by every (p, ky) with p + ky = rr: 2 (P+2) 3 LDS reads feed 27 R P MFMAs.
+//   * the A operand (weights) is pre-packed by k_pack_w3x3 into exact fragment order (16 B per lane, 1 KiB per
+//     fragment) and streamed from L2 / L1 straight into registers one kx ahead; the four waves of a workgroup
+//     read the same fragments (L1 hits).
+//   * epilogue: accumulator register r of lane (h, li) is output channel jrow(r, h), pixel column li -> 128-B
+//     row segments of the NCHW output.
+// The same kernel computes the data gradient: dx = conv3x3(dy, w') with w'[ci, co, ky, kx] = w[co, ci, 2-ky, 2-kx]
+// (k_pack_w3x3 with `transposed`).
+#include "dcl_common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int TW = 32;          // tile width in pixels (one MFMA pixel tile = 1 row x 32 columns)
+constexpr int LW = TW + 2;      // patch width incl. halo
+constexpr int PIXB = 80;        // bytes per LDS pixel record
+
+__device__ __forceinline__ int jrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct ConvArgs {
+    const float *x;
+    const uint4 *wp;
+    float *y;
+    const float *xamax, *wamax;     // max|x| as xcount partial maxima (e.g. per channel), max|w| (1 value)
+    int xcount;
+    int N, Cin, Cout, H, W;
+    int tiles_x, tiles_y, nchunk;
+};
+
+constexpr float F16_TARGET = 16384.0f;      // operands are scaled so that their absmax lands in (2^13, 2^14]
+
+// power-of-two operand scale from the tensor's absmax (same expression in the packer and in the convolution, so
+// both see the same weight scale); an all-zero tensor takes 1, inf / nan propagate into the products
+__device__ __forceinline__ float pow2_scale(float amax)
+{
+    return amax == 0.f ? 1.f : exp2f(fminf(fmaxf(floorf(log2f(F16_TARGET / amax)), -100.f), 100.f));
+}
+
+template <int R, int P>
+__global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
+{
+    constexpr int ROWS = 4 * P + 2;
+    constexpr int TP = ROWS * LW;
+    constexpr int NITEM = (2 * TP + 255) / 256;
+    constexpr int BUFB = TP * PIXB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, li = lane & 31;
+    int bx = blockIdx.x;
+    const int tx = bx % a.tiles_x;
+    bx /= a.tiles_x;
+    const int ty = bx % a.tiles_y;
+    const int n = bx / a.tiles_y;
+    const int x0 = tx * TW, y0 = ty * 4 * P;
+    const int T0 = blockIdx.y * R;
+    const size_t plane = (size_t)a.H * a.W;
+    const float *xb = a.x + (size_t)n * a.Cin * plane;
+    // operand scale of x: max over the partial maxima, exchanged between the waves through LDS
+    float xs;
+    {
+        float m = 0.f;
+        for (int i = tid; i < a.xcount; i += 256)
+            m = fmaxf(m, a.xamax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            m = fmaxf(m, __shfl_xor(m, o, 64));
+        float *wm = (float *)lds;
+        if (lane == 0)
+            wm[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        __syncthreads();
+        xs = pow2_scale(m);
+    }
+
+    // staging work items: (octet of channels, patch pixel); consecutive lanes -> consecutive pixels
+    int goff[NITEM], loff[NITEM];
+#pragma unroll
+    for (int m = 0; m < NITEM; ++m) {
+        const int it = tid + 256 * m;
+        goff[m] = -1;
+        loff[m] = -1;
+        if (it < 2 * TP) {
+            const int oct = it >= TP ? 1 : 0;
+            const int pix = it - oct * TP;
+            const int r = pix / LW, c = pix - r * LW;
+            const int gy = y0 + r - 1, gx = x0 + c - 1;
+            loff[m] = pix * PIXB + oct * 16;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                goff[m] = (int)(oct * 8 * plane) + gy * a.W + gx;
+        }
+    }
+    float g[NITEM][8];
+    auto load_items = [&](int c) {
+        const float *xc = xb + (size_t)(16 * c) * plane;
+#pragma unroll
+        for (int m = 0; m < NITEM; ++m) {
+            const int ch0 = 16 * c + 8 * (m * 256 + tid >= TP ? 1 : 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                g[m][e] = (goff[m] >= 0 && ch0 + e < a.Cin) ? xc[(size_t)goff[m] + e * plane] : 0.f;
+        }
+    };
+    auto write_items = [&](unsigned char *buf) {
+#pragma unroll
+        for (int m = 0; m < NITEM; ++m) {
+            if (loff[m] >= 0) {
+                half8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = g[m][e] * xs;
+                    hi[e] = (_Float16)v;
+                    lo[e] = (_Float16)(v - (float)hi[e]);
+                }
+                *(half8 *)(buf + loff[m]) = hi;
+                *(half8 *)(buf + loff[m] + 32) = lo;
+            }
+        }
+    };
+
+    // A fragments: wp[(((T * nchunk + c) * 9 + ky * 3 + kx) * 2 + part) * 64 + lane]
+    const uint4 *wa = a.wp + (size_t)T0 * a.nchunk * 9 * 2 * 64 + lane;
+    auto load_A = [&](half8 (&A)[3][R][2], int c, int kx) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    const uint4 v = wa[((((size_t)r * a.nchunk + c) * 9 + ky * 3 + kx) * 2 + part) * 64];
+                    A[ky][r][part] = __builtin_bit_cast(half8, v);
+                }
+    };
+
+    f32x16 acc[R][P];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                acc[r][p][q] = 0.f;
+
+    half8 Acur[3][R][2];
+    load_items(0);
+    load_A(Acur, 0, 0);
+    write_items(lds);
+    __syncthreads();
+
+    const int brow = (P * wave) * LW + li;
+    for (int c = 0; c < a.nchunk; ++c) {
+        const unsigned char *cur = lds + (c & 1) * BUFB;
+        const bool more = c + 1 < a.nchunk;
+        if (more)
+            load_items(c + 1);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            half8 Anext[3][R][2];
+            if (kx < 2)
+                load_A(Anext, c, kx + 1);
+            else if (more)
+                load_A(Anext, c + 1, 0);
+#pragma unroll
+            for (int rr = 0; rr < P + 2; ++rr) {
+                const unsigned char *bp = cur + (brow + rr * LW + kx) * PIXB + h * 16;
+                const half8 bh = *(const half8 *)bp;
+                const half8 bl = *(const half8 *)(bp + 32);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int p = rr - ky;
+                    if (p >= 0 && p < P) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Acur[ky][r][0], bh, acc[r][p], 0, 0, 0);
+                            acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Acur[ky][r][0], bl, acc[r][p], 0, 0, 0);
+                            acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Acur[ky][r][1], bh, acc[r][p], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (kx < 2 || more) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int part = 0; part < 2; ++part)
+                            Acur[ky][r][part] = Anext[ky][r][part];
+            }
+        }
+        if (more)
+            write_items(lds + ((c + 1) & 1) * BUFB);
+        __syncthreads();
+    }
+
+    const float inv = 1.0f / (xs * pow2_scale(a.wamax[0]));
+    const int col = x0 + li;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int row = y0 + P * wave + p;
+            if (row < a.H && col < a.W) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int co = (T0 + r) * 32 + jrow(q, h);
+                    if (co < a.Cout)
+                        a.y[(((size_t)n * a.Cout + co) * a.H + row) * a.W + col] = acc[r][p][q] * inv;
+                }
+            }
+        }
+}
+
+// weights -> fragment order.  transposed = 0: value(m, k, ky, kx) = w[m][k][ky][kx], w is [M][K][3][3];
+// transposed = 1 (data gradient): value(m, k, ky, kx) = w[k][m][2 - ky][2 - kx], w is [K][M][3][3].
+// One thread per (fragment pair, lane): fragment (T, c, t) lane (hh, i) holds value(32 T + i, 16 c + 8 hh + e, t).
+__global__ __launch_bounds__(256) void k_pack_w3x3(const float *__restrict__ w, int M, int K, int transposed,
+                                                  int mtiles, int nchunk, const float *__restrict__ wamax,
+                                                  uint4 *__restrict__ wp)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int total = mtiles * nchunk * 9 * 64;
+    if (gid >= total)
+        return;
+    const int lane = gid & 63;
+    int f = gid >> 6;
+    const int t = f % 9;
+    f /= 9;
+    const int c = f % nchunk;
+    const int T = f / nchunk;
+    const int i = lane & 31, hh = lane >> 5;
+    const int m = 32 * T + i;
+    const int ky = t / 3, kx = t - 3 * ky;
+    const float s = pow2_scale(wamax[0]);
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 16 * c + 8 * hh + e;
+        float v = 0.f;
+        if (m < M && k < K)
+            v = transposed ? w[(((size_t)k * M + m) * 3 + (2 - ky)) * 3 + (2 - kx)]
+                           : w[(((size_t)m * K + k) * 3 + ky) * 3 + kx];
+        v *= s;
+        hi[e] = (_Float16)v;
+        lo[e] = (_Float16)(v - (float)hi[e]);
+    }
+    const size_t o = ((((size_t)T * nchunk + c) * 9 + t) * 2) * 64 + lane;
+    wp[o] = __builtin_bit_cast(uint4, hi);
+    wp[o + 64] = __builtin_bit_cast(uint4, lo);
+}
+
+// out[0] = max(out[0], max |x|): integer atomicMax on the float bits (order independent); out starts at 0.
+// Fallback for tensors whose producer did not emit an absmax (the fused BN kernels do: dcl_bn.hip).
+__global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ x, size_t n, float *__restrict__ out)
+{
+    __shared__ float wmax[4];
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    float m = 0.f;
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    // four independent 16-B loads in flight per thread
+    for (; i + 3 * stride + 4 <= n; i += 4 * stride) {
+        const f32x4 v0 = *(const f32x4 *)(x + i), v1 = *(const f32x4 *)(x + i + stride),
+                    v2 = *(const f32x4 *)(x + i + 2 * stride), v3 = *(const f32x4 *)(x + i + 3 * stride);
+        const float m0 = fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w)));
+        const float m1 = fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)));
+        const float m2 = fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w)));
+        const float m3 = fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)));
+        m = fmaxf(m, fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
+    }
+    for (; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const f32x4 v = *(const f32x4 *)(x + i);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        } else {
+            for (size_t j = i; j < n; ++j)
+                m = fmaxf(m, fabsf(x[j]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0)
+        wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax((unsigned int *)out, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
+}  // namespace
+
+extern "C" int dcl_absmax(const float *x, int64_t n, float *out, void *stream)
+{
+    DCL_CHECK_ARG(x && out && n > 0, "bad arguments");
+    DCL_CHECK_ARG((((uintptr_t)x) & 15) == 0, "input must be 16-byte aligned");
+    size_t blocks = ((size_t)n + 4095) / 4096;     // 16 elements per thread
+    if (blocks > 4096)
+        blocks = 4096;
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_conv3x3_pack(const float *w, int M, int K, int transposed, const float *wamax, void *wp,
+                                void *stream)
+{
+    DCL_CHECK_ARG(w && wamax && wp && M > 0 && K > 0, "bad arguments");
+    const int mtiles = (M + 31) / 32, nchunk = (K + 15) / 16;
+    const int total = mtiles * nchunk * 9 * 64;
+    hipLaunchKernelGGL(k_pack_w3x3, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, M, K,
+                       transposed, mtiles, nchunk, wamax, (uint4 *)wp);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int R, int P>
+static int launch_conv(const ConvArgs &a0, hipStream_t stream)
+{
+    ConvArgs a = a0;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + 4 * P - 1) / (4 * P);
+    const int mtiles = (a.Cout + 31) / 32;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)((mtiles + R - 1) / R));
+    hipLaunchKernelGGL((k_conv3x3<R, P>), grid, dim3(256), 0, stream, a);
+    return 0;
+}
+
+extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
+                                 const float *xamax, int xcount, const float *wamax, float *y, int tile_r,
+                                 int tile_p, void *stream)
+{
+    DCL_CHECK_ARG(x && wp && xamax && wamax && y, "null pointer");
+    DCL_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && xcount > 0, "bad shape");
+    DCL_CHECK_ARG((size_t)8 * H * W + (size_t)H * W < ((size_t)1 << 31), "image plane too large");
+    ConvArgs a;
+    a.x = x;
+    a.wp = (const uint4 *)wp;
+    a.y = y;
+    a.xamax = xamax;
+    a.wamax = wamax;
+    a.xcount = xcount;
+    a.N = N;
+    a.Cin = Cin;
+    a.Cout = Cout;
+    a.H = H;
+    a.W = W;
+    a.nchunk = (Cin + 15) / 16;
+    const int mtiles = (Cout + 31) / 32;
+    int R = tile_r, P = tile_p;
+    if (R <= 0 || P <= 0) {
+        // measured on the four BasicBlock shapes of HRNet-W48 at batch 12 (tools/bench_conv3x3.py --tiles):
+        // channel tiles per wave in threes when that leaves no padded tile, else pairs; the most rows per wave
+        // that still give ~one workgroup per CU; (2, 4) loses to (2, 2), whose 54 KB of LDS and 228 registers let
+        // two workgroups share a CU; tiny images fall back to single-tile waves to get enough workgroups.
+        R = (mtiles % 3 == 0) ? 3 : (mtiles == 1 ? 1 : 2);
+        auto wgs = [&](int r, int p) {
+            return (long)((W + TW - 1) / TW) * ((H + 4 * p - 1) / (4 * p)) * N * ((mtiles + r - 1) / r);
+        };
+        P = 4;
+        while (P > 1 && wgs(R, P) < 192)
+            P >>= 1;
+        if (R == 2 && P == 4)
+            P = 2;
+        if (P == 1 && wgs(R, P) < 256)
+            R = 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+#define DCL_CONV_CASE(r, p)            \
+    if (R == r && P == p) {            \
+        launch_conv<r, p>(a, s);       \
+        DCL_LAUNCH_CHECK();            \
+        return 0;                      \
+    }
+    DCL_CONV_CASE(1, 1)
+    DCL_CONV_CASE(1, 2)
+    DCL_CONV_CASE(1, 4)
+    DCL_CONV_CASE(2, 1)
+    DCL_CONV_CASE(2, 2)
+    DCL_CONV_CASE(2, 4)
+    DCL_CONV_CASE(3, 1)
+    DCL_CONV_CASE(3, 2)
+    DCL_CONV_CASE(3, 4)
+#undef DCL_CONV_CASE
+    dcl_set_error("dcl_conv3x3_f16x3: unsupported tile (R=%d, P=%d)", R, P);
+    return DCL_EINVAL;
+}

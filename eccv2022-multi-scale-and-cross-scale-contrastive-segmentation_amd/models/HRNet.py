@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
-from .ops import conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear
+from .ops import conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear, use_direct_conv3x3
 from .fused_bn import FusedBatchNorm2d, bn_act
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
@@ -369,6 +369,11 @@ class HRNet(nn.Module):
         # 'f16x3': all three directions of that conv as split-f16 GEMMs at fp32-equivalent accuracy (models/ops.py);
         # 'gemm_wrw': only the weight gradient as an f32 GEMM; 'library': MIOpen for everything
         self.head_conv = config.get('head_conv', 'f16x3' if self.gemm_wrw_head else 'library')
+        # 'f16x3': the backbone's 3x3 / stride-1 convolutions (BasicBlock, Bottleneck, transitions: ~80 % of the
+        # FLOPs) on the direct split-f16 kernel (csrc/dcl_conv3x3.hip, fp32-equivalent); 'library': MIOpen
+        self.branch_conv = config.get('branch_conv', 'f16x3')
+        if self.branch_conv == 'f16x3':
+            use_direct_conv3x3(self.backbone)
 
     def _head(self, x):
         if self.head_conv != 'library' and self.training and x.is_cuda and x.dtype == torch.float32 \

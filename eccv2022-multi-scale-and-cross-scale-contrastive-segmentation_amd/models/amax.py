@@ -1,0 +1,44 @@
+"""Absmax side-channel for the f16x3 convolution (csrc/dcl_conv3x3.hip).
+
+The direct convolution scales each operand by a power of two derived ON THE DEVICE from the operand's absmax.
+Producers that already stream the tensor (the fused BN kernels, forward and backward) emit per-channel maxima into
+a small zero-initialised buffer and tag their output with it; a consumer finds the tag through :func:`amax_of`
+and otherwise falls back to one `dcl_absmax` pass.  A tag carries the tensor's ``_version`` and is ignored once
+the tensor was modified in place (e.g. autograd's in-place gradient accumulation)."""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+_POOL = {}
+_POOL_FLOATS = 1 << 16
+
+
+def zeros(n: int, device) -> torch.Tensor:
+    """n zero floats from a pooled buffer (one fill kernel per 64 K floats instead of one per request);
+    slices are never handed out twice, the buffer lives as long as any slice does."""
+    n_al = (n + 3) & ~3
+    key = (device.type, device.index)
+    buf, off = _POOL.get(key, (None, 0))
+    if buf is None or off + n_al > buf.numel():
+        buf, off = torch.zeros(max(_POOL_FLOATS, n_al), dtype=torch.float32, device=device), 0
+    _POOL[key] = (buf, off + n_al)
+    return buf[off:off + n]
+
+
+def tag(t: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
+    t._dcl_amax = (t._version, buf)
+    return t
+
+
+def amax_of(t: torch.Tensor) -> torch.Tensor:
+    """1-D float tensor whose maximum is max|t| (per-channel maxima from the producer, or one value)."""
+    got = getattr(t, "_dcl_amax", None)
+    if got is not None and got[0] == t._version and got[1].device == t.device:
+        return got[1]
+    buf = zeros(1, t.device)
+    st = ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    _lib.check(_lib.lib().dcl_absmax(_lib.ptr(t), t.numel(), _lib.ptr(buf), st), "dcl_absmax")
+    tag(t, buf)
+    return buf

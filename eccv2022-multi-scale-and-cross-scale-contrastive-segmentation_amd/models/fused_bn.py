@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
+from . import amax as _amax
 
 
 def _stream():
@@ -29,7 +30,7 @@ def _world():
 
 class _FusedBNFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, sync):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, sync, amax):
         L = _lib.lib()
         N, C, H, W = x.shape
         HW = H * W
@@ -59,10 +60,11 @@ class _FusedBNFunction(torch.autograd.Function):
         y = torch.empty_like(x)
         _lib.check(L.dcl_bn_apply(_lib.ptr(x), _lib.ptr(res), _lib.ptr(mean), _lib.ptr(invstd),
                                   _lib.ptr(weight), _lib.ptr(bias), N, C, HW, 1 if relu else 0, _lib.ptr(y),
-                                  st), "dcl_bn_apply")
+                                  _lib.ptr(amax), st), "dcl_bn_apply")
         ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
         ctx.relu, ctx.world, ctx.count = relu, world, count
         ctx.has_res = res is not None
+        ctx.emit_amax = amax is not None
         return y
 
     @staticmethod
@@ -90,15 +92,20 @@ class _FusedBNFunction(torch.autograd.Function):
         dx = torch.empty_like(x)
         want_res = ctx.has_res and ctx.needs_input_grad[1]
         dres = torch.empty_like(x) if want_res else None
+        # per-channel max|dx| for the consumer (the data / weight gradient of the convolution in front of this norm)
+        amax = _amax.zeros(C, dev) if ctx.emit_amax else None
         _lib.check(L.dcl_bn_bwd_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
                                       _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(sums), ctx.count, N, C,
-                                      HW, relu, _lib.ptr(dx), _lib.ptr(dres), st), "dcl_bn_bwd_apply")
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
+                                      HW, relu, _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(amax), st), "dcl_bn_bwd_apply")
+        if amax is not None:
+            _amax.tag(dx, amax)
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class FusedBatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d with an optional fused (residual add, ReLU) epilogue; see module docstring."""
     sync = False
+    emit_amax = True
 
     def _fusable(self, x, residual):
         return (self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
@@ -109,9 +116,12 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
 
     def forward(self, x, residual=None, relu=False):
         if self._fusable(x, residual):
-            return _FusedBNFunction.apply(x, residual, self.weight, self.bias, self.running_mean,
-                                          self.running_var, self.num_batches_tracked, float(self.eps),
-                                          float(self.momentum), bool(relu), bool(self.sync))
+            # per-channel max|y| side output for the f16x3 convolutions that consume y (models/amax.py)
+            amax = _amax.zeros(x.shape[1], x.device) if self.emit_amax else None
+            y = _FusedBNFunction.apply(x, residual, self.weight, self.bias, self.running_mean,
+                                       self.running_var, self.num_batches_tracked, float(self.eps),
+                                       float(self.momentum), bool(relu), bool(self.sync), amax)
+            return _amax.tag(y, amax) if amax is not None else y
         y = super().forward(x)
         if residual is not None:
             y = y + residual

@@ -201,3 +201,115 @@ def conv3x3_f16x3(x, conv: torch.nn.Conv2d):
     assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) \
         and conv.groups == 1 and conv.dilation == (1, 1)
     return _Conv3x3F16x3.apply(x.contiguous(), conv.weight, conv.bias)
+
+
+# ---- direct f16x3 3x3 convolution (csrc/dcl_conv3x3.hip) ----------------------------------------------------------
+
+def _stream(t):
+    import ctypes
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def conv3x3_pack(weight, wamax, transposed=False):
+    """Weights [Co, Ci, 3, 3] -> MFMA fragment order (f16 hi / lo), for the forward (M = Co, K = Ci) or, with
+    ``transposed``, for the data gradient (M = Ci, K = Co, taps flipped)."""
+    from .. import _lib
+    co, ci = weight.shape[0], weight.shape[1]
+    m, k = (ci, co) if transposed else (co, ci)
+    nbytes = ((m + 31) // 32) * ((k + 15) // 16) * 9 * 2 * 64 * 16
+    wp = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    _lib.check(_lib.lib().dcl_conv3x3_pack(_lib.ptr(weight), m, k, 1 if transposed else 0, _lib.ptr(wamax),
+                                           _lib.ptr(wp), _stream(weight)), "dcl_conv3x3_pack")
+    return wp
+
+
+def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0):
+    from .. import _lib
+    n, c, h, w = x.shape
+    _lib.check(_lib.lib().dcl_conv3x3_f16x3(_lib.ptr(x), n, c, h, w, _lib.ptr(wp), cout, _lib.ptr(xamax),
+                                            xamax.numel(), _lib.ptr(wamax), _lib.ptr(out), tile_r, tile_p,
+                                            _stream(x)), "dcl_conv3x3_f16x3")
+    return out
+
+
+def conv3x3_direct(x, weight, transposed=False):
+    """y = conv2d(x, weight, padding=1) (or, ``transposed``, its data gradient applied to x) on the f16x3
+    direct kernel; x [N, C, H, W] f32 contiguous, weight [Co, Ci, 3, 3] f32 contiguous."""
+    from .amax import amax_of
+    x = x.contiguous()
+    weight = weight.contiguous()
+    wamax = amax_of(weight)
+    wp = conv3x3_pack(weight, wamax, transposed)
+    cout = weight.shape[1] if transposed else weight.shape[0]
+    out = torch.empty((x.shape[0], cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+    return conv3x3_launch(x, wp, cout, amax_of(x), wamax, out)
+
+
+class _Conv3x3Direct(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 convolution through csrc/dcl_conv3x3.hip: forward and data gradient on the direct
+    f16x3 kernel (fp32-equivalent), weight gradient through ATen (MIOpen)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, mod):
+        from .amax import amax_of
+        wamax, wp, _ = mod.packed_weights()
+        out = torch.empty((x.shape[0], weight.shape[0], x.shape[2], x.shape[3]), dtype=torch.float32,
+                          device=x.device)
+        conv3x3_launch(x, wp, weight.shape[0], amax_of(x), wamax, out)
+        ctx.save_for_backward(x, weight)
+        ctx.mod = mod
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .amax import amax_of
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            wamax, _, wpt = ctx.mod.packed_weights()
+            gx = torch.empty_like(x)
+            conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx)
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return gx, gw, None
+
+
+class DirectConv2d(torch.nn.Conv2d):
+    """nn.Conv2d (same parameters / state_dict) whose 3x3, stride-1, pad-1 case runs on the direct f16x3 kernel
+    for contiguous fp32 CUDA inputs; every other configuration falls through to nn.Conv2d.forward."""
+
+    def eligible(self, x):
+        return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
+                and self.dilation == (1, 1) and self.groups == 1 and self.bias is None
+                and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and self.weight.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and x.is_contiguous())
+
+    def packed_weights(self):
+        """(max|w|, forward fragments, data-gradient fragments), rebuilt when the weight tensor was modified."""
+        from .amax import amax_of
+        w = self.weight
+        key = (w._version, w.data_ptr())
+        cache = getattr(self, "_packed", None)
+        if cache is None or cache[0] != key:
+            wd = w.detach()
+            wamax = amax_of(wd)
+            cache = (key, wamax, conv3x3_pack(wd, wamax, False), conv3x3_pack(wd, wamax, True))
+            self._packed = cache
+        return cache[1], cache[2], cache[3]
+
+    def forward(self, x):
+        if self.eligible(x):
+            return _Conv3x3Direct.apply(x, self.weight, self)
+        return super().forward(x)
+
+
+def use_direct_conv3x3(module: torch.nn.Module) -> torch.nn.Module:
+    """Switch every plain nn.Conv2d with a 3x3 / stride 1 / pad 1 / bias-free geometry to DirectConv2d in place."""
+    for m in module.modules():
+        if type(m) is torch.nn.Conv2d and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) \
+                and m.dilation == (1, 1) and m.groups == 1 and m.bias is None:
+            m.__class__ = DirectConv2d
+    return module

@@ -195,13 +195,14 @@ int dcl_bn_finalize(const float *sums, int C, double count, float eps, float mom
                     float *invstd, float *running_mean, float *running_var, void *stream);
 int dcl_bn_apply(const float *x, const float *res, const float *mean, const float *invstd,
                  const float *gamma, const float *beta, int N, int C, int HW, int relu, float *y,
-                 void *stream);
+                 float *amax /* [C] zero-initialised: per-channel max|y| is max-ed in; or NULL */, void *stream);
 int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y, const float *mean,
                       const float *invstd, int N, int C, int HW, int relu, float *part, float *sums,
                       float *dbeta /* [C] or NULL */, float *dgamma /* [C] or NULL */, void *stream);
 int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y, const float *mean,
                      const float *invstd, const float *gamma, const float *sums, double count, int N,
-                     int C, int HW, int relu, float *dx, float *dres, void *stream);
+                     int C, int HW, int relu, float *dx, float *dres,
+                     float *amax /* [C] zero-initialised: per-channel max|dx|; or NULL */, void *stream);
 
 /* ---- bilinear up-sampling, NCHW f32 (planes = N * C), ATen index arithmetic ----------------------------
  * Replaces F.interpolate(mode='bilinear') in the models (reference models/HRNet.py:279-282, 549-551, 638)
@@ -220,6 +221,27 @@ int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int w, int H, 
 int dcl_im2col3x3_split(const float *x, int N, int C, int H, int W, const float *scale, void *out_hi,
                         void *out_lo, void *stream);
 int dcl_split_f16(const float *x, int64_t n, const float *scale, void *hi, void *lo, void *stream);
+
+/* ---- direct f16x3 3x3 convolution (stride 1, pad 1, NCHW f32 in / out) --------------------------------------
+ * Replaces the nn.Conv2d(C, C, 3, 1, 1, bias=False) of the reference's BasicBlock / Bottleneck
+ * (models/HRNet.py:32-60, 63-100) -- ~80 % of HRNet-W48's FLOPs -- and its data gradient (same kernel on the
+ * transposed, tap-flipped weights).  Arithmetic: both operands split into f16 (hi, lo) pairs after a
+ * power-of-two scaling, products hi.hi + hi.lo + lo.hi on the f16 MFMA with f32 accumulation.
+ * Operand scales are derived ON THE DEVICE from absmax values (s = 2^floor(log2(2^14 / max|v|))): the fused BN
+ * kernels emit per-channel maxima of their outputs (dcl_bn_apply / dcl_bn_bwd_apply `amax`), dcl_absmax covers
+ * every other tensor.
+ *   dcl_absmax      : out[0] = max(out[0], max|x|)  (out zero-initialised by the caller)
+ *   dcl_conv3x3_pack: w [M][K][3][3] (transposed = 0) or [K][M][3][3] read as its data-gradient kernel
+ *                    (transposed = 1) -> MFMA fragment order, ceil(M/32) * ceil(K/16) * 9 * 2 KiB at wp;
+ *                    wamax = max|w| (1 float)
+ *   dcl_conv3x3_f16x3: y[N,Cout,H,W] = conv(x[N,Cin,H,W], packed weights); xamax = xcount partial maxima of |x|;
+ *                    tile_r / tile_p select the workgroup tile (channel tiles per wave / rows per wave),
+ *                    0 = automatic */
+int dcl_absmax(const float *x, int64_t n, float *out, void *stream);
+int dcl_conv3x3_pack(const float *w, int M, int K, int transposed, const float *wamax, void *wp, void *stream);
+int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
+                      const float *xamax, int xcount, const float *wamax, float *y, int tile_r, int tile_p,
+                      void *stream);
 
 /* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the
  * grid fills the 256 CUs evenly (host helper, no device work). */
