@@ -122,7 +122,8 @@ __global__ void k_bn_finalize(const float *__restrict__ sums, int C, double coun
 }
 
 // grid (ceil(HW/1024), N*C)
-// per-channel absmax side output (consumed by the f16x3 convolution to pick its power-of-two operand scale):
+// per-plane (image, channel) absmax side output (consumed by the f16x3 convolution to pick its power-of-two
+// operand scale; one slot per plane keeps the atomics per address at HW / 1024):
 // block maximum -> one integer atomicMax on the float bits (values are >= 0, so uint order == float order and
 // the result does not depend on arrival order).  All threads of a block work on the same channel.
 __device__ __forceinline__ void block_amax(float m, float *dst)
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
         }
     }
     if (amax)
-        block_amax(am, amax + c);
+        block_amax(am, amax + plane);
 }
 
 // part[(c*nslice + s)*2 + {0,1}] = {sum g, sum g * xhat},  g = dy * (y > 0 if RELU)
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
         }
     }
     if (amax)
-        block_amax(am, amax + c);
+        block_amax(am, amax + plane);
 }
 
 int pick_slices(int N, int C)

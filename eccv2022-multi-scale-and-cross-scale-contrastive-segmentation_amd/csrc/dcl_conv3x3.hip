@@ -116,9 +116,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
 #pragma unroll
         for (int m = 0; m < NITEM; ++m) {
             const int ch0 = 16 * c + 8 * (m * 256 + tid >= TP ? 1 : 0);
+            if (goff[m] >= 0 && ch0 + 8 <= a.Cin) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                g[m][e] = (goff[m] >= 0 && ch0 + e < a.Cin) ? xc[(size_t)goff[m] + e * plane] : 0.f;
+                for (int e = 0; e < 8; ++e)
+                    g[m][e] = xc[(size_t)goff[m] + e * plane];
+            } else {
+                // outside the image, or the ragged last octet of a channel count that is not a multiple of 8
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    g[m][e] = (goff[m] >= 0 && ch0 + e < a.Cin) ? xc[(size_t)goff[m] + e * plane] : 0.f;
+            }
         }
     };
     auto write_items = [&](unsigned char *buf) {

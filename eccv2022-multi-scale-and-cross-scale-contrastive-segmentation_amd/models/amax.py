@@ -1,7 +1,7 @@
 """Absmax side-channel for the f16x3 convolution (csrc/dcl_conv3x3.hip).
 
 The direct convolution scales each operand by a power of two derived ON THE DEVICE from the operand's absmax.
-Producers that already stream the tensor (the fused BN kernels, forward and backward) emit per-channel maxima into
+Producers that already stream the tensor (the fused BN kernels, forward and backward) emit per-plane maxima into
 a small zero-initialised buffer and tag their output with it; a consumer finds the tag through :func:`amax_of`
 and otherwise falls back to one `dcl_absmax` pass.  A tag carries the tensor's ``_version`` and is ignored once
 the tensor was modified in place (e.g. autograd's in-place gradient accumulation)."""
@@ -12,11 +12,11 @@ import torch
 from .. import _lib
 
 _POOL = {}
-_POOL_FLOATS = 1 << 16
+_POOL_FLOATS = 1 << 20
 
 
 def zeros(n: int, device) -> torch.Tensor:
-    """n zero floats from a pooled buffer (one fill kernel per 64 K floats instead of one per request);
+    """n zero floats from a pooled buffer (one fill kernel per 1 M floats instead of one per request);
     slices are never handed out twice, the buffer lives as long as any slice does."""
     n_al = (n + 3) & ~3
     key = (device.type, device.index)
@@ -33,7 +33,7 @@ def tag(t: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
 
 
 def amax_of(t: torch.Tensor) -> torch.Tensor:
-    """1-D float tensor whose maximum is max|t| (per-channel maxima from the producer, or one value)."""
+    """1-D float tensor whose maximum is max|t| (per-plane maxima from the producer, or one value)."""
     got = getattr(t, "_dcl_amax", None)
     if got is not None and got[0] == t._version and got[1].device == t.device:
         return got[1]

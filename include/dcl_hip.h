@@ -195,14 +195,14 @@ int dcl_bn_finalize(const float *sums, int C, double count, float eps, float mom
                     float *invstd, float *running_mean, float *running_var, void *stream);
 int dcl_bn_apply(const float *x, const float *res, const float *mean, const float *invstd,
                  const float *gamma, const float *beta, int N, int C, int HW, int relu, float *y,
-                 float *amax /* [C] zero-initialised: per-channel max|y| is max-ed in; or NULL */, void *stream);
+                 float *amax /* [N*C] zero-initialised: per-plane max|y| is max-ed in; or NULL */, void *stream);
 int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y, const float *mean,
                       const float *invstd, int N, int C, int HW, int relu, float *part, float *sums,
                       float *dbeta /* [C] or NULL */, float *dgamma /* [C] or NULL */, void *stream);
 int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y, const float *mean,
                      const float *invstd, const float *gamma, const float *sums, double count, int N,
                      int C, int HW, int relu, float *dx, float *dres,
-                     float *amax /* [C] zero-initialised: per-channel max|dx|; or NULL */, void *stream);
+                     float *amax /* [N*C] zero-initialised: per-plane max|dx|; or NULL */, void *stream);
 
 /* ---- bilinear up-sampling, NCHW f32 (planes = N * C), ATen index arithmetic ----------------------------
  * Replaces F.interpolate(mode='bilinear') in the models (reference models/HRNet.py:279-282, 549-551, 638)
@@ -228,7 +228,7 @@ int dcl_split_f16(const float *x, int64_t n, const float *scale, void *hi, void 
  * transposed, tap-flipped weights).  Arithmetic: both operands split into f16 (hi, lo) pairs after a
  * power-of-two scaling, products hi.hi + hi.lo + lo.hi on the f16 MFMA with f32 accumulation.
  * Operand scales are derived ON THE DEVICE from absmax values (s = 2^floor(log2(2^14 / max|v|))): the fused BN
- * kernels emit per-channel maxima of their outputs (dcl_bn_apply / dcl_bn_bwd_apply `amax`), dcl_absmax covers
+ * kernels emit per-plane maxima of their outputs (dcl_bn_apply / dcl_bn_bwd_apply `amax`), dcl_absmax covers
  * every other tensor.
  *   dcl_absmax      : out[0] = max(out[0], max|x|)  (out zero-initialised by the caller)
  *   dcl_conv3x3_pack: w [M][K][3][3] (transposed = 0) or [K][M][3][3] read as its data-gradient kernel
