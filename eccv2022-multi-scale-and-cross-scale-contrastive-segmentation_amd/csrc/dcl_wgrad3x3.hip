@@ -1,0 +1,430 @@
+// dcl_wgrad3x3.hip -- weight gradient of the 3x3 / stride 1 / pad 1 convolution on the f16 matrix pipe with
+// fp32-equivalent arithmetic (f16x3: hi.hi + hi.lo + lo.hi of split-f16 operands, f32 accumulation).
+//
+//   dw[co, ci, ky, kx] = sum_{n, y, x} dy[n, co, y, x] * x[n, ci, y + ky - 1, x + kx - 1]
+//
+// GEMM view per tap: D[co][ci] += dY[co][pixel] * X_tap[pixel][ci], K = pixels.  In NCHW both operands have the K
+// dimension (pixels of a row) contiguous, which is exactly what v_mfma_f32_16x16x32_f16 wants from a lane:
+// lane (q, i) supplies 8 consecutive k for row / column i.  So there is NO LDS staging at all: every lane loads
+// its 8 (+2 halo) f32 pixels straight from global memory (32-byte runs, 128-byte lines shared by the four
+// k-octets of a wave), scales, splits into f16 (hi, lo) in registers and feeds the MFMA.  The three kx-shifted B
+// fragments of an input row are three windows of the same 10 split values.
+//
+// One wave = NCO x NCI tiles of 16 x 16 (co x ci) x 9 taps of accumulators, walking down a 32-pixel-wide strip:
+// per input row r it loads X[r] (B, 3 kx windows) and keeps dY rows r-1, r, r+1 (A) in registers -- row r pairs
+// with dY row r + 1 - ky for tap row ky -- so each loaded fragment feeds 9 * NCO (B) or 9 * NCI (A) MFMAs x 3.
+// The flat (image, strip, row) sequence is cut into S contiguous runs; every split (= wave) writes its partial
+// dw to its own slab, k_wgrad_reduce sums the slabs in fixed order (deterministic, no float atomics).
+#include <type_traits>
+
+#include "dcl_common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr float F16_TARGET = 16384.0f;
+
+__device__ __forceinline__ float pow2_scale(float amax)
+{
+    return amax == 0.f ? 1.f : exp2f(fminf(fmaxf(floorf(log2f(F16_TARGET / amax)), -100.f), 100.f));
+}
+
+struct WgradArgs {
+    const float *x, *dy;
+    float *part;                 // [S][9][Cout][Cin]
+    const float *xamax, *gamax;
+    int xcount, gcount;
+    int N, Cin, Cout, H, W;
+    int strips, nseg, units, S, ncig, npairs, nx;
+};
+
+// Packed f16 pair (lo half = element 0) of hi = f16(v * s) and of lo = f16(v * s - hi) for two values.  s is a power
+// of two (or 0), so v * s is exact and the fused form computes the same value; written as v_fma_mix{lo,hi}_f16
+// (f32 / f16 inputs, f32 arithmetic, f16 result into one half of the destination): 2 VALU instructions per value
+// and no packing.  The compiler's own lowering of the C expression takes 3+ and the kernel is VALU-issue-bound.
+__device__ __forceinline__ void split2(float v0, float v1, float s, unsigned &hi, unsigned &lo)
+{
+    // (mixlo leaves the upper half of its destination alone; mixhi fills it right after, so no initialisation)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(v0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(v0), "v"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "v"(s), "v"(hi));
+}
+
+// one value: f16 hi / lo in the low halves of hi / lo (upper halves undefined)
+__device__ __forceinline__ void split1(float v0, float s, unsigned &hi, unsigned &lo)
+{
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(v0), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(v0), "v"(s), "v"(hi));
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ half8 as_half8(u32x4 v) { return __builtin_bit_cast(half8, v); }
+
+template <int NCO, int NCI>
+__global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
+{
+    __shared__ float wm[8];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q4 = lane >> 4, j = lane & 15;
+
+    // operand scales from the producers' partial maxima
+    float sx, sg;
+    {
+        float mx = 0.f, mg = 0.f;
+        for (int i = tid; i < a.xcount; i += 256)
+            mx = fmaxf(mx, a.xamax[i]);
+        for (int i = tid; i < a.gcount; i += 256)
+            mg = fmaxf(mg, a.gamax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            mg = fmaxf(mg, __shfl_xor(mg, o, 64));
+        }
+        if (lane == 0) {
+            wm[wave] = mx;
+            wm[4 + wave] = mg;
+        }
+        __syncthreads();
+        sx = pow2_scale(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
+        sg = pow2_scale(fmaxf(fmaxf(wm[4], wm[5]), fmaxf(wm[6], wm[7])));
+    }
+    // XCD-aware decode of the 1-D grid: consecutive workgroup ids go round-robin over the 8 XCDs, so
+    // id = xcd + 8 * (pair + npairs * hi) puts every (co group, ci group) pair of one pixel split on the SAME XCD,
+    // next to each other in dispatch order -- they stream the same dy / x rows, which then come out of that
+    // XCD's L2 instead of being fetched once per pair.
+    int pair, xsplit;
+    {
+        const int nx8 = a.nx & ~7, main_blocks = nx8 * a.npairs;
+        if ((int)blockIdx.x < main_blocks) {
+            const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+            pair = rest % a.npairs;
+            xsplit = (rest / a.npairs) * 8 + xcd;
+        } else {                                // the nx % 8 left-over pixel splits, in plain order
+            const int rest = blockIdx.x - main_blocks;
+            pair = rest % a.npairs;
+            xsplit = nx8 + rest / a.npairs;
+        }
+    }
+    const int split = xsplit * 4 + wave;
+    if (split >= a.S)
+        return;
+    const int cog = pair / a.ncig, cig = pair - cog * a.ncig;
+    const int co0 = cog * NCO * 16, ci0 = cig * NCI * 16;
+    const size_t plane = (size_t)a.H * a.W;
+    bool ci_ok[NCI];            // the last ci group is ragged when the tile count is not a multiple of NCI
+#pragma unroll
+    for (int u = 0; u < NCI; ++u)
+        ci_ok[u] = ci0 + 16 * u < a.Cin;
+
+    f32x4 acc[NCO][NCI][9];
+#pragma unroll
+    for (int t = 0; t < NCO; ++t)
+#pragma unroll
+        for (int u = 0; u < NCI; ++u)
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                acc[t][u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this split's share of the flat (image, strip, input row) sequence: rows [t0, t1), walked column by column
+    const long long T = (long long)a.units * a.H;              // units = images x strips (columns)
+    long long t = T * split / a.S;
+    const long long t1 = T * (split + 1) / a.S;
+    while (t < t1) {
+        const int col = (int)(t / a.H);
+        const int r0 = (int)(t - (long long)col * a.H);
+        const int r1 = (int)min((long long)a.H, r0 + (t1 - t));
+        t += r1 - r0;
+        const int strip = col % a.strips;
+        const int n = col / a.strips;
+        const int px = strip * 32 + 8 * q4;
+        // Loads are unconditional from clamped (always valid) addresses and masked through the operand scale
+        // (0 instead of s) when they are converted one iteration later: a branch around a load would make the
+        // compiler wait for it at the join, i.e. before the MFMAs it is supposed to overlap.
+        const bool oct_ok = px < a.W;
+        const int pxc = oct_ok ? px : a.W - 8;
+        const int dl = px > 0 ? -1 : 0, dr = px + 8 < a.W ? 8 : 7;
+        const float sx_c = oct_ok ? sx : 0.f;                       // elements 1..8 of the B window
+        const float sx_l = (oct_ok && px > 0) ? sx : 0.f;           // left halo (outside the image at x = -1)
+        const float sx_r = (px + 8 < a.W) ? sx : 0.f;               // right halo
+        const float *ap = a.dy + ((size_t)n * a.Cout + co0 + j) * plane + pxc;    // + t * 16 * plane + y * W
+        const float *bp = a.x + ((size_t)n * a.Cin + ci0 + j) * plane + pxc;     // + u * 16 * plane + r * W
+
+        auto load_A = [&](int y, f32x4 (&dst)[NCO][2], float &scale) {
+            scale = (oct_ok && y >= 0 && y < a.H) ? sg : 0.f;
+            const int yc = min(max(y, 0), a.H - 1);
+#pragma unroll
+            for (int t2 = 0; t2 < NCO; ++t2) {
+                const float *p = ap + (size_t)t2 * 16 * plane + (size_t)yc * a.W;
+                dst[t2][0] = *(const f32x4 *)p;
+                dst[t2][1] = *(const f32x4 *)(p + 4);
+            }
+        };
+        auto load_B = [&](int r, f32x4 (&dst)[NCI][2], float (&l)[NCI], float (&rr)[NCI]) {
+            const int rc = min(r, a.H - 1);
+#pragma unroll
+            for (int u = 0; u < NCI; ++u) {
+                const float *p = bp + (size_t)(ci_ok[u] ? u : 0) * 16 * plane + (size_t)rc * a.W;
+                dst[u][0] = *(const f32x4 *)p;
+                dst[u][1] = *(const f32x4 *)(p + 4);
+                l[u] = p[dl];
+                rr[u] = p[dr];
+            }
+        };
+        auto cvt_A = [&](const f32x4 (&src)[NCO][2], float scale, half8 (&dst)[NCO][2]) {
+#pragma unroll
+            for (int t2 = 0; t2 < NCO; ++t2) {
+                unsigned h[4], l[4];
+                split2(src[t2][0].x, src[t2][0].y, scale, h[0], l[0]);
+                split2(src[t2][0].z, src[t2][0].w, scale, h[1], l[1]);
+                split2(src[t2][1].x, src[t2][1].y, scale, h[2], l[2]);
+                split2(src[t2][1].z, src[t2][1].w, scale, h[3], l[3]);
+                dst[t2][0] = as_half8(u32x4{h[0], h[1], h[2], h[3]});
+                dst[t2][1] = as_half8(u32x4{l[0], l[1], l[2], l[3]});
+            }
+        };
+        // the three kx windows of an input row are windows of the same 10 split values w[-1 .. 8]: kx = 0 and
+        // kx = 2 share the pairing (w-1,w0)(w1,w2)...(w7,w8); kx = 1 is the 16-bit funnel shift of neighbours
+        auto cvt_B = [&](const f32x4 (&src)[NCI][2], const float (&l)[NCI], const float (&rr)[NCI],
+                         half8 (&dst)[3][NCI][2]) {
+#pragma unroll
+            for (int u = 0; u < NCI; ++u) {
+                const float sc = ci_ok[u] ? sx_c : 0.f, sl = ci_ok[u] ? sx_l : 0.f, sr = ci_ok[u] ? sx_r : 0.f;
+                unsigned h[5], q[5];
+                // the halo values have their own scale (0 outside the image): split them alone, then merge
+                unsigned hl, ql, hr, qr, hm, qm;
+                split1(l[u], sl, hl, ql);                            // w-1
+                split1(src[u][0].x, sc, hm, qm);                     // w0
+                h[0] = __builtin_amdgcn_perm(hm, hl, 0x05040100u);   // (lo16(hl), lo16(hm))
+                q[0] = __builtin_amdgcn_perm(qm, ql, 0x05040100u);
+                split2(src[u][0].y, src[u][0].z, sc, h[1], q[1]);
+                split2(src[u][0].w, src[u][1].x, sc, h[2], q[2]);
+                split2(src[u][1].y, src[u][1].z, sc, h[3], q[3]);
+                split1(src[u][1].w, sc, hm, qm);                     // w7
+                split1(rr[u], sr, hr, qr);                           // w8
+                h[4] = __builtin_amdgcn_perm(hr, hm, 0x05040100u);
+                q[4] = __builtin_amdgcn_perm(qr, qm, 0x05040100u);
+                u32x4 w0h = {h[0], h[1], h[2], h[3]}, w0l = {q[0], q[1], q[2], q[3]};
+                u32x4 w2h = {h[1], h[2], h[3], h[4]}, w2l = {q[1], q[2], q[3], q[4]};
+                unsigned a1h[4], a1l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a1h[e] = __builtin_amdgcn_alignbit(h[e + 1], h[e], 16);
+                    a1l[e] = __builtin_amdgcn_alignbit(q[e + 1], q[e], 16);
+                }
+                u32x4 w1h = {a1h[0], a1h[1], a1h[2], a1h[3]}, w1l = {a1l[0], a1l[1], a1l[2], a1l[3]};
+                dst[0][u][0] = as_half8(w0h);
+                dst[0][u][1] = as_half8(w0l);
+                dst[1][u][0] = as_half8(w1h);
+                dst[1][u][1] = as_half8(w1l);
+                dst[2][u][0] = as_half8(w2h);
+                dst[2][u][1] = as_half8(w2l);
+            }
+        };
+
+        // Software pipeline, unrolled by six so that every register array is indexed statically and nothing is
+        // copied between iterations.  dY rows live in a ring of three slots (row y in slot (y - r0 + 1) % 3), X rows
+        // in two sets.  Step i (input row r = r0 + i):
+        //   1. MFMAs of tap row ky = 2 (dY row r - 1, the oldest slot),
+        //   2. the raw values loaded one step ago are split into f16 pairs: dY row r + 2 into that slot, X row
+        //      r + 1 into the other B set -- VALU work that overlaps the remaining MFMAs,
+        //   3. the loads of dY row r + 3 / X row r + 2 are issued into the raw registers just consumed,
+        //   4. MFMAs of tap rows ky = 1, 0 (dY rows r, r + 1).
+        half8 A[3][NCO][2], B[2][3][NCI][2];
+        f32x4 rawA[NCO][2], rawB[NCI][2];
+        float rawL[NCI], rawR[NCI], rawS;
+        {
+            f32x4 p0[NCO][2], p1[NCO][2], p2[NCO][2], q0[NCI][2];
+            float s0, s1, s2, l0[NCI], rr0[NCI];
+            load_A(r0 - 1, p0, s0);
+            load_A(r0, p1, s1);
+            load_A(r0 + 1, p2, s2);
+            load_B(r0, q0, l0, rr0);
+            load_A(r0 + 2, rawA, rawS);
+            load_B(r0 + 1, rawB, rawL, rawR);
+            cvt_A(p0, s0, A[0]);
+            cvt_A(p1, s1, A[1]);
+            cvt_A(p2, s2, A[2]);
+            cvt_B(q0, l0, rr0, B[0]);
+        }
+        auto mfma_row = [&](auto SLOT, auto BSET, auto KY) {
+            constexpr int slot = decltype(SLOT)::value, bs = decltype(BSET)::value, ky = decltype(KY)::value;
+            // pass-major: all tiles hi.hi, then all hi.lo, then all lo.hi -- the three MFMAs of one accumulator are
+            // 9 NCI instructions apart and each accumulates in place (dst == srcC)
+#pragma unroll
+            for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int t2 = 0; t2 < NCO; ++t2)
+#pragma unroll
+                        for (int u = 0; u < NCI; ++u)
+                            acc[t2][u][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                A[slot][t2][pass == 2 ? 1 : 0], B[bs][kx][u][pass == 1 ? 1 : 0],
+                                acc[t2][u][ky * 3 + kx], 0, 0, 0);
+        };
+        auto step = [&](auto PH, int r) {
+            constexpr int ph = decltype(PH)::value;
+            using I = std::integral_constant<int, ph % 3>;             // slot of dY row r - 1
+            using I1 = std::integral_constant<int, (ph + 1) % 3>;      // row r
+            using I2 = std::integral_constant<int, (ph + 2) % 3>;      // row r + 1
+            using BS = std::integral_constant<int, ph % 2>;
+            mfma_row(I{}, BS{}, std::integral_constant<int, 2>{});
+            cvt_A(rawA, rawS, A[ph % 3]);
+            cvt_B(rawB, rawL, rawR, B[(ph + 1) % 2]);
+            // the loads stay between the two MFMA groups (left alone the scheduler sinks them to their use, one
+            // step later, and the wave eats the memory latency every row)
+            __builtin_amdgcn_sched_barrier(0);
+            load_A(r + 3, rawA, rawS);
+            load_B(r + 2, rawB, rawL, rawR);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(I1{}, BS{}, std::integral_constant<int, 1>{});
+            mfma_row(I2{}, BS{}, std::integral_constant<int, 0>{});
+        };
+        int r = r0;
+        for (; r + 6 <= r1; r += 6) {
+            step(std::integral_constant<int, 0>{}, r);
+            step(std::integral_constant<int, 1>{}, r + 1);
+            step(std::integral_constant<int, 2>{}, r + 2);
+            step(std::integral_constant<int, 3>{}, r + 3);
+            step(std::integral_constant<int, 4>{}, r + 4);
+            step(std::integral_constant<int, 5>{}, r + 5);
+        }
+        if (r < r1)
+            step(std::integral_constant<int, 0>{}, r);
+        if (r + 1 < r1)
+            step(std::integral_constant<int, 1>{}, r + 1);
+        if (r + 2 < r1)
+            step(std::integral_constant<int, 2>{}, r + 2);
+        if (r + 3 < r1)
+            step(std::integral_constant<int, 3>{}, r + 3);
+        if (r + 4 < r1)
+            step(std::integral_constant<int, 4>{}, r + 4);
+    }
+
+    // slab [split][tap][co][ci]; accumulator register q of lane (q4, j) is (co = 4 q4 + q, ci = j) of its tile
+    const float inv = 1.0f / (sx * sg);
+    float *out = a.part + (size_t)split * 9 * a.Cout * a.Cin;
+#pragma unroll
+    for (int t = 0; t < NCO; ++t)
+#pragma unroll
+        for (int u = 0; u < NCI; ++u)
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = co0 + 16 * t + 4 * q4 + q, ci = ci0 + 16 * u + j;
+                    if (ci_ok[u])
+                        out[((size_t)k * a.Cout + co) * a.Cin + ci] = acc[t][u][k][q] * inv;
+                }
+}
+
+// dw[co][ci][tap] = sum_s part[s][tap][co][ci].  Block = 32 outputs x 8 slab groups: group g adds slabs g, g+8, ...
+// in order, the 8 partial sums are combined in order through LDS -> fixed summation tree, deterministic.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ part, int S, int Cout, int Cin,
+                                                     float *__restrict__ dw)
+{
+    __shared__ float sh[8][32];
+    const int total = 9 * Cout * Cin;
+    const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + lane;       // (tap, co, ci) in slab order
+    float s0 = 0.f, s1 = 0.f;
+    if (idx < total) {
+        int k = g;
+        for (; k + 8 < S; k += 16) {
+            s0 += part[(size_t)k * total + idx];
+            s1 += part[(size_t)(k + 8) * total + idx];
+        }
+        if (k < S)
+            s0 += part[(size_t)k * total + idx];
+    }
+    sh[g][lane] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && idx < total) {
+        float s = sh[0][lane];
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+            s += sh[q][lane];
+        const int ci = idx % Cin;
+        const int co = (idx / Cin) % Cout;
+        const int tap = idx / (Cin * Cout);
+        dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+    }
+}
+
+}  // namespace
+
+static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nci, int &S, int &units)
+{
+    const int cot = Cout / 16, cit = Cin / 16;
+    nco = (cot % 3 == 0) ? 3 : (cot % 2 == 0) ? 2 : 1;        // (4 tiles would spill)
+    nci = cit >= 2 ? 2 : 1;     // the last group is ragged for an odd tile count
+    const int pairs = (cot / nco) * ((cit + nci - 1) / nci);
+    units = N * ((W + 31) / 32);            // columns: (image, 32-pixel strip), H input rows each
+    // One workgroup (4 waves = 4 splits of one pair) per CU is all that fits (a wave owns most of its SIMD's
+    // registers): at most 256 workgroups, or the stragglers run as a second round and double the kernel time.
+    int nx = 256 / pairs;
+    if (nx < 1)
+        nx = 1;
+    S = 4 * nx;
+    if ((long long)S > (long long)units * H)
+        S = units * H;
+}
+
+extern "C" int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W)
+{
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cin & 15) || (Cout & 15))
+        return 0;
+    int nco, nci, S, units;
+    wgrad_plan(N, Cin, Cout, H, W, nco, nci, S, units);
+    return S;
+}
+
+extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W,
+                                  const float *xamax, int xcount, const float *gamax, int gcount, float *part,
+                                  float *dw, void *stream)
+{
+    DCL_CHECK_ARG(x && dy && xamax && gamax && part && dw, "null pointer");
+    DCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && xcount > 0 && gcount > 0, "bad shape");
+    DCL_CHECK_ARG(Cin > 0 && Cout > 0 && (Cin & 15) == 0 && (Cout & 15) == 0, "channel counts must be multiples of 16");
+    DCL_CHECK_ARG((W & 7) == 0, "W must be a multiple of 8");
+    DCL_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0, "tensors must be 16-byte aligned");
+    WgradArgs a;
+    a.x = x;
+    a.dy = dy;
+    a.part = part;
+    a.xamax = xamax;
+    a.gamax = gamax;
+    a.xcount = xcount;
+    a.gcount = gcount;
+    a.N = N;
+    a.Cin = Cin;
+    a.Cout = Cout;
+    a.H = H;
+    a.W = W;
+    a.strips = (W + 31) / 32;
+    a.nseg = 1;
+    int nco, nci;
+    wgrad_plan(N, Cin, Cout, H, W, nco, nci, a.S, a.units);
+    a.ncig = (Cin / 16 + nci - 1) / nci;
+    a.npairs = (Cout / 16 / nco) * a.ncig;
+    a.nx = (a.S + 3) / 4;                                    // workgroups per pair (4 splits each)
+    dim3 grid((unsigned)(a.npairs * a.nx));      // exactly the populated workgroups, <= 256 whenever pairs <= 256
+    hipStream_t s = (hipStream_t)stream;
+#define DCL_WG_CASE(o, i)                                                        \
+    if (nco == o && nci == i)                                                    \
+        hipLaunchKernelGGL((k_wgrad3x3<o, i>), grid, dim3(256), 0, s, a);
+    DCL_WG_CASE(3, 2)
+    DCL_WG_CASE(2, 2)
+    DCL_WG_CASE(1, 2)
+    DCL_WG_CASE(3, 1)
+    DCL_WG_CASE(2, 1)
+    DCL_WG_CASE(1, 1)
+#undef DCL_WG_CASE
+    DCL_LAUNCH_CHECK();
+    const int total = 9 * Cout * Cin;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, s, part, a.S, Cout, Cin, dw);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}

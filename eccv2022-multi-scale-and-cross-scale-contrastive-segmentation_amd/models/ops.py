@@ -245,9 +245,34 @@ def conv3x3_direct(x, weight, transposed=False):
     return conv3x3_launch(x, wp, cout, amax_of(x), wamax, out)
 
 
+def conv3x3_wgrad_supported(x, cout):
+    return x.shape[1] % 16 == 0 and cout % 16 == 0 and x.shape[3] % 8 == 0
+
+
+def conv3x3_wgrad(x, gy):
+    """dw [Co, Ci, 3, 3] = weight gradient of conv2d(x, w, padding=1) for the output gradient gy, on the f16x3
+    kernel of csrc/dcl_wgrad3x3.hip (x [N, Ci, H, W], gy [N, Co, H, W], contiguous f32)."""
+    from .. import _lib
+    from .amax import amax_of
+    n, ci, h, w = x.shape
+    co = gy.shape[1]
+    L = _lib.lib()
+    splits = L.dcl_wgrad3x3_splits(n, ci, co, h, w)
+    if splits <= 0:
+        raise RuntimeError("conv3x3_wgrad: unsupported shape")
+    part = torch.empty(splits * 9 * co * ci, dtype=torch.float32, device=x.device)
+    dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)
+    xa, ga = amax_of(x), amax_of(gy)
+    _lib.check(L.dcl_wgrad3x3_f16x3(_lib.ptr(x), _lib.ptr(gy), n, ci, co, h, w, _lib.ptr(xa), xa.numel(),
+                                    _lib.ptr(ga), ga.numel(), _lib.ptr(part), _lib.ptr(dw), _stream(x)),
+               "dcl_wgrad3x3_f16x3")
+    return dw
+
+
 class _Conv3x3Direct(torch.autograd.Function):
-    """3x3 / stride 1 / pad 1 convolution through csrc/dcl_conv3x3.hip: forward and data gradient on the direct
-    f16x3 kernel (fp32-equivalent), weight gradient through ATen (MIOpen)."""
+    """3x3 / stride 1 / pad 1 convolution on the f16x3 (fp32-equivalent) kernels: forward and data gradient through
+    csrc/dcl_conv3x3.hip, weight gradient through csrc/dcl_wgrad3x3.hip (channel counts that are not multiples
+    of 16: ATen / MIOpen)."""
 
     @staticmethod
     def forward(ctx, x, weight, mod):
@@ -271,8 +296,11 @@ class _Conv3x3Direct(torch.autograd.Function):
             gx = torch.empty_like(x)
             conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx)
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            if conv3x3_wgrad_supported(x, weight.shape[0]):
+                gw = conv3x3_wgrad(x, gy)
+            else:
+                gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0],
+                                                         1, [False, True, False])[1]
         return gx, gw, None
 
 

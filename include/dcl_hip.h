@@ -243,6 +243,14 @@ int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *
                       const float *xamax, int xcount, const float *wamax, float *y, int tile_r, int tile_p,
                       void *stream);
 
+/* Weight gradient of the same convolution, dw[Cout,Cin,3,3] = sum_n dy (*) x, on the f16x3 MFMA path with no LDS
+ * staging (csrc/dcl_wgrad3x3.hip).  Cin % 16 == 0, Cout % 16 == 0, W % 8 == 0.  part: workspace of
+ * dcl_wgrad3x3_splits(...) * 9 * Cout * Cin floats (one partial slab per split, summed in fixed order). */
+int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W);
+int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W,
+                       const float *xamax, int xcount, const float *gamax, int gcount, float *part, float *dw,
+                       void *stream);
+
 /* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the
  * grid fills the 256 CUs evenly (host helper, no device work). */
 int dcl_suggest_nsplit(int N1, int N2);

@@ -61,6 +61,20 @@ def main():
         gx = ops.conv3x3_direct(gy, wt, transposed=True)
         gref = F.conv_transpose2d(gy[:2].double(), wt.double(), padding=1)
         print(f"    dgrad err {((gx[:2].double() - gref).abs().max() / gref.abs().max()).item():.2e}", flush=True)
+        # weight gradient
+        gw = ops.conv3x3_wgrad(x, gy)
+        gw_lib = torch.ops.aten.convolution_backward(gy, x, wt, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        gw64 = torch.ops.aten.convolution_backward(gy.double().cpu(), x.double().cpu(), wt.double().cpu(), None,
+                                                   [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                   [False, True, False])[1].to(dev)
+        dn = gw64.abs().max()
+        t_w = timeit(lambda: ops.conv3x3_wgrad(x, gy))
+        t_wl = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, wt, None, [1, 1], [1, 1], [1, 1], False,
+                                                                  [0, 0], 1, [False, True, False]))
+        print(f"    wgrad err direct {((gw.double() - gw64).abs().max() / dn).item():.2e} miopen "
+              f"{((gw_lib.double() - gw64).abs().max() / dn).item():.2e} | miopen {t_wl:.3f} ms direct {t_w:.3f} ms "
+              f"({flops / t_w / 1e9:.0f} TF)", flush=True)
 
 
 if __name__ == "__main__":
