@@ -600,3 +600,98 @@ def test_head_conv_f16x3_matches_fp64(dev):
         scale = w_.abs().max().item()
         err, err_lib = (g_ - w_).abs().max().item() / scale, (l_ - w_).abs().max().item() / scale
         assert err <= max(3e-6, 4 * err_lib), (name, err, err_lib)
+
+
+def _conv_ref64(x, w, gy):
+    x64 = x.double().cpu().requires_grad_(True)
+    w64 = w.double().cpu().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w64, padding=1)
+    y64.backward(gy.double().cpu())
+    return y64.detach(), x64.grad, w64.grad
+
+
+# (N, Cin, Cout, H, W): HRNet-W48 branch shapes in small, ragged tile edges (H % 16, W % 32 != 0), channel counts
+# that are not multiples of 16 / 32 (padded weight tiles, ragged last octet), a 1-pixel-high image, hrnet18's C = 18
+_DIRECT_SHAPES = [(2, 48, 48, 32, 64), (1, 96, 96, 16, 32), (3, 16, 32, 7, 40), (2, 40, 24, 19, 33),
+                  (1, 18, 18, 9, 16), (2, 64, 64, 1, 8), (1, 192, 192, 8, 8), (2, 256, 48, 12, 24)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", _DIRECT_SHAPES)
+def test_direct_conv3x3_forward_dgrad_match_fp64(dev, shape):
+    """csrc/dcl_conv3x3.hip through the C-ABI (pack + convolution, forward and transposed weights) against a
+    float64 convolution; tolerance 3e-6 of the output's max (fp32-equivalent: the f32 MIOpen convolution sits at
+    3e-7 .. 1.2e-6 on the same inputs), every workgroup tile shape."""
+    from mscs_amd.models import ops
+    from mscs_amd.models.amax import amax_of
+    n, ci, co, h, w = shape
+    torch.manual_seed(sum(shape))
+    x = torch.randn(n, ci, h, w, device=dev).relu_() * 2.5
+    wt = torch.randn(co, ci, 3, 3, device=dev) * (2.0 / (9 * ci)) ** 0.5
+    gy = torch.randn(n, co, h, w, device=dev) * 3e-5                   # gradients are small: exercises the scaling
+    y64, gx64, _ = _conv_ref64(x, wt, gy)
+    y = ops.conv3x3_direct(x, wt)
+    gx = ops.conv3x3_direct(gy, wt, transposed=True)
+    assert ((y.double().cpu() - y64).abs().max() / y64.abs().max()).item() < 3e-6
+    assert ((gx.double().cpu() - gx64).abs().max() / gx64.abs().max()).item() < 3e-6
+    # every tile configuration computes the same convolution (different accumulation order inside the MFMA only)
+    wamax, xamax = amax_of(wt), amax_of(x)
+    wp = ops.conv3x3_pack(wt, wamax)
+    for r in (1, 2, 3):
+        for p in (1, 2, 4):
+            out = torch.full_like(y, float("nan"))
+            ops.conv3x3_launch(x, wp, co, xamax, wamax, out, r, p)
+            assert ((out.double().cpu() - y64).abs().max() / y64.abs().max()).item() < 3e-6, (r, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [s for s in _DIRECT_SHAPES if s[1] % 16 == 0 and s[2] % 16 == 0 and s[4] % 8 == 0])
+def test_direct_conv3x3_wgrad_matches_fp64(dev, shape):
+    """csrc/dcl_wgrad3x3.hip against the float64 weight gradient (3e-6 of max), and bitwise run-to-run
+    reproducibility (slab reduction in fixed order, no float atomics)."""
+    from mscs_amd.models import ops
+    n, ci, co, h, w = shape
+    torch.manual_seed(sum(shape) + 1)
+    x = torch.randn(n, ci, h, w, device=dev).relu_() * 2.5
+    wt = torch.randn(co, ci, 3, 3, device=dev)
+    gy = torch.randn(n, co, h, w, device=dev) * 3e-5
+    _, _, gw64 = _conv_ref64(x, wt, gy)
+    gw = ops.conv3x3_wgrad(x, gy)
+    assert ((gw.double().cpu() - gw64).abs().max() / gw64.abs().max()).item() < 3e-6
+    assert torch.equal(gw, ops.conv3x3_wgrad(x, gy))
+
+
+@pytest.mark.gpu
+def test_direct_conv_module_autograd_and_absmax_tags(dev):
+    """DirectConv2d inside conv -> fused BN -> conv: gradients match the nn.Conv2d / nn.BatchNorm2d graph in
+    float64; the BN outputs carry absmax tags that bound the tensors they describe, and a tag is dropped once its
+    tensor is modified in place."""
+    from mscs_amd.models import ops
+    from mscs_amd.models.amax import amax_of
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d, bn_act
+    torch.manual_seed(3)
+    c1, c2 = torch.nn.Conv2d(32, 48, 3, padding=1, bias=False).to(dev), torch.nn.Conv2d(48, 32, 3, padding=1, bias=False).to(dev)
+    bn = FusedBatchNorm2d(48).to(dev)
+    ops.use_direct_conv3x3(c1), ops.use_direct_conv3x3(c2)
+    assert isinstance(c1, ops.DirectConv2d) and isinstance(c2, ops.DirectConv2d)
+    x = torch.randn(3, 32, 12, 40, device=dev, requires_grad=True)
+    mid = bn_act(bn, c1(x))
+    tag = mid._dcl_amax
+    assert tag[1].numel() == 3 * 48 and abs(tag[1].max().item() - mid.abs().max().item()) < 1e-6
+    out = c2(mid)
+    out.square().mean().backward()
+    # float64 reference of the same graph
+    r1, r2 = torch.nn.Conv2d(32, 48, 3, padding=1, bias=False).double(), torch.nn.Conv2d(48, 32, 3, padding=1, bias=False).double()
+    rb = torch.nn.BatchNorm2d(48).double()
+    r1.weight.data.copy_(c1.weight.detach().cpu()); r2.weight.data.copy_(c2.weight.detach().cpu())
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    o64 = r2(torch.relu(rb(r1(x64))))
+    o64.square().mean().backward()
+    for got, want in ((out, o64), (x.grad, x64.grad), (c1.weight.grad, r1.weight.grad), (c2.weight.grad, r2.weight.grad)):
+        assert ((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max()).item() < 2e-5
+    # stale tags are ignored
+    t = torch.randn(1, 16, 8, 8, device=dev)
+    a0 = amax_of(t)
+    t.mul_(4.0)
+    a1 = amax_of(t)
+    assert a1 is not a0 and abs(a1.max().item() - t.abs().max().item()) < 1e-6
