@@ -37,6 +37,17 @@ constexpr int PIXB = 80;        // bytes per LDS pixel record
 
 __device__ __forceinline__ int jrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Packed f16 pairs (low half = first value) of hi = f16(v * s) and lo = f16(v * s - hi) for two values.  s is a
+// power of two (or 0), so v * s is exact and the fused form is the same number; v_fma_mix{lo,hi}_f16 takes f32 /
+// f16 inputs, computes in f32 and writes one f16 half of the destination: 2 VALU instructions per value, no packing.
+__device__ __forceinline__ void split2(float v0, float v1, float s, unsigned &hi, unsigned &lo)
+{
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(v0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(v0), "v"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "v"(s), "v"(hi));
+}
+
 struct ConvArgs {
     const float *x;
     const uint4 *wp;
@@ -93,60 +104,66 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
         xs = pow2_scale(m);
     }
 
-    // staging work items: (octet of channels, patch pixel); consecutive lanes -> consecutive pixels
+    // staging work items: (octet of channels, patch pixel); consecutive lanes -> consecutive pixels.
+    // Every load is unconditional from a clamped, always valid address (a branch around a load makes the compiler
+    // wait for it at the join, i.e. in front of the MFMAs it is meant to overlap): halo pixels outside the image
+    // read pixel 0 and are zeroed through their operand scale (0 instead of s); channels past Cin read channel
+    // Cin - 1 and meet the zero weights the packer wrote for k >= Cin.
     int goff[NITEM], loff[NITEM];
+    float gsc[NITEM];
 #pragma unroll
     for (int m = 0; m < NITEM; ++m) {
-        const int it = tid + 256 * m;
-        goff[m] = -1;
-        loff[m] = -1;
-        if (it < 2 * TP) {
-            const int oct = it >= TP ? 1 : 0;
-            const int pix = it - oct * TP;
-            const int r = pix / LW, c = pix - r * LW;
-            const int gy = y0 + r - 1, gx = x0 + c - 1;
-            loff[m] = pix * PIXB + oct * 16;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                goff[m] = (int)(oct * 8 * plane) + gy * a.W + gx;
-        }
+        const int it = min(tid + 256 * m, 2 * TP - 1);          // surplus items repeat the last one
+        const int oct = it >= TP ? 1 : 0;
+        const int pix = it - oct * TP;
+        const int r = pix / LW, c = pix - r * LW;
+        const int gy = y0 + r - 1, gx = x0 + c - 1;
+        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        loff[m] = pix * PIXB + oct * 16;
+        goff[m] = ok ? gy * a.W + gx : 0;
+        gsc[m] = ok ? xs : 0.f;
     }
+    const bool ragged = (a.Cin & 15) != 0;                       // last chunk has channels past Cin
     float g[NITEM][8];
     auto load_items = [&](int c) {
-        const float *xc = xb + (size_t)(16 * c) * plane;
+        if (!ragged || c + 1 < a.nchunk) {
 #pragma unroll
-        for (int m = 0; m < NITEM; ++m) {
-            const int ch0 = 16 * c + 8 * (m * 256 + tid >= TP ? 1 : 0);
-            if (goff[m] >= 0 && ch0 + 8 <= a.Cin) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    g[m][e] = xc[(size_t)goff[m] + e * plane];
-            } else {
-                // outside the image, or the ragged last octet of a channel count that is not a multiple of 8
+            for (int m = 0; m < NITEM; ++m) {
+                const float *xc = xb + (size_t)(16 * c + 8 * (tid + 256 * m >= TP ? 1 : 0)) * plane + goff[m];
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    g[m][e] = (goff[m] >= 0 && ch0 + e < a.Cin) ? xc[(size_t)goff[m] + e * plane] : 0.f;
+                    g[m][e] = xc[e * plane];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < NITEM; ++m) {
+                const int ch0 = 16 * c + 8 * (tid + 256 * m >= TP ? 1 : 0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    g[m][e] = xb[(size_t)min(ch0 + e, a.Cin - 1) * plane + goff[m]];
             }
         }
     };
     auto write_items = [&](unsigned char *buf) {
 #pragma unroll
         for (int m = 0; m < NITEM; ++m) {
-            if (loff[m] >= 0) {
-                half8 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = g[m][e] * xs;
-                    hi[e] = (_Float16)v;
-                    lo[e] = (_Float16)(v - (float)hi[e]);
-                }
-                *(half8 *)(buf + loff[m]) = hi;
-                *(half8 *)(buf + loff[m] + 32) = lo;
-            }
+            unsigned hh[4], ll[4];
+            split2(g[m][0], g[m][1], gsc[m], hh[0], ll[0]);
+            split2(g[m][2], g[m][3], gsc[m], hh[1], ll[1]);
+            split2(g[m][4], g[m][5], gsc[m], hh[2], ll[2]);
+            split2(g[m][6], g[m][7], gsc[m], hh[3], ll[3]);
+            *(uint4 *)(buf + loff[m]) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+            *(uint4 *)(buf + loff[m] + 32) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
         }
     };
 
-    // A fragments: wp[(((T * nchunk + c) * 9 + ky * 3 + kx) * 2 + part) * 64 + lane]
-    const uint4 *wa = a.wp + (size_t)T0 * a.nchunk * 9 * 2 * 64 + lane;
+    // A fragments: wp[(((T * nchunk + c) * 9 + ky * 3 + kx) * 2 + part) * 64 + lane]; channel tiles past the last
+    // one (a workgroup tile wider than Cout) re-read the last tile, their results are never stored
+    const int mtiles = (a.Cout + 31) / 32;
+    const uint4 *wa[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        wa[r] = a.wp + (size_t)min(T0 + r, mtiles - 1) * a.nchunk * 9 * 2 * 64 + lane;
     auto load_A = [&](half8 (&A)[3][R][2], int c, int kx) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int part = 0; part < 2; ++part) {
-                    const uint4 v = wa[((((size_t)r * a.nchunk + c) * 9 + ky * 3 + kx) * 2 + part) * 64];
+                    const uint4 v = wa[r][(((size_t)c * 9 + ky * 3 + kx) * 2 + part) * 64];
                     A[ky][r][part] = __builtin_bit_cast(half8, v);
                 }
     };
@@ -168,9 +185,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
             for (int q = 0; q < 16; ++q)
                 acc[r][p][q] = 0.f;
 
-    half8 Acur[3][R][2];
+    // Weight fragments are streamed AD kx-steps ahead of their use into a ring of three register sets indexed by
+    // kx (static indices, no copies): one step ahead when a step holds >= 54 MFMAs (R = 3), two steps ahead for
+    // the smaller tiles, whose steps are shorter than an L2 round trip.
+    constexpr int AD = (R >= 3 || (R == 2 && P == 2)) ? 1 : 2;   // (2, 2) must stay under 256 registers: 2 workgroups / CU
+    half8 Ab[3][3][R][2];
+    const int nsteps = 3 * a.nchunk;
     load_items(0);
-    load_A(Acur, 0, 0);
+    load_A(Ab[0], 0, 0);
+    if (AD == 2)
+        load_A(Ab[1], 0, 1);
     write_items(lds);
     __syncthreads();
 
@@ -178,43 +202,38 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
     for (int c = 0; c < a.nchunk; ++c) {
         const unsigned char *cur = lds + (c & 1) * BUFB;
         const bool more = c + 1 < a.nchunk;
-        if (more)
-            load_items(c + 1);
+        // next chunk's patch: issued here, pinned above the MFMAs, written to LDS after them (the last
+        // iteration re-reads its own chunk and drops it)
+        __builtin_amdgcn_sched_barrier(0);
+        load_items(more ? c + 1 : c);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            half8 Anext[3][R][2];
-            if (kx < 2)
-                load_A(Anext, c, kx + 1);
-            else if (more)
-                load_A(Anext, c + 1, 0);
+            {
+                const int s2 = min(3 * c + kx + AD, nsteps - 1);      // step whose fragments are fetched now
+                load_A(Ab[(kx + AD) % 3], s2 / 3, s2 % 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rr = 0; rr < P + 2; ++rr) {
                 const unsigned char *bp = cur + (brow + rr * LW + kx) * PIXB + h * 16;
                 const half8 bh = *(const half8 *)bp;
                 const half8 bl = *(const half8 *)(bp + 32);
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int p = rr - ky;
-                    if (p >= 0 && p < P) {
+                for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Acur[ky][r][0], bh, acc[r][p], 0, 0, 0);
-                            acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Acur[ky][r][0], bl, acc[r][p], 0, 0, 0);
-                            acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Acur[ky][r][1], bh, acc[r][p], 0, 0, 0);
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int p = rr - ky;
+                        if (p >= 0 && p < P) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+                                acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p], 0, 0, 0);
                         }
                     }
-                }
-            }
-            if (kx < 2 || more) {
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-#pragma unroll
-                        for (int part = 0; part < 2; ++part)
-                            Acur[ky][r][part] = Anext[ky][r][part];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (more)
             write_items(lds + ((c + 1) & 1) * BUFB);
         __syncthreads();
@@ -227,12 +246,18 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int row = y0 + P * wave + p;
-            if (row < a.H && col < a.W) {
+            const int cob = (T0 + r) * 32 + 4 * h;
+            if (row < a.H && col < a.W && cob < a.Cout) {
+                float *yp = a.y + (((size_t)n * a.Cout + cob) * a.H + row) * a.W + col;
+                if (cob + 28 <= a.Cout) {            // whole channel tile inside Cout
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int co = (T0 + r) * 32 + jrow(q, h);
-                    if (co < a.Cout)
-                        a.y[(((size_t)n * a.Cout + co) * a.H + row) * a.W + col] = acc[r][p][q] * inv;
+                    for (int q = 0; q < 16; ++q)
+                        yp[(size_t)((q & 3) + 8 * (q >> 2)) * plane] = acc[r][p][q] * inv;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (cob + (q & 3) + 8 * (q >> 2) < a.Cout)
+                            yp[(size_t)((q & 3) + 8 * (q >> 2)) * plane] = acc[r][p][q] * inv;
                 }
             }
         }
@@ -376,8 +401,8 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
     if (R <= 0 || P <= 0) {
         // measured on the four BasicBlock shapes of HRNet-W48 at batch 12 (tools/bench_conv3x3.py --tiles):
         // channel tiles per wave in threes when that leaves no padded tile, else pairs; the most rows per wave
-        // that still give ~one workgroup per CU; (2, 4) loses to (2, 2), whose 54 KB of LDS and 228 registers let
-        // two workgroups share a CU; tiny images fall back to single-tile waves to get enough workgroups.
+        // that still give ~one workgroup per CU; tiny images fall back to single-tile waves to get enough
+        // workgroups.
         R = (mtiles % 3 == 0) ? 3 : (mtiles == 1 ? 1 : 2);
         auto wgs = [&](int r, int p) {
             return (long)((W + TW - 1) / TW) * ((H + 4 * p - 1) / (4 * p)) * N * ((mtiles + r - 1) / r);
@@ -385,8 +410,6 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
         P = 4;
         while (P > 1 && wgs(R, P) < 192)
             P >>= 1;
-        if (R == 2 && P == 4)
-            P = 2;
         if (P == 1 && wgs(R, P) < 256)
             R = 1;
     }

@@ -1,0 +1,14 @@
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mscs_amd
+from mscs_amd.models import ops
+from mscs_amd.models.amax import amax_of
+dev = torch.device("cuda:0")
+for (n, c, h, w) in [(12, 48, 128, 256), (12, 96, 64, 128), (12, 192, 32, 64), (12, 384, 16, 32)]:
+    x = torch.randn(n, c, h, w, device=dev).relu_(); wt = torch.randn(c, c, 3, 3, device=dev) * 0.05
+    sx, sw = amax_of(x), amax_of(wt)
+    wp = ops.conv3x3_pack(wt, sw)
+    out = torch.empty_like(x)
+    for _ in range(5):
+        ops.conv3x3_launch(x, wp, c, sx, sw, out)
+    torch.cuda.synchronize()
