@@ -11,12 +11,16 @@ Workloads (BASELINE.json configs[1]: HRNet-W48 + DenseContrastiveLossV2_ms (3 sc
 Cityscapes 512x1024, batch 12 per GPU):
   step  one training step: model forward, LossWrapper(CE + 0.1 * DCV2_ms), backward, SGD update
   loss  the contrastive loss alone (forward + backward) on synthetic 256-d projector outputs
-Extra keys: `roofline` (dominant hot-path kernel = InfoNCE backward sweep, algorithmic FLOPs over HIP-event
-time, peak per arithmetic mode), `cpu_baseline` (oracle/eager_torch.py + the same model code on the host cores,
+Extra keys: `roofline` (dominant hand-written kernel: for the training step the direct 3x3 convolution
+`k_conv3x3` on HRNet's 48-channel branch shape -- the convolution family is ~19 % of the step's kernel time -- for
+`--workload loss` the InfoNCE backward sweep; algorithmic FLOPs over HIP-event time, peak per arithmetic mode),
+`roofline_other` (the weight-gradient kernel and the InfoNCE backward sweep), `cpu_baseline` (oracle/eager_torch.py + the same model code on the host cores,
 bounded sample), `contrastive_loss_fwd_bwd_ms`, and with --eager-baseline the eager-structure torch loss on the
 GPU.  `dtype` "f32" = fp32-equivalent arithmetic: fp32 storage and accumulation everywhere; the loss's similarity
 product and the head convolution run as split-f16 (hi, lo) MFMA passes whose results match fp32 to round-off
-(DESIGN.md section 3); `--mfma f32` and graph key head_conv='library' select plain f32 MFMA / MIOpen instead.
+(DESIGN.md section 3); the backbone's 3x3 convolutions run on the direct split-f16 kernels (forward, data and
+weight gradient); `--mfma f32`, `--branch-conv library` and graph key head_conv='library' select plain f32 MFMA /
+MIOpen instead.
 """
 import argparse
 import contextlib
@@ -119,6 +123,60 @@ def sync(world):
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
+
+
+# HBM-side traffic of the direct convolution kernels at the benchmark's 48-channel shape (12 x 48 x 128 x 256), KiB
+# per launch (FETCH_SIZE, WRITE_SIZE) from the committed PMC passes (profiles/r01_conv_pmc_*.csv)
+PMC_CONV48 = (103105.1, 73728.0)
+PMC_WGRAD48 = (155190.0, 60815.9)
+
+
+def _time_launches(launch, iters):
+    launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def roofline_conv_kernels(args, dev, iters=20):
+    """Average launch duration of the direct f16x3 convolution (forward kernel; the data gradient is the same
+    kernel) and of the weight-gradient kernel on the backbone's highest-resolution BasicBlock shape
+    (batch x 48 x H/4 x W/4), HIP events on the launch stream.  Algorithmic FLOPs = 2 * N * Cout * Cin * 9 * H * W;
+    every one of them costs three f16 MFMA passes (hi.hi + hi.lo + lo.hi), hence peak = 2500 / 3 TFLOP/s."""
+    from mscs_amd.models import ops
+    from mscs_amd.models.amax import amax_of
+    n, c, h, w = args.batch, 48, args.height // 4, args.width // 4
+    gen = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(n, c, h, w, device=dev, generator=gen).relu_()
+    wt = torch.randn(c, c, 3, 3, device=dev, generator=gen) * (2.0 / (9 * c)) ** 0.5
+    gy = torch.randn(n, c, h, w, device=dev, generator=gen) * 1e-4
+    xa, wa = amax_of(x), amax_of(wt)
+    wp = ops.conv3x3_pack(wt, wa)
+    out = torch.empty_like(x)
+    flops = 2.0 * n * c * c * 9 * h * w
+    default_shape = (n, h, w) == (12, 128, 256)
+    ms = _time_launches(lambda: ops.conv3x3_launch(x, wp, c, xa, wa, out), iters)
+    peak = MFMA_F16_PEAK_TFLOPS / 3.0
+    note = "every algorithmic FLOP is issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): 2.5 PFLOP/s / 3"
+    main = {"bound": "mfma", "kernel": "k_conv3x3<2,4> (dcl_conv3x3_f16x3): 3x3 conv forward / data gradient, "
+                                        f"{n}x{c}x{h}x{w}",
+            "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_note": note,
+            "traffic": (2 * PMC_CONV48[0] + PMC_CONV48[1]) * 1024 if default_shape else None,
+            "traffic_source": "profiles/r01_conv_pmc_fetch.csv, r01_conv_pmc_write.csv",
+            "algorithmic_bytes": 2 * n * c * h * w * 4, "launch_ms": round(ms, 4)}
+    msw = _time_launches(lambda: ops.conv3x3_wgrad(x, gy), iters)
+    wg = {"bound": "mfma", "kernel": f"k_wgrad3x3<3,2> + k_wgrad_reduce (dcl_wgrad3x3_f16x3), {n}x{c}x{h}x{w}",
+          "achieved": round(flops / (msw * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+          "frac": round(flops / (msw * 1e-3) / 1e12 / peak, 4),
+          "traffic": (2 * PMC_WGRAD48[0] + PMC_WGRAD48[1]) * 1024 if default_shape else None,
+          "algorithmic_bytes": 2 * n * c * h * w * 4, "launch_ms": round(msw, 4)}
+    return main, wg
 
 
 def roofline_bwd_kernel(mod, iters=10):
@@ -359,7 +417,11 @@ def main():
         out.update(extra)
         if workload == "loss":
             out["contrastive_loss_fwd_bwd_ms"] = round(ms_per_step, 3)
-        out["roofline"] = roofline_bwd_kernel(mod)
+        if workload == "loss":
+            out["roofline"] = roofline_bwd_kernel(mod)
+        else:
+            out["roofline"], wg = roofline_conv_kernels(args, dev)
+            out["roofline_other"] = [wg, roofline_bwd_kernel(mod)]
         if not args.no_cpu_baseline:
             scale, lsec, cores, lsample = cpu_baseline_loss(args, n_terms)
             loss_sec = lsec * scale
