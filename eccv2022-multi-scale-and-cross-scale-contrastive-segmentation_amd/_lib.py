@@ -51,6 +51,8 @@ SIGNATURES = {
     "dcl_split_f16": [_vp, _i64, _vp, _vp, _vp, _vp],
     "dcl_absmax": [_vp, _i64, _vp, _vp],
     "dcl_conv3x3_pack": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "dcl_absmax_multi": [_vp, _vp, _i, _vp],
+    "dcl_conv3x3_pack_multi": [_vp, _vp, _i, _vp],
     "dcl_conv3x3_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _vp],
     "dcl_wgrad3x3_splits": [_i, _i, _i, _i, _i],
     "dcl_wgrad3x3_f16x3": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],

@@ -266,13 +266,11 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
 // weights -> fragment order.  transposed = 0: value(m, k, ky, kx) = w[m][k][ky][kx], w is [M][K][3][3];
 // transposed = 1 (data gradient): value(m, k, ky, kx) = w[k][m][2 - ky][2 - kx], w is [K][M][3][3].
 // One thread per (fragment pair, lane): fragment (T, c, t) lane (hh, i) holds value(32 T + i, 16 c + 8 hh + e, t).
-__global__ __launch_bounds__(256) void k_pack_w3x3(const float *__restrict__ w, int M, int K, int transposed,
-                                                  int mtiles, int nchunk, const float *__restrict__ wamax,
-                                                  uint4 *__restrict__ wp)
+__device__ __forceinline__ void pack_item(const float *__restrict__ w, int M, int K, int transposed, int gid,
+                                          float s, uint4 *__restrict__ wp)
 {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int total = mtiles * nchunk * 9 * 64;
-    if (gid >= total)
+    const int mtiles = (M + 31) / 32, nchunk = (K + 15) / 16;
+    if (gid >= mtiles * nchunk * 9 * 64)
         return;
     const int lane = gid & 63;
     int f = gid >> 6;
@@ -283,7 +281,6 @@ __global__ __launch_bounds__(256) void k_pack_w3x3(const float *__restrict__ w, 
     const int i = lane & 31, hh = lane >> 5;
     const int m = 32 * T + i;
     const int ky = t / 3, kx = t - 3 * ky;
-    const float s = pow2_scale(wamax[0]);
     half8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -299,6 +296,64 @@ __global__ __launch_bounds__(256) void k_pack_w3x3(const float *__restrict__ w, 
     const size_t o = ((((size_t)T * nchunk + c) * 9 + t) * 2) * 64 + lane;
     wp[o] = __builtin_bit_cast(uint4, hi);
     wp[o + 64] = __builtin_bit_cast(uint4, lo);
+}
+
+__global__ __launch_bounds__(256) void k_pack_w3x3(const float *__restrict__ w, int M, int K, int transposed,
+                                                  const float *__restrict__ wamax, uint4 *__restrict__ wp)
+{
+    pack_item(w, M, K, transposed, blockIdx.x * 256 + threadIdx.x, pow2_scale(wamax[0]), wp);
+}
+
+// Multi-tensor forms (one launch for all weights of a model instead of three per convolution): job tables in
+// device memory, blk2job[b] = job of workgroup b, job.first_block = its first workgroup.
+struct PackJob {
+    const float *w;
+    uint4 *wp;
+    const float *amax;
+    int M, K, transposed, first_block;
+};
+struct AbsmaxJob {
+    const float *x;
+    float *out;
+    long long n;
+    int first_block, pad;
+};
+
+__global__ __launch_bounds__(256) void k_pack_multi(const PackJob *__restrict__ jobs,
+                                                   const int *__restrict__ blk2job)
+{
+    const PackJob jb = jobs[blk2job[blockIdx.x]];
+    pack_item(jb.w, jb.M, jb.K, jb.transposed, (blockIdx.x - jb.first_block) * 256 + threadIdx.x,
+              pow2_scale(jb.amax[0]), jb.wp);
+}
+
+// each workgroup covers 4096 consecutive elements of its tensor
+__global__ __launch_bounds__(256) void k_absmax_multi(const AbsmaxJob *__restrict__ jobs,
+                                                     const int *__restrict__ blk2job)
+{
+    __shared__ float wmax[4];
+    const AbsmaxJob jb = jobs[blk2job[blockIdx.x]];
+    const long long base = (long long)(blockIdx.x - jb.first_block) * 4096;
+    float m = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long i = base + q * 1024 + threadIdx.x * 4;
+        if (i + 4 <= jb.n) {
+            const f32x4 v = *(const f32x4 *)(jb.x + i);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        } else {
+            for (long long k = i; k < jb.n; ++k)
+                m = fmaxf(m, fabsf(jb.x[k]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0)
+        wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax((unsigned int *)jb.out, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 // out[0] = max(out[0], max |x|): integer atomicMax on the float bits (order independent); out starts at 0.
@@ -359,7 +414,25 @@ extern "C" int dcl_conv3x3_pack(const float *w, int M, int K, int transposed, co
     const int mtiles = (M + 31) / 32, nchunk = (K + 15) / 16;
     const int total = mtiles * nchunk * 9 * 64;
     hipLaunchKernelGGL(k_pack_w3x3, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, M, K,
-                       transposed, mtiles, nchunk, wamax, (uint4 *)wp);
+                       transposed, wamax, (uint4 *)wp);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_absmax_multi(const void *jobs, const int32_t *blk2job, int nblocks, void *stream)
+{
+    DCL_CHECK_ARG(jobs && blk2job && nblocks > 0, "bad arguments");
+    hipLaunchKernelGGL(k_absmax_multi, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                       (const AbsmaxJob *)jobs, blk2job);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_conv3x3_pack_multi(const void *jobs, const int32_t *blk2job, int nblocks, void *stream)
+{
+    DCL_CHECK_ARG(jobs && blk2job && nblocks > 0, "bad arguments");
+    hipLaunchKernelGGL(k_pack_multi, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PackJob *)jobs, blk2job);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
-from .ops import conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear, use_direct_conv3x3
+from .ops import ConvPackGroup, conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear, use_direct_conv3x3
 from .fused_bn import FusedBatchNorm2d, bn_act
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
@@ -372,8 +372,10 @@ class HRNet(nn.Module):
         # 'f16x3': the backbone's 3x3 / stride-1 convolutions (BasicBlock, Bottleneck, transitions: ~80 % of the
         # FLOPs) on the direct split-f16 kernel (csrc/dcl_conv3x3.hip, fp32-equivalent); 'library': MIOpen
         self.branch_conv = config.get('branch_conv', 'f16x3')
+        self._conv_packs = None
         if self.branch_conv == 'f16x3':
             use_direct_conv3x3(self.backbone)
+            self._conv_packs = ConvPackGroup(self.backbone)
 
     def _head(self, x):
         if self.head_conv != 'library' and self.training and x.is_cuda and x.dtype == torch.float32 \
@@ -387,6 +389,8 @@ class HRNet(nn.Module):
 
     def forward(self, x):
         size = x.shape[-2:]
+        if self._conv_packs is not None and x.is_cuda:
+            self._conv_packs.refresh()          # all 3x3 weights re-packed by two launches per optimizer step
         feats = self.backbone(x)
         multi = self.use_ms_projector or self.return_backbone_feats
         logits = self._head(feats[0] if multi else feats)

@@ -334,6 +334,68 @@ class DirectConv2d(torch.nn.Conv2d):
         return super().forward(x)
 
 
+class ConvPackGroup:
+    """All DirectConv2d weights of a model packed by TWO launches per optimizer step (multi-tensor absmax, then
+    multi-tensor pack of both orientations) instead of three small launches per convolution.  ``refresh()`` is
+    called at the start of the model's forward; it does nothing while no weight was modified."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.convs = [m for m in module.modules() if isinstance(m, DirectConv2d)]
+        self.key = None
+        self.tables = None
+
+    def _build(self, dev):
+        import numpy as np
+        absjobs = np.zeros(len(self.convs), dtype=[("x", "<u8"), ("out", "<u8"), ("n", "<i8"), ("fb", "<i4"), ("pad", "<i4")])
+        packjobs = np.zeros(2 * len(self.convs), dtype=[("w", "<u8"), ("wp", "<u8"), ("amax", "<u8"), ("M", "<i4"),
+                                                        ("K", "<i4"), ("tr", "<i4"), ("fb", "<i4")])
+        self.amax = torch.zeros(len(self.convs), dtype=torch.float32, device=dev)
+        self.wp = []
+        ab2j, pb2j = [], []
+        for i, m in enumerate(self.convs):
+            w = m.weight
+            co, ci = w.shape[0], w.shape[1]
+            nblk = (w.numel() + 4095) // 4096
+            absjobs[i] = (w.data_ptr(), self.amax[i:i + 1].data_ptr(), w.numel(), len(ab2j), 0)
+            ab2j += [i] * nblk
+            pair = []
+            for tr in (0, 1):
+                mm, kk = (ci, co) if tr else (co, ci)
+                frags = ((mm + 31) // 32) * ((kk + 15) // 16) * 9
+                buf = torch.empty(frags * 2 * 64 * 16, dtype=torch.uint8, device=dev)
+                packjobs[2 * i + tr] = (w.data_ptr(), buf.data_ptr(), self.amax[i:i + 1].data_ptr(), mm, kk, tr,
+                                        len(pb2j))
+                pb2j += [2 * i + tr] * ((frags * 64 + 255) // 256)
+                pair.append(buf)
+            self.wp.append(pair)
+        to_dev = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(dev)
+        self.tables = (to_dev(absjobs), torch.tensor(ab2j, dtype=torch.int32, device=dev), len(ab2j),
+                       to_dev(packjobs), torch.tensor(pb2j, dtype=torch.int32, device=dev), len(pb2j))
+        self.ptrs = tuple(m.weight.data_ptr() for m in self.convs)
+
+    def refresh(self):
+        from .. import _lib
+        if not self.convs or not self.convs[0].weight.is_cuda or self.convs[0].weight.dtype != torch.float32:
+            return
+        key = tuple(m.weight._version for m in self.convs)
+        ptrs = tuple(m.weight.data_ptr() for m in self.convs)
+        if self.tables is None or ptrs != self.ptrs:
+            self._build(self.convs[0].weight.device)
+            self.key = None
+        if key == self.key:
+            return
+        L = _lib.lib()
+        aj, ab, an, pj, pb, pn = self.tables
+        st = _stream(self.amax)
+        self.amax.zero_()
+        _lib.check(L.dcl_absmax_multi(_lib.ptr(aj), _lib.ptr(ab), an, st), "dcl_absmax_multi")
+        _lib.check(L.dcl_conv3x3_pack_multi(_lib.ptr(pj), _lib.ptr(pb), pn, st), "dcl_conv3x3_pack_multi")
+        for i, m in enumerate(self.convs):
+            w = m.weight
+            m._packed = ((w._version, w.data_ptr()), self.amax[i:i + 1], self.wp[i][0], self.wp[i][1])
+        self.key = key
+
+
 def use_direct_conv3x3(module: torch.nn.Module) -> torch.nn.Module:
     """Switch every plain nn.Conv2d with a 3x3 / stride 1 / pad 1 / bias-free geometry to DirectConv2d in place."""
     for m in module.modules():

@@ -238,6 +238,12 @@ int dcl_split_f16(const float *x, int64_t n, const float *scale, void *hi, void 
  *                    tile_r / tile_p select the workgroup tile (channel tiles per wave / rows per wave),
  *                    0 = automatic */
 int dcl_absmax(const float *x, int64_t n, float *out, void *stream);
+/* Multi-tensor forms: ONE launch for all weights of a model.  Job tables live in device memory:
+ *   absmax job {const float *x; float *out; int64 n; int32 first_block; int32 pad}   (4096 elements / workgroup)
+ *   pack job   {const float *w; void *wp; const float *amax; int32 M, K, transposed, first_block}  (256 items / wg)
+ * blk2job[b] = index of the job workgroup b works on; job.first_block = its first workgroup. */
+int dcl_absmax_multi(const void *jobs, const int32_t *blk2job, int nblocks, void *stream);
+int dcl_conv3x3_pack_multi(const void *jobs, const int32_t *blk2job, int nblocks, void *stream);
 int dcl_conv3x3_pack(const float *w, int M, int K, int transposed, const float *wamax, void *wp, void *stream);
 int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
                       const float *xamax, int xcount, const float *wamax, float *y, int tile_r, int tile_p,
