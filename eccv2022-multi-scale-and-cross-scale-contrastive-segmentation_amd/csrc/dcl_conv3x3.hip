@@ -52,6 +52,7 @@ struct ConvArgs {
     const float *x;
     const uint4 *wp;
     float *y;
+    const float *addend;            // optional tensor of y's shape added in the epilogue (residual gradient)
     const float *xamax, *wamax;     // max|x| as xcount partial maxima (e.g. per channel), max|w| (1 value)
     int xcount;
     int N, Cin, Cout, H, W;
@@ -248,8 +249,20 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
             const int row = y0 + P * wave + p;
             const int cob = (T0 + r) * 32 + 4 * h;
             if (row < a.H && col < a.W && cob < a.Cout) {
-                float *yp = a.y + (((size_t)n * a.Cout + cob) * a.H + row) * a.W + col;
-                if (cob + 28 <= a.Cout) {            // whole channel tile inside Cout
+                const size_t o0 = (((size_t)n * a.Cout + cob) * a.H + row) * a.W + col;
+                float *yp = a.y + o0;
+                if (a.addend) {
+                    // all 16 addend loads first, from clamped (always valid) channel offsets, then the stores
+                    const float *ap = a.addend + o0;
+                    float ad[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        ad[q] = ap[(size_t)min((q & 3) + 8 * (q >> 2), a.Cout - 1 - cob) * plane];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (cob + (q & 3) + 8 * (q >> 2) < a.Cout)
+                            yp[(size_t)((q & 3) + 8 * (q >> 2)) * plane] = acc[r][p][q] * inv + ad[q];
+                } else if (cob + 28 <= a.Cout) {     // whole channel tile inside Cout
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
                         yp[(size_t)((q & 3) + 8 * (q >> 2)) * plane] = acc[r][p][q] * inv;
@@ -450,8 +463,8 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
 }
 
 extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
-                                 const float *xamax, int xcount, const float *wamax, float *y, int tile_r,
-                                 int tile_p, void *stream)
+                                 const float *xamax, int xcount, const float *wamax, const float *addend,
+                                 float *y, int tile_r, int tile_p, void *stream)
 {
     DCL_CHECK_ARG(x && wp && xamax && wamax && y, "null pointer");
     DCL_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && xcount > 0, "bad shape");
@@ -460,6 +473,7 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
     a.x = x;
     a.wp = (const uint4 *)wp;
     a.y = y;
+    a.addend = addend;
     a.xamax = xamax;
     a.wamax = wamax;
     a.xcount = xcount;

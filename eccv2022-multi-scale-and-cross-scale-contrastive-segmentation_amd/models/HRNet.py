@@ -19,13 +19,15 @@ Reference quirks kept on purpose: exchange modules interpola
 concat and the logits up-sampling use the configured value; ``HRNet`` always builds the W48 backbone
 unless ``config['backbone']`` names another factory (an extension: the reference hard-codes it).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
-from .ops import ConvPackGroup, conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear, use_direct_conv3x3
+from .ops import ConvPackGroup, DirectConv2d, GradToken, conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear, use_direct_conv3x3
 from .fused_bn import FusedBatchNorm2d, bn_act
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
@@ -66,6 +68,9 @@ def _conv_bn(cin, cout, k, stride=1, relu=False, norm=nn.BatchNorm2d):
     return _ConvBN(*layers)
 
 
+_FUSE_RESIDUAL_GRAD = os.environ.get('DCL_FUSE_RESIDUAL_GRAD', '1') != '0'
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -82,8 +87,16 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = bn_act(self.bn1, self.conv1(x))
-        return bn_act(self.bn2, self.conv2(out), residual=identity)
+        # x feeds conv1 AND the residual add: its two gradients are summed inside conv1's data-gradient kernel
+        # (the token carries bn2's residual gradient there) instead of by a separate autograd add
+        tok = None
+        if _FUSE_RESIDUAL_GRAD and self.downsample is None and isinstance(self.conv1, DirectConv2d) \
+                and isinstance(self.bn2, FusedBatchNorm2d) and self.conv1.fuses_residual_grad(x):
+            tok = GradToken()
+            out = bn_act(self.bn1, self.conv1(x, grad_token=tok))
+        else:
+            out = bn_act(self.bn1, self.conv1(x))
+        return bn_act(self.bn2, self.conv2(out), residual=identity, grad_token=tok)
 
 
 class Bottleneck(nn.Module):

@@ -30,7 +30,9 @@ def _world():
 
 class _FusedBNFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, sync, amax):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, sync, amax,
+                token=None):
+        ctx.token = token
         L = _lib.lib()
         N, C, H, W = x.shape
         HW = H * W
@@ -90,7 +92,7 @@ class _FusedBNFunction(torch.autograd.Function):
             import torch.distributed as dist
             dist.all_reduce(sums)
         dx = torch.empty_like(x)
-        want_res = ctx.has_res and ctx.needs_input_grad[1]
+        want_res = ctx.has_res and (ctx.needs_input_grad[1] or ctx.token is not None)
         dres = torch.empty_like(x) if want_res else None
         # per-plane max|dx| for the consumer (the data / weight gradient of the convolution in front of this norm)
         amax = _amax.zeros(N * C, dev) if ctx.emit_amax else None
@@ -99,7 +101,10 @@ class _FusedBNFunction(torch.autograd.Function):
                                       HW, relu, _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(amax), st), "dcl_bn_bwd_apply")
         if amax is not None:
             _amax.tag(dx, amax)
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
+        if ctx.token is not None:
+            # the residual's gradient travels through the token to the convolution that shares the input
+            ctx.token.dres, dres = dres, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 class FusedBatchNorm2d(nn.BatchNorm2d):
@@ -114,13 +119,14 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 and (residual is None or (residual.shape == x.shape and residual.is_contiguous()
                                           and residual.dtype == torch.float32)))
 
-    def forward(self, x, residual=None, relu=False):
+    def forward(self, x, residual=None, relu=False, grad_token=None):
         if self._fusable(x, residual):
             # per-plane max|y| side output for the f16x3 convolutions that consume y (models/amax.py)
             amax = _amax.zeros(x.shape[0] * x.shape[1], x.device) if self.emit_amax else None
             y = _FusedBNFunction.apply(x, residual, self.weight, self.bias, self.running_mean,
                                        self.running_var, self.num_batches_tracked, float(self.eps),
-                                       float(self.momentum), bool(relu), bool(self.sync), amax)
+                                       float(self.momentum), bool(relu), bool(self.sync), amax,
+                                       grad_token if residual is not None else None)
             return _amax.tag(y, amax) if amax is not None else y
         y = super().forward(x)
         if residual is not None:
@@ -128,10 +134,11 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         return F.relu(y, inplace=True) if relu else y
 
 
-def bn_act(bn, x, residual=None, relu=True):
-    """norm (+ residual) (+ ReLU) for any norm layer; one fused call when ``bn`` supports it."""
+def bn_act(bn, x, residual=None, relu=True, grad_token=None):
+    """norm (+ residual) (+ ReLU) for any norm layer; one fused call when ``bn`` supports it.  ``grad_token``
+    (models/ops.py GradToken): hand the residual's gradient to the convolution that shares the residual tensor."""
     if isinstance(bn, FusedBatchNorm2d):
-        return bn(x, residual=residual, relu=relu)
+        return bn(x, residual=residual, relu=relu, grad_token=grad_token)
     y = bn(x)
     if residual is not None:
         y = y + residual

@@ -223,13 +223,25 @@ def conv3x3_pack(weight, wamax, transposed=False):
     return wp
 
 
-def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0):
+def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0, addend=None):
     from .. import _lib
     n, c, h, w = x.shape
     _lib.check(_lib.lib().dcl_conv3x3_f16x3(_lib.ptr(x), n, c, h, w, _lib.ptr(wp), cout, _lib.ptr(xamax),
-                                            xamax.numel(), _lib.ptr(wamax), _lib.ptr(out), tile_r, tile_p,
-                                            _stream(x)), "dcl_conv3x3_f16x3")
+                                            xamax.numel(), _lib.ptr(wamax), _lib.ptr(addend), _lib.ptr(out),
+                                            tile_r, tile_p, _stream(x)), "dcl_conv3x3_f16x3")
     return out
+
+
+class GradToken:
+    """Carries the gradient of a residual connection from the norm layer that produces it (``bn(y, residual=x,
+    grad_token=tok)`` stores it here instead of handing it to autograd) to the convolution that also consumes x
+    (``conv(x, grad_token=tok)`` adds it in the epilogue of its data-gradient kernel): one tensor add per
+    residual block disappears.  Only valid when both consumers see the SAME tensor x and the convolution's
+    backward runs after the norm's (it is earlier in the forward)."""
+    __slots__ = ("dres",)
+
+    def __init__(self):
+        self.dres = None
 
 
 def conv3x3_direct(x, weight, transposed=False):
@@ -275,8 +287,9 @@ class _Conv3x3Direct(torch.autograd.Function):
     of 16: ATen / MIOpen)."""
 
     @staticmethod
-    def forward(ctx, x, weight, mod):
+    def forward(ctx, x, weight, mod, token=None):
         from .amax import amax_of
+        ctx.token = token
         wamax, wp, _ = mod.packed_weights()
         out = torch.empty((x.shape[0], weight.shape[0], x.shape[2], x.shape[3]), dtype=torch.float32,
                           device=x.device)
@@ -294,14 +307,17 @@ class _Conv3x3Direct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wamax, _, wpt = ctx.mod.packed_weights()
             gx = torch.empty_like(x)
-            conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx)
+            addend = None
+            if ctx.token is not None and ctx.token.dres is not None:
+                addend, ctx.token.dres = ctx.token.dres, None        # gradient of the residual branch, fused in
+            conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend)
         if ctx.needs_input_grad[1]:
             if conv3x3_wgrad_supported(x, weight.shape[0]):
                 gw = conv3x3_wgrad(x, gy)
             else:
                 gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0],
                                                          1, [False, True, False])[1]
-        return gx, gw, None
+        return gx, gw, None, None
 
 
 class DirectConv2d(torch.nn.Conv2d):
@@ -328,10 +344,14 @@ class DirectConv2d(torch.nn.Conv2d):
             self._packed = cache
         return cache[1], cache[2], cache[3]
 
-    def forward(self, x):
+    def forward(self, x, grad_token=None):
         if self.eligible(x):
-            return _Conv3x3Direct.apply(x, self.weight, self)
+            return _Conv3x3Direct.apply(x, self.weight, self, grad_token)
         return super().forward(x)
+
+    def fuses_residual_grad(self, x):
+        """True when a GradToken may be used for x: the direct path runs and x needs a gradient."""
+        return self.eligible(x) and x.requires_grad and torch.is_grad_enabled()
 
 
 class ConvPackGroup:

@@ -246,8 +246,9 @@ int dcl_absmax_multi(const void *jobs, const int32_t *blk2job, int nblocks, void
 int dcl_conv3x3_pack_multi(const void *jobs, const int32_t *blk2job, int nblocks, void *stream);
 int dcl_conv3x3_pack(const float *w, int M, int K, int transposed, const float *wamax, void *wp, void *stream);
 int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
-                      const float *xamax, int xcount, const float *wamax, float *y, int tile_r, int tile_p,
-                      void *stream);
+                      const float *xamax, int xcount, const float *wamax,
+                      const float *addend /* [N,Cout,H,W] added to the result, or NULL */, float *y, int tile_r,
+                      int tile_p, void *stream);
 
 /* Weight gradient of the same convolution, dw[Cout,Cin,3,3] = sum_n dy (*) x, on the f16x3 MFMA path with no LDS
  * staging (csrc/dcl_wgrad3x3.hip).  Cin % 16 == 0, Cout % 16 == 0, W % 8 == 0.  part: workspace of

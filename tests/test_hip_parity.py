@@ -695,3 +695,30 @@ def test_direct_conv_module_autograd_and_absmax_tags(dev):
     t.mul_(4.0)
     a1 = amax_of(t)
     assert a1 is not a0 and abs(a1.max().item() - t.abs().max().item()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_basicblock_residual_gradient_fused_into_dgrad(dev):
+    """BasicBlock with the direct convolutions: the residual's gradient reaches the block input through the
+    GradToken (added in the epilogue of conv1's data-gradient kernel); input and parameter gradients match the
+    plain nn.Conv2d / nn.BatchNorm2d block in float64."""
+    from mscs_amd.models import ops
+    from mscs_amd.models.HRNet import BasicBlock
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d
+    torch.manual_seed(11)
+    blk = BasicBlock(32, 32, norm_layer=FusedBatchNorm2d).to(dev).train()
+    ops.use_direct_conv3x3(blk)
+    ref = BasicBlock(32, 32, norm_layer=torch.nn.BatchNorm2d).double().train()
+    ref.load_state_dict({k: v.double().cpu() for k, v in blk.state_dict().items()})
+    x = torch.randn(2, 32, 10, 24, device=dev)
+    xin = (x * 1.0).requires_grad_(True)            # non-leaf input like inside the network
+    xin.retain_grad()
+    y = blk(xin)
+    y.square().mean().backward()
+    x64 = x.double().cpu().requires_grad_(True)
+    y64 = ref(x64)
+    y64.square().mean().backward()
+    assert ((y.detach().double().cpu() - y64.detach()).abs().max() / y64.detach().abs().max()).item() < 1e-5
+    assert ((xin.grad.double().cpu() - x64.grad).abs().max() / x64.grad.abs().max()).item() < 2e-5
+    for (n1, p1), (n2, p2) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert ((p1.grad.double().cpu() - p2.grad).abs().max() / (p2.grad.abs().max() + 1e-30)).item() < 5e-5, n1
