@@ -43,8 +43,8 @@ SIGNATURES = {
     "dcl_bn_finalize": [_vp, _i, ctypes.c_double, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "dcl_bn_stats_finalize": [_vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "dcl_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "dcl_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "dcl_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "dcl_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "dcl_upsample_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_upsample_bilinear_bwd": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_im2col3x3_split": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -143,6 +143,16 @@ __device__ __forceinline__ void block_amax(float m, float *dst)
     }
 }
 
+// y = x * sc + sh: ONE definition of the affine form, so that the backward's recomputed ReLU mask (y > 0 without
+// reading y) sees bit-identical values
+__device__ __forceinline__ void bn_affine(const float *invstd, const float *gamma, const float *beta,
+                                          const float *mean, int c, float &sc, float &sh)
+{
+    sc = invstd[c] * (gamma ? gamma[c] : 1.f);
+    sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+}
+__device__ __forceinline__ float bn_eval(float x, float sc, float sh) { return x * sc + sh; }
+
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict__ x,
                                                         const float *__restrict__ res,
@@ -154,14 +164,14 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
 {
     const int plane = blockIdx.y, c = plane % C;
     float am = 0.f;
-    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
-    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    float sc, sh;
+    bn_affine(invstd, gamma, beta, mean, c, sc, sh);
     const size_t base = (size_t)plane * HW;
     const int i4 = blockIdx.x * BN_THREADS + threadIdx.x;
     const int i = i4 << 2;
     if (i + 3 < HW && (HW & 3) == 0) {
         f32x4 v = *(const f32x4 *)(x + base + i);
-        v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+        v.x = bn_eval(v.x, sc, sh); v.y = bn_eval(v.y, sc, sh); v.z = bn_eval(v.z, sc, sh); v.w = bn_eval(v.w, sc, sh);
         if (RES) {
             const f32x4 r = *(const f32x4 *)(res + base + i);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
         am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     } else {
         for (int k = i; k < HW && k < i + 4; ++k) {
-            float v = x[base + k] * sc + sh;
+            float v = bn_eval(x[base + k], sc, sh);
             if (RES)
                 v += res[base + k];
             if (RELU)
@@ -192,13 +202,19 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__res
                                                              const float *__restrict__ x,
                                                              const float *__restrict__ y,
                                                              const float *__restrict__ mean,
-                                                             const float *__restrict__ invstd, int N,
+                                                             const float *__restrict__ invstd,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, int N,
                                                              int C, int HW, int nslice,
                                                              float *__restrict__ part)
 {
     __shared__ float sh[8];
     const int c = blockIdx.x, s = blockIdx.y;
     const float m = mean[c], is = invstd[c];
+    // y == NULL (ReLU without residual): the mask y > 0 is recomputed from x -- one tensor less to read
+    float asc, ash;
+    bn_affine(invstd, gamma, beta, mean, c, asc, ash);
+    const bool rec = RELU && y == nullptr;
     float a = 0.f, b = 0.f;
     const int hw4 = (HW & 3) ? 0 : (HW >> 2);      // see k_bn_stats
     for (int n = s; n < N; n += nslice) {
@@ -209,7 +225,13 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__res
             f32x4 g = d4[i];
             const f32x4 xv = x4[i];
             if (RELU) {
-                const f32x4 yv = y4[i];
+                f32x4 yv;
+                if (rec) {
+                    yv.x = bn_eval(xv.x, asc, ash); yv.y = bn_eval(xv.y, asc, ash);
+                    yv.z = bn_eval(xv.z, asc, ash); yv.w = bn_eval(xv.w, asc, ash);
+                } else {
+                    yv = y4[i];
+                }
                 g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                 g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
             }
@@ -219,7 +241,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__res
         for (int i = (hw4 << 2) + threadIdx.x; i < HW; i += BN_THREADS) {
             float g = dy[base + i];
             if (RELU)
-                g = y[base + i] > 0.f ? g : 0.f;
+                g = (rec ? bn_eval(x[base + i], asc, ash) : y[base + i]) > 0.f ? g : 0.f;
             a += g;
             b += g * (x[base + i] - m);
         }
@@ -240,6 +262,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta,
                                                             const float *__restrict__ sums,
                                                             float inv_count, int C, int HW,
                                                             float *__restrict__ dx,
@@ -249,6 +272,9 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
     const int plane = blockIdx.y, c = plane % C;
     float am = 0.f;
     const float m = mean[c], is = invstd[c];
+    float asc, ash;                                   // y == NULL: ReLU mask recomputed from x (see the reduce)
+    bn_affine(invstd, gamma, beta, mean, c, asc, ash);
+    const bool rec = RELU && y == nullptr;
     const float k = is * (gamma ? gamma[c] : 1.f);
     const float mg = sums[c * 2] * inv_count, mgx = sums[c * 2 + 1] * inv_count;
     const size_t base = (size_t)plane * HW;
@@ -257,7 +283,13 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
         f32x4 g = *(const f32x4 *)(dy + base + i);
         const f32x4 xv = *(const f32x4 *)(x + base + i);
         if (RELU) {
-            const f32x4 yv = *(const f32x4 *)(y + base + i);
+            f32x4 yv;
+            if (rec) {
+                yv.x = bn_eval(xv.x, asc, ash); yv.y = bn_eval(xv.y, asc, ash);
+                yv.z = bn_eval(xv.z, asc, ash); yv.w = bn_eval(xv.w, asc, ash);
+            } else {
+                yv = *(const f32x4 *)(y + base + i);
+            }
             g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
             g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
         }
@@ -274,7 +306,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
         for (int q = i; q < HW && q < i + 4; ++q) {
             float g = dy[base + q];
             if (RELU)
-                g = y[base + q] > 0.f ? g : 0.f;
+                g = (rec ? bn_eval(x[base + q], asc, ash) : y[base + q]) > 0.f ? g : 0.f;
             if (dres)
                 dres[base + q] = g;
             const float o = k * (g - mg - (x[base + q] - m) * is * mgx);
@@ -362,16 +394,17 @@ extern "C" int dcl_bn_apply(const float *x, const float *res, const float *mean,
 }
 
 extern "C" int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y, const float *mean,
-                                 const float *invstd, int N, int C, int HW, int relu, float *part,
-                                 float *sums, float *dbeta, float *dgamma, void *stream)
+                                 const float *invstd, const float *gamma, const float *beta, int N, int C,
+                                 int HW, int relu, float *part, float *sums, float *dbeta, float *dgamma,
+                                 void *stream)
 {
-    DCL_CHECK_ARG(dy && x && mean && invstd && part && sums && (!relu || y), "bad arguments");
+    DCL_CHECK_ARG(dy && x && mean && invstd && part && sums, "bad arguments");
     const int ns = pick_slices(N, C);
     hipStream_t st = (hipStream_t)stream;
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, N, C, HW, ns, part);
+        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part);
     else
-        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, N, C, HW, ns, part);
+        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part);
     DCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums, dbeta,
                        dgamma, 0, 1.0, 0.f, 0.f, (float *)nullptr, (float *)nullptr, (float *)nullptr,
@@ -381,18 +414,18 @@ extern "C" int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y
 }
 
 extern "C" int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y, const float *mean,
-                                const float *invstd, const float *gamma, const float *sums,
+                                const float *invstd, const float *gamma, const float *beta, const float *sums,
                                 double count, int N, int C, int HW, int relu, float *dx, float *dres,
                                 float *amax, void *stream)
 {
-    DCL_CHECK_ARG(dy && x && mean && invstd && sums && dx && (!relu || y) && count > 0, "bad arguments");
+    DCL_CHECK_ARG(dy && x && mean && invstd && sums && dx && count > 0, "bad arguments");
     dim3 grid((HW + BN_THREADS * 4 - 1) / (BN_THREADS * 4), N * C);
     hipStream_t st = (hipStream_t)stream;
     const float inv = (float)(1.0 / count);
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, sums, inv, C, HW, dx, dres, amax);
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax);
     else
-        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, sums, inv, C, HW, dx, dres, amax);
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -359,7 +359,7 @@ static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nc
 {
     const int cot = Cout / 16, cit = Cin / 16;
     nco = (cot % 3 == 0) ? 3 : (cot % 2 == 0) ? 2 : 1;        // (4 tiles would spill)
-    nci = cit >= 2 ? 2 : 1;     // the last group is ragged for an odd tile count
+    nci = (cit % 2 == 0) ? 2 : 1;   // pairs of ci tiles when that leaves no ragged group (an odd count pads 1/(cit+1))
     const int pairs = (cot / nco) * ((cit + nci - 1) / nci);
     units = N * ((W + 31) / 32);            // columns: (image, 32-pixel strip), H input rows each
     // One workgroup (4 waves = 4 splits of one pair) per CU is all that fits (a wave owns most of its SIMD's

@@ -63,7 +63,9 @@ class _FusedBNFunction(torch.autograd.Function):
         _lib.check(L.dcl_bn_apply(_lib.ptr(x), _lib.ptr(res), _lib.ptr(mean), _lib.ptr(invstd),
                                   _lib.ptr(weight), _lib.ptr(bias), N, C, HW, 1 if relu else 0, _lib.ptr(y),
                                   _lib.ptr(amax), st), "dcl_bn_apply")
-        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        # y is only needed for the ReLU mask when a residual was added: without one the backward recomputes
+        # y > 0 from x (one tensor less to read, twice)
+        ctx.save_for_backward(x, y if (relu and res is not None) else None, weight, bias, mean, invstd)
         ctx.relu, ctx.world, ctx.count = relu, world, count
         ctx.has_res = res is not None
         ctx.emit_amax = amax is not None
@@ -72,7 +74,7 @@ class _FusedBNFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, y, weight, bias, mean, invstd = ctx.saved_tensors
         N, C, H, W = x.shape
         HW = H * W
         dev = x.device
@@ -85,7 +87,8 @@ class _FusedBNFunction(torch.autograd.Function):
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         _lib.check(L.dcl_bn_bwd_reduce(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
-                                       _lib.ptr(invstd), N, C, HW, relu, _lib.ptr(part), _lib.ptr(sums),
+                                       _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), N, C, HW, relu,
+                                       _lib.ptr(part), _lib.ptr(sums),
                                        _lib.ptr(dbeta), _lib.ptr(dgamma), st), "dcl_bn_bwd_reduce")
         # dbeta / dgamma are the LOCAL sums (written before the all-reduce): DDP averages them
         if ctx.world > 1:
@@ -97,7 +100,7 @@ class _FusedBNFunction(torch.autograd.Function):
         # per-plane max|dx| for the consumer (the data / weight gradient of the convolution in front of this norm)
         amax = _amax.zeros(N * C, dev) if ctx.emit_amax else None
         _lib.check(L.dcl_bn_bwd_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
-                                      _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(sums), ctx.count, N, C,
+                                      _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(sums), ctx.count, N, C,
                                       HW, relu, _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(amax), st), "dcl_bn_bwd_apply")
         if amax is not None:
             _amax.tag(dx, amax)

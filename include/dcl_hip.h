@@ -196,11 +196,12 @@ int dcl_bn_finalize(const float *sums, int C, double count, float eps, float mom
 int dcl_bn_apply(const float *x, const float *res, const float *mean, const float *invstd,
                  const float *gamma, const float *beta, int N, int C, int HW, int relu, float *y,
                  float *amax /* [N*C] zero-initialised: per-plane max|y| is max-ed in; or NULL */, void *stream);
-int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y, const float *mean,
-                      const float *invstd, int N, int C, int HW, int relu, float *part, float *sums,
-                      float *dbeta /* [C] or NULL */, float *dgamma /* [C] or NULL */, void *stream);
-int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y, const float *mean,
-                     const float *invstd, const float *gamma, const float *sums, double count, int N,
+int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y /* NULL with relu and no residual: the mask
+                      y > 0 is recomputed from x, gamma, beta */, const float *mean, const float *invstd,
+                      const float *gamma, const float *beta, int N, int C, int HW, int relu, float *part,
+                      float *sums, float *dbeta /* [C] or NULL */, float *dgamma /* [C] or NULL */, void *stream);
+int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y /* as above */, const float *mean,
+                     const float *invstd, const float *gamma, const float *beta, const float *sums, double count, int N,
                      int C, int HW, int relu, float *dx, float *dres,
                      float *amax /* [N*C] zero-initialised: per-plane max|dx|; or NULL */, void *stream);
 
