@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
         // compiler wait for it at the join, i.e. before the MFMAs it is supposed to overlap.
         const bool oct_ok = px < a.W;
         const int pxc = oct_ok ? px : a.W - 8;
-        const int dl = px > 0 ? -1 : 0, dr = px + 8 < a.W ? 8 : 7;
+        const int dl = (oct_ok && px > 0) ? -1 : 0, dr = px + 8 < a.W ? 8 : 7;     // halo offsets from the CLAMPED base
         const float sx_c = oct_ok ? sx : 0.f;                       // elements 1..8 of the B window
         const float sx_l = (oct_ok && px > 0) ? sx : 0.f;           // left halo (outside the image at x = -1)
         const float sx_r = (px + 8 < a.W) ? sx : 0.f;               // right halo

@@ -69,6 +69,17 @@ def _conv_bn(cin, cout, k, stride=1, relu=False, norm=nn.BatchNorm2d):
 
 
 _FUSE_RESIDUAL_GRAD = os.environ.get('DCL_FUSE_RESIDUAL_GRAD', '1') != '0'
+_BRANCH_STREAMS = os.environ.get('DCL_BRANCH_STREAMS', '1') != '0'
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    """n persistent side streams per device, shared by all modules."""
+    key = (device.type, device.index)
+    have = _SIDE_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
 
 
 class BasicBlock(nn.Module):
@@ -181,10 +192,32 @@ class HighResolutionModule(nn.Module):
     def get_num_inchannels(self):
         return self.num_inchannels
 
+    def _run_branches(self, x):
+        """The branches of a module are independent until the fuse layers: on CUDA each runs on its own HIP stream
+        (the low-resolution branches launch far fewer workgroups than the chip has CUs, so their kernels overlap
+        with each other and with the high-resolution branch); autograd replays the same streams in the backward.
+        Tensors that cross streams are registered with the caching allocator (record_stream)."""
+        if not (_BRANCH_STREAMS and x[0].is_cuda):
+            return [branch(xi) for branch, xi in zip(self.branches, x)]
+        main = torch.cuda.current_stream(x[0].device)
+        side = _side_streams(x[0].device, self.num_branches - 1)
+        outs = [None] * self.num_branches
+        for i in range(self.num_branches - 1, 0, -1):          # smallest branch first: it has the most to gain
+            s = side[i - 1]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                x[i].record_stream(s)
+                outs[i] = self.branches[i](x[i])
+        outs[0] = self.branches[0](x[0])
+        for i in range(1, self.num_branches):
+            main.wait_stream(side[i - 1])
+            outs[i].record_stream(main)
+        return outs
+
     def forward(self, x):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        x = [branch(xi) for branch, xi in zip(self.branches, x)]
+        x = self._run_branches(x)
         fused = []
         for i, row in enumerate(self.fuse_layers):
             y = x[0] if i == 0 else row[0](x[0])

@@ -19,7 +19,8 @@ def zeros(n: int, device) -> torch.Tensor:
     """n zero floats from a pooled buffer (one fill kernel per 1 M floats instead of one per request);
     slices are never handed out twice, the buffer lives as long as any slice does."""
     n_al = (n + 3) & ~3
-    key = (device.type, device.index)
+    # one pool per stream: the fill kernel of a pool buffer is ordered only against the stream that created it
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf, off = _POOL.get(key, (None, 0))
     if buf is None or off + n_al > buf.numel():
         buf, off = torch.zeros(max(_POOL_FLOATS, n_al), dtype=torch.float32, device=device), 0

@@ -722,3 +722,45 @@ def test_basicblock_residual_gradient_fused_into_dgrad(dev):
     assert ((xin.grad.double().cpu() - x64.grad).abs().max() / x64.grad.abs().max()).item() < 2e-5
     for (n1, p1), (n2, p2) in zip(blk.named_parameters(), ref.named_parameters()):
         assert ((p1.grad.double().cpu() - p2.grad).abs().max() / (p2.grad.abs().max() + 1e-30)).item() < 5e-5, n1
+
+
+@pytest.mark.gpu
+def test_branch_streams_are_bitwise_equivalent(dev):
+    """HighResolutionModule branches on one HIP stream each (default) against single-stream execution.  The branches
+    consist of our deterministic kernels only (direct convolutions, fused BN), so outputs, input gradients and
+    parameter gradients must agree BITWISE; a missing stream dependency or allocator hazard would show up here."""
+    import importlib
+    hm = importlib.import_module("mscs_amd.models.HRNet")
+    graph = {"backbone": "hrnet48", "pretrained": False, "dataset": "CITYSCAPES", "align_corners": True}
+    torch.manual_seed(7)
+    mod = hm.HRNet(graph, 1).backbone.stage4[1].to(dev).train()
+    assert mod.num_branches == 4
+    xs0 = [torch.randn(3, 48 * 2 ** i, 64 // 2 ** i, 96 // 2 ** i, device=dev) for i in range(4)]
+
+    def run(flag):
+        hm._BRANCH_STREAMS = flag
+        mod.zero_grad(set_to_none=True)
+        state = {k: v.clone() for k, v in mod.state_dict().items()}
+        xs = [(x * 1.0).requires_grad_(True) for x in xs0]
+        for x in xs:
+            x.retain_grad()
+        outs = mod._run_branches(list(xs))
+        sum(o.square().mean() for o in outs).backward()
+        torch.cuda.synchronize()
+        res = ([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
+               {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None})
+        mod.load_state_dict(state)
+        return res
+    try:
+        ref = run(False)
+        for trial in range(3):
+            got = run(True)
+            for a, b in zip(got[0] + got[1], ref[0] + ref[1]):
+                assert torch.equal(a, b)
+            assert got[2].keys() == ref[2].keys() and len(ref[2]) == 4 * 4 * 6
+            for n in ref[2]:
+                assert torch.equal(got[2][n], ref[2][n]), n
+    finally:
+        hm._BRANCH_STREAMS = True
+
+
