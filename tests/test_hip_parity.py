@@ -764,3 +764,49 @@ def test_branch_streams_are_bitwise_equivalent(dev):
         hm._BRANCH_STREAMS = True
 
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["start", "end"])
+def test_kernels_stay_inside_their_tensors(dev, where):
+    """Out-of-bounds guard (no GPU sanitizer on this pool): operands are placed at the very start / very end of a
+    fresh 64 MiB device allocation, so a read before the first or past the last element of a tensor leaves the
+    allocation (and faults when the neighbourhood is unmapped, which is how the weight-gradient halo bug was found).
+    Ragged shapes exercise every clamped-address path of the convolution, BN and resize kernels."""
+    from mscs_amd.models import ops
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d
+    torch.cuda.empty_cache()
+
+    def place(t):
+        buf = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=dev)       # its own 64 MiB segment
+        n = t.numel()
+        view = buf[:n] if where == "start" else buf[buf.numel() - n:]
+        view.copy_(t.reshape(-1))
+        return view.view(t.shape)
+
+    torch.manual_seed(2)
+    for (n, ci, co, h, w) in [(1, 16, 16, 1, 8), (2, 40, 24, 19, 40), (1, 48, 48, 5, 8), (2, 32, 64, 3, 24)]:
+        x = place(torch.randn(n, ci, h, w, device=dev))
+        wt = place(torch.randn(co, ci, 3, 3, device=dev))
+        gy = place(torch.randn(n, co, h, w, device=dev))
+        y = ops.conv3x3_direct(x, wt)
+        gx = ops.conv3x3_direct(gy, wt, transposed=True)
+        ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)
+        assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
+        assert torch.isfinite(gx).all()
+        if ci % 16 == 0 and co % 16 == 0:
+            gw = ops.conv3x3_wgrad(x, gy)
+            gw_ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), wt.double(), None, [1, 1], [1, 1],
+                                                         [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            assert ((gw.double() - gw_ref).abs().max() / gw_ref.abs().max()).item() < 3e-6
+        bn = FusedBatchNorm2d(ci).to(dev).train()
+        xb = place(torch.randn(n, ci, h, w, device=dev)).requires_grad_(True)
+        res = place(torch.randn(n, ci, h, w, device=dev))
+        out = bn(xb, residual=res, relu=True)
+        out.backward(place(torch.randn(n, ci, h, w, device=dev)))
+        assert torch.isfinite(out).all() and torch.isfinite(xb.grad).all()
+        up_in = place(torch.randn(n, ci, h, w, device=dev)).requires_grad_(True)
+        up = ops.upsample_bilinear(up_in, (2 * h + 1, 3 * w), True)
+        up.backward(place(torch.randn_like(up)))
+        assert torch.isfinite(up).all() and torch.isfinite(up_in.grad).all()
+    torch.cuda.synchronize()
