@@ -218,22 +218,39 @@ class HighResolutionModule(nn.Module):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
         x = self._run_branches(x)
-        fused = []
-        for i, row in enumerate(self.fuse_layers):
-            y = x[0] if i == 0 else row[0](x[0])
-            for j in range(1, self.num_branches):
-                if j == i:
-                    y = y + x[j]
-                elif j > i:
-                    y = upsample_bilinear(row[j](x[j]), x[i].shape[-2:], self.align_corners, add=y)
-                else:
-                    chain = row[j]                  # stride-2 conv chain; its last norm absorbs "+ y"
-                    t = x[j]
-                    for step in list(chain)[:-1]:
-                        t = step(t)
-                    y = chain[-1](t, residual=y)
-            fused.append(self.relu(y))
+        if not (_BRANCH_STREAMS and x[0].is_cuda) or len(self.fuse_layers) == 1:
+            return [self._fuse_row(i, row, x) for i, row in enumerate(self.fuse_layers)]
+        # the fused outputs are independent of each other as well: output i on stream i
+        main = torch.cuda.current_stream(x[0].device)
+        side = _side_streams(x[0].device, len(self.fuse_layers) - 1)
+        fused = [None] * len(self.fuse_layers)
+        for i in range(len(self.fuse_layers) - 1, 0, -1):
+            s = side[i - 1]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                for t in x:
+                    t.record_stream(s)
+                fused[i] = self._fuse_row(i, self.fuse_layers[i], x)
+        fused[0] = self._fuse_row(0, self.fuse_layers[0], x)
+        for i in range(1, len(self.fuse_layers)):
+            main.wait_stream(side[i - 1])
+            fused[i].record_stream(main)
         return fused
+
+    def _fuse_row(self, i, row, x):
+        y = x[0] if i == 0 else row[0](x[0])
+        for j in range(1, self.num_branches):
+            if j == i:
+                y = y + x[j]
+            elif j > i:
+                y = upsample_bilinear(row[j](x[j]), x[i].shape[-2:], self.align_corners, add=y)
+            else:
+                chain = row[j]                  # stride-2 conv chain; its last norm absorbs "+ y"
+                t = x[j]
+                for step in list(chain)[:-1]:
+                    t = step(t)
+                y = chain[-1](t, residual=y)
+        return self.relu(y)
 
 
 class HighResolutionNet(nn.Module):

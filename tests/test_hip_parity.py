@@ -810,3 +810,50 @@ def test_kernels_stay_inside_their_tensors(dev, where):
         up.backward(place(torch.randn_like(up)))
         assert torch.isfinite(up).all() and torch.isfinite(up_in.grad).all()
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_fuse_layer_streams_match_single_stream(dev):
+    """A whole HighResolutionModule (branches + fuse layers, one stream per branch / per fused output) against its
+    single-stream execution, to within 10x the measured run-to-run noise of the library convolutions that the
+    fuse layers still use (the branches themselves are checked bitwise above)."""
+    import importlib
+    hm = importlib.import_module("mscs_amd.models.HRNet")
+    graph = {"backbone": "hrnet48", "pretrained": False, "dataset": "CITYSCAPES", "align_corners": True}
+    torch.manual_seed(9)
+    mod = hm.HRNet(graph, 1).backbone.stage4[0].to(dev).train()
+    xs0 = [torch.randn(4, 48 * 2 ** i, 64 // 2 ** i, 128 // 2 ** i, device=dev) for i in range(4)]
+
+    def run(flag):
+        hm._BRANCH_STREAMS = flag
+        mod.zero_grad(set_to_none=True)
+        state = {k: v.clone() for k, v in mod.state_dict().items()}
+        xs = [(x * 1.0).requires_grad_(True) for x in xs0]
+        for x in xs:
+            x.retain_grad()
+        outs = mod(list(xs))
+        sum(o.square().mean() for o in outs).backward()
+        torch.cuda.synchronize()
+        res = ([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
+               {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None})
+        mod.load_state_dict(state)
+        return res
+    def dist(a, b):
+        return (a - b).abs().max().item() / (b.abs().max().item() + 1e-20)
+    try:
+        ref = run(False)
+        ref2 = run(False)
+        # run-to-run noise of the library kernels in the fuse layers (0 when they happen to be reproducible)
+        noise_f = max([dist(a, b) for a, b in zip(ref2[0], ref[0])] + [1e-6])
+        noise_g = max([dist(a, b) for a, b in zip(ref2[1], ref[1])] + [dist(ref2[2][n], ref[2][n]) for n in ref[2]]
+                      + [1e-5])
+        for trial in range(2):
+            got = run(True)
+            for a, b in zip(got[0], ref[0]):
+                assert dist(a, b) <= 10 * noise_f, (dist(a, b), noise_f)
+            for a, b in zip(got[1], ref[1]):
+                assert dist(a, b) <= 10 * noise_g, (dist(a, b), noise_g)
+            for n in ref[2]:
+                assert dist(got[2][n], ref[2][n]) <= 10 * noise_g, (n, dist(got[2][n], ref[2][n]), noise_g)
+    finally:
+        hm._BRANCH_STREAMS = True
