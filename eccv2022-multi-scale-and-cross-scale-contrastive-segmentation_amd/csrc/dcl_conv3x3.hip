@@ -32,7 +32,6 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int TW = 32;          // tile width in pixels (one MFMA pixel tile = 1 row x 32 columns)
-constexpr int LW = TW + 2;      // patch width incl. halo
 constexpr int PIXB = 80;        // bytes per LDS pixel record
 
 __device__ __forceinline__ int jrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -55,7 +54,11 @@ struct ConvArgs {
     const float *addend;            // optional tensor of y's shape added in the epilogue (residual gradient)
     const float *xamax, *wamax;     // max|x| as xcount partial maxima (e.g. per channel), max|w| (1 value)
     int xcount;
-    int N, Cin, Cout, H, W;
+    int N, Cin, Cout;
+    int H, W;                       // (virtual) input height / width the 3x3 window slides over
+    int Hs, Ws, up;                 // stored input size; up = 2: the stored tensor is the virtual one sampled at even
+                                    // coordinates, zeros in between (data gradient of a stride-2 convolution)
+    int Ho, Wo;                     // output size (= H, W for stride 1)
     int tiles_x, tiles_y, nchunk;
 };
 
@@ -68,10 +71,12 @@ __device__ __forceinline__ float pow2_scale(float amax)
     return amax == 0.f ? 1.f : exp2f(fminf(fmaxf(floorf(log2f(F16_TARGET / amax)), -100.f), 100.f));
 }
 
-template <int R, int P>
+// S = stride (1 | 2).  A stride-2 tile reads a (2 * 4P + 1) x 65 patch, so S = 2 is instantiated with P = 1 only.
+template <int R, int P, int S>
 __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
 {
-    constexpr int ROWS = 4 * P + 2;
+    constexpr int LW = S * (TW - 1) + 3;          // patch width incl. halo: 34 | 65
+    constexpr int ROWS = S * (4 * P - 1) + 3;     // 4P + 2 | 8P + 1
     constexpr int TP = ROWS * LW;
     constexpr int NITEM = (2 * TP + 255) / 256;
     constexpr int BUFB = TP * PIXB;
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
     const int n = bx / a.tiles_y;
     const int x0 = tx * TW, y0 = ty * 4 * P;
     const int T0 = blockIdx.y * R;
-    const size_t plane = (size_t)a.H * a.W;
+    const size_t plane = (size_t)a.Hs * a.Ws;                // stored input plane
+    const size_t oplane = (size_t)a.Ho * a.Wo;
     const float *xb = a.x + (size_t)n * a.Cin * plane;
     // operand scale of x: max over the partial maxima, exchanged between the waves through LDS
     float xs;
@@ -118,10 +124,17 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
         const int oct = it >= TP ? 1 : 0;
         const int pix = it - oct * TP;
         const int r = pix / LW, c = pix - r * LW;
-        const int gy = y0 + r - 1, gx = x0 + c - 1;
-        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const int gy = S * y0 + r - 1, gx = S * x0 + c - 1;
+        bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        int sy = gy, sx = gx;
+        if (a.up == 2) {                                        // zero-inserted input: only even coordinates exist
+            ok = ok && !((gy | gx) & 1);
+            sy = gy >> 1;
+            sx = gx >> 1;
+            ok = ok && sy < a.Hs && sx < a.Ws;
+        }
         loff[m] = pix * PIXB + oct * 16;
-        goff[m] = ok ? gy * a.W + gx : 0;
+        goff[m] = ok ? sy * a.Ws + sx : 0;
         gsc[m] = ok ? xs : 0.f;
     }
     const bool ragged = (a.Cin & 15) != 0;                       // last chunk has channels past Cin
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
     write_items(lds);
     __syncthreads();
 
-    const int brow = (P * wave) * LW + li;
+    const int brow = (S * P * wave) * LW + S * li;      // patch pixel of this lane's output pixel, tap (0, 0)
     for (int c = 0; c < a.nchunk; ++c) {
         const unsigned char *cur = lds + (c & 1) * BUFB;
         const bool more = c + 1 < a.nchunk;
@@ -215,22 +228,41 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
                 load_A(Ab[(kx + AD) % 3], s2 / 3, s2 % 3);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (S == 1) {
+                // a fragment depends on (tile row rr = p + ky, kx) only: read once, used by every (p, ky) pair
 #pragma unroll
-            for (int rr = 0; rr < P + 2; ++rr) {
-                const unsigned char *bp = cur + (brow + rr * LW + kx) * PIXB + h * 16;
-                const half8 bh = *(const half8 *)bp;
-                const half8 bl = *(const half8 *)(bp + 32);
+                for (int rr = 0; rr < P + 2; ++rr) {
+                    const unsigned char *bp = cur + (brow + rr * LW + kx) * PIXB + h * 16;
+                    const half8 bh = *(const half8 *)bp;
+                    const half8 bl = *(const half8 *)(bp + 32);
 #pragma unroll
-                for (int pass = 0; pass < 3; ++pass)
+                    for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const int p = rr - ky;
+                            if (p >= 0 && p < P) {
+#pragma unroll
+                                for (int r = 0; r < R; ++r)
+                                    acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                        Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p], 0, 0, 0);
+                            }
+                        }
+                }
+            } else {
+                // stride 2: output pixel (p, li) reads patch pixel (2 p' + ky, 2 li + kx)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
-                        const int p = rr - ky;
-                        if (p >= 0 && p < P) {
+                        const unsigned char *bp = cur + (brow + (S * p + ky) * LW + kx) * PIXB + h * 16;
+                        const half8 bh = *(const half8 *)bp;
+                        const half8 bl = *(const half8 *)(bp + 32);
+#pragma unroll
+                        for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
                             for (int r = 0; r < R; ++r)
                                 acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                                     Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p], 0, 0, 0);
-                        }
                     }
             }
         }
@@ -248,8 +280,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
         for (int p = 0; p < P; ++p) {
             const int row = y0 + P * wave + p;
             const int cob = (T0 + r) * 32 + 4 * h;
-            if (row < a.H && col < a.W && cob < a.Cout) {
-                const size_t o0 = (((size_t)n * a.Cout + cob) * a.H + row) * a.W + col;
+            if (row < a.Ho && col < a.Wo && cob < a.Cout) {
+                const size_t o0 = (((size_t)n * a.Cout + cob) * a.Ho + row) * a.Wo + col;
                 float *yp = a.y + o0;
                 if (a.addend) {
                     // all 16 addend loads first, from clamped (always valid) channel offsets, then the stores
@@ -257,20 +289,20 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
                     float ad[16];
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        ad[q] = ap[(size_t)min((q & 3) + 8 * (q >> 2), a.Cout - 1 - cob) * plane];
+                        ad[q] = ap[(size_t)min((q & 3) + 8 * (q >> 2), a.Cout - 1 - cob) * oplane];
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
                         if (cob + (q & 3) + 8 * (q >> 2) < a.Cout)
-                            yp[(size_t)((q & 3) + 8 * (q >> 2)) * plane] = acc[r][p][q] * inv + ad[q];
+                            yp[(size_t)((q & 3) + 8 * (q >> 2)) * oplane] = acc[r][p][q] * inv + ad[q];
                 } else if (cob + 28 <= a.Cout) {     // whole channel tile inside Cout
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        yp[(size_t)((q & 3) + 8 * (q >> 2)) * plane] = acc[r][p][q] * inv;
+                        yp[(size_t)((q & 3) + 8 * (q >> 2)) * oplane] = acc[r][p][q] * inv;
                 } else {
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
                         if (cob + (q & 3) + 8 * (q >> 2) < a.Cout)
-                            yp[(size_t)((q & 3) + 8 * (q >> 2)) * plane] = acc[r][p][q] * inv;
+                            yp[(size_t)((q & 3) + 8 * (q >> 2)) * oplane] = acc[r][p][q] * inv;
                 }
             }
         }
@@ -450,24 +482,27 @@ extern "C" int dcl_conv3x3_pack_multi(const void *jobs, const int32_t *blk2job, 
     return 0;
 }
 
-template <int R, int P>
+template <int R, int P, int S>
 static int launch_conv(const ConvArgs &a0, hipStream_t stream)
 {
     ConvArgs a = a0;
-    a.tiles_x = (a.W + TW - 1) / TW;
-    a.tiles_y = (a.H + 4 * P - 1) / (4 * P);
+    a.tiles_x = (a.Wo + TW - 1) / TW;
+    a.tiles_y = (a.Ho + 4 * P - 1) / (4 * P);
     const int mtiles = (a.Cout + 31) / 32;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)((mtiles + R - 1) / R));
-    hipLaunchKernelGGL((k_conv3x3<R, P>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
     return 0;
 }
 
 extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
                                  const float *xamax, int xcount, const float *wamax, const float *addend,
-                                 float *y, int tile_r, int tile_p, void *stream)
+                                 float *y, int stride, int in_up, int Hout, int Wout, int tile_r, int tile_p,
+                                 void *stream)
 {
     DCL_CHECK_ARG(x && wp && xamax && wamax && y, "null pointer");
     DCL_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && xcount > 0, "bad shape");
+    DCL_CHECK_ARG((stride == 1 || stride == 2) && (in_up == 1 || in_up == 2) && !(stride == 2 && in_up == 2),
+                  "stride / in_up must be 1 or 2 (not both 2)");
     DCL_CHECK_ARG((size_t)8 * H * W + (size_t)H * W < ((size_t)1 << 31), "image plane too large");
     ConvArgs a;
     a.x = x;
@@ -480,43 +515,62 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
     a.N = N;
     a.Cin = Cin;
     a.Cout = Cout;
-    a.H = H;
-    a.W = W;
+    a.Hs = H;
+    a.Ws = W;
+    a.up = in_up;
+    if (in_up == 2) {
+        // the virtual (zero-inserted) input has the size of the output; the stored one must be its even samples
+        DCL_CHECK_ARG(Hout > 0 && Wout > 0 && (Hout - 1) / 2 + 1 == H && (Wout - 1) / 2 + 1 == W,
+                      "in_up = 2: H, W must be ceil(Hout / 2), ceil(Wout / 2)");
+        a.H = Hout;
+        a.W = Wout;
+    } else {
+        a.H = H;
+        a.W = W;
+    }
+    a.Ho = stride == 2 ? (a.H - 1) / 2 + 1 : a.H;
+    a.Wo = stride == 2 ? (a.W - 1) / 2 + 1 : a.W;
+    DCL_CHECK_ARG((Hout <= 0 || Hout == a.Ho) && (Wout <= 0 || Wout == a.Wo), "Hout / Wout do not match the geometry");
     a.nchunk = (Cin + 15) / 16;
     const int mtiles = (Cout + 31) / 32;
     int R = tile_r, P = tile_p;
-    if (R <= 0 || P <= 0) {
+    if (stride == 2)
+        P = 1;
+    if (R <= 0 || P <= 0 || (stride == 2 && tile_r <= 0)) {
         // measured on the four BasicBlock shapes of HRNet-W48 at batch 12 (tools/bench_conv3x3.py --tiles):
         // channel tiles per wave in threes when that leaves no padded tile, else pairs; the most rows per wave
         // that still give ~one workgroup per CU; tiny images fall back to single-tile waves to get enough
         // workgroups.
         R = (mtiles % 3 == 0) ? 3 : (mtiles == 1 ? 1 : 2);
         auto wgs = [&](int r, int p) {
-            return (long)((W + TW - 1) / TW) * ((H + 4 * p - 1) / (4 * p)) * N * ((mtiles + r - 1) / r);
+            return (long)((a.Wo + TW - 1) / TW) * ((a.Ho + 4 * p - 1) / (4 * p)) * N * ((mtiles + r - 1) / r);
         };
-        P = 4;
+        P = stride == 2 ? 1 : 4;
         while (P > 1 && wgs(R, P) < 192)
             P >>= 1;
         if (P == 1 && wgs(R, P) < 256)
             R = 1;
     }
     hipStream_t s = (hipStream_t)stream;
-#define DCL_CONV_CASE(r, p)            \
-    if (R == r && P == p) {            \
-        launch_conv<r, p>(a, s);       \
-        DCL_LAUNCH_CHECK();            \
-        return 0;                      \
+#define DCL_CONV_CASE(r, p, st)                \
+    if (R == r && P == p && stride == st) {    \
+        launch_conv<r, p, st>(a, s);           \
+        DCL_LAUNCH_CHECK();                    \
+        return 0;                              \
     }
-    DCL_CONV_CASE(1, 1)
-    DCL_CONV_CASE(1, 2)
-    DCL_CONV_CASE(1, 4)
-    DCL_CONV_CASE(2, 1)
-    DCL_CONV_CASE(2, 2)
-    DCL_CONV_CASE(2, 4)
-    DCL_CONV_CASE(3, 1)
-    DCL_CONV_CASE(3, 2)
-    DCL_CONV_CASE(3, 4)
+    DCL_CONV_CASE(1, 1, 1)
+    DCL_CONV_CASE(1, 2, 1)
+    DCL_CONV_CASE(1, 4, 1)
+    DCL_CONV_CASE(2, 1, 1)
+    DCL_CONV_CASE(2, 2, 1)
+    DCL_CONV_CASE(2, 4, 1)
+    DCL_CONV_CASE(3, 1, 1)
+    DCL_CONV_CASE(3, 2, 1)
+    DCL_CONV_CASE(3, 4, 1)
+    DCL_CONV_CASE(1, 1, 2)
+    DCL_CONV_CASE(2, 1, 2)
+    DCL_CONV_CASE(3, 1, 2)
 #undef DCL_CONV_CASE
-    dcl_set_error("dcl_conv3x3_f16x3: unsupported tile (R=%d, P=%d)", R, P);
+    dcl_set_error("dcl_conv3x3_f16x3: unsupported tile (R=%d, P=%d, stride=%d)", R, P, stride);
     return DCL_EINVAL;
 }

@@ -36,6 +36,7 @@ struct WgradArgs {
     const float *xamax, *gamax;
     int xcount, gcount;
     int N, Cin, Cout, H, W;
+    int Hd, Wd;                  // stored size of dy (= H, W; or the even samples of a zero-inserted dy: stride 2)
     int strips, nseg, units, S, ncig, npairs, nx;
 };
 
@@ -63,7 +64,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ half8 as_half8(u32x4 v) { return __builtin_bit_cast(half8, v); }
 
-template <int NCO, int NCI>
+// UPS: dy is the gradient of a STRIDE-2 convolution, i.e. the stride-1 formulation sees it zero-inserted at odd
+// coordinates: row y of the virtual dy is row y / 2 of the stored one for even y (else zero), and an octet of 8
+// virtual pixels is 4 stored values interleaved with zeros.
+template <int NCO, int NCI, bool UPS>
 __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
 {
     __shared__ float wm[8];
@@ -148,17 +152,26 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
         const float sx_c = oct_ok ? sx : 0.f;                       // elements 1..8 of the B window
         const float sx_l = (oct_ok && px > 0) ? sx : 0.f;           // left halo (outside the image at x = -1)
         const float sx_r = (px + 8 < a.W) ? sx : 0.f;               // right halo
-        const float *ap = a.dy + ((size_t)n * a.Cout + co0 + j) * plane + pxc;    // + t * 16 * plane + y * W
+        const size_t dplane = (size_t)a.Hd * a.Wd;
+        const float *ap = a.dy + ((size_t)n * a.Cout + co0 + j) * dplane + (UPS ? pxc / 2 : pxc);
         const float *bp = a.x + ((size_t)n * a.Cin + ci0 + j) * plane + pxc;     // + u * 16 * plane + r * W
 
         auto load_A = [&](int y, f32x4 (&dst)[NCO][2], float &scale) {
-            scale = (oct_ok && y >= 0 && y < a.H) ? sg : 0.f;
-            const int yc = min(max(y, 0), a.H - 1);
+            if (UPS) {
+                scale = (oct_ok && y >= 0 && !(y & 1) && (y >> 1) < a.Hd) ? sg : 0.f;
+                const int yc = min(max(y >> 1, 0), a.Hd - 1);
 #pragma unroll
-            for (int t2 = 0; t2 < NCO; ++t2) {
-                const float *p = ap + (size_t)t2 * 16 * plane + (size_t)yc * a.W;
-                dst[t2][0] = *(const f32x4 *)p;
-                dst[t2][1] = *(const f32x4 *)(p + 4);
+                for (int t2 = 0; t2 < NCO; ++t2)
+                    dst[t2][0] = *(const f32x4 *)(ap + (size_t)t2 * 16 * dplane + (size_t)yc * a.Wd);
+            } else {
+                scale = (oct_ok && y >= 0 && y < a.H) ? sg : 0.f;
+                const int yc = min(max(y, 0), a.H - 1);
+#pragma unroll
+                for (int t2 = 0; t2 < NCO; ++t2) {
+                    const float *p = ap + (size_t)t2 * 16 * dplane + (size_t)yc * a.W;
+                    dst[t2][0] = *(const f32x4 *)p;
+                    dst[t2][1] = *(const f32x4 *)(p + 4);
+                }
             }
         };
         auto load_B = [&](int r, f32x4 (&dst)[NCI][2], float (&l)[NCI], float (&rr)[NCI]) {
@@ -176,6 +189,21 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
 #pragma unroll
             for (int t2 = 0; t2 < NCO; ++t2) {
                 unsigned h[4], l[4];
+                if (UPS) {
+                    // (a0, 0, a1, 0, a2, 0, a3, 0): one split value in the low half of every pair
+                    split1(src[t2][0].x, scale, h[0], l[0]);
+                    split1(src[t2][0].y, scale, h[1], l[1]);
+                    split1(src[t2][0].z, scale, h[2], l[2]);
+                    split1(src[t2][0].w, scale, h[3], l[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] &= 0xffffu;
+                        l[e] &= 0xffffu;
+                    }
+                    dst[t2][0] = as_half8(u32x4{h[0], h[1], h[2], h[3]});
+                    dst[t2][1] = as_half8(u32x4{l[0], l[1], l[2], l[3]});
+                    continue;
+                }
                 split2(src[t2][0].x, src[t2][0].y, scale, h[0], l[0]);
                 split2(src[t2][0].z, src[t2][0].w, scale, h[1], l[1]);
                 split2(src[t2][1].x, src[t2][1].y, scale, h[2], l[2]);
@@ -382,9 +410,10 @@ extern "C" int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W)
 }
 
 extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W,
-                                  const float *xamax, int xcount, const float *gamax, int gcount, float *part,
-                                  float *dw, void *stream)
+                                  const float *xamax, int xcount, const float *gamax, int gcount, int stride,
+                                  float *part, float *dw, void *stream)
 {
+    DCL_CHECK_ARG(stride == 1 || stride == 2, "stride must be 1 or 2");
     DCL_CHECK_ARG(x && dy && xamax && gamax && part && dw, "null pointer");
     DCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && xcount > 0 && gcount > 0, "bad shape");
     DCL_CHECK_ARG(Cin > 0 && Cout > 0 && (Cin & 15) == 0 && (Cout & 15) == 0, "channel counts must be multiples of 16");
@@ -403,6 +432,8 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     a.Cout = Cout;
     a.H = H;
     a.W = W;
+    a.Hd = stride == 2 ? (H - 1) / 2 + 1 : H;
+    a.Wd = stride == 2 ? W / 2 : W;
     a.strips = (W + 31) / 32;
     a.nseg = 1;
     int nco, nci;
@@ -413,8 +444,12 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     dim3 grid((unsigned)(a.npairs * a.nx));      // exactly the populated workgroups, <= 256 whenever pairs <= 256
     hipStream_t s = (hipStream_t)stream;
 #define DCL_WG_CASE(o, i)                                                        \
-    if (nco == o && nci == i)                                                    \
-        hipLaunchKernelGGL((k_wgrad3x3<o, i>), grid, dim3(256), 0, s, a);
+    if (nco == o && nci == i) {                                                  \
+        if (stride == 2)                                                         \
+            hipLaunchKernelGGL((k_wgrad3x3<o, i, true>), grid, dim3(256), 0, s, a);  \
+        else                                                                     \
+            hipLaunchKernelGGL((k_wgrad3x3<o, i, false>), grid, dim3(256), 0, s, a); \
+    }
     DCL_WG_CASE(3, 2)
     DCL_WG_CASE(2, 2)
     DCL_WG_CASE(1, 2)

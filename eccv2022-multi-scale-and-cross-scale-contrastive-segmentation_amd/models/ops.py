@@ -223,12 +223,16 @@ def conv3x3_pack(weight, wamax, transposed=False):
     return wp
 
 
-def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0, addend=None):
+def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0, addend=None, stride=1, in_up=1):
+    """stride = 2: stride-2 convolution; in_up = 2: x is the gradient of a stride-2 convolution (its data gradient
+    is the stride-1 transposed convolution of x with zeros inserted at the odd coordinates; out has the size of the
+    convolution's input)."""
     from .. import _lib
     n, c, h, w = x.shape
     _lib.check(_lib.lib().dcl_conv3x3_f16x3(_lib.ptr(x), n, c, h, w, _lib.ptr(wp), cout, _lib.ptr(xamax),
                                             xamax.numel(), _lib.ptr(wamax), _lib.ptr(addend), _lib.ptr(out),
-                                            tile_r, tile_p, _stream(x)), "dcl_conv3x3_f16x3")
+                                            stride, in_up, out.shape[2], out.shape[3], tile_r, tile_p, _stream(x)),
+               "dcl_conv3x3_f16x3")
     return out
 
 
@@ -244,26 +248,32 @@ class GradToken:
         self.dres = None
 
 
-def conv3x3_direct(x, weight, transposed=False):
-    """y = conv2d(x, weight, padding=1) (or, ``transposed``, its data gradient applied to x) on the f16x3
-    direct kernel; x [N, C, H, W] f32 contiguous, weight [Co, Ci, 3, 3] f32 contiguous."""
+def conv3x3_direct(x, weight, transposed=False, stride=1, out_hw=None):
+    """y = conv2d(x, weight, stride=stride, padding=1) (or, ``transposed``, its data gradient applied to x; for
+    stride 2 ``out_hw`` is the size of the convolution's input) on the f16x3 direct kernel; x [N, C, H, W] f32
+    contiguous, weight [Co, Ci, 3, 3] f32 contiguous."""
     from .amax import amax_of
     x = x.contiguous()
     weight = weight.contiguous()
     wamax = amax_of(weight)
     wp = conv3x3_pack(weight, wamax, transposed)
     cout = weight.shape[1] if transposed else weight.shape[0]
-    out = torch.empty((x.shape[0], cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
-    return conv3x3_launch(x, wp, cout, amax_of(x), wamax, out)
+    if transposed:
+        oh, ow = (x.shape[2], x.shape[3]) if stride == 1 else out_hw
+        out = torch.empty((x.shape[0], cout, oh, ow), dtype=torch.float32, device=x.device)
+        return conv3x3_launch(x, wp, cout, amax_of(x), wamax, out, in_up=stride)
+    oh, ow = (x.shape[2] - 1) // stride + 1, (x.shape[3] - 1) // stride + 1
+    out = torch.empty((x.shape[0], cout, oh, ow), dtype=torch.float32, device=x.device)
+    return conv3x3_launch(x, wp, cout, amax_of(x), wamax, out, stride=stride)
 
 
 def conv3x3_wgrad_supported(x, cout):
     return x.shape[1] % 16 == 0 and cout % 16 == 0 and x.shape[3] % 8 == 0
 
 
-def conv3x3_wgrad(x, gy):
-    """dw [Co, Ci, 3, 3] = weight gradient of conv2d(x, w, padding=1) for the output gradient gy, on the f16x3
-    kernel of csrc/dcl_wgrad3x3.hip (x [N, Ci, H, W], gy [N, Co, H, W], contiguous f32)."""
+def conv3x3_wgrad(x, gy, stride=1):
+    """dw [Co, Ci, 3, 3] = weight gradient of conv2d(x, w, stride=stride, padding=1) for the output gradient gy,
+    on the f16x3 kernel of csrc/dcl_wgrad3x3.hip (x [N, Ci, H, W], gy [N, Co, Ho, Wo], contiguous f32)."""
     from .. import _lib
     from .amax import amax_of
     n, ci, h, w = x.shape
@@ -275,8 +285,9 @@ def conv3x3_wgrad(x, gy):
     part = torch.empty(splits * 9 * co * ci, dtype=torch.float32, device=x.device)
     dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)
     xa, ga = amax_of(x), amax_of(gy)
+    assert gy.shape[2] == (h - 1) // stride + 1 and gy.shape[3] == (w - 1) // stride + 1
     _lib.check(L.dcl_wgrad3x3_f16x3(_lib.ptr(x), _lib.ptr(gy), n, ci, co, h, w, _lib.ptr(xa), xa.numel(),
-                                    _lib.ptr(ga), ga.numel(), _lib.ptr(part), _lib.ptr(dw), _stream(x)),
+                                    _lib.ptr(ga), ga.numel(), stride, _lib.ptr(part), _lib.ptr(dw), _stream(x)),
                "dcl_wgrad3x3_f16x3")
     return dw
 
@@ -290,10 +301,11 @@ class _Conv3x3Direct(torch.autograd.Function):
     def forward(ctx, x, weight, mod, token=None):
         from .amax import amax_of
         ctx.token = token
+        ctx.stride = st = mod.stride[0]
         wamax, wp, _ = mod.packed_weights()
-        out = torch.empty((x.shape[0], weight.shape[0], x.shape[2], x.shape[3]), dtype=torch.float32,
-                          device=x.device)
-        conv3x3_launch(x, wp, weight.shape[0], amax_of(x), wamax, out)
+        out = torch.empty((x.shape[0], weight.shape[0], (x.shape[2] - 1) // st + 1, (x.shape[3] - 1) // st + 1),
+                          dtype=torch.float32, device=x.device)
+        conv3x3_launch(x, wp, weight.shape[0], amax_of(x), wamax, out, stride=st)
         ctx.save_for_backward(x, weight)
         ctx.mod = mod
         return out
@@ -310,22 +322,23 @@ class _Conv3x3Direct(torch.autograd.Function):
             addend = None
             if ctx.token is not None and ctx.token.dres is not None:
                 addend, ctx.token.dres = ctx.token.dres, None        # gradient of the residual branch, fused in
-            conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend)
+            conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend, in_up=ctx.stride)
         if ctx.needs_input_grad[1]:
             if conv3x3_wgrad_supported(x, weight.shape[0]):
-                gw = conv3x3_wgrad(x, gy)
+                gw = conv3x3_wgrad(x, gy, ctx.stride)
             else:
-                gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0],
-                                                         1, [False, True, False])[1]
+                st = ctx.stride
+                gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [st, st], [1, 1], [1, 1], False,
+                                                         [0, 0], 1, [False, True, False])[1]
         return gx, gw, None, None
 
 
 class DirectConv2d(torch.nn.Conv2d):
-    """nn.Conv2d (same parameters / state_dict) whose 3x3, stride-1, pad-1 case runs on the direct f16x3 kernel
-    for contiguous fp32 CUDA inputs; every other configuration falls through to nn.Conv2d.forward."""
+    """nn.Conv2d (same parameters / state_dict) whose 3x3, pad-1, stride-1 or stride-2 case runs on the direct f16x3
+    kernels for contiguous fp32 CUDA inputs; every other configuration falls through to nn.Conv2d.forward."""
 
     def eligible(self, x):
-        return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
+        return (self.kernel_size == (3, 3) and self.stride in ((1, 1), (2, 2)) and self.padding == (1, 1)
                 and self.dilation == (1, 1) and self.groups == 1 and self.bias is None
                 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
                 and self.weight.dtype == torch.float32 and not torch.is_autocast_enabled()
@@ -417,9 +430,11 @@ class ConvPackGroup:
 
 
 def use_direct_conv3x3(module: torch.nn.Module) -> torch.nn.Module:
-    """Switch every plain nn.Conv2d with a 3x3 / stride 1 / pad 1 / bias-free geometry to DirectConv2d in place."""
+    """Switch every plain nn.Conv2d with a 3x3 / stride 1 or 2 / pad 1 / bias-free geometry to DirectConv2d in
+    place."""
     for m in module.modules():
-        if type(m) is torch.nn.Conv2d and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) \
+        if type(m) is torch.nn.Conv2d and m.kernel_size == (3, 3) and m.stride in ((1, 1), (2, 2)) \
+                and m.padding == (1, 1) \
                 and m.dilation == (1, 1) and m.groups == 1 and m.bias is None:
             m.__class__ = DirectConv2d
     return module

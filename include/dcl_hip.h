@@ -246,17 +246,22 @@ int dcl_absmax(const float *x, int64_t n, float *out, void *stream);
 int dcl_absmax_multi(const void *jobs, const int32_t *blk2job, int nblocks, void *stream);
 int dcl_conv3x3_pack_multi(const void *jobs, const int32_t *blk2job, int nblocks, void *stream);
 int dcl_conv3x3_pack(const float *w, int M, int K, int transposed, const float *wamax, void *wp, void *stream);
-int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
+int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored input size */, const void *wp, int Cout,
                       const float *xamax, int xcount, const float *wamax,
-                      const float *addend /* [N,Cout,H,W] added to the result, or NULL */, float *y, int tile_r,
-                      int tile_p, void *stream);
+                      const float *addend /* [N,Cout,Hout,Wout] added to the result, or NULL */, float *y,
+                      int stride /* 1 | 2; Hout = (H - 1) / 2 + 1 for 2 */,
+                      int in_up /* 1, or 2: x holds the even samples of a zero-inserted [Hout, Wout] input --
+                                   the data gradient of a stride-2 convolution (stride must be 1) */,
+                      int Hout, int Wout /* output size (checked; required for in_up = 2, may be 0 otherwise) */,
+                      int tile_r, int tile_p, void *stream);
 
 /* Weight gradient of the same convolution, dw[Cout,Cin,3,3] = sum_n dy (*) x, on the f16x3 MFMA path with no LDS
  * staging (csrc/dcl_wgrad3x3.hip).  Cin % 16 == 0, Cout % 16 == 0, W % 8 == 0.  part: workspace of
  * dcl_wgrad3x3_splits(...) * 9 * Cout * Cin floats (one partial slab per split, summed in fixed order). */
 int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W);
-int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W,
-                       const float *xamax, int xcount, const float *gamax, int gcount, float *part, float *dw,
+int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W /* of x */,
+                       const float *xamax, int xcount, const float *gamax, int gcount,
+                       int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,
                        void *stream);
 
 /* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the

@@ -857,3 +857,39 @@ def test_fuse_layer_streams_match_single_stream(dev):
                 assert dist(got[2][n], ref[2][n]) <= 10 * noise_g, (n, dist(got[2][n], ref[2][n]), noise_g)
     finally:
         hm._BRANCH_STREAMS = True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 48, 96, 32, 64), (1, 16, 32, 7, 40), (2, 32, 16, 9, 8), (1, 64, 64, 16, 24),
+                                   (2, 3, 64, 12, 16)])
+def test_direct_conv3x3_stride2_matches_fp64(dev, shape):
+    """Stride-2 convolution on the direct kernels: forward (stride-2 tile), data gradient (stride-1 kernel over the
+    zero-inserted gradient) and weight gradient (zero-inserted dy operand) against float64, odd sizes included."""
+    from mscs_amd.models import ops
+    n, ci, co, h, w = shape
+    torch.manual_seed(sum(shape) + 5)
+    x = torch.randn(n, ci, h, w, device=dev).relu_() * 2.0
+    wt = torch.randn(co, ci, 3, 3, device=dev) * (2.0 / (9 * ci)) ** 0.5
+    x64 = x.double().cpu().requires_grad_(True)
+    w64 = wt.double().cpu().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w64, stride=2, padding=1)
+    gy = torch.randn(y64.shape, device=dev) * 1e-4
+    y64.backward(gy.double().cpu())
+    y = ops.conv3x3_direct(x, wt, stride=2)
+    assert y.shape == y64.shape
+    assert ((y.double().cpu() - y64.detach()).abs().max() / y64.detach().abs().max()).item() < 3e-6
+    gx = ops.conv3x3_direct(gy, wt, transposed=True, stride=2, out_hw=(h, w))
+    assert ((gx.double().cpu() - x64.grad).abs().max() / x64.grad.abs().max()).item() < 3e-6
+    if ci % 16 == 0 and co % 16 == 0 and w % 8 == 0:
+        gw = ops.conv3x3_wgrad(x, gy, stride=2)
+        assert ((gw.double().cpu() - w64.grad).abs().max() / w64.grad.abs().max()).item() < 3e-6
+    # the module path (autograd) agrees as well
+    conv = torch.nn.Conv2d(ci, co, 3, 2, 1, bias=False).to(dev)
+    conv.weight.data.copy_(wt)
+    ops.use_direct_conv3x3(conv)
+    assert isinstance(conv, ops.DirectConv2d)
+    xi = (x * 1.0).requires_grad_(True)
+    xi.retain_grad()
+    conv(xi).backward(gy)
+    assert ((xi.grad.double().cpu() - x64.grad).abs().max() / x64.grad.abs().max()).item() < 3e-6
+    assert ((conv.weight.grad.double().cpu() - w64.grad).abs().max() / w64.grad.abs().max()).item() < 3e-6
