@@ -93,31 +93,14 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
     const size_t plane = (size_t)a.Hs * a.Ws;                // stored input plane
     const size_t oplane = (size_t)a.Ho * a.Wo;
     const float *xb = a.x + (size_t)n * a.Cin * plane;
-    // operand scale of x: max over the partial maxima, exchanged between the waves through LDS
-    float xs;
-    {
-        float m = 0.f;
-        for (int i = tid; i < a.xcount; i += 256)
-            m = fmaxf(m, a.xamax[i]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            m = fmaxf(m, __shfl_xor(m, o, 64));
-        float *wm = (float *)lds;
-        if (lane == 0)
-            wm[wave] = m;
-        __syncthreads();
-        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-        __syncthreads();
-        xs = pow2_scale(m);
-    }
-
     // staging work items: (octet of channels, patch pixel); consecutive lanes -> consecutive pixels.
     // Every load is unconditional from a clamped, always valid address (a branch around a load makes the compiler
     // wait for it at the join, i.e. in front of the MFMAs it is meant to overlap): halo pixels outside the image
     // read pixel 0 and are zeroed through their operand scale (0 instead of s); channels past Cin read channel
     // Cin - 1 and meet the zero weights the packer wrote for k >= Cin.
     int goff[NITEM], loff[NITEM];
-    float gsc[NITEM];
+    float gsc[NITEM];               // operand scale of the item (0 for halo pixels outside the image), set below
+    bool gok[NITEM];
 #pragma unroll
     for (int m = 0; m < NITEM; ++m) {
         const int it = min(tid + 256 * m, 2 * TP - 1);          // surplus items repeat the last one
@@ -135,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
         }
         loff[m] = pix * PIXB + oct * 16;
         goff[m] = ok ? sy * a.Ws + sx : 0;
-        gsc[m] = ok ? xs : 0.f;
+        gok[m] = ok;
     }
     const bool ragged = (a.Cin & 15) != 0;                       // last chunk has channels past Cin
     float g[NITEM][8];
@@ -209,6 +192,28 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
     load_A(Ab[0], 0, 0);
     if (AD == 2)
         load_A(Ab[1], 0, 1);
+    // operand scale of x (max over the producer's partial maxima, exchanged between the waves through LDS) -- after
+    // the first patch and weight fragments are in flight, so that its memory round trip hides behind theirs
+    float xs;
+    {
+        float m = 0.f;
+        for (int i = tid; i < a.xcount; i += 256)
+            m = fmaxf(m, a.xamax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            m = fmaxf(m, __shfl_xor(m, o, 64));
+        float *wm = (float *)lds;
+        if (lane == 0)
+            wm[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        __syncthreads();
+        xs = pow2_scale(m);
+    }
+
+#pragma unroll
+    for (int m = 0; m < NITEM; ++m)
+        gsc[m] = gok[m] ? xs : 0.f;
     write_items(lds);
     __syncthreads();
 
