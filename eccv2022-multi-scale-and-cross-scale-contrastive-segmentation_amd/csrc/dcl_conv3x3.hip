@@ -52,6 +52,7 @@ struct ConvArgs {
     const uint4 *wp;
     float *y;
     const float *addend;            // optional tensor of y's shape added in the epilogue (residual gradient)
+    const float *bias;              // optional [Cout] added in the epilogue
     const float *xamax, *wamax;     // max|x| as xcount partial maxima (e.g. per channel), max|w| (1 value)
     int xcount;
     int N, Cin, Cout;
@@ -226,6 +227,18 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
         __builtin_amdgcn_sched_barrier(0);
         load_items(more ? c + 1 : c);
         __builtin_amdgcn_sched_barrier(0);
+        // B fragments (stride 1) are read ONE group ahead of the MFMAs that consume them -- group g = (kx, tile row
+        // rr) -- into two alternating register pairs, so that the LDS latency hides behind the previous group's MFMAs
+        // (the scheduling groups below pin "2 DS reads, then the group's MFMAs"; left alone the reads sit right in
+        // front of their first use and every group starts with an exposed ~100-cycle wait)
+        half8 bq[2][2];
+        auto read_b = [&](int g, half8 (&dst)[2]) {
+            const unsigned char *bp = cur + (brow + (g % (P + 2)) * LW + g / (P + 2)) * PIXB + h * 16;
+            dst[0] = *(const half8 *)bp;
+            dst[1] = *(const half8 *)(bp + 32);
+        };
+        if (S == 1)
+            read_b(0, bq[0]);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             {
@@ -237,9 +250,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
                 // a fragment depends on (tile row rr = p + ky, kx) only: read once, used by every (p, ky) pair
 #pragma unroll
                 for (int rr = 0; rr < P + 2; ++rr) {
-                    const unsigned char *bp = cur + (brow + rr * LW + kx) * PIXB + h * 16;
-                    const half8 bh = *(const half8 *)bp;
-                    const half8 bl = *(const half8 *)(bp + 32);
+                    const int g = kx * (P + 2) + rr;
+                    if (g + 1 < 3 * (P + 2))
+                        read_b(g + 1, bq[(g + 1) & 1]);
+                    const half8 bh = bq[g & 1][0], bl = bq[g & 1][1];
 #pragma unroll
                     for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
@@ -252,6 +266,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
                                         Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p], 0, 0, 0);
                             }
                         }
+                    // number of (p, ky) pairs of this tile row
+                    const int npk = (rr < 3 ? rr + 1 : 3) - (rr > P - 1 ? rr - (P - 1) : 0);
+                    if (g + 1 < 3 * (P + 2))
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (npk == 1)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * R, 0);
+                    else if (npk == 2)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6 * R, 0);
+                    else
+                        __builtin_amdgcn_sched_group_barrier(0x008, 9 * R, 0);
                 }
             } else {
                 // stride 2: output pixel (p, li) reads patch pixel (2 p' + ky, 2 li + kx)
@@ -288,13 +312,14 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
             if (row < a.Ho && col < a.Wo && cob < a.Cout) {
                 const size_t o0 = (((size_t)n * a.Cout + cob) * a.Ho + row) * a.Wo + col;
                 float *yp = a.y + o0;
-                if (a.addend) {
-                    // all 16 addend loads first, from clamped (always valid) channel offsets, then the stores
-                    const float *ap = a.addend + o0;
+                if (a.addend || a.bias) {
+                    // all 16 addend / bias loads first, from clamped (always valid) channel offsets, then the stores
                     float ad[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        ad[q] = ap[(size_t)min((q & 3) + 8 * (q >> 2), a.Cout - 1 - cob) * oplane];
+                    for (int q = 0; q < 16; ++q) {
+                        const int k = min((q & 3) + 8 * (q >> 2), a.Cout - 1 - cob);
+                        ad[q] = (a.addend ? a.addend[o0 + (size_t)k * oplane] : 0.f) + (a.bias ? a.bias[cob + k] : 0.f);
+                    }
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
                         if (cob + (q & 3) + 8 * (q >> 2) < a.Cout)
@@ -501,8 +526,8 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
 
 extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
                                  const float *xamax, int xcount, const float *wamax, const float *addend,
-                                 float *y, int stride, int in_up, int Hout, int Wout, int tile_r, int tile_p,
-                                 void *stream)
+                                 const float *bias, float *y, int stride, int in_up, int Hout, int Wout,
+                                 int tile_r, int tile_p, void *stream)
 {
     DCL_CHECK_ARG(x && wp && xamax && wamax && y, "null pointer");
     DCL_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && xcount > 0, "bad shape");
@@ -514,6 +539,7 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
     a.wp = (const uint4 *)wp;
     a.y = y;
     a.addend = addend;
+    a.bias = bias;
     a.xamax = xamax;
     a.wamax = wamax;
     a.xcount = xcount;
@@ -546,14 +572,14 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
         // channel tiles per wave in threes when that leaves no padded tile, else pairs; the most rows per wave
         // that still give ~one workgroup per CU; tiny images fall back to single-tile waves to get enough
         // workgroups.
-        R = (mtiles % 3 == 0) ? 3 : (mtiles == 1 ? 1 : 2);
+        R = (mtiles % 3 == 0 || mtiles >= 20) ? 3 : (mtiles == 1 ? 1 : 2);     // >= 20 tiles: one padded tile is < 5 %
         auto wgs = [&](int r, int p) {
             return (long)((a.Wo + TW - 1) / TW) * ((a.Ho + 4 * p - 1) / (4 * p)) * N * ((mtiles + r - 1) / r);
         };
         P = stride == 2 ? 1 : 4;
         while (P > 1 && wgs(R, P) < 192)
             P >>= 1;
-        if (P == 1 && wgs(R, P) < 256)
+        if (P == 1 && wgs(R, P) < 128)
             R = 1;
     }
     hipStream_t s = (hipStream_t)stream;

@@ -429,19 +429,24 @@ class HRNet(nn.Module):
         # weight gradient of the head's big 3x3 conv as im2col + rocBLAS GEMM (2.4x MIOpen's default
         # fp32 solver on MI355X, models/ops.py); same forward, same state_dict
         self.gemm_wrw_head = bool(config.get('gemm_wrw_head', True))
-        # 'f16x3': all three directions of that conv as split-f16 GEMMs at fp32-equivalent accuracy (models/ops.py);
-        # 'gemm_wrw': only the weight gradient as an f32 GEMM; 'library': MIOpen for everything
-        self.head_conv = config.get('head_conv', 'f16x3' if self.gemm_wrw_head else 'library')
+        # 'direct': the same direct split-f16 kernels as the backbone (fastest: 32 ms for the three directions at
+        # batch 12 against 42 ms for 'f16x3', and no 10 GB im2col buffers); 'f16x3': all three directions as
+        # split-f16 library GEMMs over an im2col copy (models/ops.py); 'gemm_wrw': only the weight gradient as an
+        # f32 GEMM; 'library': MIOpen for everything
+        self.head_conv = config.get('head_conv', 'direct' if self.gemm_wrw_head else 'library')
         # 'f16x3': the backbone's 3x3 / stride-1 convolutions (BasicBlock, Bottleneck, transitions: ~80 % of the
         # FLOPs) on the direct split-f16 kernel (csrc/dcl_conv3x3.hip, fp32-equivalent); 'library': MIOpen
         self.branch_conv = config.get('branch_conv', 'f16x3')
         self._conv_packs = None
+        if self.head_conv == 'direct':
+            use_direct_conv3x3(self.cls_head)
         if self.branch_conv == 'f16x3':
             use_direct_conv3x3(self.backbone)
-            self._conv_packs = ConvPackGroup(self.backbone)
+        if self.branch_conv == 'f16x3' or self.head_conv == 'direct':
+            self._conv_packs = ConvPackGroup(self)
 
     def _head(self, x):
-        if self.head_conv != 'library' and self.training and x.is_cuda and x.dtype == torch.float32 \
+        if self.head_conv not in ('library', 'direct') and self.training and x.is_cuda and x.dtype == torch.float32 \
                 and torch.is_grad_enabled() and not torch.is_autocast_enabled():
             if self.head_conv == 'f16x3' and x.shape[-1] % 8 == 0:
                 x = conv3x3_f16x3(x, self.cls_head[0])

@@ -223,15 +223,15 @@ def conv3x3_pack(weight, wamax, transposed=False):
     return wp
 
 
-def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0, addend=None, stride=1, in_up=1):
+def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0, addend=None, stride=1, in_up=1, bias=None):
     """stride = 2: stride-2 convolution; in_up = 2: x is the gradient of a stride-2 convolution (its data gradient
     is the stride-1 transposed convolution of x with zeros inserted at the odd coordinates; out has the size of the
     convolution's input)."""
     from .. import _lib
     n, c, h, w = x.shape
     _lib.check(_lib.lib().dcl_conv3x3_f16x3(_lib.ptr(x), n, c, h, w, _lib.ptr(wp), cout, _lib.ptr(xamax),
-                                            xamax.numel(), _lib.ptr(wamax), _lib.ptr(addend), _lib.ptr(out),
-                                            stride, in_up, out.shape[2], out.shape[3], tile_r, tile_p, _stream(x)),
+                                            xamax.numel(), _lib.ptr(wamax), _lib.ptr(addend), _lib.ptr(bias),
+                                            _lib.ptr(out), stride, in_up, out.shape[2], out.shape[3], tile_r, tile_p, _stream(x)),
                "dcl_conv3x3_f16x3")
     return out
 
@@ -298,14 +298,15 @@ class _Conv3x3Direct(torch.autograd.Function):
     of 16: ATen / MIOpen)."""
 
     @staticmethod
-    def forward(ctx, x, weight, mod, token=None):
+    def forward(ctx, x, weight, mod, token=None, bias=None):
         from .amax import amax_of
         ctx.token = token
+        ctx.has_bias = bias is not None
         ctx.stride = st = mod.stride[0]
         wamax, wp, _ = mod.packed_weights()
         out = torch.empty((x.shape[0], weight.shape[0], (x.shape[2] - 1) // st + 1, (x.shape[3] - 1) // st + 1),
                           dtype=torch.float32, device=x.device)
-        conv3x3_launch(x, wp, weight.shape[0], amax_of(x), wamax, out, stride=st)
+        conv3x3_launch(x, wp, weight.shape[0], amax_of(x), wamax, out, stride=st, bias=bias)
         ctx.save_for_backward(x, weight)
         ctx.mod = mod
         return out
@@ -330,7 +331,8 @@ class _Conv3x3Direct(torch.autograd.Function):
                 st = ctx.stride
                 gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [st, st], [1, 1], [1, 1], False,
                                                          [0, 0], 1, [False, True, False])[1]
-        return gx, gw, None, None
+        gb = gy.sum((0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
+        return gx, gw, None, None, gb
 
 
 class DirectConv2d(torch.nn.Conv2d):
@@ -339,7 +341,7 @@ class DirectConv2d(torch.nn.Conv2d):
 
     def eligible(self, x):
         return (self.kernel_size == (3, 3) and self.stride in ((1, 1), (2, 2)) and self.padding == (1, 1)
-                and self.dilation == (1, 1) and self.groups == 1 and self.bias is None
+                and self.dilation == (1, 1) and self.groups == 1
                 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
                 and self.weight.dtype == torch.float32 and not torch.is_autocast_enabled()
                 and x.is_contiguous())
@@ -359,7 +361,7 @@ class DirectConv2d(torch.nn.Conv2d):
 
     def forward(self, x, grad_token=None):
         if self.eligible(x):
-            return _Conv3x3Direct.apply(x, self.weight, self, grad_token)
+            return _Conv3x3Direct.apply(x, self.weight, self, grad_token, self.bias)
         return super().forward(x)
 
     def fuses_residual_grad(self, x):
@@ -430,11 +432,10 @@ class ConvPackGroup:
 
 
 def use_direct_conv3x3(module: torch.nn.Module) -> torch.nn.Module:
-    """Switch every plain nn.Conv2d with a 3x3 / stride 1 or 2 / pad 1 / bias-free geometry to DirectConv2d in
-    place."""
+    """Switch every plain nn.Conv2d with a 3x3 / stride 1 or 2 / pad 1 geometry to DirectConv2d in place."""
     for m in module.modules():
         if type(m) is torch.nn.Conv2d and m.kernel_size == (3, 3) and m.stride in ((1, 1), (2, 2)) \
                 and m.padding == (1, 1) \
-                and m.dilation == (1, 1) and m.groups == 1 and m.bias is None:
+                and m.dilation == (1, 1) and m.groups == 1:
             m.__class__ = DirectConv2d
     return module

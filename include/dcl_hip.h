@@ -248,7 +248,8 @@ int dcl_conv3x3_pack_multi(const void *jobs, const int32_t *blk2job, int nblocks
 int dcl_conv3x3_pack(const float *w, int M, int K, int transposed, const float *wamax, void *wp, void *stream);
 int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored input size */, const void *wp, int Cout,
                       const float *xamax, int xcount, const float *wamax,
-                      const float *addend /* [N,Cout,Hout,Wout] added to the result, or NULL */, float *y,
+                      const float *addend /* [N,Cout,Hout,Wout] added to the result, or NULL */,
+                      const float *bias /* [Cout] or NULL */, float *y,
                       int stride /* 1 | 2; Hout = (H - 1) / 2 + 1 for 2 */,
                       int in_up /* 1, or 2: x holds the even samples of a zero-inserted [Hout, Wout] input --
                                    the data gradient of a stride-2 convolution (stride must be 1) */,

@@ -893,3 +893,24 @@ def test_direct_conv3x3_stride2_matches_fp64(dev, shape):
     conv(xi).backward(gy)
     assert ((xi.grad.double().cpu() - x64.grad).abs().max() / x64.grad.abs().max()).item() < 3e-6
     assert ((conv.weight.grad.double().cpu() - w64.grad).abs().max() / w64.grad.abs().max()).item() < 3e-6
+
+
+@pytest.mark.gpu
+def test_direct_conv_with_bias_matches_fp64(dev):
+    """DirectConv2d with a bias (HRNet's head convolution 720 -> 720 has one): y, dx, dW, db against float64."""
+    from mscs_amd.models import ops
+    torch.manual_seed(21)
+    conv = torch.nn.Conv2d(48, 80, 3, padding=1).to(dev)
+    ops.use_direct_conv3x3(conv)
+    assert isinstance(conv, ops.DirectConv2d) and conv.bias is not None
+    x = (torch.randn(2, 48, 20, 40, device=dev) * 2 + 0.3).requires_grad_(True)
+    gy = torch.randn(2, 80, 20, 40, device=dev) * 1e-3
+    y = conv(x)
+    y.backward(gy)
+    ref = torch.nn.Conv2d(48, 80, 3, padding=1).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in conv.state_dict().items()})
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    y64 = ref(x64)
+    y64.backward(gy.double().cpu())
+    for got, want in ((y, y64), (x.grad, x64.grad), (conv.weight.grad, ref.weight.grad), (conv.bias.grad, ref.bias.grad)):
+        assert ((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max()).item() < 3e-6
