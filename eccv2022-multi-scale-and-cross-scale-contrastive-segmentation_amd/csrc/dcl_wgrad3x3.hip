@@ -13,8 +13,9 @@
 // One wave = NCO x NCI tiles of 16 x 16 (co x ci) x 9 taps of accumulators, walking down a 32-pixel-wide strip:
 // per input row r it loads X[r] (B, 3 kx windows) and keeps dY rows r-1, r, r+1 (A) in registers -- row r pairs
 // with dY row r + 1 - ky for tap row ky -- so each loaded fragment feeds 9 * NCO (B) or 9 * NCI (A) MFMAs x 3.
-// The flat (image, strip, row) sequence is cut into S contiguous runs; every split (= wave) writes its partial
-// dw to its own slab, k_wgrad_reduce sums the slabs in fixed order (deterministic, no float atomics).
+// The flat (image, strip, row) sequence is cut into S contiguous runs, one per wave; the four waves of a workgroup
+// combine their partial dw through LDS in a fixed order and write one slab, k_wgrad_reduce sums the slabs in fixed
+// order (deterministic, no float atomics).
 #include <type_traits>
 
 #include "dcl_common.h"
@@ -111,9 +112,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
             xsplit = nx8 + rest / a.npairs;
         }
     }
-    const int split = xsplit * 4 + wave;
-    if (split >= a.S)
-        return;
+    const int split = xsplit * 4 + wave;           // a wave past the last split gets an empty run and adds zeros
     const int cog = pair / a.ncig, cig = pair - cog * a.ncig;
     const int co0 = cog * NCO * 16, ci0 = cig * NCI * 16;
     const size_t plane = (size_t)a.H * a.W;
@@ -133,8 +132,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
 
     // this split's share of the flat (image, strip, input row) sequence: rows [t0, t1), walked column by column
     const long long T = (long long)a.units * a.H;              // units = images x strips (columns)
-    long long t = T * split / a.S;
-    const long long t1 = T * (split + 1) / a.S;
+    long long t = min(T, T * split / a.S);
+    const long long t1 = min(T, T * (split + 1) / a.S);
     while (t < t1) {
         const int col = (int)(t / a.H);
         const int r0 = (int)(t - (long long)col * a.H);
@@ -331,9 +330,54 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
             step(std::integral_constant<int, 4>{}, r + 4);
     }
 
-    // slab [split][tap][co][ci]; accumulator register q of lane (q4, j) is (co = 4 q4 + q, ci = j) of its tile
+    // The four waves of a workgroup hold partial sums of the SAME (co, ci) tiles: they are combined through LDS in
+    // a fixed order, (w0 + w1) + (w2 + w3), so that one slab per workgroup (not per wave) goes to memory.
+    // (Only for the variants with <= 3 tiles per tap: with 6 the extra live ranges make the register allocator spill
+    // inside the main loop, so those keep one slab per wave.)
+    constexpr bool LDSRED = NCO * NCI <= 3;
+    if (LDSRED) {
+        constexpr int NREG = LDSRED ? NCO * NCI * 36 : 1;
+        __shared__ float red[2][NREG][64];
+        auto put = [&](int b) {
+#pragma unroll
+            for (int t = 0; t < NCO; ++t)
+#pragma unroll
+                for (int u = 0; u < NCI; ++u)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            red[b][((t * NCI + u) * 9 + k) * 4 + q][lane] = acc[t][u][k][q];
+        };
+        auto add = [&](int b) {
+#pragma unroll
+            for (int t = 0; t < NCO; ++t)
+#pragma unroll
+                for (int u = 0; u < NCI; ++u)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[t][u][k][q] += red[b][((t * NCI + u) * 9 + k) * 4 + q][lane];
+        };
+        if (wave & 1)
+            put(wave >> 1);
+        __syncthreads();
+        if (!(wave & 1))
+            add(wave >> 1);
+        __syncthreads();
+        if (wave == 2)
+            put(0);
+        __syncthreads();
+        if (wave != 0)
+            return;
+        add(0);
+    }
+    else if (split >= a.S)
+        return;
+    // slab [xsplit | split][tap][co][ci]; accumulator register q of lane (q4, j) is (co = 4 q4 + q, ci = j) of its tile
     const float inv = 1.0f / (sx * sg);
-    float *out = a.part + (size_t)split * 9 * a.Cout * a.Cin;
+    float *out = a.part + (size_t)(LDSRED ? xsplit : split) * 9 * a.Cout * a.Cin;
 #pragma unroll
     for (int t = 0; t < NCO; ++t)
 #pragma unroll
@@ -406,7 +450,7 @@ extern "C" int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W)
         return 0;
     int nco, nci, S, units;
     wgrad_plan(N, Cin, Cout, H, W, nco, nci, S, units);
-    return S;
+    return nco * nci <= 3 ? (S + 3) / 4 : S;      // one slab per workgroup (4 splits), or per wave (6-tile variants)
 }
 
 extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W,
@@ -459,7 +503,8 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
 #undef DCL_WG_CASE
     DCL_LAUNCH_CHECK();
     const int total = 9 * Cout * Cin;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, s, part, a.S, Cout, Cin, dw);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, s, part, nco * nci <= 3 ? a.nx : a.S, Cout,
+                       Cin, dw);
     DCL_LAUNCH_CHECK();
     return 0;
 }

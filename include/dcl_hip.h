@@ -258,7 +258,7 @@ int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored inp
 
 /* Weight gradient of the same convolution, dw[Cout,Cin,3,3] = sum_n dy (*) x, on the f16x3 MFMA path with no LDS
  * staging (csrc/dcl_wgrad3x3.hip).  Cin % 16 == 0, Cout % 16 == 0, W % 8 == 0.  part: workspace of
- * dcl_wgrad3x3_splits(...) * 9 * Cout * Cin floats (one partial slab per split, summed in fixed order). */
+ * dcl_wgrad3x3_splits(...) * 9 * Cout * Cin floats (one partial slab per workgroup, summed in fixed order). */
 int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W);
 int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W /* of x */,
                        const float *xamax, int xcount, const float *gamax, int gcount,
