@@ -122,8 +122,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
         gok[m] = ok;
     }
     const bool ragged = (a.Cin & 15) != 0;                       // last chunk has channels past Cin
-    float g[NITEM][8];
-    auto load_items = [&](int c) {
+    // two register sets: gA holds the patch of the NEXT chunk (split and written to LDS while the current chunk's
+    // MFMAs run), gB receives the loads of the chunk after that
+    float gA[NITEM][8], gB[NITEM][8];
+    auto load_items = [&](int c, float (&g)[NITEM][8]) {
         if (!ragged || c + 1 < a.nchunk) {
 #pragma unroll
             for (int m = 0; m < NITEM; ++m) {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
             }
         }
     };
-    auto write_items = [&](unsigned char *buf) {
+    auto write_items = [&](unsigned char *buf, const float (&g)[NITEM][8]) {
 #pragma unroll
         for (int m = 0; m < NITEM; ++m) {
             unsigned hh[4], ll[4];
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
     constexpr int AD = (R >= 3 || (R == 2 && P == 2)) ? 1 : 2;   // (2, 2) must stay under 256 registers: 2 workgroups / CU
     half8 Ab[3][3][R][2];
     const int nsteps = 3 * a.nchunk;
-    load_items(0);
+    load_items(0, gA);
     load_A(Ab[0], 0, 0);
     if (AD == 2)
         load_A(Ab[1], 0, 1);
@@ -215,17 +217,19 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
 #pragma unroll
     for (int m = 0; m < NITEM; ++m)
         gsc[m] = gok[m] ? xs : 0.f;
-    write_items(lds);
+    write_items(lds, gA);
+    load_items(min(1, a.nchunk - 1), gA);
     __syncthreads();
 
     const int brow = (S * P * wave) * LW + S * li;      // patch pixel of this lane's output pixel, tap (0, 0)
     for (int c = 0; c < a.nchunk; ++c) {
         const unsigned char *cur = lds + (c & 1) * BUFB;
         const bool more = c + 1 < a.nchunk;
-        // next chunk's patch: issued here, pinned above the MFMAs, written to LDS after them (the last
-        // iteration re-reads its own chunk and drops it)
+        // Two chunks of look-ahead: the loads of chunk c + 2 are issued here (pinned above the MFMAs; past the end
+        // they re-read the last chunk and are dropped); the patch of chunk c + 1, loaded one iteration ago, is split
+        // and written to the other LDS buffer in the shadow of this chunk's MFMAs (after the first kx step).
         __builtin_amdgcn_sched_barrier(0);
-        load_items(more ? c + 1 : c);
+        load_items(min(c + 2, a.nchunk - 1), gB);
         __builtin_amdgcn_sched_barrier(0);
         // B fragments (stride 1) are read ONE group ahead of the MFMAs that consume them -- group g = (kx, tile row
         // rr) -- into two alternating register pairs, so that the LDS latency hides behind the previous group's MFMAs
@@ -294,11 +298,16 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
                                     Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p], 0, 0, 0);
                     }
             }
+            if (kx == 0 && more)
+                write_items(lds + ((c + 1) & 1) * BUFB, gA);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more)
-            write_items(lds + ((c + 1) & 1) * BUFB);
         __syncthreads();
+#pragma unroll
+        for (int m = 0; m < NITEM; ++m)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                gA[m][e] = gB[m][e];
     }
 
     const float inv = 1.0f / (xs * pow2_scale(a.wamax[0]));
