@@ -12,14 +12,14 @@ Cityscapes 512x1024, batch 12 per GPU):
   step  one training step: model forward, LossWrapper(CE + 0.1 * DCV2_ms), backward, SGD update
   loss  the contrastive loss alone (forward + backward) on synthetic 256-d projector outputs
 Extra keys: `roofline` (dominant hand-written kernel: for the training step the direct 3x3 convolution
-`k_conv3x3` on HRNet's 48-channel branch shape -- the convolution family is ~19 % of the step's kernel time -- for
+`k_conv3x3` on HRNet's 48-channel branch shape -- the convolution kernels are ~60 % of the step's kernel time -- for
 `--workload loss` the InfoNCE backward sweep; algorithmic FLOPs over HIP-event time, peak per arithmetic mode),
 `roofline_other` (the weight-gradient kernel and the InfoNCE backward sweep), `cpu_baseline` (oracle/eager_torch.py + the same model code on the host cores,
 bounded sample), `contrastive_loss_fwd_bwd_ms`, and with --eager-baseline the eager-structure torch loss on the
 GPU.  `dtype` "f32" = fp32-equivalent arithmetic: fp32 storage and accumulation everywhere; the loss's similarity
 product and the head convolution run as split-f16 (hi, lo) MFMA passes whose results match fp32 to round-off
-(DESIGN.md section 3); the backbone's 3x3 convolutions run on the direct split-f16 kernels (forward, data and
-weight gradient); `--mfma f32`, `--branch-conv library` and graph key head_conv='library' select plain f32 MFMA /
+(DESIGN.md section 3); every 3x3 convolution of the model (backbone, stride 1 and 2, and the head) runs on the
+direct split-f16 kernels (forward, data and weight gradient); `--mfma f32`, `--branch-conv library` and graph key head_conv='library' select plain f32 MFMA /
 MIOpen instead.
 """
 import argparse
@@ -127,8 +127,8 @@ def sync(world):
 
 # HBM-side traffic of the direct convolution kernels at the benchmark's 48-channel shape (12 x 48 x 128 x 256), KiB
 # per launch (FETCH_SIZE, WRITE_SIZE) from the committed PMC passes (profiles/r01_conv_pmc_*.csv)
-PMC_CONV48 = (103105.1, 73728.0)
-PMC_WGRAD48 = (155190.0, 60815.9)
+PMC_CONV48 = (103470.1, 73728.0)
+PMC_WGRAD48 = (153044.3, 6885.0)
 
 
 def _time_launches(launch, iters):
@@ -171,7 +171,7 @@ def roofline_conv_kernels(args, dev, iters=20):
             "traffic_source": "profiles/r01_conv_pmc_fetch.csv, r01_conv_pmc_write.csv",
             "algorithmic_bytes": 2 * n * c * h * w * 4, "launch_ms": round(ms, 4)}
     msw = _time_launches(lambda: ops.conv3x3_wgrad(x, gy), iters)
-    wg = {"bound": "mfma", "kernel": f"k_wgrad3x3<3,2> + k_wgrad_reduce (dcl_wgrad3x3_f16x3), {n}x{c}x{h}x{w}",
+    wg = {"bound": "mfma", "kernel": f"k_wgrad3x3<3,1> + k_wgrad_reduce (dcl_wgrad3x3_f16x3), {n}x{c}x{h}x{w}",
           "achieved": round(flops / (msw * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
           "frac": round(flops / (msw * 1e-3) / 1e12 / peak, 4),
           "traffic": (2 * PMC_WGRAD48[0] + PMC_WGRAD48[1]) * 1024 if default_shape else None,
