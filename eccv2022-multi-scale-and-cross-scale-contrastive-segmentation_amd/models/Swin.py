@@ -204,7 +204,7 @@ class BasicLayer(nn.Module):
                 for wsl in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
                     region[:, hs, wsl, :] = cnt
                     cnt += 1
-            mw = window_partition(region, ws).view(-1, ws * ws)
+            mw = window_partition(region, ws).reshape(-1, ws * ws)
             diff = mw.unsqueeze(1) - mw.unsqueeze(2)
             self._mask_cache[key] = torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0)).to(device)
         return self._mask_cache[key]

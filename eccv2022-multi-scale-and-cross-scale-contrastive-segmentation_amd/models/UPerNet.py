@@ -120,6 +120,15 @@ class UPerNet(nn.Module):
         self.fpn = FPN(config=self.config, experiment=experiment)
         self._get_aux_head()
         self._get_projector()
+        # the FPN's / aux head's 3x3 convolutions on the direct split-f16 kernels (models/ops.py, fp32-equivalent);
+        # same parameters and state_dict.  config['direct_conv'] = False keeps them on the library.
+        self._conv_packs = None
+        if config.get('direct_conv', True):
+            from .ops import ConvPackGroup, use_direct_conv3x3
+            use_direct_conv3x3(self.fpn)
+            if self.aux_head is not None:
+                use_direct_conv3x3(self.aux_head)
+            self._conv_packs = ConvPackGroup(self)
 
     def _get_aux_head(self):
         if 'aux_head' in self.config:
@@ -170,6 +179,8 @@ class UPerNet(nn.Module):
 
     def forward(self, x):
         size = x.shape[-2:]
+        if self._conv_packs is not None and x.is_cuda:
+            self._conv_packs.refresh()
         feats = self.backbone(x)
         logits, fpn_feats, fused = self.fpn(feats)
         up = dict(size=size, mode='bilinear', align_corners=self.align_corners)

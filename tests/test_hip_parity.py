@@ -914,3 +914,32 @@ def test_direct_conv_with_bias_matches_fp64(dev):
     y64.backward(gy.double().cpu())
     for got, want in ((y, y64), (x.grad, x64.grad), (conv.weight.grad, ref.weight.grad), (conv.bias.grad, ref.bias.grad)):
         assert ((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max()).item() < 3e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["hrnet", "upernet"])
+def test_models_with_direct_kernels_match_library_kernels(dev, family):
+    """Whole-model check of the fp32-equivalence claim: the same weights through the direct split-f16 convolution
+    kernels and through the library (MIOpen f32) give the same logits in eval mode (1e-4 of max, the tolerance of
+    the reference goldens in tests/test_models.py) and the same training-mode logits (batch statistics)."""
+    import mscs_amd.models as M
+    torch.manual_seed(4)
+    if family == "hrnet":
+        g = {"backbone": "hrnet48", "pretrained": False, "dataset": "CITYSCAPES", "align_corners": True}
+        a = M.HRNet(dict(g), 1).to(dev)
+        b = M.HRNet(dict(g, branch_conv="library", head_conv="library", fused_bn=False), 1).to(dev)
+    else:
+        g = {"backbone": "swinT", "pretrained": False, "dataset": "ADE20K", "align_corners": False,
+             "fpn_channels": 128}
+        a = M.UPerNet(dict(g), 1).to(dev)
+        b = M.UPerNet(dict(g, direct_conv=False), 1).to(dev)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(2, 3, 128, 256, device=dev)
+    # (Swin's stochastic depth makes two training-mode forwards incomparable: eval only for UPerNet)
+    for mode in (("eval", "train") if family == "hrnet" else ("eval",)):
+        getattr(a, mode)(), getattr(b, mode)()
+        with torch.no_grad():
+            ya, yb = a(x), b(x)
+        ya = ya[0] if isinstance(ya, (tuple, list)) else ya
+        yb = yb[0] if isinstance(yb, (tuple, list)) else yb
+        assert ((ya - yb).abs().max() / yb.abs().max()).item() < 1e-4, (family, mode)
