@@ -28,6 +28,7 @@ import torch.nn.functional as F
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
 from .ops import ConvPackGroup, DirectConv2d, GradToken, conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear, use_direct_conv3x3
+from .amax import record_stream as _amax_record_stream
 from .fused_bn import FusedBatchNorm2d, bn_act
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
@@ -206,12 +207,12 @@ class HighResolutionModule(nn.Module):
             s = side[i - 1]
             s.wait_stream(main)
             with torch.cuda.stream(s):
-                x[i].record_stream(s)
+                _amax_record_stream(x[i], s)
                 outs[i] = self.branches[i](x[i])
         outs[0] = self.branches[0](x[0])
         for i in range(1, self.num_branches):
             main.wait_stream(side[i - 1])
-            outs[i].record_stream(main)
+            _amax_record_stream(outs[i], main)
         return outs
 
     def forward(self, x):
@@ -229,12 +230,12 @@ class HighResolutionModule(nn.Module):
             s.wait_stream(main)
             with torch.cuda.stream(s):
                 for t in x:
-                    t.record_stream(s)
+                    _amax_record_stream(t, s)
                 fused[i] = self._fuse_row(i, self.fuse_layers[i], x)
         fused[0] = self._fuse_row(0, self.fuse_layers[0], x)
         for i in range(1, len(self.fuse_layers)):
             main.wait_stream(side[i - 1])
-            fused[i].record_stream(main)
+            _amax_record_stream(fused[i], main)
         return fused
 
     def _fuse_row(self, i, row, x):

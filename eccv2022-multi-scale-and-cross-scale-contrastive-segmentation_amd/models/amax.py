@@ -43,3 +43,13 @@ def amax_of(t: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.lib().dcl_absmax(_lib.ptr(t), t.numel(), _lib.ptr(buf), st), "dcl_absmax")
     tag(t, buf)
     return buf
+
+
+def record_stream(t: torch.Tensor, stream) -> torch.Tensor:
+    """``t.record_stream(stream)`` for a tensor that is handed to another HIP stream, including the absmax buffer
+    it is tagged with (separate storage, same lifetime hazard with the caching allocator)."""
+    t.record_stream(stream)
+    got = getattr(t, "_dcl_amax", None)
+    if got is not None and got[1].is_cuda:
+        got[1].record_stream(stream)
+    return t
