@@ -127,7 +127,7 @@ def sync(world):
 
 # HBM-side traffic of the direct convolution kernels at the benchmark's 48-channel shape (12 x 48 x 128 x 256), KiB
 # per launch (FETCH_SIZE, WRITE_SIZE) from the committed PMC passes (profiles/r01_conv_pmc_*.csv)
-PMC_CONV48 = (103470.1, 73728.0)
+PMC_CONV48 = (107438.5, 81408.0)
 PMC_WGRAD48 = (153044.3, 6885.0)
 
 
@@ -163,7 +163,7 @@ def roofline_conv_kernels(args, dev, iters=20):
     ms = _time_launches(lambda: ops.conv3x3_launch(x, wp, c, xa, wa, out), iters)
     peak = MFMA_F16_PEAK_TFLOPS / 3.0
     note = "every algorithmic FLOP is issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): 2.5 PFLOP/s / 3"
-    main = {"bound": "mfma", "kernel": "k_conv3x3<2,4> (dcl_conv3x3_f16x3): 3x3 conv forward / data gradient, "
+    main = {"bound": "mfma", "kernel": "k_conv3x3_o2<2,2> (dcl_conv3x3_f16x3): 3x3 conv forward / data gradient, "
                                         f"{n}x{c}x{h}x{w}",
             "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_note": note,

@@ -74,7 +74,7 @@ __device__ __forceinline__ float pow2_scale(float amax)
 
 // S = stride (1 | 2).  A stride-2 tile reads a (2 * 4P + 1) x 65 patch, so S = 2 is instantiated with P = 1 only.
 template <int R, int P, int S>
-__global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
+__device__ __forceinline__ void conv_body(const ConvArgs &a)
 {
     constexpr int LW = S * (TW - 1) + 3;          // patch width incl. halo: 34 | 65
     constexpr int ROWS = S * (4 * P - 1) + 3;     // 4P + 2 | 8P + 1
@@ -189,6 +189,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
     // kx (static indices, no copies): one step ahead when a step holds >= 54 MFMAs (R = 3), two steps ahead for
     // the smaller tiles, whose steps are shorter than an L2 round trip.
     constexpr int AD = (R >= 3 || (R == 2 && P == 2)) ? 1 : 2;   // (2, 2) must stay under 256 registers: 2 workgroups / CU
+    constexpr bool LA2 = !(R == 2 && P == 2 && S == 1);          // two chunks of patch look-ahead (one for (2, 2))
+    constexpr bool BPIPE = LA2;                                  // B fragments one group ahead (not for (2, 2): registers)
     half8 Ab[3][3][R][2];
     const int nsteps = 3 * a.nchunk;
     load_items(0, gA);
@@ -218,7 +220,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
     for (int m = 0; m < NITEM; ++m)
         gsc[m] = gok[m] ? xs : 0.f;
     write_items(lds, gA);
-    load_items(min(1, a.nchunk - 1), gA);
+    if (LA2)
+        load_items(min(1, a.nchunk - 1), gA);
     __syncthreads();
 
     const int brow = (S * P * wave) * LW + S * li;      // patch pixel of this lane's output pixel, tap (0, 0)
@@ -229,7 +232,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
         // they re-read the last chunk and are dropped); the patch of chunk c + 1, loaded one iteration ago, is split
         // and written to the other LDS buffer in the shadow of this chunk's MFMAs (after the first kx step).
         __builtin_amdgcn_sched_barrier(0);
-        load_items(min(c + 2, a.nchunk - 1), gB);
+        if (LA2)
+            load_items(min(c + 2, a.nchunk - 1), gB);
+        else
+            load_items(min(c + 1, a.nchunk - 1), gA);
         __builtin_amdgcn_sched_barrier(0);
         // B fragments (stride 1) are read ONE group ahead of the MFMAs that consume them -- group g = (kx, tile row
         // rr) -- into two alternating register pairs, so that the LDS latency hides behind the previous group's MFMAs
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
             dst[0] = *(const half8 *)bp;
             dst[1] = *(const half8 *)(bp + 32);
         };
-        if (S == 1)
+        if (S == 1 && BPIPE)
             read_b(0, bq[0]);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
@@ -255,7 +261,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
 #pragma unroll
                 for (int rr = 0; rr < P + 2; ++rr) {
                     const int g = kx * (P + 2) + rr;
-                    if (g + 1 < 3 * (P + 2))
+                    if (!BPIPE)
+                        read_b(g, bq[g & 1]);
+                    else if (g + 1 < 3 * (P + 2))
                         read_b(g + 1, bq[(g + 1) & 1]);
                     const half8 bh = bq[g & 1][0], bl = bq[g & 1][1];
 #pragma unroll
@@ -272,6 +280,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
                         }
                     // number of (p, ky) pairs of this tile row
                     const int npk = (rr < 3 ? rr + 1 : 3) - (rr > P - 1 ? rr - (P - 1) : 0);
+                    if (!BPIPE)
+                        continue;
                     if (g + 1 < 3 * (P + 2))
                         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     if (npk == 1)
@@ -298,16 +308,20 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
                                     Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p], 0, 0, 0);
                     }
             }
-            if (kx == 0 && more)
+            if (LA2 && kx == 0 && more)
                 write_items(lds + ((c + 1) & 1) * BUFB, gA);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!LA2 && more)
+            write_items(lds + ((c + 1) & 1) * BUFB, gA);
         __syncthreads();
+        if (LA2) {
 #pragma unroll
-        for (int m = 0; m < NITEM; ++m)
+            for (int m = 0; m < NITEM; ++m)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                gA[m][e] = gB[m][e];
+                for (int e = 0; e < 8; ++e)
+                    gA[m][e] = gB[m][e];
+        }
     }
 
     const float inv = 1.0f / (xs * pow2_scale(a.wamax[0]));
@@ -345,6 +359,20 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
                 }
             }
         }
+}
+
+template <int R, int P, int S>
+__global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
+{
+    conv_body<R, P, S>(a);
+}
+
+// same body compiled for two workgroups per CU (<= 256 registers): the (2, 2) tile of the 48-channel shape, whose
+// three-chunk K loop is too short to hide a workgroup's own prologue / epilogue
+template <int R, int P, int S>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_o2(ConvArgs a)
+{
+    conv_body<R, P, S>(a);
 }
 
 // weights -> fragment order.  transposed = 0: value(m, k, ky, kx) = w[m][k][ky][kx], w is [M][K][3][3];
@@ -529,7 +557,10 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
     a.tiles_y = (a.Ho + 4 * P - 1) / (4 * P);
     const int mtiles = (a.Cout + 31) / 32;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)((mtiles + R - 1) / R));
-    hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
+    if (R == 2 && P == 2 && S == 1)
+        hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
     return 0;
 }
 
@@ -588,6 +619,8 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
         P = stride == 2 ? 1 : 4;
         while (P > 1 && wgs(R, P) < 192)
             P >>= 1;
+        if (R == 2 && P == 4 && stride == 1)
+            P = 2;              // the (2, 2) tile runs two workgroups per CU (k_conv3x3_o2): 81 vs 100 us at 48 channels
         if (P == 1 && wgs(R, P) < 128)
             R = 1;
     }
