@@ -188,8 +188,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     // Weight fragments are streamed AD kx-steps ahead of their use into a ring of three register sets indexed by
     // kx (static indices, no copies): one step ahead when a step holds >= 54 MFMAs (R = 3), two steps ahead for
     // the smaller tiles, whose steps are shorter than an L2 round trip.
-    constexpr int AD = (R >= 3 || (R == 2 && P == 2)) ? 1 : 2;   // (2, 2) must stay under 256 registers: 2 workgroups / CU
-    constexpr bool LA2 = !(R == 2 && P == 2 && S == 1);          // two chunks of patch look-ahead (one for (2, 2))
+    constexpr int AD = (R >= 3 || (R == 2 && P == 2)) ? 1 : 2;   // (2, 2) must stay under 256 registers
+    constexpr bool O2 = S == 1 && R == 2 && P == 2;              // the tile that runs at two workgroups per CU
+                                                                 // ((3, 1) was tried: its spills cost more than it gains)
+    constexpr bool LA2 = !O2;                                    // two chunks of patch look-ahead (one for those)
     constexpr bool BPIPE = LA2;                                  // B fragments one group ahead (not for (2, 2): registers)
     half8 Ab[3][3][R][2];
     const int nsteps = 3 * a.nchunk;
@@ -557,7 +559,7 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
     a.tiles_y = (a.Ho + 4 * P - 1) / (4 * P);
     const int mtiles = (a.Cout + 31) / 32;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)((mtiles + R - 1) / R));
-    if (R == 2 && P == 2 && S == 1)
+    if (S == 1 && R == 2 && P == 2)
         hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
