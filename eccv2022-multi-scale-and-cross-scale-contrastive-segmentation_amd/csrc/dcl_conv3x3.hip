@@ -559,7 +559,7 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
     a.tiles_y = (a.Ho + 4 * P - 1) / (4 * P);
     const int mtiles = (a.Cout + 31) / 32;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)((mtiles + R - 1) / R));
-    if (S == 1 && R == 2 && P == 2)
+    if constexpr (S == 1 && R == 2 && P == 2)
         hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
