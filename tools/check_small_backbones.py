@@ -1,4 +1,5 @@
-"""hrnet18 / hrnet32 (channel counts that are not multiples of 16 or 32) through the direct kernels against the\nlibrary path: logits and gradients of one training step.  python tools/check_small_backbones.py  (GPU)"""
+"""hrnet18 / hrnet32 (channel counts that are not multiples of 16 or 32) through the direct kernels against the
+library path: logits and gradients of one training step.  python tools/check_small_backbones.py  (GPU)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mscs_amd
