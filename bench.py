@@ -12,9 +12,10 @@ Cityscapes 512x1024, batch 12 per GPU):
   step  one training step: model forward, LossWrapper(CE + 0.1 * DCV2_ms), backward, SGD update
   loss  the contrastive loss alone (forward + backward) on synthetic 256-d projector outputs
 Extra keys: `roofline` (dominant hand-written kernel: for the training step the direct 3x3 convolution
-`k_conv3x3` on HRNet's 48-channel branch shape -- the convolution kernels are ~60 % of the step's kernel time -- for
-`--workload loss` the InfoNCE backward sweep; algorithmic FLOPs over HIP-event time, peak per arithmetic mode),
-`roofline_other` (the weight-gradient kernel and the InfoNCE backward sweep), `cpu_baseline` (oracle/eager_torch.py + the same model code on the host cores,
+`k_conv3x3<3,4,1>` -- the top kernel of the step profile -- on its heaviest launch, the head convolution 720 -> 720;
+for `--workload loss` the InfoNCE backward sweep; algorithmic FLOPs over HIP-event time, peak per arithmetic mode),
+`roofline_other` (the same kernel family on the 48-channel BasicBlock shape, the weight-gradient kernel and the
+InfoNCE backward sweep), `cpu_baseline` (oracle/eager_torch.py + the same model code on the host cores,
 bounded sample), `contrastive_loss_fwd_bwd_ms`, and with --eager-baseline the eager-structure torch loss on the
 GPU.  `dtype` "f32" = fp32-equivalent arithmetic: fp32 storage and accumulation everywhere; the loss's similarity
 product and the head convolution run as split-f16 (hi, lo) MFMA passes whose results match fp32 to round-off
@@ -128,6 +129,7 @@ def sync(world):
 # HBM-side traffic of the direct convolution kernels at the benchmark's 48-channel shape (12 x 48 x 128 x 256), KiB
 # per launch (FETCH_SIZE, WRITE_SIZE) from the committed PMC passes (profiles/r01_conv_pmc_*.csv)
 PMC_CONV48 = (107438.5, 81408.0)
+PMC_CONV720 = (3408030.9, 1105920.0)      # head convolution 12 x 720 x 128 x 256, k_conv3x3<3,4,1>
 PMC_WGRAD48 = (153044.3, 6885.0)
 
 
@@ -144,39 +146,48 @@ def _time_launches(launch, iters):
 
 
 def roofline_conv_kernels(args, dev, iters=20):
-    """Average launch duration of the direct f16x3 convolution (forward kernel; the data gradient is the same
-    kernel) and of the weight-gradient kernel on the backbone's highest-resolution BasicBlock shape
-    (batch x 48 x H/4 x W/4), HIP events on the launch stream.  Algorithmic FLOPs = 2 * N * Cout * Cin * 9 * H * W;
-    every one of them costs three f16 MFMA passes (hi.hi + hi.lo + lo.hi), hence peak = 2500 / 3 TFLOP/s."""
+    """Average launch duration of the direct f16x3 convolution kernels, HIP events on the launch stream:
+      * `k_conv3x3<3,4,1>` on the head convolution (batch x 720 x H/4 x W/4, 720 -> 720; the data gradient is the same
+        kernel) -- the top kernel of the step profile, 47 % of the model's FLOPs;
+      * `k_conv3x3_o2<2,2,1>` and the weight-gradient kernel on the backbone's highest-resolution BasicBlock shape
+        (batch x 48 x H/4 x W/4).
+    Algorithmic FLOPs = 2 * N * Cout * Cin * 9 * H * W; every one of them costs three f16 MFMA passes
+    (hi.hi + hi.lo + lo.hi), hence peak = 2500 / 3 TFLOP/s."""
     from mscs_amd.models import ops
     from mscs_amd.models.amax import amax_of
-    n, c, h, w = args.batch, 48, args.height // 4, args.width // 4
+    n, h, w = args.batch, args.height // 4, args.width // 4
     gen = torch.Generator(device=dev).manual_seed(1)
-    x = torch.randn(n, c, h, w, device=dev, generator=gen).relu_()
-    wt = torch.randn(c, c, 3, 3, device=dev, generator=gen) * (2.0 / (9 * c)) ** 0.5
-    gy = torch.randn(n, c, h, w, device=dev, generator=gen) * 1e-4
-    xa, wa = amax_of(x), amax_of(wt)
-    wp = ops.conv3x3_pack(wt, wa)
-    out = torch.empty_like(x)
-    flops = 2.0 * n * c * c * 9 * h * w
-    default_shape = (n, h, w) == (12, 128, 256)
-    ms = _time_launches(lambda: ops.conv3x3_launch(x, wp, c, xa, wa, out), iters)
     peak = MFMA_F16_PEAK_TFLOPS / 3.0
     note = "every algorithmic FLOP is issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): 2.5 PFLOP/s / 3"
-    main = {"bound": "mfma", "kernel": "k_conv3x3_o2<2,2> (dcl_conv3x3_f16x3): 3x3 conv forward / data gradient, "
-                                        f"{n}x{c}x{h}x{w}",
-            "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_note": note,
-            "traffic": (2 * PMC_CONV48[0] + PMC_CONV48[1]) * 1024 if default_shape else None,
-            "traffic_source": "profiles/r01_conv_pmc_fetch.csv, r01_conv_pmc_write.csv",
-            "algorithmic_bytes": 2 * n * c * h * w * 4, "launch_ms": round(ms, 4)}
+    default_shape = (n, h, w) == (12, 128, 256)
+
+    def conv_entry(c, kernel, pmc, it):
+        x = torch.randn(n, c, h, w, device=dev, generator=gen).relu_()
+        wt = torch.randn(c, c, 3, 3, device=dev, generator=gen) * (2.0 / (9 * c)) ** 0.5
+        xa, wa = amax_of(x), amax_of(wt)
+        wp = ops.conv3x3_pack(wt, wa)
+        out = torch.empty_like(x)
+        flops = 2.0 * n * c * c * 9 * h * w
+        ms = _time_launches(lambda: ops.conv3x3_launch(x, wp, c, xa, wa, out), it)
+        return {"bound": "mfma", "kernel": f"{kernel} (dcl_conv3x3_f16x3): 3x3 conv forward / data gradient, "
+                                            f"{n}x{c}x{h}x{w}",
+                "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_note": note,
+                "traffic": (2 * pmc[0] + pmc[1]) * 1024 if default_shape else None,
+                "traffic_source": "profiles/r01_conv_pmc_fetch.csv, r01_conv_pmc_write.csv",
+                "algorithmic_bytes": 2 * n * c * h * w * 4, "launch_ms": round(ms, 4)}, x
+    main, _ = conv_entry(720, "k_conv3x3<3,4,1>", PMC_CONV720, 5)
+    torch.cuda.empty_cache()
+    c48, x = conv_entry(48, "k_conv3x3_o2<2,2,1>", PMC_CONV48, iters)
+    gy = torch.randn(n, 48, h, w, device=dev, generator=gen) * 1e-4
+    flops = 2.0 * n * 48 * 48 * 9 * h * w
     msw = _time_launches(lambda: ops.conv3x3_wgrad(x, gy), iters)
-    wg = {"bound": "mfma", "kernel": f"k_wgrad3x3<3,1> + k_wgrad_reduce (dcl_wgrad3x3_f16x3), {n}x{c}x{h}x{w}",
+    wg = {"bound": "mfma", "kernel": f"k_wgrad3x3<3,1> + k_wgrad_reduce (dcl_wgrad3x3_f16x3), {n}x48x{h}x{w}",
           "achieved": round(flops / (msw * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
           "frac": round(flops / (msw * 1e-3) / 1e12 / peak, 4),
           "traffic": (2 * PMC_WGRAD48[0] + PMC_WGRAD48[1]) * 1024 if default_shape else None,
-          "algorithmic_bytes": 2 * n * c * h * w * 4, "launch_ms": round(msw, 4)}
-    return main, wg
+          "algorithmic_bytes": 2 * n * 48 * h * w * 4, "launch_ms": round(msw, 4)}
+    return main, [c48, wg]
 
 
 def roofline_bwd_kernel(mod, iters=10):
@@ -420,8 +431,8 @@ def main():
         if workload == "loss":
             out["roofline"] = roofline_bwd_kernel(mod)
         else:
-            out["roofline"], wg = roofline_conv_kernels(args, dev)
-            out["roofline_other"] = [wg, roofline_bwd_kernel(mod)]
+            out["roofline"], others = roofline_conv_kernels(args, dev)
+            out["roofline_other"] = others + [roofline_bwd_kernel(mod)]
         if not args.no_cpu_baseline:
             scale, lsec, cores, lsample = cpu_baseline_loss(args, n_terms)
             loss_sec = lsec * scale

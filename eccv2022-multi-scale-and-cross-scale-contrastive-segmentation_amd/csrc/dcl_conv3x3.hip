@@ -60,7 +60,7 @@ struct ConvArgs {
     int Hs, Ws, up;                 // stored input size; up = 2: the stored tensor is the virtual one sampled at even
                                     // coordinates, zeros in between (data gradient of a stride-2 convolution)
     int Ho, Wo;                     // output size (= H, W for stride 1)
-    int tiles_x, tiles_y, nchunk;
+    int tiles_x, tiles_y, nchunk, groups;
 };
 
 constexpr float F16_TARGET = 16384.0f;      // operands are scaled so that their absmax lands in (2^13, 2^14]
@@ -84,13 +84,29 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, li = lane & 31;
-    int bx = blockIdx.x;
+    // XCD-aware decode of the 1-D grid (consecutive workgroup ids go round-robin over the 8 XCDs): the `groups`
+    // channel groups of one pixel tile get ids xcd + 8 * (g + groups * hi), i.e. the SAME XCD and adjacent dispatch
+    // slots, so that the input patch they all read is fetched from HBM once and then served by that XCD's L2
+    // (the head convolution has 8 groups: 12.0 GiB -> 1.8 GiB of FETCH_SIZE per launch).
+    int bx, cg;
+    {
+        const int ntile = a.tiles_x * a.tiles_y * a.N, n8 = ntile & ~7, main_blocks = n8 * a.groups;
+        if ((int)blockIdx.x < main_blocks) {
+            const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+            cg = rest % a.groups;
+            bx = (rest / a.groups) * 8 + xcd;
+        } else {
+            const int rest = blockIdx.x - main_blocks;
+            cg = rest % a.groups;
+            bx = n8 + rest / a.groups;
+        }
+    }
     const int tx = bx % a.tiles_x;
     bx /= a.tiles_x;
     const int ty = bx % a.tiles_y;
     const int n = bx / a.tiles_y;
     const int x0 = tx * TW, y0 = ty * 4 * P;
-    const int T0 = blockIdx.y * R;
+    const int T0 = cg * R;
     const size_t plane = (size_t)a.Hs * a.Ws;                // stored input plane
     const size_t oplane = (size_t)a.Ho * a.Wo;
     const float *xb = a.x + (size_t)n * a.Cin * plane;
@@ -558,7 +574,8 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
     a.tiles_x = (a.Wo + TW - 1) / TW;
     a.tiles_y = (a.Ho + 4 * P - 1) / (4 * P);
     const int mtiles = (a.Cout + 31) / 32;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)((mtiles + R - 1) / R));
+    a.groups = (mtiles + R - 1) / R;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.groups));
     if constexpr (S == 1 && R == 2 && P == 2)
         hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);
     else

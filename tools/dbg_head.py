@@ -1,3 +1,5 @@
+"""HRNet-W48 head convolution (12 x 720 x 128 x 256, 720 -> 720) on the direct kernels against the f16 GEMM path.
+    python tools/dbg_head.py [--fwd-only]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mscs_amd
@@ -19,9 +21,12 @@ sx, sw = amax_of(x), amax_of(wt)
 wp = ops.conv3x3_pack(wt, sw)
 out = torch.empty(n, c, h, w, device=dev)
 flops = 2.0 * n * c * c * 9 * h * w
-for (r, p) in ((3, 4), (2, 4), (3, 2)):
+fwd_only = "--fwd-only" in sys.argv
+for (r, p) in (((3, 4),) if fwd_only else ((3, 4), (2, 4), (3, 2))):
     t = timeit(lambda: ops.conv3x3_launch(x, wp, c, sx, sw, out, r, p))
     print(f"head fwd direct ({r},{p}): {t:.2f} ms ({flops/t/1e9:.0f} TF)", flush=True)
+if fwd_only:
+    sys.exit(0)
 t = timeit(lambda: ops.conv3x3_wgrad(x, gy), 3)
 print(f"head wgrad direct: {t:.2f} ms ({flops/t/1e9:.0f} TF)")
 conv = torch.nn.Conv2d(c, c, 3, padding=1).to(dev)
