@@ -39,6 +39,7 @@ struct WgradArgs {
     int N, Cin, Cout, H, W;
     int Hd, Wd;                  // stored size of dy (= H, W; or the even samples of a zero-inserted dy: stride 2)
     int strips, nseg, units, S, ncig, npairs, nx;
+    int rect_c, rect_i;         // nx == 1: pair-grid rectangle that shares an XCD (rect_c * rect_i = 32)
 };
 
 // Packed f16 pair (lo half = element 0) of hi = f16(v * s) and of lo = f16(v * s - hi) for two values.  s is a power
@@ -100,7 +101,21 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
     // next to each other in dispatch order -- they stream the same dy / x rows, which then come out of that
     // XCD's L2 instead of being fetched once per pair.
     int pair, xsplit;
-    {
+    if (a.nx == 1) {
+        // Many tile pairs, one pixel split (large channel counts): every workgroup streams ALL pixels, so what
+        // matters is which workgroups share an L2 while they do.  The (co group x ci group) grid is cut into
+        // rectangles of rect_c x rect_i = 32 pairs -- they read rect_c + rect_i operand row sets instead of 64 --
+        // and rectangle q of XCD k takes the ids k + 8 * (32 q .. 32 q + 31): one XCD (32 CUs), adjacent dispatch
+        // slots.  (Head convolution, 15 x 45 pairs: FETCH_SIZE 28.0 GiB -> 16.5 GiB per launch, 12.9 -> 12.5 ms.)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int rect = (slot >> 5) * 8 + xcd, idx = slot & 31;
+        const int ncog = a.npairs / a.ncig, rects_i = (a.ncig + a.rect_i - 1) / a.rect_i;
+        const int cg = (rect / rects_i) * a.rect_c + idx / a.rect_i, ci = (rect % rects_i) * a.rect_i + idx % a.rect_i;
+        if (cg >= ncog || ci >= a.ncig)
+            return;                             // padding of the last rectangles (the whole workgroup leaves)
+        pair = cg * a.ncig + ci;
+        xsplit = 0;
+    } else {
         const int nx8 = a.nx & ~7, main_blocks = nx8 * a.npairs;
         if ((int)blockIdx.x < main_blocks) {
             const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
@@ -486,6 +501,13 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     a.npairs = (Cout / 16 / nco) * a.ncig;
     a.nx = (a.S + 3) / 4;                                    // workgroups per pair (4 splits each)
     dim3 grid((unsigned)(a.npairs * a.nx));      // exactly the populated workgroups, <= 256 whenever pairs <= 256
+    a.rect_i = a.ncig >= 16 ? 16 : (a.ncig >= 8 ? 8 : (a.ncig >= 4 ? 4 : (a.ncig >= 2 ? 2 : 1)));
+    a.rect_c = 32 / a.rect_i;
+    if (a.nx == 1) {
+        const int ncog = a.npairs / a.ncig;
+        const int rects = ((ncog + a.rect_c - 1) / a.rect_c) * ((a.ncig + a.rect_i - 1) / a.rect_i);
+        grid = dim3((unsigned)(((rects + 7) / 8) * 8 * 32));
+    }
     hipStream_t s = (hipStream_t)stream;
 #define DCL_WG_CASE(o, i)                                                        \
     if (nco == o && nci == i) {                                                  \
