@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int BN_THREADS = 256;
+constexpr int BN_UNROLL = 4;       // 16-byte vectors per thread in the element-wise kernels
 
 __device__ inline void block_reduce2(float &a, float &b, float *sh)
 {
@@ -167,30 +168,46 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
     float sc, sh;
     bn_affine(invstd, gamma, beta, mean, c, sc, sh);
     const size_t base = (size_t)plane * HW;
-    const int i4 = blockIdx.x * BN_THREADS + threadIdx.x;
-    const int i = i4 << 2;
-    if (i + 3 < HW && (HW & 3) == 0) {
-        f32x4 v = *(const f32x4 *)(x + base + i);
-        v.x = bn_eval(v.x, sc, sh); v.y = bn_eval(v.y, sc, sh); v.z = bn_eval(v.z, sc, sh); v.w = bn_eval(v.w, sc, sh);
-        if (RES) {
-            const f32x4 r = *(const f32x4 *)(res + base + i);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    // BN_UNROLL 16-byte vectors per thread, BN_THREADS apart (coalesced), all loads issued before the first use
+    const int i0 = (blockIdx.x * BN_UNROLL * BN_THREADS + threadIdx.x) << 2;
+    if ((HW & 3) == 0) {
+        f32x4 v[BN_UNROLL], r[BN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+            const int i = i0 + u * BN_THREADS * 4;
+            if (i < HW) {
+                v[u] = *(const f32x4 *)(x + base + i);
+                if (RES)
+                    r[u] = *(const f32x4 *)(res + base + i);
+            }
         }
-        if (RELU) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+            const int i = i0 + u * BN_THREADS * 4;
+            if (i < HW) {
+                f32x4 w = v[u];
+                w.x = bn_eval(w.x, sc, sh); w.y = bn_eval(w.y, sc, sh); w.z = bn_eval(w.z, sc, sh); w.w = bn_eval(w.w, sc, sh);
+                if (RES) {
+                    w.x += r[u].x; w.y += r[u].y; w.z += r[u].z; w.w += r[u].w;
+                }
+                if (RELU) {
+                    w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
+                }
+                *(f32x4 *)(y + base + i) = w;
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
+            }
         }
-        *(f32x4 *)(y + base + i) = v;
-        am = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     } else {
-        for (int k = i; k < HW && k < i + 4; ++k) {
-            float v = bn_eval(x[base + k], sc, sh);
-            if (RES)
-                v += res[base + k];
-            if (RELU)
-                v = fmaxf(v, 0.f);
-            y[base + k] = v;
-            am = fmaxf(am, fabsf(v));
-        }
+        for (int u = 0; u < BN_UNROLL; ++u)
+            for (int k = i0 + u * BN_THREADS * 4; k < HW && k < i0 + u * BN_THREADS * 4 + 4; ++k) {
+                float v = bn_eval(x[base + k], sc, sh);
+                if (RES)
+                    v += res[base + k];
+                if (RELU)
+                    v = fmaxf(v, 0.f);
+                y[base + k] = v;
+                am = fmaxf(am, fabsf(v));
+            }
     }
     if (amax)
         block_amax(am, amax + plane);
@@ -278,41 +295,59 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
     const float k = is * (gamma ? gamma[c] : 1.f);
     const float mg = sums[c * 2] * inv_count, mgx = sums[c * 2 + 1] * inv_count;
     const size_t base = (size_t)plane * HW;
-    const int i = (blockIdx.x * BN_THREADS + threadIdx.x) << 2;
-    if (i + 3 < HW && (HW & 3) == 0) {
-        f32x4 g = *(const f32x4 *)(dy + base + i);
-        const f32x4 xv = *(const f32x4 *)(x + base + i);
-        if (RELU) {
-            f32x4 yv;
-            if (rec) {
-                yv.x = bn_eval(xv.x, asc, ash); yv.y = bn_eval(xv.y, asc, ash);
-                yv.z = bn_eval(xv.z, asc, ash); yv.w = bn_eval(xv.w, asc, ash);
-            } else {
-                yv = *(const f32x4 *)(y + base + i);
+    const int i0 = (blockIdx.x * BN_UNROLL * BN_THREADS + threadIdx.x) << 2;
+    if ((HW & 3) == 0) {
+        f32x4 gv[BN_UNROLL], xv[BN_UNROLL], yv[BN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+            const int i = i0 + u * BN_THREADS * 4;
+            if (i < HW) {
+                gv[u] = *(const f32x4 *)(dy + base + i);
+                xv[u] = *(const f32x4 *)(x + base + i);
+                if (RELU && !rec)
+                    yv[u] = *(const f32x4 *)(y + base + i);
             }
-            g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
-            g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
         }
-        if (dres)
-            *(f32x4 *)(dres + base + i) = g;
-        f32x4 o;
-        o.x = k * (g.x - mg - (xv.x - m) * is * mgx);
-        o.y = k * (g.y - mg - (xv.y - m) * is * mgx);
-        o.z = k * (g.z - mg - (xv.z - m) * is * mgx);
-        o.w = k * (g.w - mg - (xv.w - m) * is * mgx);
-        *(f32x4 *)(dx + base + i) = o;
-        am = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+            const int i = i0 + u * BN_THREADS * 4;
+            if (i < HW) {
+                f32x4 g = gv[u];
+                const f32x4 xx = xv[u];
+                if (RELU) {
+                    f32x4 yy;
+                    if (rec) {
+                        yy.x = bn_eval(xx.x, asc, ash); yy.y = bn_eval(xx.y, asc, ash);
+                        yy.z = bn_eval(xx.z, asc, ash); yy.w = bn_eval(xx.w, asc, ash);
+                    } else {
+                        yy = yv[u];
+                    }
+                    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+                    g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+                }
+                if (dres)
+                    *(f32x4 *)(dres + base + i) = g;
+                f32x4 o;
+                o.x = k * (g.x - mg - (xx.x - m) * is * mgx);
+                o.y = k * (g.y - mg - (xx.y - m) * is * mgx);
+                o.z = k * (g.z - mg - (xx.z - m) * is * mgx);
+                o.w = k * (g.w - mg - (xx.w - m) * is * mgx);
+                *(f32x4 *)(dx + base + i) = o;
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+            }
+        }
     } else {
-        for (int q = i; q < HW && q < i + 4; ++q) {
-            float g = dy[base + q];
-            if (RELU)
-                g = (rec ? bn_eval(x[base + q], asc, ash) : y[base + q]) > 0.f ? g : 0.f;
-            if (dres)
-                dres[base + q] = g;
-            const float o = k * (g - mg - (x[base + q] - m) * is * mgx);
-            dx[base + q] = o;
-            am = fmaxf(am, fabsf(o));
-        }
+        for (int u = 0; u < BN_UNROLL; ++u)
+            for (int q = i0 + u * BN_THREADS * 4; q < HW && q < i0 + u * BN_THREADS * 4 + 4; ++q) {
+                float g = dy[base + q];
+                if (RELU)
+                    g = (rec ? bn_eval(x[base + q], asc, ash) : y[base + q]) > 0.f ? g : 0.f;
+                if (dres)
+                    dres[base + q] = g;
+                const float o = k * (g - mg - (x[base + q] - m) * is * mgx);
+                dx[base + q] = o;
+                am = fmaxf(am, fabsf(o));
+            }
     }
     if (amax)
         block_amax(am, amax + plane);
@@ -381,7 +416,7 @@ extern "C" int dcl_bn_apply(const float *x, const float *res, const float *mean,
                             float *y, float *amax, void *stream)
 {
     DCL_CHECK_ARG(x && mean && invstd && y && N > 0 && C > 0 && HW > 0, "bad arguments");
-    dim3 grid((HW + BN_THREADS * 4 - 1) / (BN_THREADS * 4), N * C);
+    dim3 grid((HW + BN_THREADS * 4 * BN_UNROLL - 1) / (BN_THREADS * 4 * BN_UNROLL), N * C);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, mean, invstd, gamma, beta, C, HW, y, amax)
     if (relu && res) LAUNCH(true, true);
@@ -419,7 +454,7 @@ extern "C" int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y,
                                 float *amax, void *stream)
 {
     DCL_CHECK_ARG(dy && x && mean && invstd && sums && dx && count > 0, "bad arguments");
-    dim3 grid((HW + BN_THREADS * 4 - 1) / (BN_THREADS * 4), N * C);
+    dim3 grid((HW + BN_THREADS * 4 * BN_UNROLL - 1) / (BN_THREADS * 4 * BN_UNROLL), N * C);
     hipStream_t st = (hipStream_t)stream;
     const float inv = (float)(1.0 / count);
     if (relu)
