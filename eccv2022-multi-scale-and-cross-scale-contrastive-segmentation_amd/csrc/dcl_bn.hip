@@ -44,7 +44,17 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_stats(const float *__restrict
     for (int n = s; n < N; n += nslice) {
         const float *p = x + ((size_t)n * C + c) * HW;
         const f32x4 *p4 = (const f32x4 *)p;
-        for (int i = threadIdx.x; i < hw4; i += BN_THREADS) {
+        int i = threadIdx.x;
+        for (; i + 3 * BN_THREADS < hw4; i += 4 * BN_THREADS) {       // four independent 16-byte loads in flight
+            const f32x4 v0 = p4[i], v1 = p4[i + BN_THREADS], v2 = p4[i + 2 * BN_THREADS], v3 = p4[i + 3 * BN_THREADS];
+            a += ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)) +
+                 (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w)));
+            b += ((v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w)) +
+                 ((v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w)) +
+                 (((v2.x * v2.x + v2.y * v2.y) + (v2.z * v2.z + v2.w * v2.w)) +
+                  ((v3.x * v3.x + v3.y * v3.y) + (v3.z * v3.z + v3.w * v3.w)));
+        }
+        for (; i < hw4; i += BN_THREADS) {
             const f32x4 v = p4[i];
             a += (v.x + v.y) + (v.z + v.w);
             b += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -238,23 +248,34 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__res
         const size_t base = ((size_t)n * C + c) * HW;
         const f32x4 *d4 = (const f32x4 *)(dy + base), *x4 = (const f32x4 *)(x + base),
                     *y4 = (const f32x4 *)(y + base);
-        for (int i = threadIdx.x; i < hw4; i += BN_THREADS) {
-            f32x4 g = d4[i];
-            const f32x4 xv = x4[i];
+        // one vector's contribution to (sum g, sum g (x - mean)); g = dy masked by y > 0 (y read, or recomputed)
+        auto accum = [&](f32x4 g, const f32x4 &xv, const f32x4 &ym) {
             if (RELU) {
-                f32x4 yv;
+                f32x4 yv = ym;
                 if (rec) {
                     yv.x = bn_eval(xv.x, asc, ash); yv.y = bn_eval(xv.y, asc, ash);
                     yv.z = bn_eval(xv.z, asc, ash); yv.w = bn_eval(xv.w, asc, ash);
-                } else {
-                    yv = y4[i];
                 }
                 g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                 g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
             }
             a += (g.x + g.y) + (g.z + g.w);
             b += (g.x * (xv.x - m) + g.y * (xv.y - m)) + (g.z * (xv.z - m) + g.w * (xv.w - m));
+        };
+        // two vectors per iteration, all their loads issued before the first is consumed
+        int i = threadIdx.x;
+        for (; i + BN_THREADS < hw4; i += 2 * BN_THREADS) {
+            const f32x4 g0 = d4[i], x0 = x4[i], g1 = d4[i + BN_THREADS], x1 = x4[i + BN_THREADS];
+            f32x4 y0 = g0, y1 = g1;
+            if (RELU && !rec) {
+                y0 = y4[i];
+                y1 = y4[i + BN_THREADS];
+            }
+            accum(g0, x0, y0);
+            accum(g1, x1, y1);
         }
+        if (i < hw4)
+            accum(d4[i], x4[i], (RELU && !rec) ? y4[i] : d4[i]);
         for (int i = (hw4 << 2) + threadIdx.x; i < HW; i += BN_THREADS) {
             float g = dy[base + i];
             if (RELU)
