@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
-from .ops import ConvPackGroup, DirectConv2d, GradToken, conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear, use_direct_conv3x3
+from .ops import ConvPackGroup, DirectConv2d, GradToken, use_gemm_conv1x1, conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear, use_direct_conv3x3
 from .amax import record_stream as _amax_record_stream
 from .fused_bn import FusedBatchNorm2d, bn_act
 
@@ -445,6 +445,10 @@ class HRNet(nn.Module):
             use_direct_conv3x3(self.backbone)
         if self.branch_conv == 'f16x3' or self.head_conv == 'direct':
             self._conv_packs = ConvPackGroup(self)
+        # 1x1 convolutions (bottlenecks, fuse layers, projector, classifier) as plain batched GEMMs in all three
+        # directions: the library's weight gradient for them wraps an NHWC kernel in layout transposes
+        if config.get('gemm_conv1x1', True):
+            use_gemm_conv1x1(self)
 
     def _head(self, x):
         if self.head_conv not in ('library', 'direct') and self.training and x.is_cuda and x.dtype == torch.float32 \

@@ -439,3 +439,61 @@ def use_direct_conv3x3(module: torch.nn.Module) -> torch.nn.Module:
                 and m.dilation == (1, 1) and m.groups == 1:
             m.__class__ = DirectConv2d
     return module
+
+
+# ---- 1x1 convolutions as plain batched GEMMs ----------------------------------------------------------------------
+
+class _Conv1x1Gemm(torch.autograd.Function):
+    """1x1 / stride 1 convolution on NCHW as batched f32 GEMMs in all three directions.  The library's own weight
+    gradient for this case goes through an NHWC implicit-GEMM kernel with layout transposes around it (7 ms per
+    HRNet-W48 step); in NCHW it is simply dW = sum_n gy_n [Co, HW] @ x_n^T [HW, Ci]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        n, ci, h, w = x.shape
+        co = weight.shape[0]
+        y = torch.empty((n, co, h, w), dtype=x.dtype, device=x.device)       # returned as a base tensor, not a view:
+        torch.matmul(weight.view(co, ci), x.view(n, ci, h * w), out=y.view(n, co, h * w))   # callers relu_() it
+        if bias is not None:
+            y += bias.view(1, co, 1, 1)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        n, ci, h, w = x.shape
+        co = weight.shape[0]
+        gy = gy.contiguous()
+        g2 = gy.view(n, co, h * w)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            torch.matmul(weight.view(co, ci).t(), g2, out=gx.view(n, ci, h * w))
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(g2, x.view(n, ci, h * w).transpose(1, 2)).sum(0).view_as(weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum((0, 2))
+        return gx, gw, gb
+
+
+class GemmConv1x1(torch.nn.Conv2d):
+    """nn.Conv2d (same parameters / state_dict) whose 1x1 / stride 1 / unpadded case runs as batched GEMMs for
+    contiguous fp32 CUDA inputs in training; anything else falls through to nn.Conv2d.forward."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+                and self.weight.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+            return _Conv1x1Gemm.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
+def use_gemm_conv1x1(module: torch.nn.Module) -> torch.nn.Module:
+    """Switch every plain 1x1 / stride 1 / pad 0 / groups 1 nn.Conv2d of a module tree to GemmConv1x1 in place."""
+    for m in module.modules():
+        if type(m) is torch.nn.Conv2d and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0) \
+                and m.dilation == (1, 1) and m.groups == 1:
+            m.__class__ = GemmConv1x1
+    return module

@@ -943,3 +943,22 @@ def test_models_with_direct_kernels_match_library_kernels(dev, family):
         ya = ya[0] if isinstance(ya, (tuple, list)) else ya
         yb = yb[0] if isinstance(yb, (tuple, list)) else yb
         assert ((ya - yb).abs().max() / yb.abs().max()).item() < 1e-4, (family, mode)
+
+
+@pytest.mark.gpu
+def test_gemm_conv1x1_matches_library(dev):
+    """GemmConv1x1 (1x1 convolution as batched GEMMs) against nn.Conv2d: y, dx, dW, db to fp32 round-off."""
+    from mscs_amd.models import ops
+    torch.manual_seed(8)
+    a = torch.nn.Conv2d(96, 40, 1).to(dev)
+    b = torch.nn.Conv2d(96, 40, 1).to(dev)
+    b.load_state_dict(a.state_dict())
+    ops.use_gemm_conv1x1(a)
+    assert isinstance(a, ops.GemmConv1x1)
+    x1 = torch.randn(3, 96, 17, 23, device=dev, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    gy = torch.randn(3, 40, 17, 23, device=dev)
+    a(x1).backward(gy)
+    b(x2).backward(gy)
+    for got, want in ((a(x1), b(x2)), (x1.grad, x2.grad), (a.weight.grad, b.weight.grad), (a.bias.grad, b.bias.grad)):
+        assert ((got - want).abs().max() / want.abs().max()).item() < 2e-5
