@@ -433,7 +433,7 @@ def main():
         else:
             out["roofline"], others = roofline_conv_kernels(args, dev)
             out["roofline_other"] = others + [roofline_bwd_kernel(mod)]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # host baseline: rank 0 of the single-GPU run only
             scale, lsec, cores, lsample = cpu_baseline_loss(args, n_terms)
             loss_sec = lsec * scale
             if workload == "loss":
