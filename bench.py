@@ -128,8 +128,8 @@ def sync(world):
 
 # HBM-side traffic of the direct convolution kernels at the benchmark's 48-channel shape (12 x 48 x 128 x 256), KiB
 # per launch (FETCH_SIZE, WRITE_SIZE) from the committed PMC passes (profiles/r01_conv_pmc_*.csv)
-PMC_CONV48 = (107438.5, 81408.0)
-PMC_CONV720 = (3408030.9, 1105920.0)      # head convolution 12 x 720 x 128 x 256, k_conv3x3<3,4,1>
+PMC_CONV48 = (40901.9, 81408.0)
+PMC_CONV720 = (2571033.1, 1105920.0)      # head convolution 12 x 720 x 128 x 256, k_conv3x3<3,4,1>
 PMC_WGRAD48 = (153044.3, 6885.0)
 
 

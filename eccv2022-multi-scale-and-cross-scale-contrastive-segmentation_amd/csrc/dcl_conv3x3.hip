@@ -94,7 +94,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
         if ((int)blockIdx.x < main_blocks) {
             const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
             cg = rest % a.groups;
-            bx = (rest / a.groups) * 8 + xcd;
+            // each XCD takes a CONTIGUOUS eighth of the tile sequence, so that vertically / horizontally adjacent
+            // tiles (which share halo rows and columns) also share an L2
+            bx = xcd * (n8 >> 3) + rest / a.groups;
         } else {
             const int rest = blockIdx.x - main_blocks;
             cg = rest % a.groups;
