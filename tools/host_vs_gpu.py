@@ -1,0 +1,43 @@
+"""Host enqueue time against GPU time of the benchmark step (is the step host-bound?), optional cProfile.
+    python tools/host_vs_gpu.py [--profile]"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import mscs_amd
+from mscs_amd.managers import HRNetManager
+from mscs_amd.utils import set_verbosity
+set_verbosity(40)
+class A:
+    batch, height, width, scales, no_cross, channels_last, branch_conv = 12, 512, 1024, 3, False, False, "f16x3"
+mgr = HRNetManager(bench.step_config(A, 1), autostart=False); mgr.setup(); mgr.model.train()
+dev = torch.device("cuda:0")
+gen = torch.Generator().manual_seed(0)
+img = torch.randn(A.batch, 3, A.height, A.width, generator=gen).to(dev)
+lbl = torch.randint(0, 20, (A.batch, A.height, A.width), generator=gen, dtype=torch.int32).to(dev)
+def step():
+    mgr.optimiser.zero_grad(set_to_none=True)
+    t0 = time.perf_counter()
+    ret = mgr.forward_step(img, lbl)
+    t1 = time.perf_counter()
+    ret["loss"].backward()
+    t2 = time.perf_counter()
+    mgr.optimiser.step(); mgr.scheduler.step()
+    return t1 - t0, t2 - t1, time.perf_counter() - t2
+for _ in range(4): step()
+torch.cuda.synchronize()
+T0 = time.perf_counter(); acc = [0, 0, 0]
+for _ in range(10):
+    a, b, c = step(); acc[0] += a; acc[1] += b; acc[2] += c
+host = time.perf_counter() - T0
+torch.cuda.synchronize()
+tot = time.perf_counter() - T0
+print(f"host enqueue {host*100:.1f} ms/step (fwd {acc[0]*100:.1f} bwd {acc[1]*100:.1f} opt {acc[2]*100:.1f}), wall incl. GPU drain {tot*100:.1f} ms/step")
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(3):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
