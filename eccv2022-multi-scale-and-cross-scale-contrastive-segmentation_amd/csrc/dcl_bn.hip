@@ -164,6 +164,32 @@ __device__ __forceinline__ void bn_affine(const float *invstd, const float *gamm
 }
 __device__ __forceinline__ float bn_eval(float x, float sc, float sh) { return x * sc + sh; }
 
+// "Fused" mode of the apply kernels: the per-slice partial sums `part` (all-reduced across ranks by the caller for
+// SyncBatchNorm) are combined in every workgroup's prologue instead of by a k_bn_combine launch -- same fixed
+// order, same double accumulation, two tiny launches less per norm layer and direction.
+struct BnFused {
+    const float *part;          // [C][ns][2]; NULL = not fused (mean / invstd / sums are inputs)
+    const float *part_local;    // backward only: this rank's partial sums (dgamma / dbeta), may equal part
+    int ns;
+    double count;               // elements per channel over all ranks
+    float eps, momentum;
+    float *mean, *invstd;       // forward outputs (saved for the backward)
+    float *running_mean, *running_var;
+    long long *batches_tracked;
+    float *dbeta, *dgamma;      // backward outputs (may be NULL)
+};
+
+__device__ __forceinline__ void part_sums(const float *part, int c, int ns, float &a, float &b)
+{
+    double da = 0.0, db = 0.0;
+    for (int s = 0; s < ns; ++s) {
+        da += part[((size_t)c * ns + s) * 2 + 0];
+        db += part[((size_t)c * ns + s) * 2 + 1];
+    }
+    a = (float)da;
+    b = (float)db;
+}
+
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict__ x,
                                                         const float *__restrict__ res,
@@ -171,12 +197,36 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
                                                         const float *__restrict__ invstd,
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, int C, int HW,
-                                                        float *__restrict__ y, float *__restrict__ amax)
+                                                        float *__restrict__ y, float *__restrict__ amax,
+                                                        BnFused f)
 {
     const int plane = blockIdx.y, c = plane % C;
     float am = 0.f;
     float sc, sh;
-    bn_affine(invstd, gamma, beta, mean, c, sc, sh);
+    if (f.part) {
+        // statistics of channel c from the partial sums (k_bn_combine's arithmetic), written out once per channel
+        float a, b;
+        part_sums(f.part, c, f.ns, a, b);
+        const double m = (double)a / f.count;
+        double var = (double)b / f.count - m * m;
+        var = var > 0.0 ? var : 0.0;
+        const float mean_f = (float)m, invstd_f = (float)(1.0 / sqrt(var + (double)f.eps));
+        if (blockIdx.x == 0 && plane < C && threadIdx.x == 0) {
+            f.mean[c] = mean_f;
+            f.invstd[c] = invstd_f;
+            if (f.running_mean) {
+                const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+                f.running_mean[c] = (float)((1.0 - f.momentum) * f.running_mean[c] + f.momentum * m);
+                f.running_var[c] = (float)((1.0 - f.momentum) * f.running_var[c] + f.momentum * unbiased);
+            }
+            if (c == 0 && f.batches_tracked)
+                f.batches_tracked[0] += 1;
+        }
+        sc = invstd_f * (gamma ? gamma[c] : 1.f);
+        sh = (beta ? beta[c] : 0.f) - mean_f * sc;
+    } else {
+        bn_affine(invstd, gamma, beta, mean, c, sc, sh);
+    }
     const size_t base = (size_t)plane * HW;
     // BN_UNROLL 16-byte vectors per thread, BN_THREADS apart (coalesced), all loads issued before the first use
     const int i0 = (blockIdx.x * BN_UNROLL * BN_THREADS + threadIdx.x) << 2;
@@ -305,7 +355,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                                                             float inv_count, int C, int HW,
                                                             float *__restrict__ dx,
                                                             float *__restrict__ dres,
-                                                            float *__restrict__ amax)
+                                                            float *__restrict__ amax, BnFused f)
 {
     const int plane = blockIdx.y, c = plane % C;
     float am = 0.f;
@@ -314,7 +364,25 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
     bn_affine(invstd, gamma, beta, mean, c, asc, ash);
     const bool rec = RELU && y == nullptr;
     const float k = is * (gamma ? gamma[c] : 1.f);
-    const float mg = sums[c * 2] * inv_count, mgx = sums[c * 2 + 1] * inv_count;
+    float mg, mgx;
+    if (f.part) {
+        float a, b;
+        part_sums(f.part, c, f.ns, a, b);
+        mg = a * inv_count;
+        mgx = b * inv_count;
+        if (blockIdx.x == 0 && plane < C && threadIdx.x == 0 && (f.dbeta || f.dgamma)) {
+            float la = a, lb = b;
+            if (f.part_local != f.part)
+                part_sums(f.part_local, c, f.ns, la, lb);       // this rank's sums: DDP averages the parameter grads
+            if (f.dbeta)
+                f.dbeta[c] = la;
+            if (f.dgamma)
+                f.dgamma[c] = lb;
+        }
+    } else {
+        mg = sums[c * 2] * inv_count;
+        mgx = sums[c * 2 + 1] * inv_count;
+    }
     const size_t base = (size_t)plane * HW;
     const int i0 = (blockIdx.x * BN_UNROLL * BN_THREADS + threadIdx.x) << 2;
     if ((HW & 3) == 0) {
@@ -439,7 +507,7 @@ extern "C" int dcl_bn_apply(const float *x, const float *res, const float *mean,
     DCL_CHECK_ARG(x && mean && invstd && y && N > 0 && C > 0 && HW > 0, "bad arguments");
     dim3 grid((HW + BN_THREADS * 4 * BN_UNROLL - 1) / (BN_THREADS * 4 * BN_UNROLL), N * C);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, mean, invstd, gamma, beta, C, HW, y, amax)
+#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, mean, invstd, gamma, beta, C, HW, y, amax, BnFused{})
     if (relu && res) LAUNCH(true, true);
     else if (relu) LAUNCH(true, false);
     else if (res) LAUNCH(false, true);
@@ -479,9 +547,89 @@ extern "C" int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y,
     hipStream_t st = (hipStream_t)stream;
     const float inv = (float)(1.0 / count);
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax);
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{});
     else
-        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax);
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{});
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fused forms: no k_bn_combine launches (see BnFused) -------------------------------------------------------------
+
+extern "C" int dcl_bn_stats_part(const float *x, int N, int C, int HW, float *part, void *stream)
+{
+    DCL_CHECK_ARG(x && part && N > 0 && C > 0 && HW > 0, "bad arguments");
+    const int ns = pick_slices(N, C);
+    hipLaunchKernelGGL(k_bn_stats, dim3(C, ns), dim3(BN_THREADS), 0, (hipStream_t)stream, x, N, C, HW, ns, part);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_bn_apply_fused(const float *x, const float *res, const float *part, double count, float eps,
+                                  float momentum, const float *gamma, const float *beta, int N, int C, int HW,
+                                  int relu, float *y, float *mean, float *invstd, float *running_mean,
+                                  float *running_var, int64_t *batches_tracked, float *amax, void *stream)
+{
+    DCL_CHECK_ARG(x && part && y && mean && invstd && N > 0 && C > 0 && HW > 0 && count > 0, "bad arguments");
+    BnFused f{};
+    f.part = part;
+    f.ns = pick_slices(N, C);
+    f.count = count;
+    f.eps = eps;
+    f.momentum = momentum;
+    f.mean = mean;
+    f.invstd = invstd;
+    f.running_mean = running_mean;
+    f.running_var = running_var;
+    f.batches_tracked = (long long *)batches_tracked;
+    dim3 grid((HW + BN_THREADS * 4 * BN_UNROLL - 1) / (BN_THREADS * 4 * BN_UNROLL), N * C);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, (const float *)nullptr, (const float *)nullptr, gamma, beta, C, HW, y, amax, f)
+    if (relu && res) LAUNCH(true, true);
+    else if (relu) LAUNCH(true, false);
+    else if (res) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_bn_bwd_reduce_part(const float *dy, const float *x, const float *y, const float *mean,
+                                      const float *invstd, const float *gamma, const float *beta, int N, int C,
+                                      int HW, int relu, float *part, void *stream)
+{
+    DCL_CHECK_ARG(dy && x && mean && invstd && part, "bad arguments");
+    const int ns = pick_slices(N, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu)
+        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part);
+    else
+        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const float *y, const float *mean,
+                                      const float *invstd, const float *gamma, const float *beta,
+                                      const float *part, const float *part_local, double count, int N, int C,
+                                      int HW, int relu, float *dx, float *dres, float *dbeta, float *dgamma,
+                                      float *amax, void *stream)
+{
+    DCL_CHECK_ARG(dy && x && mean && invstd && part && part_local && dx && count > 0, "bad arguments");
+    BnFused f{};
+    f.part = part;
+    f.part_local = part_local;
+    f.ns = pick_slices(N, C);
+    f.count = count;
+    f.dbeta = dbeta;
+    f.dgamma = dgamma;
+    dim3 grid((HW + BN_THREADS * 4 * BN_UNROLL - 1) / (BN_THREADS * 4 * BN_UNROLL), N * C);
+    hipStream_t st = (hipStream_t)stream;
+    const float inv = (float)(1.0 / count);
+    if (relu)
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f);
+    else
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -38,31 +38,23 @@ class _FusedBNFunction(torch.autograd.Function):
         HW = H * W
         dev = x.device
         ns = L.dcl_bn_num_slices(N, C)
-        part = torch.empty((C * ns * 2,), dtype=torch.float32, device=dev)
-        sums = torch.empty((C, 2), dtype=torch.float32, device=dev)
         st = _stream()
         world = _world() if sync else 1
         count = float(N * HW * world)
-        mean = torch.empty((C,), dtype=torch.float32, device=dev)
-        invstd = torch.empty((C,), dtype=torch.float32, device=dev)
-        if world == 1:
-            _lib.check(L.dcl_bn_stats_finalize(_lib.ptr(x), N, C, HW, eps, momentum, _lib.ptr(part),
-                                               _lib.ptr(sums), _lib.ptr(mean), _lib.ptr(invstd),
-                                               _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(nbt), st),
-                       "dcl_bn_stats_finalize")
-        else:
+        # one workspace: [part C*ns*2 | mean C | invstd C]; the per-slice partial sums are combined in the prologue
+        # of the apply kernel (no combine / finalize launches); SyncBatchNorm = all-reduce of `part` in between
+        ws = torch.empty((C * ns * 2 + 2 * C,), dtype=torch.float32, device=dev)
+        part, mean, invstd = ws[:C * ns * 2], ws[C * ns * 2:C * ns * 2 + C], ws[C * ns * 2 + C:]
+        _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), st), "dcl_bn_stats_part")
+        if world > 1:
             import torch.distributed as dist
-            if nbt is not None:
-                nbt.add_(1)
-            _lib.check(L.dcl_bn_stats(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(sums), st), "dcl_bn_stats")
-            dist.all_reduce(sums)
-            _lib.check(L.dcl_bn_finalize(_lib.ptr(sums), C, count, eps, momentum, _lib.ptr(mean),
-                                         _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), st),
-                       "dcl_bn_finalize")
+            dist.all_reduce(part)
         y = torch.empty_like(x)
-        _lib.check(L.dcl_bn_apply(_lib.ptr(x), _lib.ptr(res), _lib.ptr(mean), _lib.ptr(invstd),
-                                  _lib.ptr(weight), _lib.ptr(bias), N, C, HW, 1 if relu else 0, _lib.ptr(y),
-                                  _lib.ptr(amax), st), "dcl_bn_apply")
+        _lib.check(L.dcl_bn_apply_fused(_lib.ptr(x), _lib.ptr(res), _lib.ptr(part), count, eps, momentum,
+                                        _lib.ptr(weight), _lib.ptr(bias), N, C, HW, 1 if relu else 0, _lib.ptr(y),
+                                        _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(running_mean),
+                                        _lib.ptr(running_var), _lib.ptr(nbt), _lib.ptr(amax), st),
+                   "dcl_bn_apply_fused")
         # y is only needed for the ReLU mask when a residual was added: without one the backward recomputes
         # y > 0 from x (one tensor less to read, twice)
         ctx.save_for_backward(x, y if (relu and res is not None) else None, weight, bias, mean, invstd)
@@ -81,27 +73,29 @@ class _FusedBNFunction(torch.autograd.Function):
         dy = dy.contiguous()
         ns = L.dcl_bn_num_slices(N, C)
         part = torch.empty((C * ns * 2,), dtype=torch.float32, device=dev)
-        sums = torch.empty((C, 2), dtype=torch.float32, device=dev)
         st = _stream()
         relu = 1 if ctx.relu else 0
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
-        _lib.check(L.dcl_bn_bwd_reduce(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
-                                       _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), N, C, HW, relu,
-                                       _lib.ptr(part), _lib.ptr(sums),
-                                       _lib.ptr(dbeta), _lib.ptr(dgamma), st), "dcl_bn_bwd_reduce")
-        # dbeta / dgamma are the LOCAL sums (written before the all-reduce): DDP averages them
+        _lib.check(L.dcl_bn_bwd_reduce_part(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
+                                            _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), N, C, HW, relu,
+                                            _lib.ptr(part), st), "dcl_bn_bwd_reduce_part")
+        # dx needs the sums over ALL ranks; dbeta / dgamma stay this rank's sums (DDP averages parameter gradients)
+        part_all = part
         if ctx.world > 1:
             import torch.distributed as dist
-            dist.all_reduce(sums)
+            part_all = part.clone()
+            dist.all_reduce(part_all)
         dx = torch.empty_like(x)
         want_res = ctx.has_res and (ctx.needs_input_grad[1] or ctx.token is not None)
         dres = torch.empty_like(x) if want_res else None
         # per-plane max|dx| for the consumer (the data / weight gradient of the convolution in front of this norm)
         amax = _amax.zeros(N * C, dev) if ctx.emit_amax else None
-        _lib.check(L.dcl_bn_bwd_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
-                                      _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(sums), ctx.count, N, C,
-                                      HW, relu, _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(amax), st), "dcl_bn_bwd_apply")
+        _lib.check(L.dcl_bn_bwd_apply_fused(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
+                                            _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(part_all),
+                                            _lib.ptr(part), ctx.count, N, C, HW, relu, _lib.ptr(dx), _lib.ptr(dres),
+                                            _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(amax), st),
+                   "dcl_bn_bwd_apply_fused")
         if amax is not None:
             _amax.tag(dx, amax)
         if ctx.token is not None:

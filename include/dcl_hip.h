@@ -205,6 +205,24 @@ int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y /* as above
                      int C, int HW, int relu, float *dx, float *dres,
                      float *amax /* [N*C] zero-initialised: per-plane max|dx|; or NULL */, void *stream);
 
+/* Fused forms (what FusedBatchNorm2d uses): the per-slice partial sums `part` are combined in the prologue of the
+ * apply kernels instead of by a separate launch.  Forward: dcl_bn_stats_part -> [all-reduce of part] ->
+ * dcl_bn_apply_fused (also writes mean / invstd, updates the running statistics and num_batches_tracked).
+ * Backward: dcl_bn_bwd_reduce_part -> [part_global = all-reduce of a copy] -> dcl_bn_bwd_apply_fused (dx from
+ * part_global; dbeta / dgamma from this rank's part_local).  part: f32 [C * dcl_bn_num_slices(N, C) * 2]. */
+int dcl_bn_stats_part(const float *x, int N, int C, int HW, float *part, void *stream);
+int dcl_bn_apply_fused(const float *x, const float *res, const float *part, double count, float eps, float momentum,
+                       const float *gamma, const float *beta, int N, int C, int HW, int relu, float *y, float *mean,
+                       float *invstd, float *running_mean, float *running_var, int64_t *batches_tracked,
+                       float *amax, void *stream);
+int dcl_bn_bwd_reduce_part(const float *dy, const float *x, const float *y, const float *mean, const float *invstd,
+                           const float *gamma, const float *beta, int N, int C, int HW, int relu, float *part,
+                           void *stream);
+int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const float *y, const float *mean, const float *invstd,
+                           const float *gamma, const float *beta, const float *part, const float *part_local,
+                           double count, int N, int C, int HW, int relu, float *dx, float *dres, float *dbeta,
+                           float *dgamma, float *amax, void *stream);
+
 /* ---- bilinear up-sampling, NCHW f32 (planes = N * C), ATen index arithmetic ----------------------------
  * Replaces F.interpolate(mode='bilinear') in the models (reference models/HRNet.py:279-282, 549-551, 638)
  * and its autograd backward (gather form: deterministic, no atomics). */
