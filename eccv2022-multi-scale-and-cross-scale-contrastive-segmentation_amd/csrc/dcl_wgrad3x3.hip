@@ -39,7 +39,7 @@ struct WgradArgs {
     int N, Cin, Cout, H, W;
     int Hd, Wd;                  // stored size of dy (= H, W; or the even samples of a zero-inserted dy: stride 2)
     int strips, nseg, units, S, ncig, npairs, nx;
-    int rect_c, rect_i;         // nx == 1: pair-grid rectangle that shares an XCD (rect_c * rect_i = 32)
+    int rect_c, rect_i, rect_mode;  // many pairs: pair-grid rectangle that shares an XCD (rect_c * rect_i = 32)
 };
 
 // Packed f16 pair (lo half = element 0) of hi = f16(v * s) and of lo = f16(v * s - hi) for two values.  s is a power
@@ -101,20 +101,22 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
     // next to each other in dispatch order -- they stream the same dy / x rows, which then come out of that
     // XCD's L2 instead of being fetched once per pair.
     int pair, xsplit;
-    if (a.nx == 1) {
+    if (a.rect_mode) {
         // Many tile pairs, one pixel split (large channel counts): every workgroup streams ALL pixels, so what
         // matters is which workgroups share an L2 while they do.  The (co group x ci group) grid is cut into
         // rectangles of rect_c x rect_i = 32 pairs -- they read rect_c + rect_i operand row sets instead of 64 --
         // and rectangle q of XCD k takes the ids k + 8 * (32 q .. 32 q + 31): one XCD (32 CUs), adjacent dispatch
         // slots.  (Head convolution, 15 x 45 pairs: FETCH_SIZE 28.0 GiB -> 16.5 GiB per launch, 12.9 -> 12.5 ms.)
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int rect = (slot >> 5) * 8 + xcd, idx = slot & 31;
+        const int unit = (slot >> 5) * 8 + xcd, idx = slot & 31;       // unit = (pixel split, rectangle)
         const int ncog = a.npairs / a.ncig, rects_i = (a.ncig + a.rect_i - 1) / a.rect_i;
+        const int nrect = ((ncog + a.rect_c - 1) / a.rect_c) * rects_i;
+        const int rect = unit % nrect;
+        xsplit = unit / nrect;
         const int cg = (rect / rects_i) * a.rect_c + idx / a.rect_i, ci = (rect % rects_i) * a.rect_i + idx % a.rect_i;
-        if (cg >= ncog || ci >= a.ncig)
+        if (xsplit >= a.nx || cg >= ncog || ci >= a.ncig)
             return;                             // padding of the last rectangles (the whole workgroup leaves)
         pair = cg * a.ncig + ci;
-        xsplit = 0;
     } else {
         const int nx8 = a.nx & ~7, main_blocks = nx8 * a.npairs;
         if ((int)blockIdx.x < main_blocks) {
@@ -446,14 +448,17 @@ static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nc
 {
     const int cot = Cout / 16, cit = Cin / 16;
     nco = (cot % 3 == 0) ? 3 : (cot % 2 == 0) ? 2 : 1;        // (4 tiles would spill)
-    nci = (cit % 2 == 0) ? 2 : 1;   // pairs of ci tiles when that leaves no ragged group (an odd count pads 1/(cit+1))
+    // pairs of ci tiles when that leaves no ragged group (for the head, cit = 45, the 6-tile variant with a ragged
+    // last group was tried: 27 ms against 12.5 ms -- it spills and writes per-wave slabs)
+    nci = (cit % 2 == 0) ? 2 : 1;
     const int pairs = (cot / nco) * ((cit + nci - 1) / nci);
     units = N * ((W + 31) / 32);            // columns: (image, 32-pixel strip), H input rows each
     // One workgroup (4 waves = 4 splits of one pair) per CU is all that fits (a wave owns most of its SIMD's
     // registers): at most 256 workgroups, or the stragglers run as a second round and double the kernel time.
     int nx = 256 / pairs;
     if (nx < 1)
-        nx = 1;
+        nx = 1;         // more tile pairs than CUs (head convolution): one pixel split; finer splits were tried and
+                        // lose (3 splits fill the last round better but take 26 ms against 12.5 ms)
     S = 4 * nx;
     if ((long long)S > (long long)units * H)
         S = units * H;
@@ -503,10 +508,11 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     dim3 grid((unsigned)(a.npairs * a.nx));      // exactly the populated workgroups, <= 256 whenever pairs <= 256
     a.rect_i = a.ncig >= 16 ? 16 : (a.ncig >= 8 ? 8 : (a.ncig >= 4 ? 4 : (a.ncig >= 2 ? 2 : 1)));
     a.rect_c = 32 / a.rect_i;
-    if (a.nx == 1) {
+    a.rect_mode = a.npairs > 128 ? 1 : 0;
+    if (a.rect_mode) {
         const int ncog = a.npairs / a.ncig;
-        const int rects = ((ncog + a.rect_c - 1) / a.rect_c) * ((a.ncig + a.rect_i - 1) / a.rect_i);
-        grid = dim3((unsigned)(((rects + 7) / 8) * 8 * 32));
+        const int units_r = ((ncog + a.rect_c - 1) / a.rect_c) * ((a.ncig + a.rect_i - 1) / a.rect_i) * a.nx;
+        grid = dim3((unsigned)(((units_r + 7) / 8) * 8 * 32));
     }
     hipStream_t s = (hipStream_t)stream;
 #define DCL_WG_CASE(o, i)                                                        \
