@@ -69,7 +69,7 @@ SIGNATURES = {
 
 def build(verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into libdcl_hip.so (in-tree)."""
-    out = subprocess.run(["make", "-C", CSRC_DIR], capture_output=True, text=True)
+    out = subprocess.run(["make", "-j8", "-C", CSRC_DIR], capture_output=True, text=True)
     if verbose or out.returncode != 0:
         print(out.stdout)
         print(out.stderr)

@@ -60,6 +60,9 @@ class BaseManager:
         self.global_step = 0
         self.start_epoch = 0
         self.best_miou = -1.0
+        self.best_loss = 1e10
+        self._resumed = False
+        self.load_report = None
         self.metrics = {}
         self.model = self.loss = self.optimiser = self.scheduler = None
         self.data_loaders, self.samplers = {}, {}
@@ -104,6 +107,7 @@ class BaseManager:
         self.load_loss()
         self.load_data()
         self.load_optimiser()
+        self._maybe_load_checkpoint()
 
     # ------------------------------------------------------------------ processes
     def distributed_train_worker(self, gpu):
@@ -129,6 +133,7 @@ class BaseManager:
         self.load_loss()
         self.load_data()
         self.load_optimiser()
+        self._maybe_load_checkpoint()
 
     # ------------------------------------------------------------------ construction
     def load_model(self):
@@ -265,7 +270,7 @@ class BaseManager:
                     keys.append(k)
                     vals.append(v.float())
         host = torch.stack([v.reshape(()) for v in vals]).cpu().tolist()
-        self.metrics = dict(zip(keys, host))
+        self.metrics.update(zip(keys, host))
         if self.rank == 0 and (batch_num % self.config.get('log_every_n_steps', 10) == 0):
             terms = ' '.join(f'{k}:{v:.4f}' for k, v in self.metrics.items())
             printlog(f'ep {self.epoch} it {batch_num} t:{ms:.0f}ms {terms}')
@@ -286,31 +291,139 @@ class BaseManager:
             if i + 1 >= self.config.get('max_valid_imgs', 10):
                 break
         miou = float(t_get_mean_iou(cm).item())
+        self.metrics['final_miou'] = miou
+        self.metrics['final_miou_step'] = self.global_step - 1
+        is_best = miou > self.best_miou
         self.best_miou = max(self.best_miou, miou)
         printlog(f'validation epoch {self.epoch}: mIoU {miou:.4f}')
+        # checkpoints as in valid_logging (LoggingManager.py:280-284): the best so far, and one every
+        # log_every_n_epochs plus the final epoch; `save_checkpoints: false` turns them off (benchmarks)
+        if self.config['mode'] == 'training' and self.config.get('save_checkpoints', True) \
+                and self.optimiser is not None:
+            if is_best:
+                self.save_checkpoint(is_best=True)
+            every = self.config.get('log_every_n_epochs', 100)
+            if (self.epoch % every == 0 and self.epoch > 0) or self.epoch == self.config['train']['epochs'] - 1:
+                self.save_checkpoint(is_best=False)
         self.model.train()
         return miou
 
     # ------------------------------------------------------------------ checkpoints
-    def save_checkpoint(self, path):
-        """Same dictionary layout as the reference (LoggingManager.py:293-319)."""
-        torch.save({'global_step': self.global_step, 'epoch': self.epoch,
-                    'model_state_dict': self.model.state_dict(),
-                    'optimiser_state_dict': self.optimiser.state_dict(),
-                    'scheduler_state_dict': self.scheduler.state_dict() if self.scheduler else None,
-                    'best_miou': self.best_miou}, path)
+    def _log_dir(self):
+        """``<log_path>/<run_id>`` like the reference (LoggingManager.py:81-91); created on first use so that runs
+        which never save (benchmarks, tests) leave nothing behind."""
+        if self.log_dir is None:
+            run_id = self.config.get('run_id')
+            if run_id is None:
+                run_id = '{:%Y%m%d_%H%M%S}_e{}'.format(datetime.datetime.now(), self.experiment)
+                if 'name' in self.config:
+                    run_id = '__'.join((run_id, str(self.config['name'])))
+            self.log_dir = os.path.join(self.config.get('log_path', 'logging'), run_id)
+        os.makedirs(os.path.join(str(self.log_dir), 'chkpts'), exist_ok=True)
+        return str(self.log_dir)
 
-    def load_checkpoint(self, path):
-        """Loads a reference-format checkpoint; strips DDP's ``module.`` prefix when not parallel."""
-        chk = torch.load(path, map_location=self.device)
-        state = chk['model_state_dict']
-        if not self.parallel:
-            state = {(k[7:] if k.startswith('module.') else k): v for k, v in state.items()}
-        self.model.load_state_dict(state, strict=False)
-        if 'optimiser_state_dict' in chk and self.optimiser is not None:
-            self.optimiser.load_state_dict(chk['optimiser_state_dict'])
-        if chk.get('scheduler_state_dict') and self.scheduler is not None:
-            self.scheduler.load_state_dict(chk['scheduler_state_dict'])
-        self.start_epoch = chk.get('epoch', -1) + 1
-        self.global_step = chk.get('global_step', 0)
-        self.best_miou = chk.get('best_miou', -1.0)
+    def checkpoint_state(self, is_best=False):
+        """The reference's checkpoint dictionary, key for key (LoggingManager.py:293-313)."""
+        state = {'global_step': self.global_step - 1,       # the reference saves after train_logging's increment
+                 'epoch': self.epoch,                        # absolute: train() resumes at start_epoch
+                 'model_state_dict': self.model.state_dict(),
+                 'optimiser_state_dict': self.optimiser.state_dict(),
+                 'best_loss': self.best_loss,
+                 'best_miou': self.best_miou,
+                 'final_miou': self.metrics.get('final_miou', 0),
+                 'final_miou_step': self.metrics.get('final_miou_step', 0),
+                 'is_best': bool(is_best)}
+        if self.scheduler is not None:
+            state['scheduler_state_dict'] = self.scheduler.state_dict()
+        return state
+
+    def save_checkpoint(self, is_best=False, path=None):
+        """``chkpts/chkpt_best.pt`` or ``chkpts/chkpt_epoch_NNN.pt`` under the run's log directory (or an explicit
+        ``path``), written by rank 0 only; returns the path."""
+        if self.rank != 0:
+            return None
+        state = self.checkpoint_state(is_best)
+        if path is None:
+            name = 'chkpt_best.pt' if is_best else 'chkpt_epoch_{:03d}.pt'.format(state['epoch'])
+            path = os.path.join(self._log_dir(), 'chkpts', name)
+        torch.save(state, path)
+        printlog(f'Checkpoint saved: {path}')
+        return path
+
+    def _resolve_checkpoint(self, spec, chkpt_type):
+        """``spec``: a .pt file, a run directory (with ``chkpts/``), or a run id under ``log_path``; picks
+        ``chkpt_best.pt`` or the last ``chkpt_epoch_*.pt`` like LoggingManager.py:327-344."""
+        spec = str(spec)
+        if os.path.isfile(spec):
+            return spec
+        base = spec if os.path.isdir(spec) else os.path.join(self.config.get('log_path', 'logging'), spec)
+        ck = os.path.join(base, 'chkpts') if os.path.isdir(os.path.join(base, 'chkpts')) else base
+        if not os.path.isdir(ck):
+            raise FileNotFoundError(f"load_checkpoint: '{spec}' is neither a checkpoint file nor a run directory")
+        names = sorted(os.listdir(ck))
+        epochs = [n for n in names if n.startswith('chkpt_epoch_')]
+        if chkpt_type == 'last':
+            if not epochs:
+                raise ValueError("No checkpoint of type 'last' found.")
+            return os.path.join(ck, epochs[-1])
+        if 'chkpt_best.pt' in names:
+            return os.path.join(ck, 'chkpt_best.pt')
+        if epochs:
+            printlog("No checkpoint of type 'best' found; loading the last one.")
+            return os.path.join(ck, epochs[-1])
+        raise ValueError(f'Neither chkpt of type "best" nor of type "last" was found in {names}')
+
+    @staticmethod
+    def match_module_prefix(state, target_keys):
+        """Rename ``state``'s keys so that DDP's ``module.`` prefix agrees with the model it is loaded into, in
+        BOTH directions (a single-GPU save into a DDP-wrapped model and vice versa; the reference only strips,
+        LoggingManager.py:353-354 / check_module_prefix)."""
+        want = any(k.startswith('module.') for k in target_keys)
+        out = {}
+        for k, v in state.items():
+            has = k.startswith('module.')
+            if want and not has:
+                k = 'module.' + k
+            elif has and not want:
+                k = k[len('module.'):]
+            out[k] = v
+        return out
+
+    def load_checkpoint(self, spec, chkpt_type='best', strict_keys=True):
+        """Load a checkpoint in the reference's dictionary layout (LoggingManager.py:321-368).  Missing and
+        unexpected keys are logged; a checkpoint that matches NO parameter of the model raises (the silent
+        ``strict=False`` no-op of a prefix mismatch)."""
+        path = self._resolve_checkpoint(spec, chkpt_type)
+        chk = torch.load(path, map_location=self.device, weights_only=False)
+        target = self.model.state_dict()
+        state = self.match_module_prefix(chk['model_state_dict'], target.keys())
+        matched = [k for k in state if k in target]
+        if not matched:
+            raise RuntimeError(f'checkpoint {path} shares no parameter name with the model '
+                               f'(first keys: {list(state)[:3]} vs {list(target)[:3]})')
+        ret = self.model.load_state_dict(state, strict=False)
+        if ret.missing_keys or ret.unexpected_keys:
+            printlog(f'load_state_dict: {len(matched)} tensors loaded, missing {len(ret.missing_keys)} '
+                     f'{ret.missing_keys[:5]}, unexpected {len(ret.unexpected_keys)} {ret.unexpected_keys[:5]}')
+            if strict_keys and self.config.get('strict_checkpoint', False):
+                raise RuntimeError('checkpoint does not match the model (strict_checkpoint)')
+        self.load_report = ret
+        if self.config['mode'] == 'training':
+            if 'optimiser_state_dict' in chk and self.optimiser is not None:
+                self.optimiser.load_state_dict(chk['optimiser_state_dict'])
+            if chk.get('scheduler_state_dict') and self.scheduler is not None:
+                self.scheduler.load_state_dict(chk['scheduler_state_dict'])
+            self.start_epoch = chk.get('epoch', -1) + 1
+            self.global_step = chk.get('global_step', 0)
+            self.best_loss = chk.get('best_loss', 1e10)
+            self.best_miou = chk.get('best_miou', -1.0)
+            self.metrics['final_miou'] = chk.get('final_miou')
+            self._resumed = True
+        printlog(f'rank {self.rank}: checkpoint loaded: {path} (type {chkpt_type})')
+        return path
+
+    def _maybe_load_checkpoint(self):
+        """``load_checkpoint`` / ``load_last`` config keys (BaseManager.py:76-82, 139-144)."""
+        if 'load_checkpoint' in self.config:
+            kind = 'last' if self.config.get('load_last', False) else 'best'
+            self.load_checkpoint(self.config['load_checkpoint'], kind)
