@@ -114,6 +114,8 @@ class UPerNet(nn.Module):
             self.return_features = True
         settings = dict(backbone_config_swin[self.backbone_name])
         settings['pretrained'] = config.get('pretrained', True)
+        if 'drop_path_rate' in config:          # extension: the reference fixes 0.3 in its backbone table (Swin.py:31)
+            settings['drop_path_rate'] = float(config['drop_path_rate'])
         self.backbone = SwinTransformer(**settings)
         self.config['input_channels'] = settings['out_channels']
         self.config['input_scales'] = [4, 8, 16, 32]

@@ -65,6 +65,104 @@ def test_model_matches_reference(name):
         np.testing.assert_allclose(o.double().abs().sum().item(), float(z[f"out{i}_abs_sum"]), rtol=1e-4)
 
 
+def _probe_loss(outs):
+    """Same scalar as tools/gen_golden_models.py::probe_loss."""
+    total = 0.0
+    for i, o in enumerate(outs):
+        pat = torch.cos(torch.arange(o.numel(), dtype=torch.float32) * 0.37 + i).view(o.shape).to(o.device)
+        total = total + (o * pat).mean()
+    return total
+
+
+def _check_model(name, dev):
+    """Eval-mode forward of a G7 fixture on ``dev`` (on the GPU this is the HIP model path: direct convolutions,
+    fused window attention, HIP up-sampling)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = _build(name, json.loads(str(z["config_json"])), int(z["experiment"]))
+    fill_state_dict_(model)
+    model.eval().to(dev)
+    with torch.no_grad():
+        outs = _flatten(model(model_input(tuple(int(v) for v in z["input_shape"])).to(dev)))
+    for i, o in enumerate(outs):
+        o = o.float().cpu()
+        ref = z[f"out{i}_sample"]
+        got = o.flatten()[::int(z[f"out{i}_step"])].numpy()
+        tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got, ref, atol=tol, rtol=1e-4)
+        np.testing.assert_allclose(o.double().abs().sum().item(), float(z[f"out{i}_abs_sum"]), rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", golden_names(["G7_"]))
+def test_model_matches_reference_on_gpu(name):
+    _check_model(name, torch.device("cuda:0"))
+
+
+def _check_train(name, dev):
+    """TRAIN-mode forward, input / parameter gradients and running-statistics update against the reference
+    (fixtures G11_*, tools/gen_golden_models.py::train_cases).  Tolerances: outputs 1e-4 of max; gradients 2e-3 of
+    the tensor's max (batch statistics over as few as 32 values amplify fp32 summation-order differences through
+    ~300 normalisation layers; the eval-mode goldens hold the 1e-4 bar)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg = json.loads(str(z["config_json"]))
+    if float(z["drop_path_rate"]) >= 0:
+        cfg["drop_path_rate"] = float(z["drop_path_rate"])
+    model = _build(name.replace("G11_train_", ""), cfg, int(z["experiment"]))
+    fill_state_dict_(model)
+    model.train().to(dev)
+    x = model_input(tuple(int(v) for v in z["input_shape"])).to(dev).requires_grad_(True)
+    outs = _flatten(model(x))
+    assert len(outs) == int(z["n_outputs"])
+    loss = _probe_loss(outs)
+    loss.backward()
+    for i, o in enumerate(outs):
+        o = o.detach().float().cpu()
+        assert list(o.shape) == list(z[f"out{i}_shape"])
+        ref = z[f"out{i}_sample"]
+        got = o.flatten()[::int(z[f"out{i}_step"])].numpy()
+        np.testing.assert_allclose(got, ref, atol=1e-4 * max(1.0, float(np.abs(ref).max())), rtol=1e-4)
+        np.testing.assert_allclose(o.double().abs().sum().item(), float(z[f"out{i}_abs_sum"]), rtol=1e-4)
+    np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-3, atol=1e-6)
+    gtol = 2e-3
+    dx = x.grad.float().cpu()
+    ref = z["dx_sample"]
+    np.testing.assert_allclose(dx.flatten()[::int(z["dx_step"])].numpy(), ref, atol=gtol * np.abs(ref).max())
+    names = json.loads(str(z["param_names_json"]))
+    params = dict(model.named_parameters())
+    assert list(params) == names
+    grads = [(params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])).float().cpu()
+             for k in names]
+    # tensors whose exact gradient is zero (a bias in front of a normalisation) hold round-off noise only: every
+    # tensor is measured against max(its own max, 1e-5 of the largest gradient in the model)
+    floor = 1e-5 * float(np.max(z["pgrad_abs_max"]))
+    for k, g, amax, asum, f4 in zip(names, grads, z["pgrad_abs_max"], z["pgrad_abs_sum"], z["pgrad_first4"]):
+        m = max(float(amax), floor)
+        assert abs(float(g.abs().max()) - float(amax)) <= 5 * gtol * m, (k, float(g.abs().max()), float(amax))
+        n4 = min(4, g.numel())
+        np.testing.assert_allclose(g.flatten()[:n4].numpy(), f4[:n4], atol=gtol * m, err_msg=k)
+        assert abs(g.double().abs().sum().item() - float(asum)) <= 5 * gtol * max(float(asum), floor * g.numel()), k
+    allg = torch.cat([g.flatten() for g in grads])
+    ref = z["pgrad_sample"]
+    got = allg[::int(z["pgrad_step"])].numpy()
+    # every sampled element against its OWN tensor's scale
+    bounds = np.repeat(np.maximum(z["pgrad_abs_max"], floor), [g.numel() for g in grads])[::int(z["pgrad_step"])]
+    assert np.all(np.abs(got - ref) <= gtol * bounds), float(np.max(np.abs(got - ref) / bounds))
+    stats = torch.cat([b.flatten().float().cpu() for k, b in model.named_buffers()
+                       if k.endswith("running_mean") or k.endswith("running_var")])
+    np.testing.assert_allclose(stats[::int(z["running_step"])].numpy(), z["running_sample"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", golden_names(["G11_train_"]))
+def test_train_mode_matches_reference(name):
+    _check_train(name, torch.device("cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", golden_names(["G11_train_"]))
+def test_train_mode_matches_reference_on_gpu(name):
+    _check_train(name, torch.device("cuda:0"))
+
+
 def test_hrnet_train_mode_backward_runs():
     from mscs_amd.models import HRNet
     cfg = {'backbone': 'hrnet18', 'pretrained': False, 'dataset': 'CITYSCAPES', 'align_corners': True,

@@ -90,7 +90,7 @@ def install():
         "torchvision.models", "torchvision.models._utils", "torchvision.datasets",
         "torchvision.datasets.cityscapes",
         "timm", "timm.models", "tsne_torch", "tensorboard", "h5py",
-        "torch.utils.tensorboard",
+        "torch.utils.tensorboard", "torch.utils.tensorboard.writer",
     ]:
         if name not in sys.modules:
             _stub(name)
