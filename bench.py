@@ -67,7 +67,11 @@ def parse():
                     help="cudnn.benchmark=True like the reference (BaseManager.py:122). OFF by default: on a fresh box "
                          "MIOpen's exhaustive fp32 solver search for HRNet-W48's ~300 conv shapes takes > 20 minutes")
     ap.add_argument("--eager-baseline", action="store_true",
-                    help="also time the eager-structure restatement of the loss on the GPU")
+                    help="also time the eager-structure restatement of the loss alone on the GPU")
+    ap.add_argument("--no-eager-step", action="store_true",
+                    help="skip eager_gpu_step_ms (the eager-structure reference step on the same GPU, N=1 only)")
+    ap.add_argument("--no-metrics", action="store_true",
+                    help="leave the per-step metrics tail (confusion matrix, accuracies, mIoU, logging) out of the step")
     return ap.parse_args()
 
 
@@ -259,15 +263,22 @@ def cpu_baseline_loss(args, n_terms):
     s = min(2, args.scales - 1)
     feat = torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).requires_grad_(True)
     torch.manual_seed(0)
-    t0 = time.perf_counter()
-    bank, classes = eager_torch.sample_bank(label, feat, 20, 5, 2500, 2500)
-    l = eager_torch.intra_loss(bank, classes, 0.1)
-    l.backward()
-    dt = time.perf_counter() - t0
-    N = bank.shape[0] * bank.shape[2]
-    scale = n_terms * (9804.0 / N) ** 2
-    return scale, dt, threads, (f"loss: 1 intra-scale term at N={N} (max_features_total=2500) fwd+bwd, eager torch "
-                                f"fp32 on {threads} host threads, scaled by {n_terms} terms x (9804/{N})^2")
+    times, N = [], 0
+    for it in range(4):                                    # 1 warm-up + 3 measured, same inputs
+        feat.grad = None
+        t0 = time.perf_counter()
+        bank, classes = eager_torch.sample_bank(label, feat, 20, 5, 2500, 10000)
+        l = eager_torch.intra_loss(bank, classes, 0.1)
+        l.backward()
+        if it:
+            times.append(time.perf_counter() - t0)
+        N = bank.shape[0] * bank.shape[2]
+    dt = sorted(times)[1]
+    return float(n_terms), dt, threads, (
+        f"loss: ONE full intra-scale term (stride {4 << s}, N={N}, the workload's own cap) fwd+bwd, eager torch fp32 "
+        f"on {threads} host threads, median of 3 after 1 warm-up = {dt:.2f} s; multiplied by the workload's "
+        f"{n_terms} terms (all N x N with N = {N}; the stride-4 / 8 terms gather from larger maps, so this "
+        f"under-states the CPU time)")
 
 
 def cpu_baseline_model(args):
@@ -285,15 +296,19 @@ def cpu_baseline_model(args):
     img = torch.randn(1, 3, args.height, args.width, generator=gen)
     lbl = torch.randint(0, 20, (1, args.height, args.width), generator=gen)
     ce = torch.nn.CrossEntropyLoss(ignore_index=19)
-    t0 = time.perf_counter()
-    out, proj = model(img)
-    loss = ce(out, lbl) + sum(p.mean() for p in proj) * 0.0
-    opt.zero_grad()
-    loss.backward()
-    opt.step()
-    dt = time.perf_counter() - t0
-    return dt, (f"model: HRNet-W48 + projector + CE fwd+bwd+SGD on 1 image {args.height}x{args.width}, torch CPU "
-                f"fp32 on {threads} threads, scaled by batch {args.batch}")
+    times = []
+    for it in range(4):                                    # 1 warm-up + 3 measured
+        t0 = time.perf_counter()
+        out, proj = model(img)
+        loss = ce(out, lbl) + sum(p.mean() for p in proj) * 0.0
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if it:
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
+    return dt, (f"model: HRNet-W48 + projector + CE fwd+bwd+SGD on ONE image {args.height}x{args.width}, torch CPU "
+                f"fp32 on {threads} threads, median of 3 after 1 warm-up = {dt:.2f} s; multiplied by batch {args.batch}")
 
 
 def workload_name(args, workload):
@@ -335,18 +350,25 @@ def time_train_step(args, dev, rank, world):
     mgr.model.train()
     gen = torch.Generator().manual_seed(1000 * rank)
     img = torch.randn(args.batch, 3, args.height, args.width, generator=gen).to(dev)
-    lbl = torch.randint(0, 20, (args.batch, args.height, args.width), generator=gen, dtype=torch.int32).to(dev)
+    lbl = torch.randint(0, 20, (args.batch, args.height, args.width), generator=gen).to(dev)    # int64, as loaded
     if args.channels_last:
         img = img.contiguous(memory_format=torch.channels_last)
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if args.amp else contextlib.nullcontext()
+    torch.cuda.synchronize()
+    ready = torch.cuda.Event()          # inputs are resident before the timed region: "label complete" has fired
+    ready.record()
 
-    def step():
+    def step(i=0):
+        # exactly BaseManager.train_one_epoch's loop body on a resident batch: forward, loss, backward, SGD, LR
+        # schedule, then the per-step metrics tail of the reference (HRNet_Manager.py:117-121)
         mgr.optimiser.zero_grad(set_to_none=True)
         with amp:
-            ret = mgr.forward_step(img, lbl)
+            ret = mgr.forward_step(img, lbl, label_ready=ready)
         ret["loss"].backward()
         mgr.optimiser.step()
         mgr.scheduler.step()
+        if not args.no_metrics:
+            mgr.step_metrics(1, ret, lbl, 0.0)
         return ret
 
     for _ in range(args.warmup):
@@ -357,11 +379,14 @@ def time_train_step(args, dev, rank, world):
         step()
     sync(world)
     dt = time.perf_counter() - t0
+    mgr.flush_logging()
     mod = mgr.loss.loss_classes["DenseContrastiveLossV2_ms"]
     extra = {"contrastive_loss_fwd_bwd_ms": round(loss_only_ms(mod, dev, args), 3),
+             "metrics_in_step": not args.no_metrics,
              "model_dtype": "bf16-autocast" if args.amp else "f32",
              "memory_format": "channels_last" if args.channels_last else "contiguous",
              "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    del mgr
     return dt, mod, extra
 
 
@@ -420,7 +445,8 @@ def main():
         out = {
             "metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (f16x3-emulated)" if (MFMA_MODE or "f16x3") == "f16x3" else "f32",
             "data": "synthetic",
             "config": {"workload": workload_name(args, workload),
                        "terms": [[t.a, t.b, st_n(mod, t.a), st_n(mod, t.b)] for t in mod.last_state.terms]},
@@ -447,10 +473,61 @@ def main():
                                        "sample_seconds": round(msec + lsec, 2)}
         if args.eager_baseline:
             out["eager_gpu_loss_ms"] = round(eager_gpu_loss_ms(args, dev), 2)
+        if workload == "step" and world == 1 and not args.no_eager_step:
+            torch.cuda.empty_cache()
+            eager_ms = eager_gpu_step_ms(args, dev)
+            out["eager_gpu_step_ms"] = round(eager_ms, 1)
+            out["speedup_vs_eager_gpu_step"] = round(eager_ms / ms_per_step, 2)
+            out["eager_gpu_step_note"] = ("same architecture on stock PyTorch-ROCm kernels (MIOpen / ATen, one stream) + "
+                                          "eager-structure contrastive loss (oracle/eager_torch.py) + SGD, same GPU, "
+                                          "median of 3 after 1 warm-up; BASELINE.json target: >= 5x")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def eager_gpu_step_ms(args, dev, iters=3):
+    """The "reference PyTorch-eager GPU step" of BASELINE.json's >= 5x target (SURVEY.md section 8 row d), measured
+    on THIS MI355X in the same run: the same HRNet-W48 + projector architecture on stock PyTorch-ROCm kernels only
+    (MIOpen convolutions and batch norm, ATen interpolate, one stream; mscs_amd.models.ops.library_kernels_only),
+    torch's CrossEntropyLoss, and the eager-structure restatement of the contrastive loss (oracle/eager_torch.py:
+    the reference's per-(image, class) Python loop with .item() indexing, nonzero, host randperm, N x N matrices
+    and autograd index-backward), SGD step.  Same batch, same labels; median of ``iters`` after one warm-up step
+    (which also absorbs MIOpen's kernel selection)."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import HRNet
+    from mscs_amd.models.ops import library_kernels_only
+    from oracle import eager_torch
+    S = args.scales
+    graph = {"backbone": "hrnet48", "pretrained": False, "dataset": "CITYSCAPES", "align_corners": True,
+             "branch_conv": "library", "head_conv": "library", "fused_bn": False, "gemm_conv1x1": False,
+             "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True}}
+    torch.backends.cudnn.benchmark = False
+    model = HRNet(graph, 1).to(dev).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+    gen = torch.Generator().manual_seed(0)
+    img = torch.randn(args.batch, 3, args.height, args.width, generator=gen).to(dev)
+    lbl = torch.randint(0, 20, (args.batch, args.height, args.width), generator=gen).to(dev)
+    ce = torch.nn.CrossEntropyLoss(ignore_index=19)
+    w = [1.0, 0.7, 0.4, 0.1][:S]
+    times = []
+    with library_kernels_only():
+        for it in range(iters + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            out, proj = model(img)
+            dc, _, _ = eager_torch.dcv2_ms(lbl, proj, 20, 0.1, w, cross=not args.no_cross)
+            loss = ce(out, lbl) + 0.1 * dc
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            if it:
+                times.append((time.perf_counter() - t0) * 1e3)
+    del model, opt
+    torch.cuda.empty_cache()
+    return sorted(times)[len(times) // 2]
 
 
 def st_n(mod, s):

@@ -62,6 +62,7 @@ SIGNATURES = {
     "dcl_conv3x3_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "dcl_wgrad3x3_splits": [_i, _i, _i, _i, _i],
     "dcl_wgrad3x3_f16x3": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],
+    "dcl_confusion_matrix": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp],
     "dcl_suggest_nsplit": [_i, _i],
     "dcl_version": [],
 }

@@ -48,7 +48,7 @@ class DenseContrastiveLossV2_ms(nn.Module):
             printlog(f'using cross-scale contrast with detach_cs_deepest set to {self.detach_cs_deepest}, '
                      f'w_high_low: {self.w_high_low}, w_high_mid: {self.w_high_mid}')
 
-    def prepare(self, label: torch.Tensor):
+    def prepare(self, label: torch.Tensor, ready_event=None):
         """Optional, call BEFORE the model forward is enqueued: runs the label stage (stride-sample +
         class histograms of every scale, 960-byte D2H) on a side stream so that it -- and the host-side
         sampling plan that needs its result -- overlap the model forward instead of waiting behind it.
@@ -60,7 +60,7 @@ class DenseContrastiveLossV2_ms(nn.Module):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=label.device)
         self._staged = stage_labels(int(self.DCV2_scale0.num_all_classes), label, geoms,
-                                    side_stream=self._side_stream)
+                                    side_stream=self._side_stream, ready_event=ready_event)
         return True
 
     def forward(self, label: torch.Tensor, features: list, **kwargs):

@@ -46,14 +46,14 @@ class LossWrapper(nn.Module):
         self.info_string = self.info_string[:-2]
         self.dc_off = True if 'dc_off_at_epoch' in self.config else False
 
-    def prepare(self, labels: torch.Tensor):
+    def prepare(self, labels: torch.Tensor, ready_event=None):
         """Forward the label tensor to components that can start work before the model forward
         (DenseContrastiveLossV2_ms.prepare).  Optional; not part of the reference surface."""
         if labels.dtype != torch.int64:       # forward() would see a different (converted) tensor
             return
         for fn in self.loss_classes.values():
             if hasattr(fn, 'prepare'):
-                fn.prepare(labels)
+                fn.prepare(labels, ready_event=ready_event)
 
     def _zero(self):
         return torch.tensor(0.0, dtype=torch.float, device=self.device)

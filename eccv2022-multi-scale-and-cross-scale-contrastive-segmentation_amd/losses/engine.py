@@ -112,21 +112,30 @@ class _PinnedRing:
     """Persistent pinned host staging buffers.  Allocating pinned memory per step (hipHostMalloc) costs
     tens of milliseconds whenever the host allocator cannot recycle a block that is still in flight,
     so the loss keeps a small ring of grow-only buffers instead.  A slot is reused every ``depth``
-    uses; every use is followed (stream-ordered) by the next step's label stage, whose completion the
-    host waits for before it writes the following slot."""
+    uses; ``release_after(event)`` ties the slot handed out last to an event (recorded after the
+    asynchronous copy that reads it), and ``get`` waits for that event before it hands the slot out
+    again -- the host may run several steps ahead of the GPU (nothing else in a training step makes
+    it wait), so "it was three steps ago" is not a guarantee that the copy has happened."""
 
     def __init__(self, dtype, depth=3):
         self.dtype, self.depth = dtype, depth
         self.slots = [None] * depth
+        self.events = [None] * depth
         self.i = 0
 
     def get(self, numel: int) -> torch.Tensor:
         self.i = (self.i + 1) % self.depth
+        if self.events[self.i] is not None:
+            self.events[self.i].synchronize()
+            self.events[self.i] = None
         buf = self.slots[self.i]
         if buf is None or buf.numel() < numel:
             buf = torch.empty((max(numel, 1) * 3 // 2 + 64,), dtype=self.dtype, pin_memory=True)
             self.slots[self.i] = buf
         return buf[:numel]
+
+    def release_after(self, event):
+        self.events[self.i] = event
 
 
 _PACK_RING = _PinnedRing(torch.int32)
@@ -204,10 +213,13 @@ def feature_geometry(label_shape, feats: Sequence[torch.Tensor]):
     return geoms
 
 
-def stage_labels(K: int, label: torch.Tensor, geoms, side_stream=None) -> StagedLabels:
+def stage_labels(K: int, label: torch.Tensor, geoms, side_stream=None, ready_event=None) -> StagedLabels:
     """K1 for every scale + asynchronous D2H of the [S, n, K] histogram into pinned memory.
-    With ``side_stream`` the work is enqueued there (after everything already queued on the current
-    stream), so it overlaps whatever the caller enqueues next on the current stream."""
+    With ``side_stream`` the work is enqueued there, so it overlaps whatever the caller enqueues next on the
+    current stream.  It starts after ``ready_event`` (an event recorded once the label tensor is complete, e.g.
+    right after its H2D copy) or, without one, after everything already queued on the current stream -- the
+    event form lets the label stage (and the host-side plan that waits for it) run while the GPU is still busy
+    with the PREVIOUS step, so the host never waits for the device inside a training step."""
     L = _lib.lib()
     if not 0 < K <= _lib.MAX_CLASSES:
         raise RuntimeError(f"num_all_classes={K} outside the supported range [1, 255]")
@@ -221,7 +233,10 @@ def stage_labels(K: int, label: torch.Tensor, geoms, side_stream=None) -> Staged
     cur = torch.cuda.current_stream()
     run = side_stream if side_stream is not None else cur
     if side_stream is not None:
-        side_stream.wait_stream(cur)                # label is produced on the current stream
+        if ready_event is not None:
+            side_stream.wait_event(ready_event)     # the label is complete once this event has fired
+        else:
+            side_stream.wait_stream(cur)            # label is produced on the current stream
         label.record_stream(side_stream)
     with torch.cuda.stream(run):
         stream = ctypes.c_void_p(run.cuda_stream)
@@ -328,6 +343,9 @@ def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torc
     pack_host = _PACK_RING.get(total)
     np.concatenate(chunks, out=pack_host.numpy())
     pack = pack_host.to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _PACK_RING.release_after(ev)
     st.keepalive += [pack_host, pack]
 
     def view(idx):
@@ -424,6 +442,9 @@ def attach_global_segments(st: StepState, rank: int, peer_banks, peer_layouts):
     pack_host = _PACK_RING.get(sum(c.size for c in chunks))
     np.concatenate(chunks, out=pack_host.numpy())
     pack = pack_host.to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _PACK_RING.release_after(ev)
     st.keepalive += [pack_host, pack]
 
     def view(idx):

@@ -29,7 +29,7 @@ from ..losses import LossWrapper
 from ..utils import DATASETS_INFO, printlog
 from ..utils.config import parse_config
 from ..utils.lr_functions import LRFcts
-from ..utils.metrics import t_get_confusion_matrix, t_get_mean_iou, t_get_pixel_accuracy
+from ..utils.metrics import out_of_range, t_get_confusion_matrix, t_get_mean_iou, t_get_pixel_accuracy
 
 
 def set_seeds(seed):
@@ -236,43 +236,96 @@ class BaseManager:
         if self.parallel and dist.is_initialized():
             dist.barrier()
 
+    def _upload(self, img, lbl):
+        """H2D of a batch on a dedicated input stream (+ the label's int64 conversion), and the event that marks
+        it complete: the loss's label stage waits for THAT event only (engine.stage_labels), so it -- and the host
+        plan built from it -- can run while the GPU is still in the previous step's backward."""
+        if self.device.type != 'cuda':
+            return img.to(self.device), lbl.to(self.device), None
+        if getattr(self, '_in_stream', None) is None:
+            self._in_stream = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._in_stream):
+            img = img.to(self.device, non_blocking=True)
+            lbl = lbl.to(self.device, non_blocking=True).long()
+            ready = torch.cuda.Event()
+            ready.record(self._in_stream)
+        cur.wait_event(ready)
+        img.record_stream(cur)
+        lbl.record_stream(cur)
+        return img, lbl, ready
+
     def train_one_epoch(self):
         self.model.train()
         t_prev = time.perf_counter()
         for batch_num, batch in enumerate(self.data_loaders[self.train_schedule[self.epoch]]):
-            img, lbl = batch[0], batch[1]
-            img = img.to(self.device, non_blocking=True)
-            lbl = lbl.to(self.device, non_blocking=True)
+            img, lbl, ready = self._upload(batch[0], batch[1])
             self.optimiser.zero_grad()
-            ret = self.forward_step(img, lbl)
+            ret = self.forward_step(img, lbl, label_ready=ready)
             ret['loss'].backward()
             self.optimiser.step()
             if self.scheduler is not None and self.config['train']['lr_batchwise']:
                 self.scheduler.step()
             if batch_num == 2 and self.debugging:
                 break
-            cm = t_get_confusion_matrix(ret['output'], lbl, self.dataset)
-            pa, pac = t_get_pixel_accuracy(cm)
-            miou = t_get_mean_iou(cm)
-            now = time.perf_counter()
-            self.train_logging(batch_num, ret['loss'], pa, pac, miou, (now - t_prev) * 1e3)
-            t_prev = now
+            self.step_metrics(batch_num, ret, lbl, (time.perf_counter() - t_prev) * 1e3)
+            t_prev = time.perf_counter()
             self.global_step += 1
+        self.flush_logging()
         if self.scheduler is not None and not self.config['train']['lr_batchwise']:
             self.scheduler.step()
 
+    def step_metrics(self, batch_num, ret, lbl, ms):
+        """The per-step tail of the reference's loop (HRNet_Manager.py:117-121): confusion matrix (one HIP pass over
+        the logits, utils/metrics.py), pixel accuracies, mIoU, logging."""
+        cm = t_get_confusion_matrix(ret['output'], lbl, self.dataset)
+        pa, pac = t_get_pixel_accuracy(cm)
+        miou = t_get_mean_iou(cm)
+        self.train_logging(batch_num, ret['loss'], pa, pac, miou, ms)
+
     def train_logging(self, batch_num, loss, pa, pac, miou, ms):
-        """One D2H for all scalars of the step (the reference issues one .item() per logged value)."""
+        """All scalars of the step travel in ONE asynchronous D2H (the reference issues one blocking .item() per
+        logged value) and are read one step LATER, when the copy has long finished: the host never waits for the
+        device here.  ``self.metrics`` therefore describes the previous step until ``flush_logging()``."""
         keys, vals = ['loss', 'pa', 'pac', 'miou'], [loss.detach().float(), pa, pac, miou]
         if isinstance(self.loss, LossWrapper):
             for k, v in self.loss.loss_vals.items():
                 if torch.is_tensor(v):
                     keys.append(k)
                     vals.append(v.float())
-        host = torch.stack([v.reshape(()) for v in vals]).cpu().tolist()
-        self.metrics.update(zip(keys, host))
+        if loss.is_cuda:          # targets outside the class range, counted by the confusion-matrix kernel
+            keys.append('_oob')
+            vals.append(out_of_range(loss.device).float())
+        dev_vals = torch.stack([v.reshape(()) for v in vals])
+        self.flush_logging()                                        # the PREVIOUS step's record
+        if loss.is_cuda:
+            host = getattr(self, '_log_host', None)
+            if host is None or host.numel() < dev_vals.numel():
+                host = self._log_host = torch.empty(max(64, dev_vals.numel()), dtype=torch.float32, pin_memory=True)
+            host[:dev_vals.numel()].copy_(dev_vals, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._log_pending = (keys, host, dev_vals.numel(), ev, batch_num, ms)
+        else:
+            self._log_pending = (keys, dev_vals, dev_vals.numel(), None, batch_num, ms)
+            self.flush_logging()
+
+    def flush_logging(self):
+        pend, self._log_pending = getattr(self, '_log_pending', None), None
+        if pend is None:
+            return
+        keys, host, n, ev, batch_num, ms = pend
+        if ev is not None:
+            ev.synchronize()
+        vals = host[:n].tolist()
+        if keys[-1] == '_oob':
+            keys = keys[:-1]
+            if vals.pop() > 0:
+                raise RuntimeError('Class values must be smaller than num_classes.')   # F.one_hot's error in the
+                # reference's t_get_confusion_matrix (utils/torch_utils.py:172-177), reported one step late
+        self.metrics.update(zip(keys, vals))
         if self.rank == 0 and (batch_num % self.config.get('log_every_n_steps', 10) == 0):
-            terms = ' '.join(f'{k}:{v:.4f}' for k, v in self.metrics.items())
+            terms = ' '.join(f'{k}:{v:.4f}' for k, v in zip(keys, vals))
             printlog(f'ep {self.epoch} it {batch_num} t:{ms:.0f}ms {terms}')
 
     @torch.no_grad()

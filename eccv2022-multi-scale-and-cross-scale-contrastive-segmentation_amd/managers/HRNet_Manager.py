@@ -14,7 +14,9 @@ class HRNetManager(BaseManager):
         if isinstance(self.loss, LossWrapper):
             lbl = lbl.long()                      # converted once so that prepare() and forward() see one tensor
             if self.return_features and self.model.training:
-                self.loss.prepare(lbl)            # label stage on a side stream, overlaps the model forward
+                # label stage on a side stream: overlaps the model forward and, given the label's ready event,
+                # the tail of the previous step as well
+                self.loss.prepare(lbl, ready_event=kwargs.get('label_ready'))
             if self.return_features:
                 output, proj_features = self.model(img.float())
                 loss = self.loss(output, lbl.long(), deep_features=proj_features, epoch=self.epoch,

@@ -79,12 +79,35 @@ class _UpsampleBilinear(torch.autograd.Function):
         return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None
 
 
+HIP_UPSAMPLE = True        # False: F.interpolate everywhere (library_kernels_only(), the eager comparator of bench.py)
+
+
+class library_kernels_only:
+    """Context manager for the eager-structure comparator (bench.py ``eager_gpu_step_ms``): inside it the model code
+    of this package runs on stock PyTorch-ROCm kernels only -- F.interpolate instead of the HIP resize kernels and
+    one stream instead of one per HRNet branch.  (The convolution / norm classes are selected at construction:
+    graph keys branch_conv='library', head_conv='library', fused_bn=False, gemm_conv1x1=False.)"""
+
+    def __enter__(self):
+        from . import HRNet as _h
+        global HIP_UPSAMPLE
+        self.prev = (HIP_UPSAMPLE, _h._BRANCH_STREAMS)
+        HIP_UPSAMPLE, _h._BRANCH_STREAMS = False, False
+        return self
+
+    def __exit__(self, *exc):
+        from . import HRNet as _h
+        global HIP_UPSAMPLE
+        HIP_UPSAMPLE, _h._BRANCH_STREAMS = self.prev
+        return False
+
+
 def upsample_bilinear(x, size, align_corners, add=None):
     """``add + F.interpolate(x, size, mode='bilinear', align_corners=...)`` (``add`` optional) on the HIP
     kernels of csrc/dcl_resize.hip for CUDA / float32 / contiguous NCHW inputs (16-B stores forward with the
     addend folded in, deterministic gather backward); PyTorch's own kernels otherwise."""
     H, W = int(size[0]), int(size[1])
-    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() \
+    if HIP_UPSAMPLE and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() \
             and not torch.is_autocast_enabled() and (H, W) != tuple(x.shape[-2:]) \
             and (add is None or (add.is_contiguous() and add.dtype == torch.float32
                                  and tuple(add.shape) == tuple(x.shape[:2]) + (H, W))):

@@ -283,6 +283,20 @@ int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout
                        int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,
                        void *stream);
 
+/* ---- per-step metrics -----------------------------------------------------
+ * Confusion matrix of argmax(logits, dim=1) against the target, rows = predicted class, columns = target class:
+ * replaces t_get_confusion_matrix (reference utils/torch_utils.py:157-183: transpose copy + argmax + two one-hot
+ * matrices + float matmul, called after every training step, managers/HRNet_Manager.py:117-121) by one pass over
+ * the logits (csrc/dcl_metrics.hip).  Integer arithmetic: bit-exact.
+ *   logits  f32 [N, C, HW] (NCHW contiguous)       target  int64 | int32 | uint8 [N, HW] (target_bytes = 8 | 4 | 1)
+ *   cols    C, or C + 1 when the dataset's experiment has an ignore id (the reference one-hots the target with
+ *           C + 1 classes and drops the last column afterwards, :172-175)
+ *   cm      int32 [C, cols], ACCUMULATED into (zero it for a fresh matrix; pass a running one for existing_matrix)
+ *   oob     int32 [1], accumulated count of targets outside [0, cols) (the reference's one_hot raises on them)
+ * argmax follows torch: first maximal index, NaN is maximal. */
+int dcl_confusion_matrix(const float *logits, int N, int C, int HW, const void *target, int target_bytes,
+                         int cols, int32_t *cm, int32_t *oob, void *stream);
+
 /* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the
  * grid fills the 256 CUs evenly (host helper, no device work). */
 int dcl_suggest_nsplit(int N1, int N2);

@@ -446,3 +446,41 @@ def dcv2_ms_global(labels, features, cfg: LossConfig, seeds, rank: int, dtype=np
     grads = [scatter_grad(normalize_backward(Xs[rank][s], dF[s]), plans[rank][s], features[rank][s].shape)
              for s in range(S)]
     return Result(float(total), ms, cs, plans[rank], grads, [p.log_this_step for p in plans[rank]])
+
+
+# ---- per-step metrics -------------------------------------------------------------
+
+def confusion_matrix(logits: np.ndarray, target: np.ndarray, with_ignore: bool) -> np.ndarray:
+    """t_get_confusion_matrix (utils/torch_utils.py:157-183), restated with integer arithmetic:
+    p = argmax over C (first maximal index, NaN maximal -- torch.argmax); one_hot(target, C + 1)[:, :-1] when the
+    experiment has an ignore class (:172-175) else one_hot(target, C); cm = one_hot(p)^T @ one_hot(t) -> int32
+    [C, C], rows = predicted, columns = target.  Targets outside the one-hot range raise, like F.one_hot."""
+    n, C = logits.shape[0], logits.shape[1]
+    flat = np.moveaxis(logits.reshape(n, C, -1), 1, 0).reshape(C, -1)          # :163-164
+    nan = np.isnan(flat)
+    key = np.where(nan, np.inf, flat)
+    pred = np.argmax(key, axis=0)                                               # first maximum; NaN first among NaNs
+    t = target.reshape(-1).astype(np.int64)
+    cols = C + 1 if with_ignore else C
+    if t.size and (t.min() < 0 or t.max() >= cols):
+        raise RuntimeError("Class values must be smaller than num_classes.")
+    cm = np.bincount(pred * cols + t, minlength=C * cols).reshape(C, cols)[:, :C]
+    return cm.astype(np.int32)
+
+
+def pixel_accuracy(cm: np.ndarray):
+    """t_get_pixel_accuracy (utils/torch_utils.py:201-213), fp32."""
+    diag = np.diag(cm).astype(np.float32)
+    acc = diag.sum(dtype=np.float32) / np.float32(cm.sum())
+    rows = cm.sum(1).astype(np.float32)
+    rows[rows == 0] = 1
+    return np.float32(acc), np.float32(np.mean(diag / rows, dtype=np.float32))
+
+
+def mean_iou(cm: np.ndarray) -> np.float32:
+    """t_get_miou over all classes (utils/torch_utils.py:253-283): NaN IoU -> 0 and kept in the mean."""
+    diag = np.diag(cm).astype(np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        iou = diag / (cm.sum(0).astype(np.float32) + cm.sum(1).astype(np.float32) - diag)
+    iou[np.isnan(iou)] = 0
+    return np.float32(iou.mean(dtype=np.float32))
