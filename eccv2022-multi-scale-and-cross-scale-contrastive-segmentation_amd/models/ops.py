@@ -89,14 +89,16 @@ class library_kernels_only:
     graph keys branch_conv='library', head_conv='library', fused_bn=False, gemm_conv1x1=False.)"""
 
     def __enter__(self):
-        from . import HRNet as _h
+        import importlib
+        _h = importlib.import_module(__package__ + '.HRNet')        # the module (the package exports the class too)
         global HIP_UPSAMPLE
         self.prev = (HIP_UPSAMPLE, _h._BRANCH_STREAMS)
         HIP_UPSAMPLE, _h._BRANCH_STREAMS = False, False
         return self
 
     def __exit__(self, *exc):
-        from . import HRNet as _h
+        import importlib
+        _h = importlib.import_module(__package__ + '.HRNet')
         global HIP_UPSAMPLE
         HIP_UPSAMPLE, _h._BRANCH_STREAMS = self.prev
         return False

@@ -93,7 +93,9 @@ def _run_case(dev, case, mfma, S, cross, weights):
     for s in range(S):
         g, r = feats[s].grad, ref_feats[s].grad
         scale = r.abs().max().item()
-        assert scale > 0
+        if scale == 0:                          # a scale no weighted term touches (cross-scale-only weights)
+            assert g.abs().max().item() == 0
+            continue
         err = (g - r).abs().max().item()
         assert err <= GRAD_ATOL_REL * scale, (case, s, err, scale)
         assert torch.equal(g != 0, r != 0) or ((g != 0) & (r == 0)).sum().item() == 0     # support = sampled pixels

@@ -61,7 +61,7 @@ def flatten(out):
 # Stochastic layers are switched off (Dropout2d rate 0, Swin drop_path_rate 0: DropPath is third-party timm code the
 # reference does not pin), everything else is the shipped architecture.
 TRAIN_CASES = {
-    "G11_train_hrnet48_ms4": dict(cls="HRNet", shape=(2, 3, 128, 128), cfg=CASES["G7_hrnet48_ms4"]["cfg"], exp=1),
+    "G11_train_hrnet48_ms4": dict(cls="HRNet", shape=(2, 3, 128, 256), cfg=CASES["G7_hrnet48_ms4"]["cfg"], exp=1),
     "G11_train_upernet_swinT_fpn": dict(cls="UPerNet", shape=(2, 3, 64, 64), drop_path=0.0, cfg={
         'backbone': 'swinT', 'pretrained': False, 'dataset': 'ADE20K', 'align_corners': False, 'out_stride': 4,
         'aux_head': {'in_index': 2, 'dropout_rate': 0.0, 'out_channels': 256}, 'dropout_rate': 0.0,
@@ -83,53 +83,70 @@ def strided(flat, n=4096):
     return flat[::step].numpy().copy(), step
 
 
+def _train_run(model, x, dtype):
+    """One train-mode forward + backward of the probe loss in ``dtype``; returns the record of samples."""
+    model = model.to(dtype).train()
+    x = x.detach().to(dtype).requires_grad_(True)
+    outs = flatten(model(x))
+    loss = 0.0
+    for i, o in enumerate(outs):
+        pat = torch.cos(torch.arange(o.numel(), dtype=torch.float32) * 0.37 + i).view(o.shape).to(dtype)
+        loss = loss + (o * pat).mean()
+    loss.backward()
+    d = {"loss": np.float64(loss.item())}
+    for i, o in enumerate(outs):
+        d[f"out{i}_shape"] = np.array(o.shape, dtype=np.int32)
+        d[f"out{i}_abs_sum"] = np.float64(o.detach().double().abs().sum().item())
+        d[f"out{i}_sample"], d[f"out{i}_step"] = strided(o.detach().float().flatten())
+    d["dx_sample"], d["dx_step"] = strided(x.grad.float().flatten())
+    d["dx_abs_sum"] = np.float64(x.grad.double().abs().sum().item())
+    names, asum, amax, first = [], [], [], []
+    for k, p in model.named_parameters():
+        g = (p.grad if p.grad is not None else torch.zeros_like(p)).float()
+        names.append(k)
+        asum.append(g.double().abs().sum().item())
+        amax.append(g.abs().max().item())
+        first.append(g.flatten()[:4].tolist() + [0.0] * max(0, 4 - g.numel()))
+    d["param_names_json"] = np.array(json.dumps(names))
+    d["pgrad_abs_sum"] = np.array(asum, dtype=np.float64)
+    d["pgrad_abs_max"] = np.array(amax, dtype=np.float32)
+    d["pgrad_first4"] = np.array(first, dtype=np.float32)
+    allg = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).float().flatten()
+                      for _, p in model.named_parameters()])
+    d["pgrad_sample"], d["pgrad_step"] = strided(allg, 16384)
+    stats = torch.cat([b.flatten().float() for k, b in model.named_buffers()
+                       if k.endswith("running_mean") or k.endswith("running_var")])
+    d["running_sample"], d["running_step"] = strided(stats, 8192)
+    return d, len(outs), [tuple(o.shape) for o in outs]
+
+
 def train_cases(only):
+    """Each case is run twice by the reference code: in fp32 (what the reference computes; the CPU test matches it
+    to round-off because it runs the same ATen kernels) and in fp64 (keys ``f64_*``: the same computation without
+    rounding noise -- train-mode statistics over few values amplify fp32 summation-order differences, so GPU
+    kernels are judged by their distance to THIS, next to the distance of stock fp32 GPU kernels)."""
     import importlib
     ref_upernet = importlib.import_module("models.UPerNet")
     for name, case in TRAIN_CASES.items():
         if only and not any(o in name for o in only):
             continue
-        cfg = json.loads(json.dumps(case["cfg"]))
-        if "drop_path" in case:
-            ref_upernet.backbone_config_swin[cfg["backbone"]]["drop_path_rate"] = case["drop_path"]
-        model = {"HRNet": HRNet, "UPerNet": UPerNet}[case["cls"]](config=cfg, experiment=case["exp"])
-        fill_state_dict_(model)
-        model.train()
-        x = model_input(case["shape"]).requires_grad_(True)
-        outs = flatten(model(x))
-        loss = probe_loss(outs)
-        loss.backward()
+        recs = {}
+        for tag, dtype in (("", torch.float32), ("f64_", torch.float64)):
+            cfg = json.loads(json.dumps(case["cfg"]))
+            if "drop_path" in case:
+                ref_upernet.backbone_config_swin[cfg["backbone"]]["drop_path_rate"] = case["drop_path"]
+            model = {"HRNet": HRNet, "UPerNet": UPerNet}[case["cls"]](config=cfg, experiment=case["exp"])
+            fill_state_dict_(model)
+            rec, n_out, shapes = _train_run(model, model_input(case["shape"]), dtype)
+            recs.update({tag + k: v for k, v in rec.items()})
         d = {"config_json": np.array(json.dumps(case["cfg"])), "experiment": np.int32(case["exp"]),
-             "input_shape": np.array(case["shape"], dtype=np.int32), "n_outputs": np.int32(len(outs)),
-             "drop_path_rate": np.float32(case.get("drop_path", -1.0)), "loss": np.float64(loss.item()),
-             "torch_version": np.array(torch.__version__)}
-        for i, o in enumerate(outs):
-            d[f"out{i}_shape"] = np.array(o.shape, dtype=np.int32)
-            d[f"out{i}_abs_sum"] = np.float64(o.detach().double().abs().sum().item())
-            d[f"out{i}_sample"], d[f"out{i}_step"] = strided(o.detach().flatten())
-        d["dx_sample"], d["dx_step"] = strided(x.grad.flatten())
-        d["dx_abs_sum"] = np.float64(x.grad.double().abs().sum().item())
-        names, asum, amax, first = [], [], [], []
-        for k, p in model.named_parameters():
-            g = p.grad if p.grad is not None else torch.zeros_like(p)
-            names.append(k)
-            asum.append(g.double().abs().sum().item())
-            amax.append(g.abs().max().item())
-            first.append(g.flatten()[:4].tolist() + [0.0] * max(0, 4 - g.numel()))
-        d["param_names_json"] = np.array(json.dumps(names))
-        d["pgrad_abs_sum"] = np.array(asum, dtype=np.float64)
-        d["pgrad_abs_max"] = np.array(amax, dtype=np.float32)
-        d["pgrad_first4"] = np.array(first, dtype=np.float32)
-        allg = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten()
-                          for _, p in model.named_parameters()])
-        d["pgrad_sample"], d["pgrad_step"] = strided(allg, 16384)
-        stats = torch.cat([b.flatten().float() for k, b in model.named_buffers()
-                           if k.endswith("running_mean") or k.endswith("running_var")])
-        d["running_sample"], d["running_step"] = strided(stats, 8192)
+             "input_shape": np.array(case["shape"], dtype=np.int32), "n_outputs": np.int32(n_out),
+             "drop_path_rate": np.float32(case.get("drop_path", -1.0)), "torch_version": np.array(torch.__version__)}
+        d.update(recs)
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **d)
-        _print(f"wrote {path} ({os.path.getsize(path) // 1024} KiB), loss {loss.item():.6f}, outputs: "
-               f"{[tuple(o.shape) for o in outs]}")
+        _print(f"wrote {path} ({os.path.getsize(path) // 1024} KiB), loss f32 {d['loss']:.6f} f64 {d['f64_loss']:.6f}, "
+               f"outputs: {shapes}")
 
 
 def main():
