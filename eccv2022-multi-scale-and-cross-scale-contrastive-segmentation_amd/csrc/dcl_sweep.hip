@@ -18,6 +18,8 @@
 // :132-161; and the autograd backward of all of them.
 #include <limits.h>
 
+#include <type_traits>
+
 #include "dcl_common.h"
 
 namespace {
@@ -63,6 +65,32 @@ struct SweepArgs {
     float *dpart;          // MODE_BWD out: [nsplit, N1pad, CP]
 };
 
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to the wave-uniform LDS address
+// `lds_dst` + lane * 16.  Issued through inline asm ON PURPOSE: hipcc tracks a builtin LDS-DMA as a pending LDS write
+// and puts `s_waitcnt vmcnt(0)` in front of the next ds_read that may alias it -- i.e. directly behind the prefetch,
+// which exposes the whole DMA latency in every chunk (measured: 41 % of the backward sweep's wave cycles parked in
+// s_waitcnt).  An asm DMA is invisible to that bookkeeping; its completion is counted by hand (`dma_wait<N>()` +
+// `s_barrier`, then the reads), cdna_hip_programming.md "Pipelining across barriers".
+__device__ __forceinline__ void dma_row(const void *gsrc, const float *lds_dst)
+{
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+
+// wait until at most N of this wave's vector-memory operations (the asm DMAs: the loops below issue no other ones
+// that matter) are outstanding and every LDS read has returned, then the workgroup barrier
+template <int N>
+__device__ __forceinline__ void dma_wait_barrier()
+{
+    static_assert(N >= 0 && N < 16, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 __device__ __forceinline__ void stage_chunk(float *buf, const float *B, int j0, int wave, int lane)
 {
     // 32 bank rows per chunk, 8 per wave; one LDS-DMA wave-instruction moves one 1-KiB row:
@@ -70,10 +98,7 @@ __device__ __forceinline__ void stage_chunk(float *buf, const float *B, int j0, 
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int row = wave * 8 + r;
-        const float *g = B + (size_t)(j0 + row) * CP + lane * 4;
-        float *l = buf + row * ROWF;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+        dma_row(B + (size_t)(j0 + row) * CP + lane * 4, buf + row * ROWF);
     }
 }
 
@@ -83,14 +108,24 @@ __device__ __forceinline__ void stage_chunk_h(float *buf, const _Float16 *Bh, in
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int row = wave * 8 + r;
-        const _Float16 *g = Bh + (size_t)(j0 + row) * (2 * CP) + lane * 8;
-        float *l = buf + row * ROWF;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+        dma_row(Bh + (size_t)(j0 + row) * (2 * CP) + lane * 8, buf + row * ROWF);
     }
 }
 
 __device__ __forceinline__ int jrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Packed f16 pair (low half = first value) of hi = f16(v * s) and lo = f16(v * s - hi) for two values; s is a power of
+// two, so v * s is exact and the fused form is the same number.  v_fma_mix{lo,hi}_f16: f32 / f16 inputs, f32
+// arithmetic, one f16 half of the destination written -- 2 VALU per value, no separate packing (the compiler's own
+// lowering of the C expression takes 3+ and a v_pack).
+__device__ __forceinline__ void split2(float v0, float v1, float s, unsigned &hi, unsigned &lo)
+{
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(v0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(v0), "v"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "v"(s), "v"(hi));
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // LDS operand fetch, software-pipelined by hand: the reads for step q+1 are issued right after the
 // FIRST MFMA of step q, so they land under the remaining MFMAs of that step (sched_group_barrier pins
@@ -108,7 +143,14 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
     // per buffer: one 32-row chunk of the contrast bank, f32 rows or (hi | lo) half rows (same 1040-B stride);
     // in f16x3 mode both products of the backward read the half rows
     constexpr int BUF = BUF_FLOATS;
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    // f16x3 backward: software-pipelined over chunks (S recompute of chunk c + 1 under the epilogue of chunk c), four
+    // buffers: chunk c (second product), chunk c + 1 (S recompute), chunks c + 2 and c + 3 (LDS-DMA in flight)
+    constexpr bool PIPE = (MODE == MODE_BWD) && F16;
+    constexpr int NBUF = PIPE ? 4 : 2;
+    constexpr int CSTF = 256;                      // floats per column-statistics piece (one 1-KiB DMA: 64 rows x 16 B)
+    // PIPE image: rows of exactly 1 KiB (no pad), 16-byte slots XOR-swizzled by the row (below); else padded rows
+    constexpr int PBUF = CJ * CP;                  // floats per PIPE buffer (32 KiB)
+    __shared__ __attribute__((aligned(1024))) float lds[PIPE ? NBUF * PBUF + (USE_COL ? NBUF * CSTF : 0) : NBUF * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, li = lane & 31;
@@ -120,8 +162,29 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
     // all k, so any k order works as long as both operands use the same one.
     float a[F16 ? 1 : 128];
     half8 ahi[F16 ? 16 : 1], alo[F16 ? 16 : 1];
-    if (F16) {
-        // lane half h holds k in {16 kb + 8h .. 16 kb + 8h + 7} of k-block kb (MFMA 32x32x16 operand map)
+    if (PIPE) {
+        // lane half h holds k in {16 kb + 8h .. 16 kb + 8h + 7} of k-block kb (MFMA 32x32x16 operand map).  Straight
+        // from memory that is 32 load instructions per wave that each touch 32 different 128-byte lines (row stride
+        // 1 KiB between lanes); instead the wave's 32 rows travel as 32 coalesced 1-KiB LDS-DMA rows into chunk buffer
+        // `wave` (free until the sweep starts; same slot swizzle as the chunks, so the fragment reads are
+        // conflict-free) and are read back as fragments.
+        const unsigned g_li = (((unsigned)li & 3u) << 2) | (((unsigned)li >> 2) & 3u);
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+            const unsigned g_r = (((unsigned)r & 3u) << 2) | (((unsigned)r >> 2) & 3u);
+            dma_row(p.Ah + (size_t)(rb * BM + wave * 32 + r) * (2 * CP) + ((unsigned)lane ^ g_r) * 8,
+                    lds + wave * PBUF + r * CP);
+        }
+        dma_wait_barrier<0>();
+        const unsigned a_off = (unsigned)wave * (PBUF * 4) + (unsigned)li * 1024u + ((((unsigned)h) ^ g_li) << 4);
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const char *a16 = (const char *)lds + (a_off ^ ((unsigned)kb << 5));
+            ahi[kb] = *(const half8 *)a16;
+            alo[kb] = *(const half8 *)(a16 + 512);
+        }
+        dma_wait_barrier<0>();          // every wave holds its fragments: the buffers may take the first chunks
+    } else if (F16) {
         const _Float16 *arow = p.Ah + (size_t)i * (2 * CP) + 8 * h;
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
@@ -220,10 +283,199 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             stage_chunk(dst, p.B, j0s, wave, lane);
         }
     };
+    if constexpr (PIPE) {
+        // ---- f16x3 backward, two-stage software pipeline over chunks.  At one wave per SIMD nothing else can fill the
+        // matrix pipe while this wave runs its exp / scale / split epilogue, so the epilogue of chunk c is interleaved,
+        // instruction by instruction, with the 48 MFMAs of the S recompute of chunk c + 1 (independent work: a second
+        // accumulator tile); the second product of chunk c follows.  Chunks c + 2 and c + 3 are in flight as asm
+        // LDS-DMA (counted vmcnt + raw barrier), together with their 32 rows of column statistics {Z, cW, cZ, 0}: the
+        // loop contains no compiler-visible global load at all.
+        constexpr int NV = USE_COL ? 9 : 8;        // DMA wave-instructions per chunk and wave
+        // LDS image of a chunk: 32 rows x 1 KiB, row r = [32 hi slots | 32 lo slots] of 16 B; the slot that holds
+        // piece q (8 halves) of row r is q ^ g(r), g(r) = ((r & 3) << 2) | ((r >> 2) & 3) (4 bits, so hi / lo stay
+        // apart).  With it BOTH operand fetches are bank-conflict free: the S recompute reads one piece of 16 different
+        // rows per LDS cycle (ds_read_b128 lane groups), the second product reads 4 pieces x 4 rows (ds_read_b64_tr_b16,
+        // 32 lanes per cycle) -- on padded rows the latter was 4-way conflicted and the LDS array, not the matrix
+        // pipe, paced the loop (SQ_LDS_BANK_CONFLICT 56 % of SQ_LDS_IDX_ACTIVE).  The DMA fills rows lane-linearly, so
+        // the swizzle is applied on the SOURCE address: lane l of row r fetches piece l ^ g(r).
+        constexpr unsigned PBUFB = PBUF * 4;       // bytes per buffer
+        const char *lb = (const char *)lds;
+        float *cst = lds + NBUF * PBUF;
+        const unsigned trq = (lane & 15) >> 2, trp = lane & 3, gq = (lane >> 4) & 1;
+        const int nrows_c = (p.N2 + BM - 1) / BM * BM;             // rows of the column-statistics array
+        auto gsw = [](unsigned r) { return ((r & 3u) << 2) | ((r >> 2) & 3u); };
+        auto dma_piece = [&](int slot, int j0s, int row) {
+            dma_row(p.Bh + (size_t)(j0s + row) * (2 * CP) + ((unsigned)lane ^ gsw(row)) * 8,
+                    lds + slot * PBUF + row * CP);
+        };
+        auto dma_stats = [&](int slot, int j0s) {       // every wave copies the same piece: uniform DMA count per wave
+            dma_row(p.cstat + (size_t)min(j0s + lane, nrows_c - 1) * 4, cst + slot * CSTF);
+        };
+        auto stage_p = [&](int slot, int j0s) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                dma_piece(slot, j0s, wave * 8 + r);
+            if (USE_COL)
+                dma_stats(slot, j0s);
+        };
+        // S recompute operand: lane (h, li) reads piece 2 kb + h of row li -> slot (2 kb + h) ^ g(li); the buffers are
+        // 1-KiB aligned, so the whole address is (row base + ((h ^ g) << 4)) ^ (kb << 5): one v_xor per k-block
+        const unsigned s_off = (unsigned)li * 1024u + ((((unsigned)h) ^ gsw(li)) << 4);
+        // second product operand (transposing read): lane (gq, trq, trp) supplies 8 bytes of row R + trq, piece
+        // 4 ct + 2 gq + (trp >> 1) (R = 16 kb + 4 h, or + 8) -> slot ((4 ct) ^ (trq << 2)) | ((2 gq + (trp >> 1)) ^ hh),
+        // hh = h (rows R ..) or h + 2 (rows R + 8 ..): address = lane constant ^ (ct << 6) + kb * 16 KiB
+        const unsigned lowp = 2 * gq + (trp >> 1);
+        const unsigned pa_off = (4 * h + trq) * 1024u + (trq << 6) + ((lowp ^ (unsigned)h) << 4) + 8 * (trp & 1);
+        const unsigned pb_off = (4 * h + trq + 8) * 1024u + (trq << 6) + ((lowp ^ (unsigned)(h + 2)) << 4) + 8 * (trp & 1);
+        // S tile of the chunk in buffer `sslot`: X[j][i] = sum_k B[j][k] A[i][k] (3 MFMAs per k-block), optionally
+        // carrying the epilogue of the PREVIOUS tile (`eacc`, column statistics in `cs`) two elements per odd k-block
+        // ... and, `WITH_DMA`, the nine LDS-DMA pieces of the chunk that is staged during this iteration, one per even
+        // k-block (issued among the MFMAs)
+        f32x16 accN;
+        u32x4 hhv[2], hlv[2];
+        auto s_tile = [&](int sslot, auto WITH_E, const f32x16 &eacc, const float *cs, auto WITH_DMA, int dslot,
+                          int dj0) {
+            constexpr bool with_e = decltype(WITH_E)::value;
+            constexpr bool with_dma = decltype(WITH_DMA)::value;
+            const char *sb = lb + (unsigned)sslot * PBUFB;
+            auto rd = [&](int kb, half8 &hi8, half8 &lo8) {
+                const char *a = sb + (s_off ^ ((unsigned)kb << 5));
+                hi8 = *(const half8 *)a;
+                lo8 = *(const half8 *)(a + 512);
+            };
+            half8 bh, bl;
+            rd(0, bh, bl);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                accN[r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) {
+                half8 nh, nl;
+                rd(kb < 15 ? kb + 1 : 15, nh, nl);
+                accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ahi[kb], accN, 0, 0, 0);
+                accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, alo[kb], accN, 0, 0, 0);
+                accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ahi[kb], accN, 0, 0, 0);
+                if (with_e && (kb & 1)) {
+                    // elements r0, r0 + 1 of the previous tile: H = e^{s} (cW_i + cW_j) on tiles without positives,
+                    // scaled by G and split into f16 (hi, lo)
+                    const int r0 = kb - 1;
+                    const float w0 = USE_COL ? cs[jrow(r0, h) * 4 + 1] : 0.f;
+                    const float w1 = USE_COL ? cs[jrow(r0 + 1, h) * 4 + 1] : 0.f;
+                    const float v0 = __builtin_amdgcn_exp2f(eacc[r0] * p.c1) * (rcW + w0);
+                    const float v1 = __builtin_amdgcn_exp2f(eacc[r0 + 1] * p.c1) * (rcW + w1);
+                    unsigned hi, lo2;
+                    split2(v0, v1, hG, hi, lo2);
+                    hhv[r0 >> 3][(r0 & 7) >> 1] = hi;
+                    hlv[r0 >> 3][(r0 & 7) >> 1] = lo2;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, USE_COL ? 4 : 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);       // first half of the epilogue VALU
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);       // the rest
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                } else {
+                    if (with_dma) {
+                        dma_piece(dslot, dj0, wave * 8 + (kb >> 1));
+                        if (USE_COL && kb == 14)
+                            dma_stats(dslot, dj0);
+                    }
+                    DCL_SCHED_MFMA_DS_MFMA(2, 3);
+                }
+                bh = nh;
+                bl = nl;
+            }
+        };
+        const int nck = c1 - c0;
+        f32x16 zero16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            zero16[r] = 0.f;
+        if (nck > 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)             // past the last chunk the last one is staged again (uniform DMA count)
+                stage_p(q, min(c0 + q, c1 - 1) * CJ);
+            dma_wait_barrier<0>();                 // once per workgroup: everything staged so far has landed
+            s_tile(0, std::false_type{}, zero16, cst, std::false_type{}, 0, 0);
+        }
+        for (int k = 0; k < nck; ++k) {
+            const int c = c0 + k;
+            // chunk c + 1 (issued two iterations ago) has landed once at most the NV DMAs of chunk c + 2 are still
+            // outstanding; behind the barrier every wave has also left the second product of chunk c - 1, whose buffer
+            // takes chunk c + 3 during this iteration's S recompute
+            dma_wait_barrier<NV>();
+            const int dslot = (k + 3) & 3, dj0 = min(c + 3, c1 - 1) * CJ;
+            const int nxt = (k + 1) & 3;                       // past the last chunk: stale data, result unused
+            const float *cs = cst + (k & 3) * CSTF;
+            const int j0 = c * CJ;
+            const f32x16 acc = accN;
+            const bool plain = !((j0 < whi) && (j0 + CJ > wlo)) && (j0 + CJ <= p.N2);  // wave-uniform
+            if (plain) {
+                s_tile(nxt, std::true_type{}, acc, cs, std::true_type{}, dslot, dj0);
+            } else {
+                // tile with positives / ragged edge: masked epilogue first (VALU only), then the plain S recompute
+                f32x16 hv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jj = j0 + jrow(r, h);
+                    const float e = __builtin_amdgcn_exp2f(acc[r] * p.c1);
+                    const bool valid = jj < p.N2;
+                    const bool inr = (unsigned)(jj - lo) < span;
+                    bool pos = inr && valid;
+                    if (p.intra)
+                        pos = pos && (jj != i);
+                    f32x4 cst4 = {0.f, 0.f, 0.f, 0.f};                      // {Z_j, cW_j, cZ_j, -}
+                    if (USE_COL)
+                        cst4 = *(const f32x4 *)(cs + jrow(r, h) * 4);
+                    const float hn = e * (rcW + cst4.y);
+                    const float hp = -(rcZ * __builtin_amdgcn_rcpf(e + rZ) + cst4.z * __builtin_amdgcn_rcpf(e + cst4.x));
+                    hv[r] = pos ? hp : ((valid && !inr) ? hn : 0.f);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    unsigned hi, lo2;
+                    split2(hv[r], hv[r + 1], hG, hi, lo2);
+                    hhv[r >> 3][(r & 7) >> 1] = hi;
+                    hlv[r >> 3][(r & 7) >> 1] = lo2;
+                }
+                s_tile(nxt, std::false_type{}, zero16, cs, std::true_type{}, dslot, dj0);
+            }
+            // second product: dA[i][c] += sum_j H[j][i] * B[j0 + j][c] (see the generic loop below for the operand
+            // maps); the four transposing reads of step (kb, ct) + 1 are issued behind the first MFMA of step (kb, ct)
+            const char *hb = lb + (unsigned)(k & 3) * PBUFB;
+            union TR { half8 v; fp16x4 q[2]; };
+            auto read_b = [&](int st, TR &bh, TR &bl) {
+                const int kb = st >> 3, ct = st & 7;
+                const char *pa = hb + kb * 16384 + (pa_off ^ ((unsigned)ct << 6));
+                const char *pb = hb + kb * 16384 + (pb_off ^ ((unsigned)ct << 6));
+                bh.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_FP16X4 *)pa);
+                bh.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_FP16X4 *)pb);
+                bl.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_FP16X4 *)(pa + 512));
+                bl.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_FP16X4 *)(pb + 512));
+            };
+            TR bh, bl;
+            read_b(0, bh, bl);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int kb = st >> 3, ct = st & 7;
+                const half8 hh = __builtin_bit_cast(half8, hhv[kb]), hl = __builtin_bit_cast(half8, hlv[kb]);
+                TR nh, nl;
+                read_b(st < 15 ? st + 1 : 15, nh, nl);
+                dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh, bh.v, dacc[ct], 0, 0, 0);
+                dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh, bl.v, dacc[ct], 0, 0, 0);
+                dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl, bh.v, dacc[ct], 0, 0, 0);
+                DCL_SCHED_MFMA_DS_MFMA(4, 3);
+                bh = nh;
+                bl = nl;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the loop
+    } else {
     if (c0 < c1)
         stage(lds, c0 * CJ);
     for (int c = c0; c < c1; ++c) {
-        __syncthreads();       // (drains the LDS-DMA: chunk c has landed; everyone left chunk c-1)
+        dma_wait_barrier<0>();  // chunk c has landed (asm LDS-DMA: waited for by hand); everyone left chunk c-1
         const float *cur = lds + ((c - c0) & 1) * BUF;
         const float *buf = cur;
         if (c + 1 < c1)
@@ -398,6 +650,8 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             }
         }
     }
+
+    }   // !PIPE
 
     // ---- outputs
     if (MODE == MODE_Z) {
