@@ -61,8 +61,10 @@ SIGNATURES = {
     "dcl_conv3x3_pack_multi": [_vp, _vp, _i, _vp],
     "dcl_conv3x3_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "dcl_wgrad3x3_splits": [_i, _i, _i, _i, _i],
+    "dcl_wgrad3x3_set_tile": [_i, _i],
     "dcl_wgrad3x3_f16x3": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],
     "dcl_confusion_matrix": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp],
+    "dcl_metrics_from_cm": [_vp, _i, _i, _vp, _vp],
     "dcl_suggest_nsplit": [_i, _i],
     "dcl_version": [],
 }
@@ -105,7 +107,19 @@ def check(rc: int, what: str):
 
 
 def ptr(t):
-    """Device (or host) address of a torch tensor as c_void_p; None -> NULL."""
+    """Device (or host) address of a torch tensor for a ``void *`` argument (a plain int: ctypes converts it, and
+    building a c_void_p object per argument costs more than the call on this launch-bound path); None -> NULL."""
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
+
+
+def stream_ptr(device=None):
+    """The current HIP stream of ``device`` (default: the current device) as an int for a ``void *stream`` argument;
+    torch's raw-stream query is ~10x cheaper than building a torch.cuda.Stream object per launch."""
+    import torch
+    if device is None or device.index is None:
+        idx = torch.cuda.current_device()
+    else:
+        idx = device.index
+    return torch._C._cuda_getCurrentRawStream(idx)

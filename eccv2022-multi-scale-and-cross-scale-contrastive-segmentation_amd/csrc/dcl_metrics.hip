@@ -116,7 +116,64 @@ __global__ __launch_bounds__(256) void k_confusion(CmArgs a)
     }
 }
 
+// pa, pac, mIoU from the confusion matrix in ONE launch (the torch formulation is ~25 tiny kernels, each followed by
+// a dispatch gap: ~1 ms of mostly idle GPU at the end of every step).  One workgroup, thread c owns class c.
+//   pa   = sum_c cm[c][c] / sum cm                                   (utils/torch_utils.py:208-209)
+//   pac  = mean_c cm[c][c] / max(rowsum_c, 1 if rowsum_c == 0)        (:210-212)
+//   miou = mean_c cm[c][c] / (rowsum_c + colsum_c - cm[c][c]), NaN -> 0 (:268-275), c over the C real classes
+// Integer sums are exact; the float arithmetic follows torch's (sums of float-converted integers, f32 division).
+__global__ __launch_bounds__(256) void k_metrics_from_cm(const int *__restrict__ cm, int C, int ld, float *__restrict__ out)
+{
+    __shared__ float sh[3][4];
+    const int c = threadIdx.x;
+    float diag = 0.f, pacv = 0.f, iou = 0.f;
+    long long tot = 0;
+    if (c < C) {
+        long long row = 0, col = 0;
+        for (int j = 0; j < C; ++j) {
+            row += cm[c * ld + j];
+            col += cm[j * ld + c];
+        }
+        tot = row;
+        const int d = cm[c * ld + c];
+        diag = (float)d;
+        pacv = diag / (row == 0 ? 1.0f : (float)row);
+        const float den = (float)col + (float)row - diag;      // torch: row_sum (dim 0) + col_sum (dim 1) - diagonal, f32
+        const float v = diag / den;
+        iou = (v != v) ? 0.f : v;
+    }
+    float ftot = (float)tot;                                    // per-class row totals < 2^24 at any realistic batch
+    diag = wave_sum(diag);
+    pacv = wave_sum(pacv);
+    iou = wave_sum(iou);
+    ftot = wave_sum(ftot);
+    __shared__ float st[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][w] = diag;
+        sh[1][w] = pacv;
+        sh[2][w] = iou;
+        st[w] = ftot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float d = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        const float t = (st[0] + st[1]) + (st[2] + st[3]);
+        out[0] = d / t;
+        out[1] = ((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3])) / (float)C;
+        out[2] = ((sh[2][0] + sh[2][1]) + (sh[2][2] + sh[2][3])) / (float)C;
+    }
+}
+
 }  // namespace
+
+extern "C" int dcl_metrics_from_cm(const int32_t *cm, int C, int ld, float *out3, void *stream)
+{
+    DCL_CHECK_ARG(cm && out3 && C > 0 && C <= 256 && ld >= C, "bad arguments (C <= 256)");
+    hipLaunchKernelGGL(k_metrics_from_cm, dim3(1), dim3(256), 0, (hipStream_t)stream, cm, C, ld, out3);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int dcl_confusion_matrix(const float *logits, int N, int C, int HW, const void *target, int target_bytes,
                                     int cols, int32_t *cm, int32_t *oob, void *stream)

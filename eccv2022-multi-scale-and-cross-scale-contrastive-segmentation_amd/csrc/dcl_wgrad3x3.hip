@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
     // a fixed order, (w0 + w1) + (w2 + w3), so that one slab per workgroup (not per wave) goes to memory.
     // (Only for the variants with <= 3 tiles per tap: with 6 the extra live ranges make the register allocator spill
     // inside the main loop, so those keep one slab per wave.)
-    constexpr bool LDSRED = NCO * NCI <= 3;
+    constexpr bool LDSRED = NCO * NCI <= 4;
     if (LDSRED) {
         constexpr int NREG = LDSRED ? NCO * NCI * 36 : 1;
         __shared__ float red[2][NREG][64];
@@ -444,6 +444,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
 
 }  // namespace
 
+static int g_tile_nco = 0, g_tile_nci = 0;      // tuning override (dcl_wgrad3x3_set_tile), 0 = automatic
+
 static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nci, int &S, int &units)
 {
     const int cot = Cout / 16, cit = Cin / 16;
@@ -451,6 +453,24 @@ static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nc
     // pairs of ci tiles when that leaves no ragged group (for the head, cit = 45, the 6-tile variant with a ragged
     // last group was tried: 27 ms against 12.5 ms -- it spills and writes per-wave slabs)
     nci = (cit % 2 == 0) ? 2 : 1;
+    // measured on the HRNet-W48 branch shapes at batch 12 (tools/wgrad_tiles.py): the six-tile wave (3, 2) spills
+    // (70 registers) and only pays off when the tile-pair grid is large (384 channels); few pairs -> (3, 1) with many
+    // pixel splits (96 channels: 64.8 vs 75.6 us); otherwise the spill-free four-tile wave (2, 2) (192 channels: 66.9
+    // vs 71.3 us)
+    if (cot % 3 == 0 && cit % 2 == 0 && (cot / 3) * (cit / 2) >= 64) {
+        nco = 3;
+        nci = 2;
+    } else if (cot % 3 == 0 && (cot / 3) * cit <= 16) {
+        nco = 3;
+        nci = 1;
+    } else if (cot % 2 == 0 && cit % 2 == 0) {
+        nco = 2;
+        nci = 2;
+    }
+    if (g_tile_nco > 0 && cot % g_tile_nco == 0)
+        nco = g_tile_nco;
+    if (g_tile_nci > 0)
+        nci = g_tile_nci;
     const int pairs = (cot / nco) * ((cit + nci - 1) / nci);
     units = N * ((W + 31) / 32);            // columns: (image, 32-pixel strip), H input rows each
     // One workgroup (4 waves = 4 splits of one pair) per CU is all that fits (a wave owns most of its SIMD's
@@ -464,13 +484,22 @@ static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nc
         S = units * H;
 }
 
+extern "C" int dcl_wgrad3x3_set_tile(int nco, int nci)
+{
+    if (nco < 0 || nco > 3 || nci < 0 || nci > 2)
+        return DCL_EINVAL;
+    g_tile_nco = nco;
+    g_tile_nci = nci;
+    return 0;
+}
+
 extern "C" int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W)
 {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cin & 15) || (Cout & 15))
         return 0;
     int nco, nci, S, units;
     wgrad_plan(N, Cin, Cout, H, W, nco, nci, S, units);
-    return nco * nci <= 3 ? (S + 3) / 4 : S;      // one slab per workgroup (4 splits), or per wave (6-tile variants)
+    return nco * nci <= 4 ? (S + 3) / 4 : S;      // one slab per workgroup (4 splits), or per wave (6-tile variant)
 }
 
 extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W,
@@ -531,7 +560,7 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
 #undef DCL_WG_CASE
     DCL_LAUNCH_CHECK();
     const int total = 9 * Cout * Cin;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, s, part, nco * nci <= 3 ? a.nx : a.S, Cout,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, s, part, nco * nci <= 4 ? a.nx : a.S, Cout,
                        Cin, dw);
     DCL_LAUNCH_CHECK();
     return 0;

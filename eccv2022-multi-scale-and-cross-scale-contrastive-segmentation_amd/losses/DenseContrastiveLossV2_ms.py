@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from ..utils import DATASETS_INFO, is_distributed, printlog
 from .DenseContrastiveLossV2 import DenseContrastiveLossV2 as DCV2
-from .engine import dense_contrast_terms, stage_labels
+from .engine import dense_contrast_terms, presample
 
 
 class DenseContrastiveLossV2_ms(nn.Module):
@@ -49,19 +49,29 @@ class DenseContrastiveLossV2_ms(nn.Module):
                      f'w_high_low: {self.w_high_low}, w_high_mid: {self.w_high_mid}')
 
     def prepare(self, label: torch.Tensor, ready_event=None):
-        """Optional, call BEFORE the model forward is enqueued: runs the label stage (stride-sample +
-        class histograms of every scale, 960-byte D2H) on a side stream so that it -- and the host-side
-        sampling plan that needs its result -- overlap the model forward instead of waiting behind it.
-        A no-op until one forward has been seen for this label shape (the strides come from the feature
-        maps).  Does not touch the RNG; forward() ignores the staged result if the label changed."""
+        """Optional, call BEFORE the model forward is enqueued: runs everything of the loss that depends on the
+        labels only -- stride-sample + class histograms of every scale, the 960-byte D2H, the host-side sampling
+        plan (the reference's randperm draws, same order) and the pixel selection kernel -- on a side stream, so
+        that none of it waits behind the model forward and the forward pass is not followed by ~1.5 ms of host work
+        with the GPU idle.  A no-op until one forward has been seen for this label shape (the strides come from the
+        feature maps).  Does not touch the RNG; forward() ignores the staged result if the label changed."""
         geoms = self._geoms.get(tuple(label.shape))
         if geoms is None or not label.is_cuda:
             return False
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=label.device)
-        self._staged = stage_labels(int(self.DCV2_scale0.num_all_classes), label, geoms,
-                                    side_stream=self._side_stream, ready_event=ready_event)
+            # high priority: its own hardware queue, so that the label stage is not queued behind the previous step's
+            # backward (HIP maps the ordinary streams of a process onto a few shared hardware queues)
+            self._side_stream = torch.cuda.Stream(device=label.device, priority=-1)
+        self._staged = presample(self._engine_cfg(), label, geoms, bool(self.cross_scale_contrast),
+                                 self._side_stream, ready_event=ready_event)
         return True
+
+    def _engine_cfg(self):
+        return self.DCV2_scale0.engine_config(weights=tuple(float(w) for w in self.weights),
+                                              cross_scale_contrast=bool(self.cross_scale_contrast),
+                                              cross_scale_temperature=float(self.cross_scale_temperature),
+                                              detach_deepest=bool(self.detach_cs_deepest),
+                                              w_high_low=float(self.w_high_low), w_high_mid=float(self.w_high_mid))
 
     def forward(self, label: torch.Tensor, features: list, **kwargs):
         self.cs_losses = []
@@ -71,11 +81,7 @@ class DenseContrastiveLossV2_ms(nn.Module):
         with_cross = bool(self.cross_scale_contrast)
         if with_cross:
             assert S > 1 and len(features) > 1
-        cfg = sub0.engine_config(weights=tuple(float(w) for w in self.weights),
-                                 cross_scale_contrast=with_cross,
-                                 cross_scale_temperature=float(self.cross_scale_temperature),
-                                 detach_deepest=bool(self.detach_cs_deepest),
-                                 w_high_low=float(self.w_high_low), w_high_mid=float(self.w_high_mid))
+        cfg = self._engine_cfg()
         feats = [features[s] for s in range(S)]
         staged, self._staged = self._staged, None
         terms, st = dense_contrast_terms(cfg, label, feats, staged=staged,

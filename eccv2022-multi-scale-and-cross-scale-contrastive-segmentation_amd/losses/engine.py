@@ -105,6 +105,7 @@ class StepState:
         self.scales: List[_Scale] = []
         self.terms: List[_Term] = []
         self.loss_buf: Optional[torch.Tensor] = None     # f32 [n_terms] raw (unweighted) term losses
+        self.pack: Optional[torch.Tensor] = None         # device copy of the plan upload pack
         self.keepalive: list = []
 
 
@@ -148,7 +149,7 @@ def _dist_world() -> int:
 
 
 def _stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.stream_ptr()
 
 
 def _feature_strides(f: torch.Tensor):
@@ -258,39 +259,22 @@ def stage_labels(K: int, label: torch.Tensor, geoms, side_stream=None, ready_eve
     return st
 
 
-def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torch.Tensor],
-                    with_cross: bool, staged: Optional[StagedLabels] = None) -> StepState:
-    """label stage (or a pre-staged one) -> host plan -> K2 for every scale; builds the term list with
-    its positive ranges."""
+def _plan_terms_and_sample(cfg: EngineConfig, staged: StagedLabels, with_cross: bool, dev) -> StepState:
+    """Everything of the sampling stage that needs the LABELS only: waits for the staged histograms, builds the
+    host plans (this is where the reference's RNG draws happen, in its order: scale 0 pairs ..., scale 1 pairs ...),
+    uploads the plan pack and runs K2 for every scale -- all on the CURRENT stream.  Feature geometry (channel
+    count, strides) is bound later by ``_bind_features``."""
     L = _lib.lib()
-    dev = feats[0].device
-    if dev.type != "cuda":
-        raise RuntimeError("mscs_amd dense contrastive loss runs on the MI355X only: features are on "
-                           f"{dev}; there is no CPU fallback")
-    n, H, W = label.shape
-    K = cfg.num_all_classes
-    S = len(feats)
-    geoms = feature_geometry((n, H, W), feats)
-    if staged is not None and (staged.key != _label_key(label) or staged.geoms != geoms
-                               or staged.counts.shape[-1] != K):
-        staged = None                               # stale: made from another label / geometry
-    if staged is None:
-        staged = stage_labels(K, label.to(dev) if label.device != dev else label, geoms)
+    K = staged.counts.shape[-1]
+    n = staged.counts.shape[1]
+    S = len(staged.geoms)
     st = StepState()
     stream = _stream_ptr()
-    for s, f in enumerate(feats):
-        if f.dtype != torch.float32:
-            raise RuntimeError(f"features[{s}] must be float32, got {f.dtype}")
-        C = f.shape[1]
-        if C > _lib.CP:
-            raise RuntimeError(f"embedding width {C} > {_lib.CP} is not supported by the sweep kernels")
-        strides = _feature_strides(f)
-        if strides is None:
-            raise RuntimeError(f"features[{s}] has a non-collapsible (h, w) layout; call .contiguous()")
-        _, h, w = geoms[s]
-        st.scales.append(_Scale(plan=None, h=h, w=w, C=C, strides=strides, lbl_s=staged.lbl_s[s]))
+    for s in range(S):
+        _, h, w = staged.geoms[s]
+        st.scales.append(_Scale(plan=None, h=h, w=w, C=0, strides=None, lbl_s=staged.lbl_s[s]))
     seg_hists = staged.seg_hists
-    staged.event.synchronize()                      # the one host wait of the forward (K1 + 960-B D2H)
+    staged.event.synchronize()                      # the one host wait of the loss (K1 + 960-B D2H)
     counts_host = staged.counts_host.numpy()
     cur = torch.cuda.current_stream()
     if staged.stream is not cur:
@@ -366,6 +350,84 @@ def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torc
         if not t.intra:
             t.rev_lo, t.rev_hi = view(ids[2]), view(ids[3])
     st.keepalive += seg_hists
+    st.pack = pack
+    return st
+
+
+class PreSampled:
+    """A StepState whose label-only half (plans, RNG draws, K2) was computed ahead of the model forward on a side
+    stream (DenseContrastiveLossV2_ms.prepare); ``event`` marks its completion on that stream."""
+
+    def __init__(self, st, key, geoms, cfg_key, stream, event):
+        self.st, self.key, self.geoms, self.cfg_key, self.stream, self.event = st, key, geoms, cfg_key, stream, event
+
+
+def _cfg_key(cfg: EngineConfig, with_cross: bool):
+    return (cfg.num_all_classes, cfg.min_views_per_class, cfg.max_views_per_class, cfg.max_features_total,
+            tuple(cfg.weights), bool(with_cross), cfg.temperature, cfg.cross_scale_temperature, bool(cfg.detach_deepest),
+            cfg.w_high_low, cfg.w_high_mid)
+
+
+def presample(cfg: EngineConfig, label: torch.Tensor, geoms, with_cross: bool, side_stream,
+              ready_event=None) -> PreSampled:
+    """Label stage + host plans + K2 on ``side_stream``, before the model forward is enqueued: the host builds the
+    sampling plan (its ~1 ms and the wait for the 960-byte histogram) while the GPU is still busy with the previous
+    step, instead of after the forward with the GPU idle.  Consumes the CPU RNG exactly like the in-forward path
+    (same draws, same order); nothing else in a training step draws from the CPU generator."""
+    key = _label_key(label)
+    staged = stage_labels(cfg.num_all_classes, label, geoms, side_stream=side_stream, ready_event=ready_event)
+    with torch.cuda.stream(side_stream):
+        st = _plan_terms_and_sample(cfg, staged, with_cross, staged.label.device)
+        ev = torch.cuda.Event()
+        ev.record(side_stream)
+    return PreSampled(st, key, list(geoms), _cfg_key(cfg, with_cross), side_stream, ev)
+
+
+def _bind_features(st: StepState, feats: Sequence[torch.Tensor]):
+    for s, (sc, f) in enumerate(zip(st.scales, feats)):
+        if f.dtype != torch.float32:
+            raise RuntimeError(f"features[{s}] must be float32, got {f.dtype}")
+        C = f.shape[1]
+        if C > _lib.CP:
+            raise RuntimeError(f"embedding width {C} > {_lib.CP} is not supported by the sweep kernels")
+        strides = _feature_strides(f)
+        if strides is None:
+            raise RuntimeError(f"features[{s}] has a non-collapsible (h, w) layout; call .contiguous()")
+        sc.C, sc.strides = C, strides
+
+
+def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torch.Tensor],
+                    with_cross: bool, staged=None) -> StepState:
+    """label stage (or a pre-staged / pre-sampled one) -> host plan -> K2 for every scale; builds the term list with
+    its positive ranges.  ``staged``: a ``StagedLabels`` (label stage done ahead) or a ``PreSampled`` (plans and K2
+    done ahead as well); either is ignored when it was made from another label tensor / geometry / configuration."""
+    dev = feats[0].device
+    if dev.type != "cuda":
+        raise RuntimeError("mscs_amd dense contrastive loss runs on the MI355X only: features are on "
+                           f"{dev}; there is no CPU fallback")
+    n, H, W = label.shape
+    K = cfg.num_all_classes
+    geoms = feature_geometry((n, H, W), feats)
+    if isinstance(staged, PreSampled):
+        pre, staged = staged, None
+        if pre.key == _label_key(label) and pre.geoms == geoms and pre.cfg_key == _cfg_key(cfg, with_cross):
+            st = pre.st
+            cur = torch.cuda.current_stream()
+            if pre.stream is not cur:
+                cur.wait_event(pre.event)
+                for sc in st.scales:
+                    sc.pix.record_stream(cur)
+                st.pack.record_stream(cur)
+            _bind_features(st, feats)
+            return st
+        # stale: fall through to the in-forward path.  NOTE the pre-sampling already consumed its RNG draws.
+    if staged is not None and (staged.key != _label_key(label) or staged.geoms != geoms
+                               or staged.counts.shape[-1] != K):
+        staged = None                               # stale: made from another label / geometry
+    if staged is None:
+        staged = stage_labels(K, label.to(dev) if label.device != dev else label, geoms)
+    st = _plan_terms_and_sample(cfg, staged, with_cross, dev)
+    _bind_features(st, feats)
     return st
 
 

@@ -29,7 +29,8 @@ from ..losses import LossWrapper
 from ..utils import DATASETS_INFO, printlog
 from ..utils.config import parse_config
 from ..utils.lr_functions import LRFcts
-from ..utils.metrics import out_of_range, t_get_confusion_matrix, t_get_mean_iou, t_get_pixel_accuracy
+from ..utils.metrics import (out_of_range, t_get_confusion_matrix, t_get_mean_iou, t_get_pixel_accuracy,
+                             t_metrics_from_confusion_matrix)
 
 
 def set_seeds(seed):
@@ -243,7 +244,7 @@ class BaseManager:
         if self.device.type != 'cuda':
             return img.to(self.device), lbl.to(self.device), None
         if getattr(self, '_in_stream', None) is None:
-            self._in_stream = torch.cuda.Stream(device=self.device)
+            self._in_stream = torch.cuda.Stream(device=self.device, priority=-1)    # own hardware queue
         cur = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self._in_stream):
             img = img.to(self.device, non_blocking=True)
@@ -279,8 +280,7 @@ class BaseManager:
         """The per-step tail of the reference's loop (HRNet_Manager.py:117-121): confusion matrix (one HIP pass over
         the logits, utils/metrics.py), pixel accuracies, mIoU, logging."""
         cm = t_get_confusion_matrix(ret['output'], lbl, self.dataset)
-        pa, pac = t_get_pixel_accuracy(cm)
-        miou = t_get_mean_iou(cm)
+        pa, pac, miou = t_metrics_from_confusion_matrix(cm)
         self.train_logging(batch_num, ret['loss'], pa, pac, miou, ms)
 
     def train_logging(self, batch_num, loss, pa, pac, miou, ms):

@@ -20,7 +20,7 @@ def zeros(n: int, device) -> torch.Tensor:
     slices are never handed out twice, the buffer lives as long as any slice does."""
     n_al = (n + 3) & ~3
     # one pool per stream: the fill kernel of a pool buffer is ordered only against the stream that created it
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = (device.type, device.index, _lib.stream_ptr(device) if device.type == "cuda" else 0)
     buf, off = _POOL.get(key, (None, 0))
     if buf is None or off + n_al > buf.numel():
         buf, off = torch.zeros(max(_POOL_FLOATS, n_al), dtype=torch.float32, device=device), 0
@@ -39,7 +39,7 @@ def amax_of(t: torch.Tensor) -> torch.Tensor:
     if got is not None and got[0] == t._version and got[1].device == t.device:
         return got[1]
     buf = zeros(1, t.device)
-    st = ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    st = _lib.stream_ptr(t.device)
     _lib.check(_lib.lib().dcl_absmax(_lib.ptr(t), t.numel(), _lib.ptr(buf), st), "dcl_absmax")
     tag(t, buf)
     return buf

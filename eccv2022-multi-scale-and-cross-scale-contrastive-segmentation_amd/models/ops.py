@@ -55,7 +55,7 @@ class _UpsampleBilinear(torch.autograd.Function):
         L = _lib.lib()
         n, c, h, w = x.shape
         y = torch.empty((n, c, H, W), dtype=torch.float32, device=x.device)
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = _lib.stream_ptr()
         _lib.check(L.dcl_upsample_bilinear_fwd(_lib.ptr(x), _lib.ptr(addend), n * c, h, w, H, W,
                                                1 if align_corners else 0, _lib.ptr(y), st),
                    "dcl_upsample_bilinear_fwd")
@@ -73,7 +73,7 @@ class _UpsampleBilinear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
-            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            st = _lib.stream_ptr()
             _lib.check(L.dcl_upsample_bilinear_bwd(_lib.ptr(dy), n * c, h, w, H, W, 1 if ctx.align else 0,
                                                    _lib.ptr(dx), st), "dcl_upsample_bilinear_bwd")
         return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None
@@ -147,7 +147,7 @@ def _split(t, scale):
     t = t.contiguous()
     hi = torch.empty(t.shape, dtype=torch.float16, device=t.device)
     lo = torch.empty(t.shape, dtype=torch.float16, device=t.device)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = _lib.stream_ptr()
     _lib.check(_lib.lib().dcl_split_f16(_lib.ptr(t), t.numel(), _lib.ptr(scale), _lib.ptr(hi), _lib.ptr(lo), st),
                "dcl_split_f16")
     return hi, lo
@@ -159,7 +159,7 @@ def _im2col_split(x, scale):
     n, c, h, w = x.shape
     hi = torch.empty((n, c * 9, h * w), dtype=torch.float16, device=x.device)
     lo = torch.empty((n, c * 9, h * w), dtype=torch.float16, device=x.device)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = _lib.stream_ptr()
     _lib.check(_lib.lib().dcl_im2col3x3_split(_lib.ptr(x), n, c, h, w, _lib.ptr(scale), _lib.ptr(hi),
                                               _lib.ptr(lo), st), "dcl_im2col3x3_split")
     return hi, lo
@@ -232,7 +232,8 @@ def conv3x3_f16x3(x, conv: torch.nn.Conv2d):
 
 def _stream(t):
     import ctypes
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    from .. import _lib
+    return _lib.stream_ptr(t.device)
 
 
 def conv3x3_pack(weight, wamax, transposed=False):

@@ -49,7 +49,7 @@ def t_get_confusion_matrix(prediction, target, dataset, existing_matrix=None, no
         t = t.contiguous()
         assert t.numel() == p.shape[0] * p.shape[2] * p.shape[3], "target must be [N, H, W]"
         cm = torch.zeros((C, cols), dtype=torch.int32, device=p.device)
-        st = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+        st = _lib.stream_ptr(p.device)
         _lib.check(L.dcl_confusion_matrix(_lib.ptr(p), p.shape[0], C, p.shape[2] * p.shape[3], _lib.ptr(t),
                                           t.element_size(), cols, _lib.ptr(cm), _lib.ptr(_oob_counter(p.device)), st),
                    "dcl_confusion_matrix")
@@ -114,3 +114,20 @@ def t_get_mean_iou(confusion_matrix, experiment=None, dataset=None, categories=F
             mious['categories'][categ] = t_get_miou(confusion_matrix, experiment, dataset, indices=cats[categ],
                                                     calculate_mean=calculate_mean)
     return mious
+
+
+@torch.no_grad()
+def t_metrics_from_confusion_matrix(confusion_matrix):
+    """(pa, pac, miou) as three 0-dim tensors -- ``t_get_pixel_accuracy`` + ``t_get_mean_iou`` (all classes) of the
+    reference in one HIP launch for int32 CUDA matrices (csrc/dcl_metrics.hip: the torch formulation is ~25 tiny
+    kernels per training step); CPU / other dtypes take the torch path."""
+    cm = confusion_matrix
+    if cm.is_cuda and cm.dtype == torch.int32 and cm.dim() == 2 and cm.shape[0] == cm.shape[1] \
+            and cm.shape[0] <= 256 and cm.stride(1) == 1:
+        from .. import _lib
+        out = torch.empty(3, dtype=torch.float32, device=cm.device)
+        _lib.check(_lib.lib().dcl_metrics_from_cm(_lib.ptr(cm), cm.shape[0], cm.stride(0), _lib.ptr(out),
+                                                  _lib.stream_ptr(cm.device)), "dcl_metrics_from_cm")
+        return out[0], out[1], out[2]
+    pa, pac = t_get_pixel_accuracy(cm)
+    return pa, pac, t_get_miou(cm)

@@ -278,6 +278,8 @@ int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored inp
  * staging (csrc/dcl_wgrad3x3.hip).  Cin % 16 == 0, Cout % 16 == 0, W % 8 == 0.  part: workspace of
  * dcl_wgrad3x3_splits(...) * 9 * Cout * Cin floats (one partial slab per workgroup, summed in fixed order). */
 int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W);
+/* tuning hook: force the (co tiles, ci tiles) per wave of the weight-gradient kernel (0, 0 = automatic choice) */
+int dcl_wgrad3x3_set_tile(int nco, int nci);
 int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W /* of x */,
                        const float *xamax, int xcount, const float *gamax, int gcount,
                        int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,
@@ -296,6 +298,12 @@ int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout
  * argmax follows torch: first maximal index, NaN is maximal. */
 int dcl_confusion_matrix(const float *logits, int N, int C, int HW, const void *target, int target_bytes,
                          int cols, int32_t *cm, int32_t *oob, void *stream);
+
+/* Pixel accuracy, mean per-class accuracy and mean IoU of a confusion matrix in one launch: replaces
+ * t_get_pixel_accuracy (utils/torch_utils.py:201-213) and t_get_miou over all classes (:253-283).
+ *   cm int32 [C, ld] (ld >= C: row stride; ld = C + 1 for the uncropped matrix of dcl_confusion_matrix)
+ *   out3 f32 {pa, pac, miou} */
+int dcl_metrics_from_cm(const int32_t *cm, int C, int ld, float *out3, void *stream);
 
 /* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the
  * grid fills the 256 CUs evenly (host helper, no device work). */

@@ -10,7 +10,8 @@ import torch
 from conftest import GOLDEN
 
 import mscs_amd  # noqa: F401
-from mscs_amd.utils.metrics import t_get_confusion_matrix, t_get_mean_iou, t_get_pixel_accuracy, out_of_range
+from mscs_amd.utils.metrics import (t_get_confusion_matrix, t_get_mean_iou, t_get_pixel_accuracy, out_of_range,
+                                    t_metrics_from_confusion_matrix)
 
 CASES = ["cts", "cts_ties", "ade", "cadis_noignore"]
 
@@ -44,6 +45,8 @@ def _check_host(g, dev):
     np.testing.assert_allclose([pa.item(), pac.item()], [g["pa"], g["pac"]], rtol=1e-6)
     np.testing.assert_allclose(t_get_mean_iou(cm, exp, ds)["mean_iou"].item(), g["miou"], rtol=1e-6)
     np.testing.assert_allclose(t_get_mean_iou(cm).item(), g["miou"], rtol=1e-6)
+    fused = t_metrics_from_confusion_matrix(cm)           # one HIP launch on the GPU, the torch path on the CPU
+    np.testing.assert_allclose([v.item() for v in fused], [g["pa"], g["pac"], g["miou"]], rtol=2e-6)
 
 
 @pytest.mark.parametrize("name", CASES)

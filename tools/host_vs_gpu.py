@@ -13,11 +13,13 @@ mgr = HRNetManager(bench.step_config(A, 1), autostart=False); mgr.setup(); mgr.m
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(0)
 img = torch.randn(A.batch, 3, A.height, A.width, generator=gen).to(dev)
-lbl = torch.randint(0, 20, (A.batch, A.height, A.width), generator=gen, dtype=torch.int32).to(dev)
+lbl = torch.randint(0, 20, (A.batch, A.height, A.width), generator=gen).to(dev)
+torch.cuda.synchronize()
+ready = torch.cuda.Event(); ready.record()
 def step():
     mgr.optimiser.zero_grad(set_to_none=True)
     t0 = time.perf_counter()
-    ret = mgr.forward_step(img, lbl)
+    ret = mgr.forward_step(img, lbl, label_ready=ready)
     t1 = time.perf_counter()
     ret["loss"].backward()
     t2 = time.perf_counter()

@@ -7,6 +7,7 @@
 """
 import collections
 import csv
+import os
 import sys
 
 
@@ -23,8 +24,40 @@ def trace(path, scales=3, step=3):
         a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         a[1] += 1
     tot = sum(a[0] for a in agg.values())
+    # time with at least one kernel running (union of the kernel intervals) and concurrency histogram
+    ev = sorted([(int(r["Start_Timestamp"]), 1) for r in sel] + [(int(r["End_Timestamp"]), -1) for r in sel])
+    busy, depth, last, by_depth = 0, 0, t0, collections.defaultdict(int)
+    for t, d in ev:
+        if depth > 0:
+            busy += t - last
+        by_depth[min(depth, 4)] += t - last
+        depth += d
+        last = t
+    conc = ", ".join(f"{k if k < 4 else '>=4'} running: {1e-6 * v:.1f} ms" for k, v in sorted(by_depth.items()))
     print(f"# one steady-state step (#{step}): wall {1e-6 * (t1 - t0):.3f} ms, kernel time {1e-6 * tot:.3f} ms, "
-          f"{len(sel)} launches")
+          f"{len(sel)} launches; some kernel running for {1e-6 * busy:.3f} ms ({conc})")
+    # idle gaps (no kernel running): histogram and the longest ones with the kernels around them
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]) for r in sel)
+    gaps, end, prev = [], iv[0][1], iv[0][2]
+    for a, b, name in iv[1:]:
+        if a > end:
+            gaps.append((a - end, prev, name))
+        if b > end:
+            end, prev = b, name
+    hist = collections.Counter(min(int(g[0] / 1e3) // 5 * 5, 50) for g in gaps)
+    print("# idle gaps by length (us): " + ", ".join(f"{k}{'+' if k == 50 else f'-{k + 5}'}: {v} ({1e-6 * sum(g[0] for g in gaps if min(int(g[0] / 1e3) // 5 * 5, 50) == k):.2f} ms)"
+                                                    for k, v in sorted(hist.items())))
+    for g in sorted(gaps, reverse=True)[:8]:
+        print(f"#   gap {g[0] / 1e3:.0f} us after {g[1]} before {g[2]}")
+    if os.environ.get("DCL_TRACE_WINDOW"):
+        # rows around the longest gap: start (us from the step start), duration, queue, kernel
+        big = max(gaps)
+        rowsel = sorted(sel, key=lambda r: int(r["Start_Timestamp"]))
+        idx = next(i for i, r in enumerate(rowsel) if r["Kernel_Name"][:60] == big[2] and
+                   any(int(r["Start_Timestamp"]) - e == big[0] for e in [int(x["End_Timestamp"]) for x in rowsel[max(0, i - 40):i]]))
+        for r in rowsel[max(0, idx - 30):idx + 25]:
+            print(f"#   t={1e-3 * (int(r['Start_Timestamp']) - t0):9.1f} us dur {1e-3 * (int(r['End_Timestamp']) - int(r['Start_Timestamp'])):8.1f} "
+                  f"q={r.get('Queue_Id', '?')} {r['Kernel_Name'][:70]}")
     print("kernel,calls,total_ms,avg_us,percent")
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][0]):
         print(f"\"{k[:140]}\",{a[1]},{a[0] / 1e6:.3f},{a[0] / a[1] / 1e3:.2f},{100 * a[0] / tot:.2f}")
