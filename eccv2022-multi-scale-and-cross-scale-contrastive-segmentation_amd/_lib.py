@@ -51,7 +51,7 @@ SIGNATURES = {
                                _vp, _vp, _vp],
     "dcl_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "dcl_upsample_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "dcl_upsample_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_upsample_bilinear_bwd": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_im2col3x3_split": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "dcl_split_f16": [_vp, _i64, _vp, _vp, _vp, _vp],

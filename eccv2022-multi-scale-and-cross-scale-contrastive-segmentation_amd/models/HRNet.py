@@ -58,8 +58,8 @@ class _ConvBN(nn.Sequential):
     """Sequential(conv, norm[, ReLU]) -- same indices / state_dict keys as the reference's Sequentials --
     whose forward hands the ReLU (and an optional residual) to the norm layer when it can fuse them."""
 
-    def forward(self, x, residual=None):
-        return bn_act(self[1], self[0](x), residual=residual, relu=len(self) == 3)
+    def forward(self, x, residual=None, relu=False):
+        return bn_act(self[1], self[0](x), residual=residual, relu=relu or len(self) == 3)
 
 
 def _conv_bn(cin, cout, k, stride=1, relu=False, norm=nn.BatchNorm2d):
@@ -239,19 +239,38 @@ class HighResolutionModule(nn.Module):
         return fused
 
     def _fuse_row(self, i, row, x):
-        y = x[0] if i == 0 else row[0](x[0])
-        for j in range(1, self.num_branches):
-            if j == i:
-                y = y + x[j]
-            elif j > i:
-                y = upsample_bilinear(row[j](x[j]), x[i].shape[-2:], self.align_corners, add=y)
+        """relu(sum_j f_ij(x_j)) (reference HRNet.py:270-285).  The identity term x_i opens the sum (so it costs no add
+        kernel) and every other contribution adds into the running sum inside the kernel that produces it: the
+        up-sampling kernel for coarser branches, the last norm of the stride-2 chain for finer ones; the closing ReLU
+        rides on the last contribution.  (Summation order differs from the reference's j = 0, 1, ... by fp32
+        round-off only.)"""
+        if not x[0].is_cuda:                   # CPU: the reference's own order, op for op (tight parity tests)
+            y = x[0] if i == 0 else row[0](x[0])
+            for j in range(1, self.num_branches):
+                if j == i:
+                    y = y + x[j]
+                elif j > i:
+                    y = upsample_bilinear(row[j](x[j]), x[i].shape[-2:], self.align_corners, add=y)
+                else:
+                    chain = row[j]
+                    t = x[j]
+                    for step in list(chain)[:-1]:
+                        t = step(t)
+                    y = chain[-1](t, residual=y)
+            return self.relu(y)
+        others = [j for j in range(self.num_branches) if j != i]
+        y = x[i]
+        for pos, j in enumerate(others):
+            last = pos == len(others) - 1
+            if j > i:
+                y = upsample_bilinear(row[j](x[j]), x[i].shape[-2:], self.align_corners, add=y, relu=last)
             else:
-                chain = row[j]                  # stride-2 conv chain; its last norm absorbs "+ y"
+                chain = row[j]                  # stride-2 conv chain; its last norm absorbs "+ y" (and the ReLU)
                 t = x[j]
                 for step in list(chain)[:-1]:
                     t = step(t)
-                y = chain[-1](t, residual=y)
-        return self.relu(y)
+                y = chain[-1](t, residual=y, relu=last)
+        return y if others else self.relu(y)
 
 
 class HighResolutionNet(nn.Module):

@@ -49,34 +49,37 @@ def conv3x3_gemm_wrw(x, conv: torch.nn.Conv2d, chunk: int = 4):
 
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, addend, H, W, align_corners):
-        import ctypes
+    def forward(ctx, x, addend, H, W, align_corners, relu):
         from .. import _lib
         L = _lib.lib()
         n, c, h, w = x.shape
         y = torch.empty((n, c, H, W), dtype=torch.float32, device=x.device)
-        st = _lib.stream_ptr()
+        st = _lib.stream_ptr(x.device)
         _lib.check(L.dcl_upsample_bilinear_fwd(_lib.ptr(x), _lib.ptr(addend), n * c, h, w, H, W,
-                                               1 if align_corners else 0, _lib.ptr(y), st),
+                                               1 if align_corners else 0, 1 if relu else 0, _lib.ptr(y), st),
                    "dcl_upsample_bilinear_fwd")
-        ctx.shape, ctx.align = (n, c, h, w), bool(align_corners)
+        ctx.shape, ctx.align, ctx.relu = (n, c, h, w), bool(align_corners), bool(relu)
+        if relu:
+            ctx.save_for_backward(y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        import ctypes
         from .. import _lib
         L = _lib.lib()
         n, c, h, w = ctx.shape
+        if ctx.relu:                                   # gradient of the fused ReLU: dy where y > 0
+            (y,) = ctx.saved_tensors
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)
         dy = dy.contiguous()
         H, W = dy.shape[-2:]
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
-            st = _lib.stream_ptr()
+            st = _lib.stream_ptr(dy.device)
             _lib.check(L.dcl_upsample_bilinear_bwd(_lib.ptr(dy), n * c, h, w, H, W, 1 if ctx.align else 0,
                                                    _lib.ptr(dx), st), "dcl_upsample_bilinear_bwd")
-        return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None
+        return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
 HIP_UPSAMPLE = True        # False: F.interpolate everywhere (library_kernels_only(), the eager comparator of bench.py)
@@ -104,8 +107,9 @@ class library_kernels_only:
         return False
 
 
-def upsample_bilinear(x, size, align_corners, add=None):
-    """``add + F.interpolate(x, size, mode='bilinear', align_corners=...)`` (``add`` optional) on the HIP
+def upsample_bilinear(x, size, align_corners, add=None, relu=False):
+    """``add + F.interpolate(x, size, mode='bilinear', align_corners=...)`` (``add`` optional; ``relu``: followed by a
+    ReLU, fused into the same pass) on the HIP
     kernels of csrc/dcl_resize.hip for CUDA / float32 / contiguous NCHW inputs (16-B stores forward with the
     addend folded in, deterministic gather backward); PyTorch's own kernels otherwise."""
     H, W = int(size[0]), int(size[1])
@@ -113,10 +117,11 @@ def upsample_bilinear(x, size, align_corners, add=None):
             and not torch.is_autocast_enabled() and (H, W) != tuple(x.shape[-2:]) \
             and (add is None or (add.is_contiguous() and add.dtype == torch.float32
                                  and tuple(add.shape) == tuple(x.shape[:2]) + (H, W))):
-        return _UpsampleBilinear.apply(x, add, H, W, bool(align_corners))
+        return _UpsampleBilinear.apply(x, add, H, W, bool(align_corners), bool(relu))
     y = x if (H, W) == tuple(x.shape[-2:]) else F.interpolate(x, size=(H, W), mode='bilinear',
                                                               align_corners=align_corners)
-    return y if add is None else add + y
+    y = y if add is None else add + y
+    return F.relu(y) if relu else y
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -227,8 +227,9 @@ int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const float *y, cons
  * Replaces F.interpolate(mode='bilinear') in the models (reference models/HRNet.py:279-282, 549-551, 638)
  * and its autograd backward (gather form: deterministic, no atomics). */
 int dcl_upsample_bilinear_fwd(const float *x, const float *addend /* [planes,H,W] or NULL: y = addend + up(x) */,
-                              int planes, int h, int w, int H, int W, int align_corners, float *y,
-                              void *stream);
+                              int planes, int h, int w, int H, int W, int align_corners,
+                              int relu /* y = max(y, 0): the ReLU that ends an exchange-module sum, HRNet.py:285 */,
+                              float *y, void *stream);
 int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int w, int H, int W, int align_corners,
                               float *dx, void *stream);
 

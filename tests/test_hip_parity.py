@@ -447,7 +447,8 @@ def test_fused_batchnorm_matches_fp64_reference(dev, relu, use_res, shape):
 
 
 @pytest.mark.parametrize("align", [True, False])
-@pytest.mark.parametrize("shape,size", [((2, 5, 16, 32), (64, 128)), ((3, 7, 9, 13), (36, 52)),
+@pytest.mark.parametrize("shape,size", [((2, 5, 16, 32), (64, 128)), ((3, 7, 9, 13), (36, 52)), ((2, 3, 16, 32), (128, 256)),
+                                        ((1, 4, 7, 5), (56, 44)), ((2, 2, 128, 256), (512, 1024)),
                                         ((1, 4, 8, 8), (30, 33)), ((2, 3, 1, 5), (4, 20)),
                                         ((2, 19, 32, 64), (128, 256))])
 def test_upsample_bilinear_matches_torch(dev, align, shape, size):
