@@ -137,11 +137,32 @@ class SwinTransformerBlock(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.H = self.W = None
 
+    hip_attention = True       # class switch (UPerNet graph key 'hip_attention'): False = the library path below
+
+    def _hip_path(self, x):
+        a = self.attn
+        return (self.hip_attention and x.is_cuda and x.dtype == torch.float32 and self.window_size == 7
+                and a.dim == 32 * a.num_heads and a.attn_drop.p == 0.0 and not torch.is_autocast_enabled()
+                and a.qkv.weight.dtype == torch.float32)
+
     def forward(self, x, mask_matrix):
         B, L, C = x.shape
         H, W, ws = self.H, self.W, self.window_size
         assert L == H * W, "input feature has wrong size"
         shortcut = x
+        if self._hip_path(x):
+            # The qkv projection is token-wise, so it commutes with pad / roll / window_partition: it runs on the tokens
+            # in their natural order and the attention kernel gathers each window's 49 tokens itself (and writes the
+            # result back in natural order): no pad, roll, partition, reverse, roll, crop copies (csrc/dcl_winattn.hip).
+            from .ops import window_attention
+            a = self.attn
+            qkv = a.qkv(self.norm1(x))
+            qb = a.qkv.bias if a.qkv.bias is not None else torch.zeros(3 * C, dtype=x.dtype, device=x.device)
+            N = ws * ws
+            bias = a.relative_position_bias_table[a.relative_position_index.view(-1)].view(N, N, a.num_heads)
+            att = window_attention(qkv, qb, bias.permute(2, 0, 1), H, W, a.num_heads, self.shift_size, a.scale)
+            x = shortcut + self.drop_path(a.proj_drop(a.proj(att)))
+            return x + self.drop_path(self.mlp(self.norm2(x)))
         x = self.norm1(x).view(B, H, W, C)
         pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
         if pad_r or pad_b:

@@ -117,6 +117,10 @@ class UPerNet(nn.Module):
         if 'drop_path_rate' in config:          # extension: the reference fixes 0.3 in its backbone table (Swin.py:31)
             settings['drop_path_rate'] = float(config['drop_path_rate'])
         self.backbone = SwinTransformer(**settings)
+        if not config.get('hip_attention', True):       # keep the library (SDPA) attention path: calibration runs
+            for m in self.backbone.modules():
+                if hasattr(m, 'hip_attention'):
+                    m.hip_attention = False
         self.config['input_channels'] = settings['out_channels']
         self.config['input_scales'] = [4, 8, 16, 32]
         self.fpn = FPN(config=self.config, experiment=experiment)

@@ -528,3 +528,55 @@ def use_gemm_conv1x1(module: torch.nn.Module) -> torch.nn.Module:
                 and m.dilation == (1, 1) and m.groups == 1:
             m.__class__ = GemmConv1x1
     return module
+
+
+# ---- Swin window attention (csrc/dcl_winattn.hip) -----------------------------------------------------------------
+
+class _WindowAttention(torch.autograd.Function):
+    """softmax(q k^T * scale + bias (+ shift mask)) v over 7 x 7 windows of tokens kept in their natural order."""
+
+    @staticmethod
+    def forward(ctx, qkv, qkv_bias, bias, H, W, heads, shift, scale):
+        from .. import _lib
+        L = _lib.lib()
+        B, Ltok, C3 = qkv.shape
+        C = C3 // 3
+        out = torch.empty((B, Ltok, C), dtype=torch.float32, device=qkv.device)
+        nW = ((H + 6) // 7) * ((W + 6) // 7)
+        lse = torch.empty((B, nW, heads, 49), dtype=torch.float32, device=qkv.device)
+        _lib.check(L.dcl_winattn_fwd(_lib.ptr(qkv), _lib.ptr(qkv_bias), _lib.ptr(bias), B, H, W, C, heads, shift,
+                                     scale, _lib.ptr(out), _lib.ptr(lse), _lib.stream_ptr(qkv.device)),
+                   "dcl_winattn_fwd")
+        ctx.save_for_backward(qkv, qkv_bias, bias, lse)
+        ctx.geom = (H, W, heads, shift, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .. import _lib
+        L = _lib.lib()
+        qkv, qkv_bias, bias, lse = ctx.saved_tensors
+        H, W, heads, shift, scale = ctx.geom
+        B, Ltok, C3 = qkv.shape
+        C = C3 // 3
+        dout = dout.contiguous()
+        npad = L.dcl_winattn_npad(H, W)
+        nwaves = L.dcl_winattn_bwd_waves(B, H, W, heads)
+        dqkv = torch.empty_like(qkv)
+        dpad = torch.empty((B, npad, C3), dtype=torch.float32, device=qkv.device) if npad else None
+        part = torch.empty((nwaves, 49, 49), dtype=torch.float32, device=qkv.device)
+        _lib.check(L.dcl_winattn_bwd(_lib.ptr(qkv), _lib.ptr(qkv_bias), _lib.ptr(bias), _lib.ptr(lse), _lib.ptr(dout),
+                                     B, H, W, C, heads, shift, scale, _lib.ptr(dqkv), _lib.ptr(dpad), _lib.ptr(part),
+                                     _lib.stream_ptr(qkv.device)), "dcl_winattn_bwd")
+        dbias = part.view(nwaves // heads, heads, 49, 49).sum(0) if ctx.needs_input_grad[2] else None
+        dqb = None
+        if ctx.needs_input_grad[1]:
+            dqb = dpad.sum((0, 1)) if npad else torch.zeros_like(qkv_bias)
+        return dqkv, dqb, dbias, None, None, None, None, None
+
+
+def window_attention(qkv, qkv_bias, bias, H, W, heads, shift, scale):
+    """qkv [B, H*W, 3C] (projection of the tokens in natural order), qkv_bias [3C] (qkv of zero-padded tokens),
+    bias [heads, 49, 49] -> [B, H*W, C]; window 7, head_dim 32, fp32 (csrc/dcl_winattn.hip)."""
+    return _WindowAttention.apply(qkv.contiguous(), qkv_bias.contiguous(), bias.contiguous(), int(H), int(W),
+                                  int(heads), int(shift), float(scale))

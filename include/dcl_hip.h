@@ -306,6 +306,29 @@ int dcl_confusion_matrix(const float *logits, int N, int C, int HW, const void *
  *   out3 f32 {pa, pac, miou} */
 int dcl_metrics_from_cm(const int32_t *cm, int C, int ld, float *out3, void *stream);
 
+/* ---- Swin window attention, fp32, window 7 x 7, head_dim 32 -----------------------
+ * Replaces WindowAttention.forward (reference models/Swin.py:198-230) and the pad / roll / window_partition /
+ * window_reverse / roll / crop data movement of SwinTransformerBlock.forward around it (:286-318): tokens are read
+ * from and written to their natural [B, H*W, .] order (csrc/dcl_winattn.hip).
+ *   qkv       f32 [B, H*W, 3*C]   output of the qkv projection applied to the un-permuted tokens (C = 32 * heads)
+ *   qkv_bias  f32 [3*C]           qkv of the tokens in the zero-padded border (= the projection's bias; zeros if none)
+ *   bias      f32 [heads, 49, 49] relative-position bias gathered from the table (:216-219)
+ *   shift     0 or window // 2; the shifted-window mask (:448-466) is computed from the coordinates
+ *   out       f32 [B, H*W, C]     lse f32 [B, nW, heads, 49] (log-sum-exp of every score row, for the backward)
+ * backward:
+ *   dqkv       f32 [B, H*W, 3*C]
+ *   dpad       f32 [B, npad, 3*C], npad = dcl_winattn_npad(H, W): gradient of the padded tokens' qkv (it belongs to
+ *              the projection's bias: the caller adds its sum over the first two axes to the bias gradient)
+ *   dbias_part f32 [nwaves, 49, 49], nwaves = dcl_winattn_bwd_waves(...): partial bias gradients, wave w -> head
+ *              w % heads; the caller sums them in index order (deterministic) */
+int dcl_winattn_npad(int H, int W);
+int dcl_winattn_fwd(const float *qkv, const float *qkv_bias, const float *bias, int B, int H, int W, int C, int heads,
+                    int shift, float scale, float *out, float *lse, void *stream);
+int dcl_winattn_bwd_waves(int B, int H, int W, int heads);
+int dcl_winattn_bwd(const float *qkv, const float *qkv_bias, const float *bias, const float *lse, const float *dout,
+                    int B, int H, int W, int C, int heads, int shift, float scale, float *dqkv, float *dpad,
+                    float *dbias_part, void *stream);
+
 /* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the
  * grid fills the 256 CUs evenly (host helper, no device work). */
 int dcl_suggest_nsplit(int N1, int N2);

@@ -1,0 +1,130 @@
+"""Swin window attention kernels through the C ABI against the reference's formulation
+(models/Swin.py:198-230 inside :286-318: zero-pad -> roll -> window_partition -> (q * scale) k^T + relative-position
+bias + shift mask -> softmax -> v -> window_reverse -> roll back -> crop), restated here with torch ops in fp64.
+Tolerance: forward 2e-6 of max, gradients 1e-5 of max (fp32 round-off; the arithmetic is fp32 FMAs)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _partition(x, ws):
+    B, H, W, C = x.shape
+    return x.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+
+
+def _reverse(w, ws, H, W):
+    B = w.shape[0] // ((H // ws) * (W // ws))
+    return w.view(B, H // ws, W // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, -1)
+
+
+def _shift_mask(Hp, Wp, ws, ss, device, dtype):
+    region = torch.zeros((1, Hp, Wp, 1), dtype=dtype)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -ss), slice(-ss, None)):
+            region[:, hs, wsl, :] = cnt
+            cnt += 1
+    mw = _partition(region, ws).reshape(-1, ws * ws)
+    diff = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff)).to(device)
+
+
+def reference_block_attention(xn, wqkv, bqkv, bias, H, W, heads, shift, scale):
+    """xn [B, H*W, C] normalised tokens -> attention output [B, H*W, C], the reference's data flow."""
+    B, L, C = xn.shape
+    ws = 7
+    x = xn.view(B, H, W, C)
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
+    Hp, Wp = H + pad_b, W + pad_r
+    if shift:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    win = _partition(x, ws)                                             # [B_, 49, C]
+    B_, N, _ = win.shape
+    qkv = F.linear(win, wqkv, bqkv).reshape(B_, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * scale, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1) + bias.unsqueeze(0)
+    if shift:
+        mask = _shift_mask(Hp, Wp, ws, shift, xn.device, xn.dtype)
+        nW = mask.shape[0]
+        attn = attn.view(B_ // nW, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)
+        attn = attn.view(-1, heads, N, N)
+    attn = attn.softmax(-1)
+    out = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    x = _reverse(out, ws, Hp, Wp)
+    if shift:
+        x = torch.roll(x, shifts=(shift, shift), dims=(1, 2))
+    return x[:, :H, :W, :].reshape(B, H * W, C)
+
+
+@pytest.mark.parametrize("B,H,W,heads,shift", [(2, 14, 21, 3, 0), (2, 14, 21, 3, 3), (1, 16, 20, 2, 3), (2, 9, 5, 1, 3),
+                                               (1, 32, 32, 6, 3), (3, 7, 7, 2, 0), (1, 5, 6, 1, 3)])
+def test_window_attention_matches_reference_formulation(B, H, W, heads, shift):
+    from mscs_amd.models.ops import window_attention
+    dev = torch.device("cuda:0")
+    C = 32 * heads
+    gen = torch.Generator().manual_seed(H * 100 + W + shift)
+    xn = torch.randn(B, H * W, C, generator=gen, dtype=torch.float64)
+    wqkv = torch.randn(3 * C, C, generator=gen, dtype=torch.float64) / C ** 0.5
+    bqkv = torch.randn(3 * C, generator=gen, dtype=torch.float64) * 0.5
+    bias = torch.randn(heads, 49, 49, generator=gen, dtype=torch.float64)
+    gout = torch.randn(B, H * W, C, generator=gen, dtype=torch.float64)
+    scale = 32 ** -0.5
+    # fp64 reference through autograd
+    rx, rw, rb, rbias = [t.clone().requires_grad_(True) for t in (xn, wqkv, bqkv, bias)]
+    ref = reference_block_attention(rx, rw, rb, rbias, H, W, heads, shift, scale)
+    ref.backward(gout)
+    # HIP path: projection on the natural token order + the kernel
+    hx, hw, hb, hbias = [t.float().to(dev).requires_grad_(True) for t in (xn, wqkv, bqkv, bias)]
+    qkv = F.linear(hx, hw, hb)
+    out = window_attention(qkv, hb, hbias, H, W, heads, shift, scale)
+    out.backward(gout.float().to(dev))
+
+    def close(got, want, tol, what):
+        err = (got.detach().double().cpu() - want.detach()).abs().max().item()
+        assert err <= tol * max(1.0, want.detach().abs().max().item()), (what, err)
+    close(out, ref, 2e-6, "out")
+    close(hx.grad, rx.grad, 1e-5, "dx")
+    close(hw.grad, rw.grad, 1e-5, "dW")
+    close(hb.grad, rb.grad, 1e-5, "db (incl. the padded tokens)")
+    close(hbias.grad, rbias.grad, 1e-5, "d relative-position bias")
+    # bitwise run-to-run determinism (fixed-order partial sums)
+    hx2, hb2, hbias2 = [t.detach().clone().requires_grad_(True) for t in (hx, hb, hbias)]
+    out2 = window_attention(F.linear(hx2, hw.detach(), hb2), hb2, hbias2, H, W, heads, shift, scale)
+    out2.backward(gout.float().to(dev))
+    assert torch.equal(out2, out) and torch.equal(hbias2.grad, hbias.grad) and torch.equal(hx2.grad, hx.grad)
+
+
+def test_swin_block_hip_path_matches_library_path():
+    """SwinTransformerBlock with the HIP attention against the same block on the library path (pad / roll /
+    partition / SDPA): forward and all parameter gradients, shifted and unshifted, non-multiple-of-7 map."""
+    from mscs_amd.models.Swin import SwinTransformerBlock
+    dev = torch.device("cuda:0")
+    for shift in (0, 3):
+        torch.manual_seed(3)
+        blk = SwinTransformerBlock(dim=96, num_heads=3, window_size=7, shift_size=shift).to(dev)
+        torch.nn.init.normal_(blk.attn.relative_position_bias_table, std=0.5)
+        H, W = 18, 25
+        blk.H, blk.W = H, W
+        x = torch.randn(2, H * W, 96, device=dev)
+        from mscs_amd.models.Swin import BasicLayer
+        layer = BasicLayer(dim=96, depth=2, num_heads=3)
+        mask = layer._shift_mask(H, W, dev)
+        res = {}
+        for hip in (True, False):
+            blk.hip_attention = hip
+            for p in blk.parameters():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            y = blk(xi, mask)
+            (y * torch.cos(torch.arange(y.numel(), device=dev).view_as(y) * 0.37)).sum().backward()
+            res[hip] = (y.detach(), xi.grad, {k: p.grad.clone() for k, p in blk.named_parameters()})
+        ya, ga, pa = res[True]
+        yb, gb, pb = res[False]
+        assert (ya - yb).abs().max().item() <= 2e-5 * yb.abs().max().item()
+        assert (ga - gb).abs().max().item() <= 1e-4 * gb.abs().max().item()
+        for k in pa:
+            assert (pa[k] - pb[k]).abs().max().item() <= 1e-4 * max(pb[k].abs().max().item(), 1e-6), k
