@@ -51,10 +51,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=["step", "loss"])
-    ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--scales", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+                    help="BASELINE.json configs[] index of the timed workload: 2 = HRNet-W48 Cityscapes 512x1024 (the "
+                         "headline metric, default), 4 = UPerNet + Swin-T ADE20K 512x512 with per-GPU batch 16 "
+                         "(SURVEY.md Appendix C case 4': the whole global batch of configs[3] on one GPU)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 12 / 16 by config")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--scales", type=int, default=None)
     ap.add_argument("--no-cross", action="store_true")
     ap.add_argument("--mfma", default=None, choices=["f32", "f16x3"],
                     help="similarity-product arithmetic of the loss kernels (default: the library default)")
@@ -72,16 +76,24 @@ def parse():
                     help="skip eager_gpu_step_ms (the eager-structure reference step on the same GPU, N=1 only)")
     ap.add_argument("--no-metrics", action="store_true",
                     help="leave the per-step metrics tail (confusion matrix, accuracies, mIoU, logging) out of the step")
-    return ap.parse_args()
+    a = ap.parse_args()
+    d = {2: (12, 512, 1024, 3), 4: (16, 512, 512, 4)}[a.config]
+    a.batch = a.batch or d[0]
+    a.height = a.height or d[1]
+    a.width = a.width or d[2]
+    a.scales = a.scales or d[3]
+    a.classes = 20 if a.config == 2 else 151
+    a.dataset = "CITYSCAPES" if a.config == 2 else "ADE20K"
+    return a
 
 
 MFMA_MODE = None
 
 
-def loss_config(S, cross):
+def loss_config(S, cross, dataset="CITYSCAPES"):
     weights = [1.0, 0.7, 0.4, 0.1][:S]
     extra = {"mfma_mode": MFMA_MODE} if MFMA_MODE else {}
-    return {**extra, "dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": S,
+    return {**extra, "dataset": dataset, "experiment": 1, "temperature": 0.1, "scales": S,
             "weights": weights, "cross_scale_contrast": cross, "min_views_per_class": 5,
             "max_views_per_class": 2500, "max_features_total": 10000, "label_scaling_mode": "nn"}
 
@@ -89,7 +101,7 @@ def loss_config(S, cross):
 def synth_loss_inputs(args, dev, rank):
     gen = torch.Generator().manual_seed(1000 * rank)
     n, H, W = args.batch, args.height, args.width
-    label = torch.randint(0, 20, (n, H, W), generator=gen).to(dev)          # iid: worst-case load (N at the cap)
+    label = torch.randint(0, getattr(args, "classes", 20), (n, H, W), generator=gen).to(dev)   # iid: worst-case load
     feats = [torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).to(dev).requires_grad_(True)
              for s in range(args.scales)]
     return label, feats
@@ -101,7 +113,7 @@ def time_loss_only(args, dev, rank, world):
     from mscs_amd.utils import set_verbosity
     set_verbosity(40)
     cross = not args.no_cross
-    mod = DenseContrastiveLossV2_ms(loss_config(args.scales, cross))
+    mod = DenseContrastiveLossV2_ms(loss_config(args.scales, cross, getattr(args, "dataset", "CITYSCAPES")))
     label, feats = synth_loss_inputs(args, dev, rank)
     torch.manual_seed(0)
 
@@ -315,12 +327,43 @@ def workload_name(args, workload):
     cross = "" if args.no_cross else " + cross-scale"
     if workload == "loss":
         return (f"DenseContrastiveLossV2_ms fwd+bwd, {args.scales} scales{cross}, n={args.batch} "
-                f"{args.height}x{args.width} iid labels K=20, C=256, per GPU")
+                f"{args.height}x{args.width} iid labels K={args.classes}, C=256, per GPU")
+    if args.config == 4:
+        return (f"BASELINE configs[3] on one GPU (SURVEY App. C 4'): UPerNet + Swin-T + LossWrapper(TwoScaleLoss + "
+                f"0.1*DenseContrastiveLossV2_ms, {args.scales} scales{cross}, fpn projector) train step (fwd+bwd+AdamW), "
+                f"synthetic ADE20K {args.height}x{args.width}, batch {args.batch} per GPU, iid labels")
     return (f"HRNet-W48 + LossWrapper(CE + 0.1*DenseContrastiveLossV2_ms, {args.scales} scales{cross}) train step "
             f"(fwd+bwd+SGD), synthetic Cityscapes {args.height}x{args.width}, batch {args.batch} per GPU, iid labels")
 
 
+def step_config_upernet(args, world):
+    """configs/ADE20K/upnswin_contrastive_ADE20K.json of the reference (graph / loss / train blocks as shipped), on the
+    synthetic dataset."""
+    S = args.scales
+    return {
+        "name": "bench4", "mode": "training", "manager": "OCRNet", "cuda": True, "seed": 0,
+        "parallel": world > 1, "batch_is_global": False,
+        "graph": {"model": "UPerNet", "backbone": "swinT", "sync_bn": True, "out_stride": 32, "pretrained": False,
+                  "align_corners": False, "aux_head": {"in_index": 3, "dropout_rate": 0.1}, "dropout_rate": 0.1,
+                  "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "position": "fpn"}},
+        "data": {"dataset": "ADE20K", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
+                 "synthetic": True, "synthetic_length": args.batch * 2,
+                 "transform_values": {"crop_shape": [args.height, args.width]}},
+        "loss": dict(loss_config(S, not args.no_cross, "ADE20K"), name="LossWrapper",
+                     interm={"name": "CrossEntropyLoss", "args": [], "weight": 0.4},
+                     final={"name": "CrossEntropyLoss", "args": [], "weight": 1.0},
+                     losses={"TwoScaleLoss": 1.0, "DenseContrastiveLossV2_ms": 0.1}),
+        "train": {"lr_batchwise": True, "learning_rate": 0.00006, "lr_fct": "linear-warmup-polynomial",
+                  "lr_params": {"power": 1.0, "warmup_iters": 1500, "warmup_rate": 1e-6, "min_lr": 0.0},
+                  "optim": "AdamW", "epochs": 127, "momentum": 0.9, "betas": [0.9, 0.999], "weight_decay": 0.01,
+                  "opt_keys": {"absolute_pos_embed": {"wd_mult": 0.0}, "norm": {"wd_mult": 0.0},
+                               "relative_position_bias_table": {"wd_mult": 0.0}}},
+    }
+
+
 def step_config(args, world):
+    if getattr(args, "config", 2) == 4:
+        return step_config_upernet(args, world)
     S = args.scales
     return {
         "name": "bench", "mode": "training", "manager": "HRNet", "cuda": True, "seed": 0,
@@ -341,16 +384,16 @@ def step_config(args, world):
 def time_train_step(args, dev, rank, world):
     """K training steps of HRNetManager on one resident synthetic batch per rank."""
     import mscs_amd  # noqa: F401
-    from mscs_amd.managers import HRNetManager
+    from mscs_amd.managers import HRNetManager, OCRNetManager
     from mscs_amd.utils import set_verbosity
     set_verbosity(40)
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
-    mgr = HRNetManager(step_config(args, world), autostart=False)
+    mgr = (OCRNetManager if args.config == 4 else HRNetManager)(step_config(args, world), autostart=False)
     mgr.setup()
     mgr.model.train()
     gen = torch.Generator().manual_seed(1000 * rank)
     img = torch.randn(args.batch, 3, args.height, args.width, generator=gen).to(dev)
-    lbl = torch.randint(0, 20, (args.batch, args.height, args.width), generator=gen).to(dev)    # int64, as loaded
+    lbl = torch.randint(0, args.classes, (args.batch, args.height, args.width), generator=gen).to(dev)  # int64
     if args.channels_last:
         img = img.contiguous(memory_format=torch.channels_last)
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if args.amp else contextlib.nullcontext()
@@ -454,12 +497,12 @@ def main():
         out.update(extra)
         if workload == "loss":
             out["contrastive_loss_fwd_bwd_ms"] = round(ms_per_step, 3)
-        if workload == "loss":
+        if workload == "loss" or args.config != 2:
             out["roofline"] = roofline_bwd_kernel(mod)
         else:
             out["roofline"], others = roofline_conv_kernels(args, dev)
             out["roofline_other"] = others + [roofline_bwd_kernel(mod)]
-        if not args.no_cpu_baseline and world == 1:        # host baseline: rank 0 of the single-GPU run only
+        if not args.no_cpu_baseline and world == 1 and args.config == 2:    # host baseline: single-GPU headline run only
             scale, lsec, cores, lsample = cpu_baseline_loss(args, n_terms)
             loss_sec = lsec * scale
             if workload == "loss":
@@ -473,7 +516,7 @@ def main():
                                        "sample_seconds": round(msec + lsec, 2)}
         if args.eager_baseline:
             out["eager_gpu_loss_ms"] = round(eager_gpu_loss_ms(args, dev), 2)
-        if workload == "step" and world == 1 and not args.no_eager_step:
+        if workload == "step" and world == 1 and not args.no_eager_step and args.config == 2:
             torch.cuda.empty_cache()
             eager_ms = eager_gpu_step_ms(args, dev)
             out["eager_gpu_step_ms"] = round(eager_ms, 1)

@@ -199,9 +199,34 @@ class BaseManager:
                                                        num_workers=0)
         self.train_schedule = {e: 'train_loader' for e in range(self.config['train']['epochs'])}
 
+    def _param_groups(self):
+        """``train.opt_keys`` {substring: {lr_mult, wd_mult}} -> optimizer parameter groups (reference:
+        utils/optimizer_utils.py:34-80): a parameter joins the group of the FIRST key its name contains, every other
+        parameter the base group; frozen parameters stay out."""
+        tcfg = self.config['train']
+        keys = tcfg.get('opt_keys')
+        if not keys:
+            return self.model.parameters()
+        base_lr, base_wd = tcfg['learning_rate'], tcfg.get('weight_decay', 0.0)
+        groups = {}
+        for name, p in self.model.named_parameters():
+            if not p.requires_grad:
+                continue
+            gname, lr, wd = 'base_lr_wd', base_lr, base_wd
+            for key, mult in keys.items():
+                if key in name:
+                    lm, wm = mult.get('lr_mult', 1.0), mult.get('wd_mult', 1.0)
+                    gname, lr, wd = f'{key}_lrm{lm}_wdm{wm}', lm * base_lr, wm * base_wd
+                    break
+            g = groups.setdefault(gname, {'params': [], 'group_name': gname, 'param_names': [], 'lr': lr,
+                                          'weight_decay': wd})
+            g['params'].append(p)
+            g['param_names'].append(name)
+        return list(groups.values())
+
     def load_optimiser(self):
         tcfg = self.config['train']
-        params = self.model.parameters()
+        params = self._param_groups()
         optim = tcfg.get('optim', 'Adam')
         if optim == 'SGD':
             self.optimiser = torch.optim.SGD(params, lr=tcfg['learning_rate'], momentum=tcfg.get('momentum', 0.9),

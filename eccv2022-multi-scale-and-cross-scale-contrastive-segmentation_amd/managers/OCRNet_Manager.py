@@ -15,7 +15,7 @@ class OCRNetManager(BaseManager):
         if isinstance(self.loss, LossWrapper):
             lbl = lbl.long()                      # converted once so that prepare() and forward() see one tensor
             if self.return_features and self.model.training:
-                self.loss.prepare(lbl)            # label stage on a side stream, overlaps the model forward
+                self.loss.prepare(lbl, ready_event=kwargs.get('label_ready'))     # see HRNet_Manager.forward_step
             if self.return_features:
                 out = self.model(img.float())
                 if len(out) == 3:

@@ -14,19 +14,31 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..utils import DATASETS_INFO, printlog
+from .fused_bn import FusedBatchNorm2d, bn_act
+from .ops import upsample_bilinear
 from .Projector import Projector
 from .Swin import SwinTransformer
 from .Swin import backbone_config as backbone_config_swin
 
 
-def conv3x3(in_planes, out_planes, batch_norm, relu, stride=1):
+class _ConvBNAct(nn.Sequential):
+    """Sequential(conv, BatchNorm2d[, ReLU]) -- the reference's layout and state_dict keys -- whose forward hands the
+    ReLU to the norm layer when that can fuse it (models/fused_bn.py: one statistics + one apply pass on the GPU)."""
+
+    def forward(self, x):
+        if len(self) >= 2 and isinstance(self[1], FusedBatchNorm2d) and (len(self) == 2 or isinstance(self[2], nn.ReLU)):
+            return bn_act(self[1], self[0](x), relu=len(self) == 3)
+        return super().forward(x)
+
+
+def conv3x3(in_planes, out_planes, batch_norm, relu, stride=1, norm=nn.BatchNorm2d):
     """conv3x3 (+BN) (+ReLU) builder with the reference's Sequential layout (utils/torch_utils.py:107-123)."""
     layers = [nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)]
     if batch_norm:
-        layers.append(nn.BatchNorm2d(out_planes))
+        layers.append(norm(out_planes))
     if relu:
         layers.append(nn.ReLU(inplace=True))
-    return layers[0] if len(layers) == 1 else nn.Sequential(*layers)
+    return layers[0] if len(layers) == 1 else _ConvBNAct(*layers)
 
 
 def _num_classes(dataset, experiment):
@@ -34,8 +46,8 @@ def _num_classes(dataset, experiment):
     return len(names) - 1 if 255 in names.keys() else len(names)
 
 
-def _conv1x1_bn_relu(cin, cout):
-    return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+def _conv1x1_bn_relu(cin, cout, norm=nn.BatchNorm2d):
+    return _ConvBNAct(nn.Conv2d(cin, cout, kernel_size=1, bias=False), norm(cout), nn.ReLU(inplace=True))
 
 
 class FPN(nn.Module):
@@ -53,38 +65,39 @@ class FPN(nn.Module):
         self.fpn_num_lvl = min(max(config.get('fpn_num_lvl', len(self.in_scales)), 1), len(self.in_scales))
         self.interpolate_result_up = config.get('interpolate_result_up', True)
         self.return_features = True
+        # 'hip_decoder' (default on): fused BN(+ReLU) kernels, HIP bilinear resize (forward with the lateral add folded
+        # in, deterministic gather backward) and 1x1 convolutions as batched GEMMs -- same parameters / state_dict
+        norm = FusedBatchNorm2d if config.get('hip_decoder', True) else nn.BatchNorm2d
         top = self.in_channels[-1]
         self.ppm_pooling = nn.ModuleList([nn.AdaptiveAvgPool2d(s) for s in self.pool_scales])
-        self.ppm_conv = nn.ModuleList([_conv1x1_bn_relu(top, self.ppm_num_ch) for _ in self.pool_scales])
+        self.ppm_conv = nn.ModuleList([_conv1x1_bn_relu(top, self.ppm_num_ch, norm) for _ in self.pool_scales])
         self.ppm_last_conv = conv3x3(top + len(self.pool_scales) * self.ppm_num_ch, self.fpn_num_ch,
-                                     batch_norm=True, relu=True)
-        self.fpn_in = nn.ModuleList([_conv1x1_bn_relu(c, self.fpn_num_ch)
+                                     batch_norm=True, relu=True, norm=norm)
+        self.fpn_in = nn.ModuleList([_conv1x1_bn_relu(c, self.fpn_num_ch, norm)
                                      for c in self.in_channels[-self.fpn_num_lvl:-1]])
-        self.fpn_out = nn.ModuleList([nn.Sequential(conv3x3(self.fpn_num_ch, self.fpn_num_ch, True, True))
+        self.fpn_out = nn.ModuleList([nn.Sequential(conv3x3(self.fpn_num_ch, self.fpn_num_ch, True, True, norm=norm))
                                       for _ in range(self.fpn_num_lvl - 1)])
         self.conv_last = nn.Sequential(
-            conv3x3(self.fpn_num_lvl * self.fpn_num_ch, self.fpn_num_ch, batch_norm=True, relu=True),
+            conv3x3(self.fpn_num_lvl * self.fpn_num_ch, self.fpn_num_ch, batch_norm=True, relu=True, norm=norm),
             nn.Dropout2d(self.dropout),
             nn.Conv2d(self.fpn_num_ch, self.num_classes, kernel_size=1))
 
     def forward(self, conv_out):
         c5 = conv_out[-1]
         size5 = c5.shape[2:]
-        ppm = [c5] + [conv(F.interpolate(pool(c5), size5, mode='bilinear', align_corners=False))
+        ppm = [c5] + [conv(upsample_bilinear(pool(c5), size5, False))
                       for pool, conv in zip(self.ppm_pooling, self.ppm_conv)]
         feature = self.ppm_last_conv(torch.cat(ppm, 1))
         pyramid = [feature]
         for i in range(2, self.fpn_num_lvl + 1):
             lateral = self.fpn_in[-i + 1](conv_out[-i])
-            feature = lateral + F.interpolate(feature, size=lateral.shape[2:], mode='bilinear',
-                                              align_corners=self.align_corners)
+            feature = upsample_bilinear(feature, lateral.shape[2:], self.align_corners, add=lateral)
             pyramid.append(self.fpn_out[-i + 1](feature))
         pyramid.reverse()                                       # [P2 .. P5]
         out_size = pyramid[0].shape[2:]
         # concat order is [P2, P5, P4, P3]: the reference walks the reversed list from its END
         # (UPerNet.py:96-101), and conv_last's input channels are laid out accordingly
-        fused = torch.cat([pyramid[0]] + [F.interpolate(pyramid[-i + 1], out_size, mode='bilinear',
-                                                        align_corners=self.align_corners)
+        fused = torch.cat([pyramid[0]] + [upsample_bilinear(pyramid[-i + 1], out_size, self.align_corners)
                                           for i in range(2, self.fpn_num_lvl + 1)], 1)
         x = self.conv_last(fused)
         if self.return_features:
@@ -103,7 +116,7 @@ class UPerNet(nn.Module):
         self.out_stride = 32
         self.dataset = config['dataset']
         self.backbone_name = config['backbone']
-        self.norm = nn.BatchNorm2d
+        self.norm = FusedBatchNorm2d if config.get('hip_decoder', True) else nn.BatchNorm2d
         assert self.backbone_name in self.eligible_backbones, \
             f'backbone must be in {self.eligible_backbones} (torchvision ResNets of the reference are not built here)'
         self.num_classes = _num_classes(self.dataset, experiment)
@@ -135,6 +148,13 @@ class UPerNet(nn.Module):
             if self.aux_head is not None:
                 use_direct_conv3x3(self.aux_head)
             self._conv_packs = ConvPackGroup(self)
+        if config.get('hip_decoder', True):
+            from .ops import use_gemm_conv1x1
+            use_gemm_conv1x1(self.fpn)
+            if self.aux_head is not None:
+                use_gemm_conv1x1(self.aux_head)
+            if self.projector_model is not None:
+                use_gemm_conv1x1(self.projector_model)
 
     def _get_aux_head(self):
         if 'aux_head' in self.config:
@@ -152,6 +172,13 @@ class UPerNet(nn.Module):
             self.in_index = None
             self.aux_head = None
             self.get_intermediate = False
+
+    def _aux(self, x):
+        """aux_head = Sequential(conv3x3 + bias, norm, ReLU, Dropout2d, conv1x1): norm + ReLU in one fused pass."""
+        h = self.aux_head
+        if isinstance(h[1], FusedBatchNorm2d):
+            return h[4](h[3](bn_act(h[1], h[0](x), relu=True)))
+        return h(x)
 
     def _get_projector(self):
         self.projector_position = None
@@ -189,11 +216,10 @@ class UPerNet(nn.Module):
             self._conv_packs.refresh()
         feats = self.backbone(x)
         logits, fpn_feats, fused = self.fpn(feats)
-        up = dict(size=size, mode='bilinear', align_corners=self.align_corners)
-        logits = F.interpolate(logits, **up)
+        logits = upsample_bilinear(logits, size, self.align_corners)
         interm = None
         if self.get_intermediate and self.aux_head is not None:
-            interm = F.interpolate(self.aux_head(feats[self.aux_in_index]), **up)
+            interm = upsample_bilinear(self._aux(feats[self.aux_in_index]), size, self.align_corners)
         if self.projector_model is not None:
             if self.use_ms_projector:
                 if self.projector_position == 'backbone':
