@@ -460,6 +460,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
+        # one host core per rank is what the launch loop needs; leave the rest to the other ranks
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
         dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)

@@ -431,8 +431,10 @@ def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torc
     return st
 
 
-def build_banks(st: StepState, feats: Sequence[torch.Tensor], f16x3: bool = False):
-    """K3 for every scale (optionally also the f16x3 copy of each bank)."""
+def build_banks(st: StepState, feats: Sequence[torch.Tensor], f16x3: bool = False, gather=None):
+    """K3 for every scale (optionally also the f16x3 copy of each bank).  ``gather``: a ``_BankGather`` -- the
+    all-gather of a scale's bank is issued right behind its K3, so that it travels over xGMI while the next scale's
+    bank is gathered from HBM (K3) instead of after all of them."""
     L = _lib.lib()
     stream = _stream_ptr()
     for sc, f in zip(st.scales, feats):
@@ -446,6 +448,8 @@ def build_banks(st: StepState, feats: Sequence[torch.Tensor], f16x3: bool = Fals
                                           _lib.ptr(sc.pair_b), _lib.ptr(sc.slot_pair), p.T, p.V,
                                           _lib.ptr(sc.bank), _lib.ptr(sc.nrm), _lib.ptr(sc.bank_h), stream),
                    "dcl_gather_normalize")
+        if gather is not None:
+            gather.issue(sc)
 
 
 def _own_segments(st: StepState):
@@ -463,11 +467,13 @@ def class_layout(plan: HostPlan) -> np.ndarray:
     return np.concatenate([[plan.V], plan.cls_hi - plan.cls_lo]).astype(np.int32)
 
 
-def attach_global_segments(st: StepState, rank: int, peer_banks, peer_layouts):
+def attach_global_segments(st: StepState, rank: int, peer_banks, peer_layouts, peer_banks_h=None):
     """Replace every term's contrast bank by the concatenation of all ranks' banks.
 
-    peer_banks[q][s]: f32 [>= N_q, 256] bank of rank q at scale s (entry ``rank`` is ignored: the local
-    bank is used); peer_layouts[q][s]: ``class_layout`` of that bank (host int32 [K + 1]).
+    peer_banks[q][s]: f32 [>= N_q, 256] bank of rank q at scale s, and / or peer_banks_h[q][s]: its (hi | lo) half
+    rows f16 [>= N_q, 512] (entry ``rank`` is ignored: the local bank is used; with only the half rows the peers'
+    segments run on the f16x3 path like the local one); peer_layouts[q][s]: ``class_layout`` of that bank (host
+    int32 [K + 1]).
     Positives of a local anchor = rows of its class in EVERY segment (minus itself), negatives = all
     other rows of every segment; gradients flow to the local bank only (all_gather has no gradient,
     the convention of the reference's unused concat_all_gather, utils/distributed.py:50-55)."""
@@ -521,44 +527,85 @@ def attach_global_segments(st: StepState, rank: int, peer_banks, peer_layouts):
             if Nq == 0:
                 continue
             own = q == rank
-            bank = st.scales[t.b].bank if own else peer_banks[q][t.b]
+            if own:
+                bank, bank_h = st.scales[t.b].bank, st.scales[t.b].bank_h
+            else:
+                bank_h = peer_banks_h[q][t.b] if peer_banks_h is not None else None
+                # the f32 rows of a peer are only read by the f32 kernels; in f16x3 mode the local bank stands in as
+                # the (unused) f32 argument of the C ABI
+                bank = peer_banks[q][t.b] if peer_banks is not None else st.scales[t.b].bank
             t.segs.append(_Seg(bank=bank, N=Nq, rng_lo=view(lo_id), rng_hi=view(hi_id), own=own,
-                               nsplit=min(per_seg, max(1, (Nq + 31) // 32)),
-                               bank_h=st.scales[t.b].bank_h if own else None))   # peers: f32 product
+                               nsplit=min(per_seg, max(1, (Nq + 31) // 32)), bank_h=bank_h))
         t.pcount = view(pc_id)
 
 
-def gather_peer_banks(st: StepState, max_features_total: int, group=None):
-    """RCCL all-gather of every scale's bank (padded to a fixed row count) and class layout.
-    Returns (rank, peer_banks, peer_layouts) for ``attach_global_segments``.  The bank gathers are
-    issued asynchronously, one per scale, and awaited together; the layout gather is a few hundred
-    bytes followed by the only extra host sync of this extension."""
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    dev = st.scales[0].bank.device
-    cap = _npad(max(max_features_total, max(sc.plan.N for sc in st.scales)))
-    K = st.scales[0].plan.K
-    lay = torch.from_numpy(np.stack([class_layout(sc.plan) for sc in st.scales])).to(dev)
-    # outputs are laid out [world * rows, ...] (concatenation along dim 0) and viewed per rank afterwards
-    lay_all = torch.empty((world * lay.shape[0], lay.shape[1]), dtype=torch.int32, device=dev)
-    work = [dist.all_gather_into_tensor(lay_all, lay, group=group, async_op=True)]
-    gathered = []
-    for sc in st.scales:
-        src = sc.bank
-        if src.shape[0] != cap:
-            pad = torch.zeros((cap, _lib.CP), dtype=torch.float32, device=dev)
+class _BankGather:
+    """RCCL all-gather of every scale's bank (padded to a fixed row count) and class layout for the shared negative
+    bank.  What travels is the representation the sweep kernels read: in ``f16x3`` mode the (hi | lo) half rows
+    (``bank_h``, so that peers' segments run on the f16 matrix pipe like the local one), else the f32 rows -- 1 KiB per
+    row either way (<= 10.24 MB per rank and scale).  ``issue(scale)`` is called right behind the scale's K3 (async
+    collective on RCCL's own stream, ordered after the producer through the work object); ``finish()`` waits for all of
+    them just before the first sweep and returns (rank, peer_banks, peer_banks_h, peer_layouts)."""
+
+    def __init__(self, st: StepState, max_features_total: int, f16x3: bool, group=None):
+        import torch.distributed as dist
+        self.dist, self.group, self.st, self.f16x3 = dist, group, st, f16x3
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        sc0 = st.scales[0]
+        dev = (sc0.pix if sc0.pix is not None else sc0.bank).device
+        self.cap = _npad(max(max_features_total, max(sc.plan.N for sc in st.scales)))
+        lay = torch.from_numpy(np.stack([class_layout(sc.plan) for sc in st.scales])).to(dev)
+        # outputs are laid out [world * rows, ...] (concatenation along dim 0) and viewed per rank afterwards
+        self.lay_all = torch.empty((self.world * lay.shape[0], lay.shape[1]), dtype=torch.int32, device=dev)
+        self.work = [dist.all_gather_into_tensor(self.lay_all, lay, group=group, async_op=True)]
+        self.gathered = []
+        st.keepalive.append(lay)
+
+    def issue(self, sc: _Scale):
+        src = sc.bank_h if self.f16x3 else sc.bank
+        width = src.shape[1]
+        if src.shape[0] != self.cap:
+            pad = torch.zeros((self.cap, width), dtype=src.dtype, device=src.device)
             pad[:src.shape[0]] = src
             src = pad
-        out = torch.empty((world * cap, _lib.CP), dtype=torch.float32, device=dev)
-        work.append(dist.all_gather_into_tensor(out, src, group=group, async_op=True))
-        gathered.append(out.view(world, cap, _lib.CP))
-    for w in work:
-        w.wait()
-    layouts = lay_all.view(world, len(st.scales), -1).cpu().numpy()   # [world, S, K + 1]
-    peer_banks = [[gathered[s][q] for s in range(len(st.scales))] for q in range(world)]
-    peer_layouts = [[layouts[q, s] for s in range(len(st.scales))] for q in range(world)]
-    st.keepalive += gathered
-    return rank, peer_banks, peer_layouts
+        out = torch.empty((self.world * self.cap, width), dtype=src.dtype, device=src.device)
+        self.work.append(self.dist.all_gather_into_tensor(out, src, group=self.group, async_op=True))
+        self.gathered.append(out.view(self.world, self.cap, width))
+        self.st.keepalive.append(src)
+
+    def finish(self):
+        for w in self.work:
+            w.wait()
+        S = len(self.st.scales)
+        layouts = self.lay_all.view(self.world, S, -1).cpu().numpy()   # [world, S, K + 1]: the one extra host sync
+        peer = [[self.gathered[s][q] for s in range(S)] for q in range(self.world)]
+        peer_layouts = [[layouts[q, s] for s in range(S)] for q in range(self.world)]
+        self.st.keepalive += self.gathered
+        if self.f16x3:
+            return self.rank, None, peer, peer_layouts
+        return self.rank, peer, None, peer_layouts
+
+
+def gather_peer_banks(st: StepState, max_features_total: int, group=None, f16x3: bool = False):
+    """All scales at once (banks already built): (rank, peer_banks, peer_banks_h, peer_layouts)."""
+    g = _BankGather(st, max_features_total, f16x3, group)
+    for sc in st.scales:
+        g.issue(sc)
+    return g.finish()
+
+
+def agree_or_raise(error: Optional[BaseException], device, group=None):
+    """Shared-negative-bank mode: every rank is about to enter collectives; if ANY rank failed while planning
+    (e.g. no (image, class) pair with min_views pixels on its shard), all ranks must raise instead of some of them
+    hanging in the all-gather.  One 4-byte all-reduce(MAX)."""
+    import torch.distributed as dist
+    flag = torch.tensor([1 if error is not None else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if error is not None:
+        raise error
+    if int(flag.item()):
+        raise RuntimeError("another rank failed while planning the contrastive loss (shared negative bank): "
+                           "aborting this step on every rank")
 
 
 def run_forward_terms(st: StepState):
@@ -607,18 +654,32 @@ class DenseContrastFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg: EngineConfig, label: torch.Tensor, holder: dict, *feats):
         with_cross = bool(cfg.cross_scale_contrast) and len(feats) > 1
-        st = plan_and_sample(cfg, label, feats, with_cross, staged=holder.get("staged"))
-        build_banks(st, feats, f16x3=(cfg.mfma == "f16x3"))
+        f16x3 = cfg.mfma == "f16x3"
         peers = holder.get("emulated_peers")
-        if peers is not None:                       # single-process emulation of other ranks (tests)
-            rank, peer_banks, peer_layouts = peers
-            peer_layouts = list(peer_layouts)
-            peer_layouts[rank] = [class_layout(sc.plan) for sc in st.scales]
-            attach_global_segments(st, rank, peer_banks, peer_layouts)
-        elif cfg.global_negatives and _dist_world() > 1:
-            attach_global_segments(st, *gather_peer_banks(st, cfg.max_features_total))
+        shared = peers is None and cfg.global_negatives and _dist_world() > 1
+        if shared:
+            # planning can fail on ONE rank (no qualifying pair on its shard): agree before any collective
+            err = None
+            try:
+                st = plan_and_sample(cfg, label, feats, with_cross, staged=holder.get("staged"))
+            except Exception as e:  # noqa: BLE001
+                err = e
+            agree_or_raise(err, feats[0].device)
+            gather = _BankGather(st, cfg.max_features_total, f16x3)
+            build_banks(st, feats, f16x3=f16x3, gather=gather)     # gathers issued per scale, behind its K3
+            rank, pb, pbh, lay = gather.finish()                   # waited for just before the first sweep
+            attach_global_segments(st, rank, pb, lay, peer_banks_h=pbh)
         else:
-            _own_segments(st)
+            st = plan_and_sample(cfg, label, feats, with_cross, staged=holder.get("staged"))
+            build_banks(st, feats, f16x3=f16x3)
+            if peers is not None:                   # single-process emulation of other ranks (tests)
+                rank, peer_banks, peer_layouts = peers[:3]
+                peer_banks_h = peers[3] if len(peers) > 3 else None
+                peer_layouts = list(peer_layouts)
+                peer_layouts[rank] = [class_layout(sc.plan) for sc in st.scales]
+                attach_global_segments(st, rank, peer_banks, peer_layouts, peer_banks_h=peer_banks_h)
+            else:
+                _own_segments(st)
         run_forward_terms(st)
         ctx.st = st
         ctx.feats_meta = [(tuple(f.shape), tuple(f.stride()), f.dtype) for f in feats]

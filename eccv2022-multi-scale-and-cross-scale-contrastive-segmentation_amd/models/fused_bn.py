@@ -28,6 +28,26 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+_EQUAL_BATCH_CHECKED = set()
+
+
+def _check_equal_batch(n, device):
+    """SyncBatchNorm path: the statistics are all-reduced as per-slice partial sums whose layout (and the element
+    count N * H * W * world) assumes the SAME per-rank batch on every rank -- true for DistributedSampler with
+    drop_last=True, which the managers use.  Verified once per batch size (one tiny all-reduce + host read) instead
+    of being assumed: unequal batches would give wrong statistics or mismatched collective sizes."""
+    if n in _EQUAL_BATCH_CHECKED:
+        return
+    import torch.distributed as dist
+    t = torch.tensor([n, -n], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    lo_hi = t.tolist()
+    if lo_hi[0] != -lo_hi[1]:
+        raise RuntimeError(f"FusedBatchNorm2d(sync): per-rank batch sizes differ across ranks (max {lo_hi[0]}, min "
+                           f"{-lo_hi[1]}); use a sampler that gives every rank the same batch (drop_last=True)")
+    _EQUAL_BATCH_CHECKED.add(n)
+
+
 class _FusedBNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, sync, amax,
@@ -48,6 +68,7 @@ class _FusedBNFunction(torch.autograd.Function):
         _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), st), "dcl_bn_stats_part")
         if world > 1:
             import torch.distributed as dist
+            _check_equal_batch(N, dev)
             dist.all_reduce(part)
         y = torch.empty_like(x)
         _lib.check(L.dcl_bn_apply_fused(_lib.ptr(x), _lib.ptr(res), _lib.ptr(part), count, eps, momentum,
@@ -111,6 +132,7 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
 
     def _fusable(self, x, residual):
         return (self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and x.shape[0] * x.shape[1] <= 65535        # the element-wise kernels put the (n, c) plane on grid.y
                 and x.is_contiguous() and self.affine and self.track_running_stats
                 and self.momentum is not None and not torch.is_autocast_enabled()
                 and (residual is None or (residual.shape == x.shape and residual.is_contiguous()

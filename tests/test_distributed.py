@@ -93,7 +93,8 @@ def _gather_worker(rank, world, port, out_dir):
         bank = torch.zeros(_npad(plan.N), 256)
         bank[:plan.N] = float(rank + 1) + 0.01 * s
         st.scales.append(_Scale(plan=plan, h=1, w=1, C=256, strides=(1, 1, 1), bank=bank))
-    r, banks, layouts = gather_peer_banks(st, max_features_total=200)
+    r, banks, banks_h, layouts = gather_peer_banks(st, max_features_total=200)
+    assert banks_h is None                      # f32 mode: the f32 rows travel
     assert r == rank and len(banks) == world and len(layouts) == world
     for q in range(world):
         for s in range(2):

@@ -78,7 +78,7 @@ def test_fused_bn_sync_two_ranks_one_gpu(tmp_path):
     assert torch.allclose((outs[0]["db"] + outs[1]["db"]).double(), ref.bias.grad, atol=2e-4)
 
 
-def _train_worker(rank, world, port, out_dir, global_negatives):
+def _train_worker(rank, world, port, out_dir, global_negatives, backbone="hrnet18", scales=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import mscs_amd  # noqa: F401
@@ -87,14 +87,15 @@ def _train_worker(rank, world, port, out_dir, global_negatives):
     set_verbosity(40)
     cfg = {"name": "t", "mode": "training", "manager": "HRNet", "cuda": True, "parallel": True,
            "gpu_device": [0, 0], "seed": 3, "log_every_n_steps": 1000, "dist_backend": "gloo",
-           "graph": {"model": "HRNet", "backbone": "hrnet18", "sync_bn": True, "pretrained": False,
+           "graph": {"model": "HRNet", "backbone": backbone, "sync_bn": True, "pretrained": False,
                      "align_corners": True,
-                     "ms_projector": {"mlp": [[1, -1, 1]], "scales": 2, "d": 64, "use_bn": True}},
+                     "ms_projector": {"mlp": [[1, -1, 1]], "scales": scales, "d": 64, "use_bn": True}},
            "data": {"dataset": "CITYSCAPES", "experiment": 1, "batch_size": 4, "synthetic": True,
                     "synthetic_length": 8, "synthetic_mode": "blocky",
                     "transform_values": {"crop_shape": [64, 128]}},
            "loss": {"name": "LossWrapper", "losses": {"CrossEntropyLoss": 1, "DenseContrastiveLossV2_ms": 0.1},
-                    "temperature": 0.1, "scales": 2, "weights": [1.0, 0.5], "cross_scale_contrast": True,
+                    "temperature": 0.1, "scales": scales, "weights": [1.0, 0.5, 0.3][:scales],
+                    "cross_scale_contrast": True,
                     "min_views_per_class": 2, "max_features_total": 600, "global_negatives": global_negatives},
            "train": {"learning_rate": 0.01, "lr_fct": "polynomial", "optim": "SGD", "lr_batchwise": True,
                      "epochs": 1}}
@@ -103,7 +104,9 @@ def _train_worker(rank, world, port, out_dir, global_negatives):
     mgr._worker_setup(0, rank)
     mgr.train_one_epoch()
     flat = torch.cat([p.detach().flatten() for p in mgr.model.parameters()]).cpu()
-    torch.save({"params": flat, "metrics": mgr.metrics,
+    from mscs_amd.models.ops import DirectConv2d
+    direct = sum(isinstance(m, DirectConv2d) for m in mgr.model.modules())
+    torch.save({"params": flat, "metrics": mgr.metrics, "direct_convs": direct,
                 "segs": [len(t.segs) for t in mgr.loss.loss_classes["DenseContrastiveLossV2_ms"].last_state.terms]},
                os.path.join(out_dir, f"train{rank}.pt"))
     dist.barrier()
@@ -119,3 +122,19 @@ def test_ddp_training_step_two_ranks_one_gpu(tmp_path, global_negatives):
     assert torch.equal(a["params"], b["params"]), "parameters diverged across ranks"
     assert np.isfinite(a["metrics"]["loss"]) and np.isfinite(b["metrics"]["loss"])
     assert a["segs"] == ([2, 2, 2] if global_negatives else [1, 1, 1])
+
+
+@pytest.mark.timeout(900)
+def test_ddp_hrnet48_direct_kernels_and_branch_streams_two_ranks_one_gpu(tmp_path):
+    """The W48 backbone under DDP + fused SyncBatchNorm with two ranks: unlike hrnet18 its channel counts (48 / 96 /
+    192 / 384, head 720) take the direct f16x3 forward, data-gradient AND weight-gradient kernels, on one HIP stream
+    per branch, with the blocking per-norm all-reduce between the statistics and the apply kernels -- the schedule
+    that runs on an 8-GPU node (there over RCCL; gloo here because both ranks share the one GPU of this box).
+    Shared negative bank on: the overlapped per-scale bank gathers run too."""
+    port = _free_port()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path), True, "hrnet48", 3), nprocs=2, join=True)
+    a, b = [torch.load(os.path.join(str(tmp_path), f"train{q}.pt")) for q in range(2)]
+    assert a["direct_convs"] > 250                                   # every 3x3 convolution of W48 is a DirectConv2d
+    assert torch.equal(a["params"], b["params"]), "parameters diverged across ranks"
+    assert np.isfinite(a["metrics"]["loss"]) and np.isfinite(b["metrics"]["loss"])
+    assert a["segs"] == [2] * 5                                      # 3 intra + 2 cross terms, 2 segments each

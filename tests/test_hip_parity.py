@@ -365,10 +365,13 @@ def test_head_conv_gemm_wrw_matches_default_backward(dev):
         assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
 
 
-def test_global_negative_bank_two_virtual_ranks(dev, oracle):
+@pytest.mark.parametrize("halves", [False, True])
+def test_global_negative_bank_two_virtual_ranks(dev, oracle, halves):
     """Extension (no reference oracle, SURVEY section 8 row e): every term contrasts against the banks of
     all ranks.  Two virtual ranks on one GPU (the peer's banks are injected where the RCCL all-gather
-    would deliver them) against the oracle's single-process emulation on the concatenated banks."""
+    would deliver them) against the oracle's single-process emulation on the concatenated banks.
+    ``halves``: the peer's banks arrive as (hi | lo) f16 rows -- what the f16x3 mode gathers -- so the peer segments
+    run on the f16 matrix pipe too; otherwise as f32 rows (peer segments on the f32 kernels)."""
     from mscs_amd.losses import DenseContrastiveLossV2_ms
     from mscs_amd.losses.engine import class_layout
     cfg = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": 2, "weights": [1.0, 0.6],
@@ -386,7 +389,11 @@ def test_global_negative_bank_two_virtual_ranks(dev, oracle):
     st1 = mods[1].last_state
     peer_banks = [None, [sc.bank for sc in st1.scales]]
     peer_layouts = [None, [class_layout(sc.plan) for sc in st1.scales]]
-    mods[0]._emulated_peers = (0, peer_banks, peer_layouts)
+    if halves:
+        assert all(sc.bank_h is not None for sc in st1.scales)
+        mods[0]._emulated_peers = (0, None, peer_layouts, [None, [sc.bank_h for sc in st1.scales]])
+    else:
+        mods[0]._emulated_peers = (0, peer_banks, peer_layouts)
     f0 = [f.to(dev).requires_grad_(True) for f in data[0][1]]
     torch.manual_seed(seeds[0])
     loss = mods[0](data[0][0].to(dev), f0)
