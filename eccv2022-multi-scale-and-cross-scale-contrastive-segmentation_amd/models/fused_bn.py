@@ -61,11 +61,14 @@ class _FusedBNFunction(torch.autograd.Function):
         st = _stream()
         world = _world() if sync else 1
         count = float(N * HW * world)
-        # one workspace: [part C*ns*2 | mean C | invstd C]; the per-slice partial sums are combined in the prologue
-        # of the apply kernel (no combine / finalize launches); SyncBatchNorm = all-reduce of `part` in between
-        ws = torch.empty((C * ns * 2 + 2 * C,), dtype=torch.float32, device=dev)
-        part, mean, invstd = ws[:C * ns * 2], ws[C * ns * 2:C * ns * 2 + C], ws[C * ns * 2 + C:]
-        _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), st), "dcl_bn_stats_part")
+        # one workspace: [part C*ns*2 | mean C | invstd C | pivot C]; the per-slice partial sums are combined in the
+        # prologue of the apply kernel (no combine / finalize launches); SyncBatchNorm = all-reduce of `part` in
+        # between.  The sums are shifted by the running mean (identical on every rank) against cancellation.
+        ws = torch.empty((C * ns * 2 + 3 * C,), dtype=torch.float32, device=dev)
+        part, mean, invstd = ws[:C * ns * 2], ws[C * ns * 2:C * ns * 2 + C], ws[C * ns * 2 + C:C * ns * 2 + 2 * C]
+        pivot = ws[C * ns * 2 + 2 * C:]
+        _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(running_mean), _lib.ptr(pivot),
+                                       st), "dcl_bn_stats_part")
         if world > 1:
             import torch.distributed as dist
             _check_equal_batch(N, dev)
@@ -74,7 +77,7 @@ class _FusedBNFunction(torch.autograd.Function):
         _lib.check(L.dcl_bn_apply_fused(_lib.ptr(x), _lib.ptr(res), _lib.ptr(part), count, eps, momentum,
                                         _lib.ptr(weight), _lib.ptr(bias), N, C, HW, 1 if relu else 0, _lib.ptr(y),
                                         _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(running_mean),
-                                        _lib.ptr(running_var), _lib.ptr(nbt), _lib.ptr(amax), st),
+                                        _lib.ptr(running_var), _lib.ptr(nbt), _lib.ptr(amax), _lib.ptr(pivot), st),
                    "dcl_bn_apply_fused")
         # y is only needed for the ReLU mask when a residual was added: without one the backward recomputes
         # y > 0 from x (one tensor less to read, twice)

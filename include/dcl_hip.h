@@ -210,11 +210,16 @@ int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y /* as above
  * dcl_bn_apply_fused (also writes mean / invstd, updates the running statistics and num_batches_tracked).
  * Backward: dcl_bn_bwd_reduce_part -> [part_global = all-reduce of a copy] -> dcl_bn_bwd_apply_fused (dx from
  * part_global; dbeta / dgamma from this rank's part_local).  part: f32 [C * dcl_bn_num_slices(N, C) * 2]. */
-int dcl_bn_stats_part(const float *x, int N, int C, int HW, float *part, void *stream);
+int dcl_bn_stats_part(const float *x, int N, int C, int HW, float *part,
+                      const float *pivot_src /* [C] or NULL: shift of the sums (the running mean: equal on all ranks);
+                                                part then holds sum (x - p), sum (x - p)^2 -- no cancellation in
+                                                E[x^2] - mean^2 when |mean| >> std */,
+                      float *pivot_out /* [C]: the pivot used, handed to dcl_bn_apply_fused (NULL iff pivot_src is) */,
+                      void *stream);
 int dcl_bn_apply_fused(const float *x, const float *res, const float *part, double count, float eps, float momentum,
                        const float *gamma, const float *beta, int N, int C, int HW, int relu, float *y, float *mean,
                        float *invstd, float *running_mean, float *running_var, int64_t *batches_tracked,
-                       float *amax, void *stream);
+                       float *amax, const float *pivot /* pivot_out of dcl_bn_stats_part, or NULL */, void *stream);
 int dcl_bn_bwd_reduce_part(const float *dy, const float *x, const float *y, const float *mean, const float *invstd,
                            const float *gamma, const float *beta, int N, int C, int HW, int relu, float *part,
                            void *stream);

@@ -453,6 +453,40 @@ def test_fused_batchnorm_matches_fp64_reference(dev, relu, use_res, shape):
     assert torch.allclose(fus(x.to(dev)).cpu().double(), ref(x.double()), atol=1e-5)
 
 
+def test_fused_batchnorm_large_mean_small_std_at_benchmark_plane_size(dev):
+    """|mean| >> std over 393k elements per channel (12 x 48 x 128 x 256, mean 50, std 0.1): plain f32 sums of x and x^2
+    lose the variance to cancellation (E[x^2] - mean^2 = 2500.01 - 2500); the statistics kernel shifts its sums by the
+    running mean.  Checked against float64 after the running mean has moved to the data (second step), and -- looser --
+    on the very first step, where the pivot is still 0."""
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d
+    torch.manual_seed(0)
+    shape = (12, 48, 128, 256)
+    x = (torch.randn(shape, device=dev) * 0.1 + 50.0)
+    xd = x.double()
+    mean = xd.mean((0, 2, 3))
+    var = xd.var((0, 2, 3), unbiased=False)
+    bn = FusedBatchNorm2d(48, momentum=1.0).to(dev)         # momentum 1: running mean = the batch mean after one step
+    y1 = bn(x)
+    want = (xd - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + bn.eps)
+    err_first = (y1.double() - want).abs().max().item()
+    y2 = bn(x)                                              # pivot = running mean ~ 50 now
+    err = (y2.double() - want).abs().max().item()
+    assert err <= 2e-3, err                                 # x itself carries 50 * 2^-24 = 3e-6 of rounding, / std 0.1
+    assert err_first <= 0.5, err_first                      # un-shifted first step: finite, within the f32 sum error
+    xg = x.clone().requires_grad_(True)
+    bn2 = FusedBatchNorm2d(48, momentum=1.0).to(dev)
+    with torch.no_grad():
+        bn2.running_mean.copy_(mean.float())
+    gy = torch.randn(shape, device=dev)
+    bn2(xg).backward(gy)
+    xr = xd.clone().requires_grad_(True)
+    ref = torch.nn.functional.batch_norm(xr, None, None, torch.ones(48, device=dev, dtype=torch.float64),
+                                         torch.zeros(48, device=dev, dtype=torch.float64), True, 0.0, bn.eps)
+    ref.backward(gy.double())
+    rel = (xg.grad.double() - xr.grad).abs().max().item() / xr.grad.abs().max().item()
+    assert rel <= 2e-3, rel
+
+
 @pytest.mark.parametrize("align", [True, False])
 @pytest.mark.parametrize("shape,size", [((2, 5, 16, 32), (64, 128)), ((3, 7, 9, 13), (36, 52)), ((2, 3, 16, 32), (128, 256)),
                                         ((1, 4, 7, 5), (56, 44)), ((2, 2, 128, 256), (512, 1024)),
