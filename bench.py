@@ -74,6 +74,9 @@ def parse():
                     help="also time the eager-structure restatement of the loss alone on the GPU")
     ap.add_argument("--no-eager-step", action="store_true",
                     help="skip eager_gpu_step_ms (the eager-structure reference step on the same GPU, N=1 only)")
+    ap.add_argument("--materialize-logits", action="store_true",
+                    help="HRNet returns the up-sampled logits like the reference instead of the lazy 1/4-resolution form "
+                         "(graph key lazy_logits) that the fused up-sampling + cross-entropy kernels consume")
     ap.add_argument("--no-metrics", action="store_true",
                     help="leave the per-step metrics tail (confusion matrix, accuracies, mIoU, logging) out of the step")
     a = ap.parse_args()
@@ -369,7 +372,7 @@ def step_config(args, world):
         "name": "bench", "mode": "training", "manager": "HRNet", "cuda": True, "seed": 0,
         "parallel": world > 1, "batch_is_global": False, "channels_last": args.channels_last,
         "graph": {"model": "HRNet", "backbone": "hrnet48", "sync_bn": True, "out_stride": 4, "pretrained": False,
-                  "align_corners": True, "branch_conv": args.branch_conv,
+                  "align_corners": True, "branch_conv": args.branch_conv, "lazy_logits": not args.materialize_logits,
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "before_context": True}},
         "data": {"dataset": "CITYSCAPES", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
                  "synthetic": True, "synthetic_length": args.batch * 2,

@@ -65,10 +65,13 @@ SIGNATURES = {
     "dcl_wgrad3x3_f16x3": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],
     "dcl_confusion_matrix": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp],
     "dcl_metrics_from_cm": [_vp, _i, _i, _vp, _vp],
+    "dcl_confusion_matrix_pred": [_vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp],
     "dcl_winattn_npad": [_i, _i],
     "dcl_winattn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp],
     "dcl_winattn_bwd_waves": [_i, _i, _i, _i],
     "dcl_winattn_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "dcl_upsample_ce_fwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "dcl_upsample_ce_bwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "dcl_suggest_nsplit": [_i, _i],
     "dcl_version": [],
 }

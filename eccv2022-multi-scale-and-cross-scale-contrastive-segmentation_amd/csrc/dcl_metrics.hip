@@ -165,7 +165,57 @@ __global__ __launch_bounds__(256) void k_metrics_from_cm(const int *__restrict__
     }
 }
 
+// confusion matrix from an arg-max map (uint8, produced by the fused up-sampling + cross-entropy forward): the
+// histogram half of k_confusion only, 1 + target bytes per pixel
+__global__ __launch_bounds__(256) void k_confusion_pred(const unsigned char *__restrict__ pred, const void *target,
+                                                       int tbytes, long long total, int C, int cols, int *cm, int *oob)
+{
+    __shared__ int hist[2048];
+    const int cells = C * cols;
+    const bool use_lds = cells <= 2048;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < cells; i += 256)
+            hist[i] = 0;
+        __syncthreads();
+    }
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int t = load_target(target, tbytes, (size_t)i);
+        const int p = pred[i];
+        if ((unsigned)t >= (unsigned)cols || p >= C) {
+            bad += (unsigned)t >= (unsigned)cols ? 1 : 0;
+            continue;
+        }
+        if (use_lds)
+            atomicAdd(&hist[p * cols + t], 1);
+        else
+            atomicAdd(&cm[p * cols + t], 1);
+    }
+    if (bad)
+        atomicAdd(oob, bad);
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < cells; i += 256)
+            if (hist[i])
+                atomicAdd(&cm[i], hist[i]);
+    }
+}
+
 }  // namespace
+
+extern "C" int dcl_confusion_matrix_pred(const uint8_t *pred, int64_t total, const void *target, int target_bytes, int C,
+                                         int cols, int32_t *cm, int32_t *oob, void *stream)
+{
+    DCL_CHECK_ARG(pred && target && cm && oob && total > 0 && C > 0 && (cols == C || cols == C + 1), "bad arguments");
+    DCL_CHECK_ARG(target_bytes == 8 || target_bytes == 4 || target_bytes == 1, "target must be int64, int32 or uint8");
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048)
+        blocks = 2048;
+    hipLaunchKernelGGL(k_confusion_pred, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, target,
+                       target_bytes, (long long)total, C, cols, cm, oob);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int dcl_metrics_from_cm(const int32_t *cm, int C, int ld, float *out3, void *stream)
 {

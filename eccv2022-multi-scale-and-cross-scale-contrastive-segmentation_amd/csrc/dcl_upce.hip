@@ -1,0 +1,314 @@
+// dcl_upce.hip -- fused bilinear up-sampling + class-weighted cross-entropy.
+//
+// Replaces, for the segmentation logits, F.interpolate(logits_1/4, size, 'bilinear', align_corners) (reference
+// models/HRNet.py:638) followed by nn.CrossEntropyLoss(weight, ignore_index) (losses/LossWrapper.py:26-30, :82) and
+// their autograd backward.  At BASELINE config 2 the up-sampled logits are 12 x 19 x 512 x 1024 f32 = 478 MB; the
+// unfused chain writes / reads that tensor (and its gradient) ~9 times per step.  Here the full-resolution logits exist
+// only in registers:
+//   forward : one workgroup per OUTPUT row; the two source rows of every class are staged in LDS; each thread owns 4
+//             consecutive pixels, interpolates the class logits on the fly (ATen's index arithmetic, dcl_resize.hip),
+//             online log-sum-exp, picks the target logit, emits  lse [N,H,W] (saved for the backward), the arg-max
+//             class (uint8 map: the confusion matrix needs nothing else) and per-row partial sums {sum w_t (lse - v_t),
+//             sum w_t}: loss = sum / sum, PyTorch's weighted-mean reduction (ignored pixels in neither);
+//   backward: one workgroup per LOW-RES row (gather form, deterministic, no atomics): vertical pass over the output
+//             rows that touch it -- g_c = w_t (softmax_c - [c = t]) recomputed from the staged low-res rows and the
+//             saved lse, accumulated with the y-weights into an LDS tile [classes][W] -- then a horizontal pass in which
+//             every low-res column gathers its x-footprint.  The upstream gradient and 1 / sum w are a device scalar.
+// Classes are processed in chunks that fit LDS (19 Cityscapes classes: one chunk; 150 ADE20K classes: several).
+// HBM-bound: reads z (30 MB), labels and lse; writes lse / prediction / dz.
+#include "dcl_common.h"
+
+namespace {
+
+struct Axis {
+    float scale;
+    int align;
+};
+
+__device__ __forceinline__ void src_index(const Axis a, int dst, int in_size, int &i0, int &i1, float &l0, float &l1)
+{
+    float s = a.align ? a.scale * (float)dst : fmaxf(a.scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+    i0 = (int)s;
+    if (i0 > in_size - 1)
+        i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__device__ __forceinline__ float axis_weight(const Axis a, int o, int in_size, int i)
+{
+    int i0, i1;
+    float l0, l1;
+    src_index(a, o, in_size, i0, i1, l0, l1);
+    return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+__device__ __forceinline__ void out_range(const Axis a, int i, int in_size, int out_size, int &lo, int &hi)
+{
+    const float inv = a.scale > 0.f ? 1.f / a.scale : 0.f;
+    float flo, fhi;
+    if (a.align) {
+        flo = ((float)i - 1.f) * inv;
+        fhi = ((float)i + 1.f) * inv;
+    } else {
+        flo = ((float)i - 1.f + 0.5f) * inv - 0.5f;
+        fhi = ((float)i + 1.f + 0.5f) * inv - 0.5f;
+    }
+    lo = (int)floorf(flo) - 1;
+    hi = (int)ceilf(fhi) + 1;
+    if (a.scale <= 0.f) {
+        lo = 0;
+        hi = out_size - 1;
+    }
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > out_size - 1 ? out_size - 1 : hi;
+}
+
+Axis make_axis(int in_size, int out_size, int align)
+{
+    Axis a;
+    a.align = align;
+    if (align)
+        a.scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    else
+        a.scale = (float)in_size / (float)out_size;
+    return a;
+}
+
+struct UpceArgs {
+    const float *z;             // [N, C, h, w]
+    const long long *target;    // [N, H, W]
+    const float *weight;        // [C] or null
+    float *lse;                 // [N, H, W]
+    unsigned char *pred;        // [N, H, W] or null
+    float *partial;             // fwd: [N*H, 2]
+    const float *gscale;        // bwd: device scalar: grad_out / sum w
+    float *dz;                  // bwd: [N, C, h, w]
+    int N, C, h, w, H, W, ignore, cc;
+    Axis ay, ax;
+};
+
+constexpr int FWD_LDS_FLOATS = 12288;       // 48 KiB: class chunk x 2 source rows x w
+constexpr int PIX = 4;                      // pixels per thread
+
+__global__ __launch_bounds__(256) void k_upce_fwd(UpceArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float zs[FWD_LDS_FLOATS];
+    __shared__ float red[2][4];
+    const int row = blockIdx.x;                     // n * H + oy
+    const int oy = row % a.H, n = row / a.H;
+    int y0, y1;
+    float ly0, ly1;
+    src_index(a.ay, oy, a.h, y0, y1, ly0, ly1);
+    const size_t plane = (size_t)a.h * a.w;
+    float num = 0.f, den = 0.f;
+    for (int trip = 0; trip * 256 * PIX < a.W; ++trip) {            // uniform trip count: barriers inside
+        const int px0 = trip * 256 * PIX + threadIdx.x * PIX;
+        int x0[PIX], x1[PIX], tgt[PIX];
+        float lx0[PIX], lx1[PIX], m[PIX], l[PIX], vt[PIX], best[PIX];
+        int arg[PIX];
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) {
+            const int ox = min(px0 + k, a.W - 1);
+            src_index(a.ax, ox, a.w, x0[k], x1[k], lx0[k], lx1[k]);
+            const long long t = px0 + k < a.W ? a.target[(size_t)row * a.W + ox] : (long long)a.ignore;
+            tgt[k] = (t < 0 || t > 0x7fffffff) ? -1 : (int)t;
+            m[k] = -INFINITY;
+            l[k] = 0.f;
+            vt[k] = 0.f;
+            best[k] = -INFINITY;
+            arg[k] = 0;
+        }
+        for (int c0 = 0; c0 < a.C; c0 += a.cc) {
+            const int nc = min(a.cc, a.C - c0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < nc * 2 * a.w; i += 256) {      // stage rows y0, y1 of classes c0 .. c0 + nc
+                const int c = i / (2 * a.w), r = (i / a.w) & 1, x = i % a.w;
+                zs[i] = a.z[((size_t)n * a.C + c0 + c) * plane + (size_t)(r ? y1 : y0) * a.w + x];
+            }
+            __syncthreads();
+            for (int c = 0; c < nc; ++c) {
+                const float *r0 = zs + (c * 2) * a.w, *r1 = r0 + a.w;
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) {
+                    const float v = ly0 * (lx0[k] * r0[x0[k]] + lx1[k] * r0[x1[k]]) +
+                                    ly1 * (lx0[k] * r1[x0[k]] + lx1[k] * r1[x1[k]]);
+                    const float mn = fmaxf(m[k], v);
+                    l[k] = l[k] * expf(m[k] - mn) + expf(v - mn);
+                    m[k] = mn;
+                    if (c0 + c == tgt[k])
+                        vt[k] = v;
+                    const bool take = (v > best[k]) || (v != v && best[k] == best[k]);     // torch.argmax rule
+                    best[k] = take ? v : best[k];
+                    arg[k] = take ? c0 + c : arg[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) {
+            const int ox = px0 + k;
+            if (ox >= a.W)
+                continue;
+            const float lse = m[k] + logf(l[k]);
+            a.lse[(size_t)row * a.W + ox] = lse;
+            if (a.pred)
+                a.pred[(size_t)row * a.W + ox] = (unsigned char)arg[k];
+            if (tgt[k] != a.ignore && tgt[k] >= 0 && tgt[k] < a.C) {
+                const float wt = a.weight ? a.weight[tgt[k]] : 1.f;
+                num += wt * (lse - vt[k]);
+                den += wt;
+            }
+        }
+    }
+    num = wave_sum(num);
+    den = wave_sum(den);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][wv] = num;
+        red[1][wv] = den;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.partial[(size_t)row * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        a.partial[(size_t)row * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// fixed-order reduction of the per-row partials: out = {sum num / sum den, sum den}
+__global__ __launch_bounds__(256) void k_upce_finish(const float *__restrict__ partial, int rows, float *__restrict__ out)
+{
+    __shared__ double sh[2][256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < rows; i += 256) {
+        a += partial[(size_t)i * 2];
+        b += partial[(size_t)i * 2 + 1];
+    }
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)(sh[0][0] / sh[1][0]);          // 0 / 0 = NaN when every pixel is ignored, like PyTorch
+        out[1] = (float)sh[1][0];
+    }
+}
+
+constexpr int BWD_LDS_FLOATS = 36864;       // 144 KiB: 3 staged low-res rows + the [classes][W] tile of a class chunk
+
+__global__ __launch_bounds__(256) void k_upce_bwd(UpceArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_FLOATS];
+    const int row = blockIdx.x;                     // n * h + iy
+    const int iy = row % a.h, n = row / a.h;
+    const size_t plane = (size_t)a.h * a.w;
+    int oy_lo, oy_hi;
+    out_range(a.ay, iy, a.h, a.H, oy_lo, oy_hi);
+    const float gs = a.gscale[0];
+    const int ya = max(iy - 1, 0);                  // staged rows ya .. ya + 2 (clamped to the image)
+    for (int c0 = 0; c0 < a.C; c0 += a.cc) {
+        const int nc = min(a.cc, a.C - c0);
+        float *zr = lds;                            // [nc][3][w]
+        float *tile = lds + nc * 3 * a.w;           // [nc][W]
+        __syncthreads();
+        for (int i = threadIdx.x; i < nc * 3 * a.w; i += 256) {
+            const int c = i / (3 * a.w), r = (i / a.w) % 3, x = i % a.w;
+            zr[i] = a.z[((size_t)n * a.C + c0 + c) * plane + (size_t)min(ya + r, a.h - 1) * a.w + x];
+        }
+        __syncthreads();
+        // vertical pass: tile[c][ox] = sum_oy wy(oy -> iy) * w_t (softmax_c - [c = t])
+        for (int ox = threadIdx.x; ox < a.W; ox += 256) {
+            int x0, x1;
+            float lx0, lx1;
+            src_index(a.ax, ox, a.w, x0, x1, lx0, lx1);
+            for (int c = 0; c < nc; ++c)
+                tile[c * a.W + ox] = 0.f;
+            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                const float wy = axis_weight(a.ay, oy, a.h, iy);
+                if (wy == 0.f)
+                    continue;
+                const size_t p = ((size_t)n * a.H + oy) * a.W + ox;
+                const long long t = a.target[p];
+                if (t == a.ignore || t < 0 || t >= a.C)
+                    continue;
+                const float coef = wy * (a.weight ? a.weight[t] : 1.f) * gs;
+                const float lse = a.lse[p];
+                int y0, y1;
+                float ly0, ly1;
+                src_index(a.ay, oy, a.h, y0, y1, ly0, ly1);
+                const int r0 = y0 - ya, r1 = y1 - ya;           // both in 0 .. 2
+                for (int c = 0; c < nc; ++c) {
+                    const float *b0 = zr + (c * 3 + r0) * a.w, *b1 = zr + (c * 3 + r1) * a.w;
+                    const float v = ly0 * (lx0 * b0[x0] + lx1 * b0[x1]) + ly1 * (lx0 * b1[x0] + lx1 * b1[x1]);
+                    float g = expf(v - lse);
+                    if (c0 + c == (int)t)
+                        g -= 1.f;
+                    tile[c * a.W + ox] += coef * g;
+                }
+            }
+        }
+        __syncthreads();
+        // horizontal pass: dz[n, c, iy, ix] = sum_ox wx(ox -> ix) * tile[c][ox]
+        for (int i = threadIdx.x; i < nc * a.w; i += 256) {
+            const int c = i / a.w, ix = i % a.w;
+            int ox_lo, ox_hi;
+            out_range(a.ax, ix, a.w, a.W, ox_lo, ox_hi);
+            float acc = 0.f;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox)
+                acc += axis_weight(a.ax, ox, a.w, ix) * tile[c * a.W + ox];
+            a.dz[((size_t)n * a.C + c0 + c) * plane + (size_t)iy * a.w + ix] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dcl_upsample_ce_fwd(const float *z, int N, int C, int h, int w, int H, int W, int align_corners,
+                                   const int64_t *target, const float *weight, int ignore_index, float *lse,
+                                   uint8_t *pred, float *partial, float *out2, void *stream)
+{
+    DCL_CHECK_ARG(z && target && lse && partial && out2, "null pointer");
+    DCL_CHECK_ARG(N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H >= h && W >= w, "bad shape (C <= 255, up-sampling only)");
+    DCL_CHECK_ARG(2 * w <= FWD_LDS_FLOATS, "low-resolution row too wide for the LDS stage");
+    UpceArgs a = {};
+    a.z = z; a.target = (const long long *)target; a.weight = weight; a.lse = lse; a.pred = pred; a.partial = partial;
+    a.N = N; a.C = C; a.h = h; a.w = w; a.H = H; a.W = W; a.ignore = ignore_index;
+    a.ay = make_axis(h, H, align_corners);
+    a.ax = make_axis(w, W, align_corners);
+    a.cc = FWD_LDS_FLOATS / (2 * w);
+    if (a.cc > C)
+        a.cc = C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_upce_fwd, dim3((unsigned)(N * H)), dim3(256), 0, st, a);
+    DCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_upce_finish, dim3(1), dim3(256), 0, st, partial, N * H, out2);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_upsample_ce_bwd(const float *z, int N, int C, int h, int w, int H, int W, int align_corners,
+                                   const int64_t *target, const float *weight, int ignore_index, const float *lse,
+                                   const float *gscale, float *dz, void *stream)
+{
+    DCL_CHECK_ARG(z && target && lse && gscale && dz, "null pointer");
+    DCL_CHECK_ARG(N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H >= h && W >= w, "bad shape");
+    DCL_CHECK_ARG(3 * w + W <= BWD_LDS_FLOATS, "rows too wide for the LDS tile");
+    UpceArgs a = {};
+    a.z = z; a.target = (const long long *)target; a.weight = weight; a.lse = const_cast<float *>(lse);
+    a.gscale = gscale; a.dz = dz;
+    a.N = N; a.C = C; a.h = h; a.w = w; a.H = H; a.W = W; a.ignore = ignore_index;
+    a.ay = make_axis(h, H, align_corners);
+    a.ax = make_axis(w, W, align_corners);
+    a.cc = BWD_LDS_FLOATS / (3 * w + W);
+    if (a.cc > C)
+        a.cc = C;
+    hipLaunchKernelGGL(k_upce_bwd, dim3((unsigned)(N * h)), dim3(256), 0, (hipStream_t)stream, a);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}

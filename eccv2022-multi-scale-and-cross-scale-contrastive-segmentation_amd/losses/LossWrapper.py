@@ -71,6 +71,10 @@ class LossWrapper(nn.Module):
                 skip_mem_update: bool = False) -> torch.Tensor:
         self.total_loss = self._zero()
         loss_list = list(self.loss_weightings.keys()) if loss_list is None else loss_list
+        lazy = prediction if hasattr(prediction, 'materialize') else None     # models.ops.UpsampledLogits
+        if lazy is not None and any(k not in ('CrossEntropyLoss', 'DenseContrastiveLossV2', 'DenseContrastiveLossV2_ms')
+                                    for k in self.loss_weightings if k in loss_list):
+            prediction = lazy.materialize()           # a component without a fused path wants the full tensor
         for loss_class in self.loss_weightings:
             if loss_class in loss_list:
                 if 'DenseContrastive' in loss_class:
@@ -88,8 +92,12 @@ class LossWrapper(nn.Module):
                     loss = fn(labels, deep_features)
                     if isinstance(loss, tuple):     # bare DCV2 configured with cross_scale_contrast
                         loss = loss[0]
+                elif loss_class == 'CrossEntropyLoss' and lazy is not None and type(fn) is nn.CrossEntropyLoss \
+                        and fn.reduction == 'mean' and fn.label_smoothing == 0.0:
+                    # bilinear up-sampling + weighted CE in one kernel, no full-resolution logits (csrc/dcl_upce.hip)
+                    loss = lazy.cross_entropy(labels, weight=fn.weight, ignore_index=fn.ignore_index)
                 elif loss_class in ('CrossEntropyLoss', 'OhemCrossEntropy'):
-                    loss = fn(prediction, labels)
+                    loss = fn(prediction if lazy is None else lazy.materialize(), labels)
                 else:
                     print("Error: Loss class '{}' not recognised!".format(loss_class))
                     loss = self._zero()

@@ -486,7 +486,13 @@ class HRNet(nn.Module):
         feats = self.backbone(x)
         multi = self.use_ms_projector or self.return_backbone_feats
         logits = self._head(feats[0] if multi else feats)
-        logits = upsample_bilinear(logits, size, self.align_corners)
+        if self.config.get('lazy_logits', False) and self.training:
+            # extension (default off = the reference's return value): the logits stay at 1/4 resolution; this repo's
+            # LossWrapper / metrics apply up-sampling + cross-entropy / arg-max in fused kernels (models/ops.py)
+            from .ops import UpsampledLogits
+            logits = UpsampledLogits(logits, size, self.align_corners)
+        else:
+            logits = upsample_bilinear(logits, size, self.align_corners)
         if self.projector_model is not None:
             if self.use_ms_projector:
                 proj = self.projector_model(feats[1][:self.ms_projector_scales])

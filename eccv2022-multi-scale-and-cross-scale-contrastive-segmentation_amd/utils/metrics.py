@@ -38,6 +38,21 @@ def t_get_confusion_matrix(prediction, target, dataset, existing_matrix=None, no
     columns = target class; pixels whose target is the dataset's ignore id (== C) are dropped."""
     C = prediction.shape[1]
     cols = _cols(C, dataset, no_ignore_class)
+    if hasattr(prediction, 'materialize'):          # models.ops.UpsampledLogits: logits kept at 1/4 resolution
+        pred = getattr(prediction, 'pred', None)
+        if pred is not None and pred.is_cuda:       # arg-max map left behind by the fused up-sampling + CE forward
+            from .. import _lib
+            t = target if target.dtype in (torch.int64, torch.int32, torch.uint8) else target.to(torch.int64)
+            t = t.contiguous()
+            assert t.numel() == pred.numel(), "target must be [N, H, W]"
+            cm = torch.zeros((C, cols), dtype=torch.int32, device=pred.device)
+            _lib.check(_lib.lib().dcl_confusion_matrix_pred(_lib.ptr(pred), pred.numel(), _lib.ptr(t),
+                                                            t.element_size(), C, cols, _lib.ptr(cm),
+                                                            _lib.ptr(_oob_counter(pred.device)),
+                                                            _lib.stream_ptr(pred.device)), "dcl_confusion_matrix_pred")
+            cm = cm[:, :C]
+            return cm + existing_matrix if existing_matrix is not None else cm
+        prediction = prediction.materialize().detach()
     if prediction.is_cuda:
         from .. import _lib
         L = _lib.lib()                                  # raises if libdcl_hip.so is missing: no silent fallback

@@ -305,6 +305,10 @@ int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout
 int dcl_confusion_matrix(const float *logits, int N, int C, int HW, const void *target, int target_bytes,
                          int cols, int32_t *cm, int32_t *oob, void *stream);
 
+/* The same matrix from an arg-max map (uint8 [total], e.g. the `pred` output of dcl_upsample_ce_fwd). */
+int dcl_confusion_matrix_pred(const uint8_t *pred, int64_t total, const void *target, int target_bytes, int C, int cols,
+                              int32_t *cm, int32_t *oob, void *stream);
+
 /* Pixel accuracy, mean per-class accuracy and mean IoU of a confusion matrix in one launch: replaces
  * t_get_pixel_accuracy (utils/torch_utils.py:201-213) and t_get_miou over all classes (:253-283).
  *   cm int32 [C, ld] (ld >= C: row stride; ld = C + 1 for the uncropped matrix of dcl_confusion_matrix)
@@ -333,6 +337,23 @@ int dcl_winattn_bwd_waves(int B, int H, int W, int heads);
 int dcl_winattn_bwd(const float *qkv, const float *qkv_bias, const float *bias, const float *lse, const float *dout,
                     int B, int H, int W, int C, int heads, int shift, float scale, float *dqkv, float *dpad,
                     float *dbias_part, void *stream);
+
+/* ---- fused bilinear up-sampling + class-weighted cross-entropy --------------------
+ * loss = CrossEntropyLoss(weight, ignore_index)(F.interpolate(z, (H, W), 'bilinear', align_corners), target) without
+ * materialising the up-sampled logits (reference models/HRNet.py:638 + losses/LossWrapper.py:26-30, :82); PyTorch's
+ * weighted-mean reduction: sum_p w[t_p] (lse_p - v_{p,t_p}) / sum_p w[t_p] over the non-ignored pixels.
+ *   z f32 [N, C, h, w] (C <= 255)      target int64 [N, H, W]      weight f32 [C] or NULL
+ *   lse f32 [N, H, W]   (out; input of the backward)       pred uint8 [N, H, W] or NULL (out: argmax class, torch's
+ *   tie / NaN rule -- what the per-step confusion matrix needs)
+ *   partial f32 [N * H, 2] workspace          out2 f32 {loss, sum of weights}
+ * backward: dz = d loss / d z for the upstream gradient folded into gscale = grad_out / out2[1] (device scalar);
+ * gather form, deterministic. */
+int dcl_upsample_ce_fwd(const float *z, int N, int C, int h, int w, int H, int W, int align_corners,
+                        const int64_t *target, const float *weight, int ignore_index, float *lse, uint8_t *pred,
+                        float *partial, float *out2, void *stream);
+int dcl_upsample_ce_bwd(const float *z, int N, int C, int h, int w, int H, int W, int align_corners,
+                        const int64_t *target, const float *weight, int ignore_index, const float *lse,
+                        const float *gscale, float *dz, void *stream);
 
 /* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the
  * grid fills the 256 CUs evenly (host helper, no device work). */
