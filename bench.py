@@ -1,27 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native dense contrastive segmentation hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload step|loss]
+    python bench.py --gpus N --steps K --warmup W [--config 2|4] [--workload step|loss]
 
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).  Rank 0
 prints ONE JSON line.  `value` is the whole-job rate; the timed region is bracketed by a barrier and
 torch.cuda.synchronize() on both sides and the maximum over ranks is taken.
 
-Workloads (BASELINE.json configs[1]: HRNet-W48 + DenseContrastiveLossV2_ms (3 scales), synthetic
-Cityscapes 512x1024, batch 12 per GPU):
-  step  one training step: model forward, LossWrapper(CE + 0.1 * DCV2_ms), backward, SGD update
+Workloads:
+  step  (default) one training step of BASELINE.json configs[1] -- HRNet-W48 + LossWrapper(CE + 0.1 * DCV2_ms, 3 scales
+        + cross-scale), synthetic Cityscapes 512x1024, batch 12 per GPU -- exactly the body of
+        BaseManager.train_one_epoch on a resident batch: forward, loss, backward, SGD, LR schedule AND the per-step
+        metrics tail of the reference (confusion matrix, pixel accuracies, mIoU, logging; HRNet_Manager.py:117-121).
+        `--config 4`: UPerNet + Swin-T, ADE20K 512x512, TwoScaleLoss + DCV2_ms (4 scales), AdamW, batch 16 per GPU.
   loss  the contrastive loss alone (forward + backward) on synthetic 256-d projector outputs
-Extra keys: `roofline` (dominant hand-written kernel: for the training step the direct 3x3 convolution
-`k_conv3x3<3,4,1>` -- the top kernel of the step profile -- on its heaviest launch, the head convolution 720 -> 720;
-for `--workload loss` the InfoNCE backward sweep; algorithmic FLOPs over HIP-event time, peak per arithmetic mode),
-`roofline_other` (the same kernel family on the 48-channel BasicBlock shape, the weight-gradient kernel and the
-InfoNCE backward sweep), `cpu_baseline` (oracle/eager_torch.py + the same model code on the host cores,
-bounded sample), `contrastive_loss_fwd_bwd_ms`, and with --eager-baseline the eager-structure torch loss on the
-GPU.  `dtype` "f32" = fp32-equivalent arithmetic: fp32 storage and accumulation everywhere; the loss's similarity
-product and the head convolution run as split-f16 (hi, lo) MFMA passes whose results match fp32 to round-off
-(DESIGN.md section 3); every 3x3 convolution of the model (backbone, stride 1 and 2, and the head) runs on the
-direct split-f16 kernels (forward, data and weight gradient); `--mfma f32`, `--branch-conv library` and graph key head_conv='library' select plain f32 MFMA /
-MIOpen instead.
+Extra keys of the JSON line:
+  roofline / roofline_other   dominant hand-written kernel (step: the direct 3x3 convolution `k_conv3x3<3,4,1>` on its
+        heaviest launch, the head convolution 720 -> 720; loss: the InfoNCE backward sweep): algorithmic FLOPs over the
+        HIP-event launch time measured live, against the peak of its arithmetic mode; `traffic` from the committed PMC
+        passes (profiles/r02_*_pmc_*.csv); per-shape rows: profiles/r02_conv_per_shape.csv
+  cpu_baseline                oracle/eager_torch.py + the same model code on the host cores: median of 3 after one
+        warm-up, ONE image of the model (x batch) and ONE full N = 9804 loss term (x number of terms)
+  eager_gpu_step_ms, speedup_vs_eager_gpu_step   the reference-structure eager step on the same GPU in the same run
+        (stock MIOpen / ATen kernels + the eager-structure loss of oracle/eager_torch.py): BASELINE.json's >= 5x target
+  contrastive_loss_fwd_bwd_ms, metrics_in_step, peak_mem_gb
+`dtype` "f32 (f16x3-emulated)": fp32 storage and accumulation everywhere; the matrix products of the loss and of every
+3x3 convolution run as three split-f16 (hi, lo) MFMA passes whose results match fp32 to round-off (DESIGN.md section
+3); `--mfma f32`, `--branch-conv library` and graph key head_conv='library' select plain f32 MFMA / MIOpen instead.
 """
 import argparse
 import contextlib
@@ -147,9 +152,11 @@ def sync(world):
 
 # HBM-side traffic of the direct convolution kernels at the benchmark's 48-channel shape (12 x 48 x 128 x 256), KiB
 # per launch (FETCH_SIZE, WRITE_SIZE) from the committed PMC passes (profiles/r01_conv_pmc_*.csv)
-PMC_CONV48 = (40901.9, 81408.0)
-PMC_CONV720 = (2571033.1, 1105920.0)      # head convolution 12 x 720 x 128 x 256, k_conv3x3<3,4,1>
-PMC_WGRAD48 = (153044.3, 6885.0)
+# (round 2: profiles/r02_conv_pmc_fetch.csv / _write.csv; the head launch is the per-kernel maximum of its family.  The
+# 48-channel rows of those files average several shapes of the same kernel family, so no per-launch figure is given)
+PMC_CONV48 = None
+PMC_CONV720 = (2585440.6, 1105920.0)      # head convolution 12 x 720 x 128 x 256, k_conv3x3<3,4,1>
+PMC_WGRAD48 = None
 
 
 def _time_launches(launch, iters):
@@ -192,8 +199,8 @@ def roofline_conv_kernels(args, dev, iters=20):
                                             f"{n}x{c}x{h}x{w}",
                 "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_note": note,
-                "traffic": (2 * pmc[0] + pmc[1]) * 1024 if default_shape else None,
-                "traffic_source": "profiles/r01_conv_pmc_fetch.csv, r01_conv_pmc_write.csv",
+                "traffic": (2 * pmc[0] + pmc[1]) * 1024 if (default_shape and pmc) else None,
+                "traffic_source": "profiles/r02_conv_pmc_fetch.csv, r02_conv_pmc_write.csv (FETCH_SIZE x 2 + WRITE_SIZE)",
                 "algorithmic_bytes": 2 * n * c * h * w * 4, "launch_ms": round(ms, 4)}, x
     main, _ = conv_entry(720, "k_conv3x3<3,4,1>", PMC_CONV720, 5)
     torch.cuda.empty_cache()
@@ -204,7 +211,7 @@ def roofline_conv_kernels(args, dev, iters=20):
     wg = {"bound": "mfma", "kernel": f"k_wgrad3x3<3,1> + k_wgrad_reduce (dcl_wgrad3x3_f16x3), {n}x48x{h}x{w}",
           "achieved": round(flops / (msw * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
           "frac": round(flops / (msw * 1e-3) / 1e12 / peak, 4),
-          "traffic": (2 * PMC_WGRAD48[0] + PMC_WGRAD48[1]) * 1024 if default_shape else None,
+          "traffic": (2 * PMC_WGRAD48[0] + PMC_WGRAD48[1]) * 1024 if (default_shape and PMC_WGRAD48) else None,
           "algorithmic_bytes": 2 * n * 48 * h * w * 4, "launch_ms": round(msw, 4)}
     return main, [c48, wg]
 
@@ -247,7 +254,7 @@ def roofline_bwd_kernel(mod, iters=10):
     # HBM traffic per launch of this kernel at N = 9804 from the committed PMC passes (profiles/README.md):
     # (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the gfx950 correction in MI355X_MICROARCH.md;
     # only valid for the benchmark shape, else null
-    pmc = {"f32": (102168.7, 128128.0), "f16x3": PMC_F16X3}.get(mode)       # f32 pair: round-1 f32 passes (README)
+    pmc = {"f32": (102168.7, 128128.0), "f16x3": PMC_F16X3}.get(mode)       # f32 pair: round-1 f32 passes
     traffic = (2 * pmc[0] + pmc[1]) * 1024 if (pmc and N == 9804 and ns == 13) else None
     return {"bound": "mfma", "kernel": f"k_sweep<MODE_BWD> (dcl_infonce_bwd), both products in {mode}",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -255,12 +262,12 @@ def roofline_bwd_kernel(mod, iters=10):
             "peak_note": ("f32 MFMA 157.3 TFLOP/s" if mode == "f32" else
                           "4NMC algorithmic FLOP issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): "
                           "2.5 PFLOP/s / 3 = 833.3 TFLOP/s"),
-            "traffic": traffic, "traffic_source": "profiles/r01_loss_pmc_fetch.csv, r01_loss_pmc_write.csv",
+            "traffic": traffic, "traffic_source": "profiles/r02_loss_pmc_fetch.csv, r02_loss_pmc_write.csv",
             "algorithmic_bytes": 3 * N * 256 * 4, "launch_ms": round(ms, 4), "N1": N, "N2": N, "C": 256,
             "nsplit": ns}
 
 
-PMC_F16X3 = (106934.6, 128128.0)      # KiB per launch (FETCH_SIZE, WRITE_SIZE), profiles/r01_loss_pmc_*.csv
+PMC_F16X3 = (104540.5, 128128.0)      # KiB per launch (FETCH_SIZE, WRITE_SIZE), profiles/r02_loss_pmc_*.csv
 
 
 def cpu_baseline_loss(args, n_terms):
