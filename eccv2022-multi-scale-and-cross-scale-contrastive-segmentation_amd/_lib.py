@@ -53,8 +53,6 @@ SIGNATURES = {
     "dcl_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "dcl_upsample_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_upsample_bilinear_bwd": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "dcl_im2col3x3_split": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "dcl_split_f16": [_vp, _i64, _vp, _vp, _vp, _vp],
     "dcl_absmax": [_vp, _i64, _vp, _vp],
     "dcl_conv3x3_pack": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "dcl_absmax_multi": [_vp, _vp, _i, _vp],

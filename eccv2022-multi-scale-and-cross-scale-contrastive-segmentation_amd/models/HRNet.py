@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
-from .ops import ConvPackGroup, DirectConv2d, GradToken, use_gemm_conv1x1, conv3x3_f16x3, conv3x3_gemm_wrw, upsample_bilinear, use_direct_conv3x3
+from .ops import ConvPackGroup, DirectConv2d, GradToken, use_gemm_conv1x1, upsample_bilinear, use_direct_conv3x3
 from .amax import record_stream as _amax_record_stream
 from .fused_bn import FusedBatchNorm2d, bn_act
 
@@ -446,14 +446,9 @@ class HRNet(nn.Module):
             self.return_features = False
         if 'return_all_scales' in config:
             self.return_features = True
-        # weight gradient of the head's big 3x3 conv as im2col + rocBLAS GEMM (2.4x MIOpen's default
-        # fp32 solver on MI355X, models/ops.py); same forward, same state_dict
-        self.gemm_wrw_head = bool(config.get('gemm_wrw_head', True))
-        # 'direct': the same direct split-f16 kernels as the backbone (fastest: 32 ms for the three directions at
-        # batch 12 against 42 ms for 'f16x3', and no 10 GB im2col buffers); 'f16x3': all three directions as
-        # split-f16 library GEMMs over an im2col copy (models/ops.py); 'gemm_wrw': only the weight gradient as an
-        # f32 GEMM; 'library': MIOpen for everything
-        self.head_conv = config.get('head_conv', 'direct' if self.gemm_wrw_head else 'library')
+        # 'direct' (default): the head's 720 -> 720 convolution on the same direct split-f16 kernels as the backbone
+        # (32 ms for its three directions at batch 12); 'library': MIOpen
+        self.head_conv = config.get('head_conv', 'direct')
         # 'f16x3': the backbone's 3x3 / stride-1 convolutions (BasicBlock, Bottleneck, transitions: ~80 % of the
         # FLOPs) on the direct split-f16 kernel (csrc/dcl_conv3x3.hip, fp32-equivalent); 'library': MIOpen
         self.branch_conv = config.get('branch_conv', 'f16x3')
@@ -470,13 +465,6 @@ class HRNet(nn.Module):
             use_gemm_conv1x1(self)
 
     def _head(self, x):
-        if self.head_conv not in ('library', 'direct') and self.training and x.is_cuda and x.dtype == torch.float32 \
-                and torch.is_grad_enabled() and not torch.is_autocast_enabled():
-            if self.head_conv == 'f16x3' and x.shape[-1] % 8 == 0:
-                x = conv3x3_f16x3(x, self.cls_head[0])
-            else:
-                x = conv3x3_gemm_wrw(x, self.cls_head[0])
-            return self.cls_head[2](self.cls_head[1](x))
         return self.cls_head(x)
 
     def forward(self, x):

@@ -4,49 +4,6 @@ import torch
 import torch.nn.functional as F
 
 
-class _Conv3x3GemmWrw(torch.autograd.Function):
-    """3x3 / stride 1 / pad 1 convolution whose WEIGHT gradient is computed as im2col + batched GEMM.
-
-    HRNet's segmentation head (models/HRNet.py:596-600 in the reference: conv3x3 720 -> 720 at 1/4
-    resolution) holds 47 % of the model's FLOPs.  For its weight gradient (a 720 x 6480 x 393,216 GEMM
-    at batch 12, 512x1024) MIOpen's default fp32 solver runs at 44 TFLOP/s (83.7 ms); unfolding the
-    input and calling rocBLAS' batched SGEMM runs the same contraction at 113 TFLOP/s (32-35 ms
-    including the im2col), bit-compatible up to fp32 summation order (2.5e-5 of max).  Forward and
-    input-gradient stay on MIOpen (they already run at ~110 TFLOP/s)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, chunk):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        ctx.chunk = chunk
-        return F.conv2d(x, weight, bias, stride=1, padding=1)
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.nn.grad.conv2d_input(x.shape, weight, gy, stride=1, padding=1)
-        if ctx.needs_input_grad[1]:
-            n = x.shape[0]
-            gyf = gy.flatten(2)                                        # [N, Cout, HW]
-            for i in range(0, n, ctx.chunk):
-                cols = F.unfold(x[i:i + ctx.chunk], 3, padding=1)      # [n, Cin*9, HW]
-                part = torch.bmm(gyf[i:i + ctx.chunk], cols.transpose(1, 2)).sum(0)
-                gw = part if gw is None else gw + part
-            gw = gw.view_as(weight)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3))
-        return gx, gw, gb, None
-
-
-def conv3x3_gemm_wrw(x, conv: torch.nn.Conv2d, chunk: int = 4):
-    """Apply ``conv`` (3x3, stride 1, padding 1, groups 1) with the GEMM weight-gradient path."""
-    assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) \
-        and conv.groups == 1 and conv.dilation == (1, 1)
-    return _Conv3x3GemmWrw.apply(x, conv.weight, conv.bias, chunk)
-
-
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, addend, H, W, align_corners, relu):
@@ -122,115 +79,6 @@ def upsample_bilinear(x, size, align_corners, add=None, relu=False):
                                                               align_corners=align_corners)
     y = y if add is None else add + y
     return F.relu(y) if relu else y
-
-
-# ---------------------------------------------------------------------------------------------------
-# f16x3 convolution: fp32-equivalent 3x3 conv on the f16 matrix cores
-# ---------------------------------------------------------------------------------------------------
-def _pow2_scale(t, target=16384.0):
-    """Device scalar 2^k with |t| * 2^k <= target (k from the tensor's absmax; no host sync)."""
-    amax = t.detach().abs().amax().clamp_min(1e-30)
-    return torch.exp2(torch.floor(torch.log2(target / amax))).reshape(1).float()
-
-
-def _bmm32(a, b):
-    """f16 x f16 -> f32 batched GEMM (f32 accumulation AND f32 output)."""
-    return torch.bmm(a, b, out_dtype=torch.float32)
-
-
-def _mm3(ah, al, bh, bl):
-    """(ah + al) @ (bh + bl) without the lo.lo term: three f16 GEMMs accumulated in f32."""
-    out = _bmm32(ah, bh)
-    out += _bmm32(ah, bl)
-    out += _bmm32(al, bh)
-    return out
-
-
-def _split(t, scale):
-    import ctypes
-    from .. import _lib
-    t = t.contiguous()
-    hi = torch.empty(t.shape, dtype=torch.float16, device=t.device)
-    lo = torch.empty(t.shape, dtype=torch.float16, device=t.device)
-    st = _lib.stream_ptr()
-    _lib.check(_lib.lib().dcl_split_f16(_lib.ptr(t), t.numel(), _lib.ptr(scale), _lib.ptr(hi), _lib.ptr(lo), st),
-               "dcl_split_f16")
-    return hi, lo
-
-
-def _im2col_split(x, scale):
-    import ctypes
-    from .. import _lib
-    n, c, h, w = x.shape
-    hi = torch.empty((n, c * 9, h * w), dtype=torch.float16, device=x.device)
-    lo = torch.empty((n, c * 9, h * w), dtype=torch.float16, device=x.device)
-    st = _lib.stream_ptr()
-    _lib.check(_lib.lib().dcl_im2col3x3_split(_lib.ptr(x), n, c, h, w, _lib.ptr(scale), _lib.ptr(hi),
-                                              _lib.ptr(lo), st), "dcl_im2col3x3_split")
-    return hi, lo
-
-
-class _Conv3x3F16x3(torch.autograd.Function):
-    """3x3 / stride 1 / pad 1 convolution evaluated as GEMMs on (hi, lo)-split f16 operands.
-
-    Every f32 operand x is scaled by a power of two and stored as hi = f16(x), lo = f16(x - hi) (22 mantissa
-    bits); A @ B = Ahi.Bhi + Ahi.Blo + Alo.Bhi with f32 accumulation and f32 output (the dropped lo.lo term is
-    2^-22 relative).  On MI355X one such f16 GEMM runs at ~725 TFLOP/s against 125 TFLOP/s for the f32 GEMM,
-    so the three passes cost about half of one f32 pass, and the result is at least as close to the exact
-    product as the f32 GEMM (measured 1.1e-6 vs 2.9e-6 of max against fp64, tools/bench_f16x3_gemm.py).
-    All three directions of HRNet's head conv (47 % of the model's FLOPs) go through it:
-      forward  y_n  = W[co, (c,ky,kx)]            @ im2col(x)_n
-      wgrad    dW   = sum_n gy_n[co, HW]          @ im2col(x)_n^T        (im2col(x) kept from the forward)
-      dgrad    dx_n = W'[c, (co,ky,kx)] (flipped) @ im2col(gy)_n
-    im2col + scaling + split is one HBM-bound HIP kernel (csrc/dcl_conv.hip)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        n, c, h, w = x.shape
-        co = weight.shape[0]
-        sx, sw = _pow2_scale(x), _pow2_scale(weight)
-        xh, xl = _im2col_split(x, sx)
-        wh, wl = _split(weight.reshape(1, co, c * 9), sw)
-        y = _mm3(wh.expand(n, -1, -1), wl.expand(n, -1, -1), xh, xl)
-        y *= (1.0 / (sx * sw))
-        y = y.view(n, co, h, w)
-        if bias is not None:
-            y += bias.view(1, -1, 1, 1)
-        ctx.save_for_backward(xh, xl, sx, weight)
-        ctx.has_bias = bias is not None
-        ctx.xshape = (n, c, h, w)
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        xh, xl, sx, weight = ctx.saved_tensors
-        n, c, h, w = ctx.xshape
-        co = weight.shape[0]
-        gy = gy.contiguous()
-        sg = _pow2_scale(gy)
-        gx = gw = gb = None
-        if ctx.needs_input_grad[1]:
-            gh, gl = _split(gy.view(n, co, h * w), sg)
-            part = _mm3(gh, gl, xh.transpose(1, 2), xl.transpose(1, 2))          # [n, co, c*9]
-            gw = (part.sum(0) * (1.0 / (sg * sx))).view_as(weight)
-        if ctx.needs_input_grad[0]:
-            sw = _pow2_scale(weight)
-            wrot = weight.flip(2, 3).permute(1, 0, 2, 3).reshape(1, c, co * 9)
-            rh, rl = _split(wrot, sw)
-            gch, gcl = _im2col_split(gy, sg)                                    # [n, co*9, hw]
-            gx = _mm3(rh.expand(n, -1, -1), rl.expand(n, -1, -1), gch, gcl)
-            gx *= (1.0 / (sg * sw))
-            gx = gx.view(n, c, h, w)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3))
-        return gx, gw, gb
-
-
-def conv3x3_f16x3(x, conv: torch.nn.Conv2d):
-    """Apply ``conv`` (3x3, stride 1, padding 1, groups 1) through the f16x3 GEMM formulation."""
-    assert conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) \
-        and conv.groups == 1 and conv.dilation == (1, 1)
-    return _Conv3x3F16x3.apply(x.contiguous(), conv.weight, conv.bias)
 
 
 # ---- direct f16x3 3x3 convolution (csrc/dcl_conv3x3.hip) ----------------------------------------------------------

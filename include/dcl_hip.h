@@ -238,15 +238,6 @@ int dcl_upsample_bilinear_fwd(const float *x, const float *addend /* [planes,H,W
 int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int w, int H, int W, int align_corners,
                               float *dx, void *stream);
 
-/* ---- f16x3 convolution helpers (the head conv holds 47 % of HRNet's FLOPs) ----
- * dcl_im2col3x3_split: unfold (3x3, stride 1, pad 1) of x [N,C,H,W] f32 into [N, C*9, H*W], scaled by the device
- * scalar `scale` and split into f16 (hi, lo) pairs; dcl_split_f16: the same split for a contiguous tensor.
- * Three f16 GEMMs with f32 output on these operands (hi.hi + hi.lo + lo.hi) reproduce the f32 convolution to
- * fp32 round-off at ~2x the f32 matrix rate (models/ops.py: Conv3x3F16x3). */
-int dcl_im2col3x3_split(const float *x, int N, int C, int H, int W, const float *scale, void *out_hi,
-                        void *out_lo, void *stream);
-int dcl_split_f16(const float *x, int64_t n, const float *scale, void *hi, void *lo, void *stream);
-
 /* ---- direct f16x3 3x3 convolution (stride 1, pad 1, NCHW f32 in / out) --------------------------------------
  * Replaces the nn.Conv2d(C, C, 3, 1, 1, bias=False) of the reference's BasicBlock / Bottleneck
  * (models/HRNet.py:32-60, 63-100) -- ~80 % of HRNet-W48's FLOPs -- and its data gradient (same kernel on the

@@ -347,24 +347,6 @@ def test_k1_k2_direct_odd_sizes(dev, oracle):
     np.testing.assert_array_equal(pix.cpu().numpy(), want)
 
 
-def test_head_conv_gemm_wrw_matches_default_backward(dev):
-    """models/ops.py: im2col + GEMM weight gradient == the library conv backward (fp32, 1e-4 of max)."""
-    from mscs_amd.models.ops import conv3x3_gemm_wrw
-    torch.manual_seed(0)
-    conv = torch.nn.Conv2d(48, 40, 3, padding=1).to(dev)
-    x = torch.randn(5, 48, 33, 47, device=dev, requires_grad=True)
-    gy = torch.randn(5, 40, 33, 47, device=dev)
-    ref = conv(x)
-    ref.backward(gy)
-    g_ref = (x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
-    x.grad = None; conv.weight.grad = None; conv.bias.grad = None
-    out = conv3x3_gemm_wrw(x, conv, chunk=2)
-    assert torch.allclose(out, ref, atol=1e-5)
-    out.backward(gy)
-    for got, want in zip((x.grad, conv.weight.grad, conv.bias.grad), g_ref):
-        assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
-
-
 @pytest.mark.parametrize("halves", [False, True])
 def test_global_negative_bank_two_virtual_ranks(dev, oracle, halves):
     """Extension (no reference oracle, SURVEY section 8 row e): every term contrasts against the banks of
@@ -612,36 +594,6 @@ def test_ade20k_class_count_and_mixed_input_dtypes(dev):
     torch.manual_seed(0)
     loss_bf16 = mod(label, [f.detach().bfloat16() for f in feats])
     assert torch.isfinite(loss_bf16).item() and abs(loss_bf16.item() - loss.item()) < 0.05 * abs(loss.item())
-
-
-def test_head_conv_f16x3_matches_fp64(dev):
-    """models/ops.py Conv3x3F16x3 (split-f16 GEMMs) against a float64 convolution: forward, dx, dW, db; the
-    f32 library convolution is measured beside it so the tolerance is anchored to what fp32 itself achieves."""
-    from mscs_amd.models.ops import conv3x3_f16x3
-    torch.manual_seed(0)
-    conv = torch.nn.Conv2d(40, 24, 3, padding=1).to(dev)
-    x = (torch.randn(3, 40, 20, 32, device=dev) * 3 + 0.5)
-    gy = torch.randn(3, 24, 20, 32, device=dev) * 1e-4
-    ref = torch.nn.Conv2d(40, 24, 3, padding=1).double()
-    ref.load_state_dict({k: v.double().cpu() for k, v in conv.state_dict().items()})
-    x64 = x.double().cpu().requires_grad_(True)
-    y64 = ref(x64)
-    y64.backward(gy.double().cpu())
-    want = (y64.detach(), x64.grad, ref.weight.grad, ref.bias.grad)
-
-    def run(fn):
-        xi = x.clone().requires_grad_(True)
-        conv.weight.grad = None; conv.bias.grad = None
-        y = fn(xi)
-        y.backward(gy)
-        return (y.detach().double().cpu(), xi.grad.double().cpu(), conv.weight.grad.double().cpu(),
-                conv.bias.grad.double().cpu())
-    got = run(lambda t: conv3x3_f16x3(t, conv))
-    lib = run(lambda t: conv(t))
-    for name, w_, g_, l_ in zip(("y", "dx", "dW", "db"), want, got, lib):
-        scale = w_.abs().max().item()
-        err, err_lib = (g_ - w_).abs().max().item() / scale, (l_ - w_).abs().max().item() / scale
-        assert err <= max(3e-6, 4 * err_lib), (name, err, err_lib)
 
 
 def _conv_ref64(x, w, gy):
