@@ -445,6 +445,18 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
 }  // namespace
 
 static int g_tile_nco = 0, g_tile_nci = 0;      // tuning override (dcl_wgrad3x3_set_tile), 0 = automatic
+static int g_variant = -1;     // 1 = shared-dY workgroups (dcl_wgrad3x3s.hip), 0 = per-wave operands, -1 = by shape
+
+// measured (tools/wgrad_head.py): sharing dY through LDS pays from 12 input-channel tiles on (192 channels: 58.6 vs
+// 64.3 us, 384: 73.4 vs 89.3 us, 720: 10.1 vs 11.7 ms); below that the four-times larger slabs cost more than the loads
+static bool use_shared(int Cin) { return g_variant < 0 ? Cin / 16 >= 12 : g_variant == 1; }
+
+// dcl_wgrad3x3s.hip
+int dcl_wgrad_shared_slabs(int N, int Cin, int Cout, int H, int W, int force_nco, int force_nci);
+void dcl_wgrad_shared_launch(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax,
+                             int xcount, const float *gamax, int gcount, int stride, float *part, float *dw, int force_nco,
+                             int force_nci, hipStream_t s);
+void dcl_wgrad_shared_tune(int sk_mode, int nwg);
 
 static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nci, int &S, int &units)
 {
@@ -467,7 +479,7 @@ static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nc
         nco = 2;
         nci = 2;
     }
-    if (g_tile_nco > 0 && cot % g_tile_nco == 0)
+    if (g_tile_nco > 0 && g_tile_nco <= 3 && cot % g_tile_nco == 0)
         nco = g_tile_nco;
     if (g_tile_nci > 0)
         nci = g_tile_nci;
@@ -486,10 +498,26 @@ static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nc
 
 extern "C" int dcl_wgrad3x3_set_tile(int nco, int nci)
 {
-    if (nco < 0 || nco > 3 || nci < 0 || nci > 2)
+    if (nco < 0 || nco > 5 || nco == 4 || nci < 0 || nci > 2)
         return DCL_EINVAL;
     g_tile_nco = nco;
     g_tile_nci = nci;
+    return 0;
+}
+
+extern "C" int dcl_wgrad3x3_set_variant(int variant)
+{
+    if (variant < -1 || variant > 1)
+        return DCL_EINVAL;
+    g_variant = variant;
+    return 0;
+}
+
+extern "C" int dcl_wgrad3x3_set_partition(int stream_k, int nwg)
+{
+    if (stream_k < -1 || stream_k > 1 || nwg < 0)
+        return DCL_EINVAL;
+    dcl_wgrad_shared_tune(stream_k, nwg);
     return 0;
 }
 
@@ -498,6 +526,8 @@ extern "C" int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W)
     if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cin & 15) || (Cout & 15))
         return 0;
     int nco, nci, S, units;
+    if (use_shared(Cin))
+        return dcl_wgrad_shared_slabs(N, Cin, Cout, H, W, g_tile_nco, g_tile_nci);
     wgrad_plan(N, Cin, Cout, H, W, nco, nci, S, units);
     return nco * nci <= 4 ? (S + 3) / 4 : S;      // one slab per workgroup (4 splits), or per wave (6-tile variant)
 }
@@ -512,6 +542,12 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     DCL_CHECK_ARG(Cin > 0 && Cout > 0 && (Cin & 15) == 0 && (Cout & 15) == 0, "channel counts must be multiples of 16");
     DCL_CHECK_ARG((W & 7) == 0, "W must be a multiple of 8");
     DCL_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0, "tensors must be 16-byte aligned");
+    if (use_shared(Cin)) {
+        dcl_wgrad_shared_launch(x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, stride, part, dw, g_tile_nco,
+                                g_tile_nci, (hipStream_t)stream);
+        DCL_LAUNCH_CHECK();
+        return 0;
+    }
     WgradArgs a;
     a.x = x;
     a.dy = dy;

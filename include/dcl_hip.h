@@ -277,6 +277,12 @@ int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored inp
 int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W);
 /* tuning hook: force the (co tiles, ci tiles) per wave of the weight-gradient kernel (0, 0 = automatic choice) */
 int dcl_wgrad3x3_set_tile(int nco, int nci);
+/* tuning hook: -1 (default) = by shape, 1 = workgroups that share the dY rows of a co group through LDS (csrc/dcl_wgrad3x3s.hip),
+ * 0 = every wave loads both operands itself (csrc/dcl_wgrad3x3.hip).  Changes dcl_wgrad3x3_splits(). */
+int dcl_wgrad3x3_set_variant(int variant);
+/* tuning hook (shared-dY variant): stream_k = -1 automatic, 0 equal pixel splits, 1 one contiguous (type, row step)
+ * range per workgroup; nwg = workgroups of that partition (0 = 256, one per CU).  Changes dcl_wgrad3x3_splits(). */
+int dcl_wgrad3x3_set_partition(int stream_k, int nwg);
 int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W /* of x */,
                        const float *xamax, int xcount, const float *gamax, int gcount,
                        int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,

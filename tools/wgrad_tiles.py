@@ -10,8 +10,11 @@ from per_shape_roofline import timeit
 L = _lib.lib()
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(0)
-for (c, h, w) in [(48, 128, 256), (96, 64, 128), (192, 32, 64), (384, 16, 32), (64, 128, 256)]:
-    x = torch.randn(12, c, h, w, device=dev, generator=gen).relu_()
+VARIANT = int(os.environ.get("DCL_WGRAD_VARIANT", "-1"))
+L.dcl_wgrad3x3_set_variant(VARIANT)
+print("variant", VARIANT)
+for (c, h, w) in [(48, 128, 256), (96, 64, 128), (192, 32, 64), (384, 16, 32), (64, 128, 256), (720, 128, 256)]:
+    x = torch.randn(12 if c != 720 else 12, c, h, w, device=dev, generator=gen).relu_()
     gy = torch.randn(12, c, h, w, device=dev, generator=gen) * 1e-3
     flops = 2.0 * 12 * c * c * 9 * h * w
     res = []
