@@ -1,0 +1,18 @@
+// dcl_wgrad.h -- launch arguments shared by the per-wave weight-gradient kernels (dcl_wgrad3x3.hip, dcl_wgrad3x3d.hip)
+#pragma once
+#include "dcl_common.h"
+
+struct WgradArgs {
+    const float *x, *dy;
+    float *part;                 // [S][9][Cout][Cin]
+    const float *xamax, *gamax;
+    int xcount, gcount;
+    int N, Cin, Cout, H, W;
+    int Hd, Wd;                  // stored size of dy (= H, W; or the even samples of a zero-inserted dy: stride 2)
+    int strips, nseg, units, S, ncig, npairs, nx;
+    int rect_c, rect_i, rect_mode;  // many pairs: pair-grid rectangle that shares an XCD (rect_c * rect_i = 32)
+};
+
+// dcl_wgrad3x3d.hip: the stride-1 kernel with LDS-DMA operand staging; same grid, slabs and arguments as k_wgrad3x3
+bool dcl_wgrad_dma_supported(int nco, int nci);
+void dcl_wgrad_dma_launch(const WgradArgs &a, int nco, int nci, dim3 grid, hipStream_t s);

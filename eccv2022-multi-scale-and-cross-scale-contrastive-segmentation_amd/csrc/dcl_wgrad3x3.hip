@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "dcl_common.h"
+#include "dcl_wgrad.h"
 
 namespace {
 
@@ -30,17 +31,6 @@ __device__ __forceinline__ float pow2_scale(float amax)
 {
     return amax == 0.f ? 1.f : exp2f(fminf(fmaxf(floorf(log2f(F16_TARGET / amax)), -100.f), 100.f));
 }
-
-struct WgradArgs {
-    const float *x, *dy;
-    float *part;                 // [S][9][Cout][Cin]
-    const float *xamax, *gamax;
-    int xcount, gcount;
-    int N, Cin, Cout, H, W;
-    int Hd, Wd;                  // stored size of dy (= H, W; or the even samples of a zero-inserted dy: stride 2)
-    int strips, nseg, units, S, ncig, npairs, nx;
-    int rect_c, rect_i, rect_mode;  // many pairs: pair-grid rectangle that shares an XCD (rect_c * rect_i = 32)
-};
 
 // Packed f16 pair (lo half = element 0) of hi = f16(v * s) and of lo = f16(v * s - hi) for two values.  s is a power
 // of two (or 0), so v * s is exact and the fused form computes the same value; written as v_fma_mix{lo,hi}_f16
@@ -450,6 +440,8 @@ static int g_variant = -1;     // 1 = shared-dY workgroups (dcl_wgrad3x3s.hip), 
 // measured (tools/wgrad_head.py): sharing dY through LDS pays from 12 input-channel tiles on (192 channels: 58.6 vs
 // 64.3 us, 384: 73.4 vs 89.3 us, 720: 10.1 vs 11.7 ms); below that the four-times larger slabs cost more than the loads
 static bool use_shared(int Cin) { return g_variant < 0 ? Cin / 16 >= 12 : g_variant == 1; }
+// per-wave kernel: operands staged by LDS-DMA (dcl_wgrad3x3d.hip) unless variant 0 asks for the direct loads
+static bool use_dma(int Cin, int H, int W) { return g_variant != 0 && (size_t)Cin * H * W * 4 < ((size_t)1 << 32); }
 
 // dcl_wgrad3x3s.hip
 int dcl_wgrad_shared_slabs(int N, int Cin, int Cout, int H, int W, int force_nco, int force_nci);
@@ -457,6 +449,13 @@ void dcl_wgrad_shared_launch(const float *x, const float *dy, int N, int Cin, in
                              int xcount, const float *gamax, int gcount, int stride, float *part, float *dw, int force_nco,
                              int force_nci, hipStream_t s);
 void dcl_wgrad_shared_tune(int sk_mode, int nwg);
+// dcl_wgrad3x3_s2.hip
+bool dcl_wgrad_s2_supported(int H, int W);
+int dcl_wgrad_s2_slabs(int N, int Cin, int Cout, int H, int W, int force_nco, int force_nci);
+void dcl_wgrad_s2_launch(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax,
+                         int xcount, const float *gamax, int gcount, float *part, int force_nco, int force_nci,
+                         hipStream_t s, int *nslab);
+static int g_s2_native = 1;     // stride 2: 1 = output-pixel formulation (dcl_wgrad3x3_s2.hip), 0 = zero-inserted dy
 
 static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nci, int &S, int &units)
 {
@@ -507,7 +506,7 @@ extern "C" int dcl_wgrad3x3_set_tile(int nco, int nci)
 
 extern "C" int dcl_wgrad3x3_set_variant(int variant)
 {
-    if (variant < -1 || variant > 1)
+    if (variant < -1 || variant > 2)
         return DCL_EINVAL;
     g_variant = variant;
     return 0;
@@ -521,10 +520,18 @@ extern "C" int dcl_wgrad3x3_set_partition(int stream_k, int nwg)
     return 0;
 }
 
-extern "C" int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W)
+extern "C" int dcl_wgrad3x3_set_stride2(int native)
 {
-    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cin & 15) || (Cout & 15))
+    g_s2_native = native ? 1 : 0;
+    return 0;
+}
+
+extern "C" int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W, int stride)
+{
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cin & 15) || (Cout & 15) || stride < 1 || stride > 2)
         return 0;
+    if (stride == 2 && g_s2_native && dcl_wgrad_s2_supported(H, W))
+        return dcl_wgrad_s2_slabs(N, Cin, Cout, H, W, g_tile_nco, g_tile_nci);
     int nco, nci, S, units;
     if (use_shared(Cin))
         return dcl_wgrad_shared_slabs(N, Cin, Cout, H, W, g_tile_nco, g_tile_nci);
@@ -542,6 +549,17 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     DCL_CHECK_ARG(Cin > 0 && Cout > 0 && (Cin & 15) == 0 && (Cout & 15) == 0, "channel counts must be multiples of 16");
     DCL_CHECK_ARG((W & 7) == 0, "W must be a multiple of 8");
     DCL_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0, "tensors must be 16-byte aligned");
+    if (stride == 2 && g_s2_native && dcl_wgrad_s2_supported(H, W)) {
+        int nslab = 0;
+        dcl_wgrad_s2_launch(x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, part, g_tile_nco, g_tile_nci,
+                            (hipStream_t)stream, &nslab);
+        DCL_LAUNCH_CHECK();
+        const int total = 9 * Cout * Cin;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nslab, Cout,
+                           Cin, dw);
+        DCL_LAUNCH_CHECK();
+        return 0;
+    }
     if (use_shared(Cin)) {
         dcl_wgrad_shared_launch(x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, stride, part, dw, g_tile_nco,
                                 g_tile_nci, (hipStream_t)stream);
@@ -580,6 +598,15 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
         grid = dim3((unsigned)(((units_r + 7) / 8) * 8 * 32));
     }
     hipStream_t s = (hipStream_t)stream;
+    if (stride == 1 && use_dma(Cin > Cout ? Cin : Cout, H, W) && dcl_wgrad_dma_supported(nco, nci)) {
+        dcl_wgrad_dma_launch(a, nco, nci, grid, s);
+        DCL_LAUNCH_CHECK();
+        const int total = 9 * Cout * Cin;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, s, part, nco * nci <= 4 ? a.nx : a.S, Cout,
+                           Cin, dw);
+        DCL_LAUNCH_CHECK();
+        return 0;
+    }
 #define DCL_WG_CASE(o, i)                                                        \
     if (nco == o && nci == i) {                                                  \
         if (stride == 2)                                                         \

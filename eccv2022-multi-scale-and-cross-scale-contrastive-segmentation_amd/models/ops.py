@@ -158,7 +158,7 @@ def conv3x3_wgrad(x, gy, stride=1):
     n, ci, h, w = x.shape
     co = gy.shape[1]
     L = _lib.lib()
-    splits = L.dcl_wgrad3x3_splits(n, ci, co, h, w)
+    splits = L.dcl_wgrad3x3_splits(n, ci, co, h, w, stride)
     if splits <= 0:
         raise RuntimeError("conv3x3_wgrad: unsupported shape")
     part = torch.empty(splits * 9 * co * ci, dtype=torch.float32, device=x.device)

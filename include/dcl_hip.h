@@ -274,7 +274,7 @@ int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored inp
 /* Weight gradient of the same convolution, dw[Cout,Cin,3,3] = sum_n dy (*) x, on the f16x3 MFMA path with no LDS
  * staging (csrc/dcl_wgrad3x3.hip).  Cin % 16 == 0, Cout % 16 == 0, W % 8 == 0.  part: workspace of
  * dcl_wgrad3x3_splits(...) * 9 * Cout * Cin floats (one partial slab per workgroup, summed in fixed order). */
-int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W);
+int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W /* of x */, int stride);
 /* tuning hook: force the (co tiles, ci tiles) per wave of the weight-gradient kernel (0, 0 = automatic choice) */
 int dcl_wgrad3x3_set_tile(int nco, int nci);
 /* tuning hook: -1 (default) = by shape, 1 = workgroups that share the dY rows of a co group through LDS (csrc/dcl_wgrad3x3s.hip),
@@ -283,6 +283,9 @@ int dcl_wgrad3x3_set_variant(int variant);
 /* tuning hook (shared-dY variant): stream_k = -1 automatic, 0 equal pixel splits, 1 one contiguous (type, row step)
  * range per workgroup; nwg = workgroups of that partition (0 = 256, one per CU).  Changes dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_partition(int stream_k, int nwg);
+/* tuning hook (stride 2): 1 (default) = GEMM over the output pixels (csrc/dcl_wgrad3x3_s2.hip, needs W % 16 == 0),
+ * 0 = the stride-1 kernels on a zero-inserted dy.  Changes dcl_wgrad3x3_splits(). */
+int dcl_wgrad3x3_set_stride2(int native);
 int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W /* of x */,
                        const float *xamax, int xcount, const float *gamax, int gcount,
                        int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,

@@ -855,10 +855,12 @@ def test_fuse_layer_streams_match_single_stream(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 48, 96, 32, 64), (1, 16, 32, 7, 40), (2, 32, 16, 9, 8), (1, 64, 64, 16, 24),
-                                   (2, 3, 64, 12, 16)])
+                                   (2, 3, 64, 12, 16), (1, 16, 32, 7, 48), (2, 32, 48, 9, 32), (1, 48, 16, 5, 16),
+                                   (3, 96, 32, 6, 80)])
 def test_direct_conv3x3_stride2_matches_fp64(dev, shape):
     """Stride-2 convolution on the direct kernels: forward (stride-2 tile), data gradient (stride-1 kernel over the
-    zero-inserted gradient) and weight gradient (zero-inserted dy operand) against float64, odd sizes included."""
+    zero-inserted gradient) and weight gradient (GEMM over the output pixels, csrc/dcl_wgrad3x3_s2.hip, when W % 16 == 0;
+    else the stride-1 kernel on a zero-inserted dy) against float64, odd sizes included."""
     from mscs_amd.models import ops
     n, ci, co, h, w = shape
     torch.manual_seed(sum(shape) + 5)

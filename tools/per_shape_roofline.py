@@ -36,6 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--only", default=None, help="substring filter on the shape names")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     n = a.batch
@@ -44,7 +45,10 @@ def main():
               ("branch2 basicblock", 192, 192, 32, 64, 1), ("branch3 basicblock", 384, 384, 16, 32, 1),
               ("cls_head", 720, 720, 128, 256, 1), ("layer1 bottleneck", 64, 64, 128, 256, 1),
               ("fuse 48->96 s2", 48, 96, 128, 256, 2), ("fuse 96->192 s2", 96, 192, 64, 128, 2),
-              ("fuse 192->384 s2", 192, 384, 32, 64, 2)]
+              ("fuse 192->384 s2", 192, 384, 32, 64, 2), ("fuse 48->48 s2", 48, 48, 128, 256, 2),
+              ("stem conv2 s2", 64, 64, 256, 512, 2)]
+    if a.only:
+        shapes = [s for s in shapes if a.only in s[0]]
     rows = ["op,shape,n,cin,cout,h,w,stride,ms_per_launch,algorithmic_tflops,frac_of_f16x3_roofline"]
     gen = torch.Generator(device=dev).manual_seed(0)
     for name, ci, co, h, w, st in shapes:
