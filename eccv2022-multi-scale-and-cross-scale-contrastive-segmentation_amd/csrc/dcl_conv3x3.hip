@@ -61,6 +61,7 @@ struct ConvArgs {
                                     // coordinates, zeros in between (data gradient of a stride-2 convolution)
     int Ho, Wo;                     // output size (= H, W for stride 1)
     int tiles_x, tiles_y, nchunk, groups;
+    int phases;                     // 1: data gradient of a stride-2 convolution, one output parity class per workgroup
 };
 
 constexpr float F16_TARGET = 16384.0f;      // operands are scaled so that their absmax lands in (2^13, 2^14]
@@ -73,9 +74,17 @@ __device__ __forceinline__ float pow2_scale(float amax)
 }
 
 // S = stride (1 | 2).  A stride-2 tile reads a (2 * 4P + 1) x 65 patch, so S = 2 is instantiated with P = 1 only.
-template <int R, int P, int S>
+//
+// PH ("phases"): data gradient of a stride-2 convolution, dx = conv3x3(dy zero-inserted at the odd coordinates, w').  An
+// output pixel (2 i + py, 2 j + px) only sees the taps whose input coordinate is even: ky = 1 for py = 0 (stored row
+// i), ky = 0 and 2 for py = 1 (stored rows i and i + 1), the same along x -- 1, 2, 2 or 4 taps instead of 9.  Each
+// workgroup takes ONE parity class: it runs the stride-1 tile over the STORED dy with the taps remapped (kernel tap
+// 1 -> ky 1 | 0, kernel tap 2 -> ky 2, kernel tap 0 unused), skips the others, and scatters its tile to the class's
+// pixels.  A quarter of the matrix work of the zero-inserted formulation (which spends 3/4 of it on zeros).
+template <int R, int P, int S, bool PH = false>
 __device__ __forceinline__ void conv_body(const ConvArgs &a)
 {
+    static_assert(!PH || S == 1, "phases: stride-1 tile");
     constexpr int LW = S * (TW - 1) + 3;          // patch width incl. halo: 34 | 65
     constexpr int ROWS = S * (4 * P - 1) + 3;     // 4P + 2 | 8P + 1
     constexpr int TP = ROWS * LW;
@@ -90,19 +99,28 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     // (the head convolution has 8 groups: 12.0 GiB -> 1.8 GiB of FETCH_SIZE per launch).
     int bx, cg;
     {
-        const int ntile = a.tiles_x * a.tiles_y * a.N, n8 = ntile & ~7, main_blocks = n8 * a.groups;
+        // (phases: the four parity classes of a tile are four more "groups" -- same input patch, same XCD)
+        const int ngrp = PH ? 4 * a.groups : a.groups;
+        const int ntile = a.tiles_x * a.tiles_y * a.N, n8 = ntile & ~7, main_blocks = n8 * ngrp;
         if ((int)blockIdx.x < main_blocks) {
             const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-            cg = rest % a.groups;
+            cg = rest % ngrp;
             // each XCD takes a CONTIGUOUS eighth of the tile sequence, so that vertically / horizontally adjacent
             // tiles (which share halo rows and columns) also share an L2
-            bx = xcd * (n8 >> 3) + rest / a.groups;
+            bx = xcd * (n8 >> 3) + rest / ngrp;
         } else {
             const int rest = blockIdx.x - main_blocks;
-            cg = rest % a.groups;
-            bx = n8 + rest / a.groups;
+            cg = rest % ngrp;
+            bx = n8 + rest / ngrp;
         }
     }
+    // parity class (py, px) and its taps: kernel tap k reads original tap ko[k]; bit k of the mask = tap in use
+    const int phase = PH ? cg / a.groups : 0;
+    if (PH)
+        cg -= phase * a.groups;
+    const int py = phase >> 1, px = phase & 1;
+    const int kym = PH ? (py ? 6 : 2) : 7, kxm = PH ? (px ? 6 : 2) : 7;
+    const int kyo1 = PH ? (py ? 0 : 1) : 1, kxo1 = PH ? (px ? 0 : 1) : 1;       // kernel tap 1 (tap 2 -> 2, tap 0 -> 0)
     const int tx = bx % a.tiles_x;
     bx /= a.tiles_x;
     const int ty = bx % a.tiles_y;
@@ -189,7 +207,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int part = 0; part < 2; ++part) {
-                    const uint4 v = wa[r][(((size_t)c * 9 + ky * 3 + kx) * 2 + part) * 64];
+                    const int tap = PH ? (ky == 1 ? kyo1 : ky) * 3 + (kx == 1 ? kxo1 : kx) : ky * 3 + kx;
+                    const uint4 v = wa[r][(((size_t)c * 9 + tap) * 2 + part) * 64];
                     A[ky][r][part] = __builtin_bit_cast(half8, v);
                 }
     };
@@ -210,7 +229,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     constexpr bool O2 = S == 1 && R == 2 && P == 2;              // the tile that runs at two workgroups per CU
                                                                  // ((3, 1) was tried: its spills cost more than it gains)
     constexpr bool LA2 = !O2;                                    // two chunks of patch look-ahead (one for those)
-    constexpr bool BPIPE = LA2;                                  // B fragments one group ahead (not for (2, 2): registers)
+    constexpr bool BPIPE = LA2 && !PH;                           // B fragments one group ahead (not for (2, 2): registers;
+                                                                 // not with skipped taps: plain reads there)
     half8 Ab[3][3][R][2];
     const int nsteps = 3 * a.nchunk;
     load_items(0, gA);
@@ -276,11 +296,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
                 load_A(Ab[(kx + AD) % 3], s2 / 3, s2 % 3);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (S == 1) {
+            if (S == 1 && (!PH || ((kxm >> kx) & 1))) {
                 // a fragment depends on (tile row rr = p + ky, kx) only: read once, used by every (p, ky) pair
 #pragma unroll
                 for (int rr = 0; rr < P + 2; ++rr) {
                     const int g = kx * (P + 2) + rr;
+                    if (PH && rr == 0)
+                        continue;                                       // kernel tap row 0 is never in use
                     if (!BPIPE)
                         read_b(g, bq[g & 1]);
                     else if (g + 1 < 3 * (P + 2))
@@ -291,7 +313,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
 #pragma unroll
                         for (int ky = 0; ky < 3; ++ky) {
                             const int p = rr - ky;
-                            if (p >= 0 && p < P) {
+                            if (p >= 0 && p < P && (!PH || ((kym >> ky) & 1))) {
 #pragma unroll
                                 for (int r = 0; r < R; ++r)
                                     acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
@@ -311,7 +333,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
                     else
                         __builtin_amdgcn_sched_group_barrier(0x008, 9 * R, 0);
                 }
-            } else {
+            } else if (S == 2) {
                 // stride 2: output pixel (p, li) reads patch pixel (2 p' + ky, 2 li + kx)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
@@ -345,12 +367,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     }
 
     const float inv = 1.0f / (xs * pow2_scale(a.wamax[0]));
-    const int col = x0 + li;
+    const int col = PH ? 2 * (x0 + li) + px : x0 + li;
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const int row = y0 + P * wave + p;
+            const int row = PH ? 2 * (y0 + P * wave + p) + py : y0 + P * wave + p;
             const int cob = (T0 + r) * 32 + 4 * h;
             if (row < a.Ho && col < a.Wo && cob < a.Cout) {
                 const size_t o0 = (((size_t)n * a.Cout + cob) * a.Ho + row) * a.Wo + col;
@@ -385,6 +407,12 @@ template <int R, int P, int S>
 __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
 {
     conv_body<R, P, S>(a);
+}
+
+template <int R, int P>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_phases(ConvArgs a)
+{
+    conv_body<R, P, 1, true>(a);
 }
 
 // same body compiled for two workgroups per CU (<= 256 registers): the (2, 2) tile of the 48-channel shape, whose
@@ -573,15 +601,30 @@ template <int R, int P, int S>
 static int launch_conv(const ConvArgs &a0, hipStream_t stream)
 {
     ConvArgs a = a0;
-    a.tiles_x = (a.Wo + TW - 1) / TW;
-    a.tiles_y = (a.Ho + 4 * P - 1) / (4 * P);
+    // (phases: tiles over one parity class of the output, ceil(Ho / 2) x ceil(Wo / 2) pixels, four classes per tile)
+    a.tiles_x = ((a.phases ? (a.Wo + 1) / 2 : a.Wo) + TW - 1) / TW;
+    a.tiles_y = ((a.phases ? (a.Ho + 1) / 2 : a.Ho) + 4 * P - 1) / (4 * P);
     const int mtiles = (a.Cout + 31) / 32;
     a.groups = (mtiles + R - 1) / R;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.groups));
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.groups * (a.phases ? 4 : 1)));
+    if constexpr (S == 1) {
+        if (a.phases) {
+            hipLaunchKernelGGL((k_conv3x3_phases<R, P>), grid, dim3(256), 0, stream, a);
+            return 0;
+        }
+    }
     if constexpr (S == 1 && R == 2 && P == 2)
         hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
+    return 0;
+}
+
+static int g_up2_phases = 1;    // in_up = 2: 1 = one output parity class per workgroup, 0 = zero-inserted input
+
+extern "C" int dcl_conv3x3_set_up2_phases(int on)
+{
+    g_up2_phases = on ? 1 : 0;
     return 0;
 }
 
@@ -610,7 +653,16 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
     a.Hs = H;
     a.Ws = W;
     a.up = in_up;
-    if (in_up == 2) {
+    a.phases = 0;
+    if (in_up == 2 && g_up2_phases) {
+        // one parity class of the output per workgroup, over the stored input (see conv_body, PH)
+        DCL_CHECK_ARG(Hout > 0 && Wout > 0 && (Hout - 1) / 2 + 1 == H && (Wout - 1) / 2 + 1 == W,
+                      "in_up = 2: H, W must be ceil(Hout / 2), ceil(Wout / 2)");
+        a.up = 1;
+        a.phases = 1;
+        a.H = H;
+        a.W = W;
+    } else if (in_up == 2) {
         // the virtual (zero-inserted) input has the size of the output; the stored one must be its even samples
         DCL_CHECK_ARG(Hout > 0 && Wout > 0 && (Hout - 1) / 2 + 1 == H && (Wout - 1) / 2 + 1 == W,
                       "in_up = 2: H, W must be ceil(Hout / 2), ceil(Wout / 2)");
@@ -620,8 +672,8 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
         a.H = H;
         a.W = W;
     }
-    a.Ho = stride == 2 ? (a.H - 1) / 2 + 1 : a.H;
-    a.Wo = stride == 2 ? (a.W - 1) / 2 + 1 : a.W;
+    a.Ho = a.phases ? Hout : (stride == 2 ? (a.H - 1) / 2 + 1 : a.H);
+    a.Wo = a.phases ? Wout : (stride == 2 ? (a.W - 1) / 2 + 1 : a.W);
     DCL_CHECK_ARG((Hout <= 0 || Hout == a.Ho) && (Wout <= 0 || Wout == a.Wo), "Hout / Wout do not match the geometry");
     a.nchunk = (Cin + 15) / 16;
     const int mtiles = (Cout + 31) / 32;
@@ -635,12 +687,15 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
         // workgroups.
         R = (mtiles % 3 == 0 || mtiles >= 20) ? 3 : (mtiles == 1 ? 1 : 2);     // >= 20 tiles: one padded tile is < 5 %
         auto wgs = [&](int r, int p) {
+            if (a.phases)
+                return (long)(((a.Wo + 1) / 2 + TW - 1) / TW) * (((a.Ho + 1) / 2 + 4 * p - 1) / (4 * p)) * N *
+                       ((mtiles + r - 1) / r) * 4;
             return (long)((a.Wo + TW - 1) / TW) * ((a.Ho + 4 * p - 1) / (4 * p)) * N * ((mtiles + r - 1) / r);
         };
         P = stride == 2 ? 1 : 4;
         while (P > 1 && wgs(R, P) < 192)
             P >>= 1;
-        if (R == 2 && P == 4 && stride == 1)
+        if (R == 2 && P == 4 && stride == 1 && !a.phases)
             P = 2;              // the (2, 2) tile runs two workgroups per CU (k_conv3x3_o2): 81 vs 100 us at 48 channels
         if (P == 1 && wgs(R, P) < 128)
             R = 1;

@@ -271,6 +271,10 @@ int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored inp
                       int Hout, int Wout /* output size (checked; required for in_up = 2, may be 0 otherwise) */,
                       int tile_r, int tile_p, void *stream);
 
+/* tuning hook: in_up = 2 (data gradient of a stride-2 convolution) -- 1 (default): every workgroup computes one parity
+ * class of the output pixels with the 1, 2 or 4 taps that class sees; 0: stride-1 tile over the zero-inserted input */
+int dcl_conv3x3_set_up2_phases(int on);
+
 /* Weight gradient of the same convolution, dw[Cout,Cin,3,3] = sum_n dy (*) x, on the f16x3 MFMA path with no LDS
  * staging (csrc/dcl_wgrad3x3.hip).  Cin % 16 == 0, Cout % 16 == 0, W % 8 == 0.  part: workspace of
  * dcl_wgrad3x3_splits(...) * 9 * Cout * Cin floats (one partial slab per workgroup, summed in fixed order). */
