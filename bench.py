@@ -69,6 +69,9 @@ def parse():
                     help="similarity-product arithmetic of the loss kernels (default: the library default)")
     ap.add_argument("--branch-conv", default="f16x3", choices=["f16x3", "library"],
                     help="backbone 3x3 convolutions: direct split-f16 kernel (fp32-equivalent) or MIOpen f32")
+    ap.add_argument("--conv1x1", default="f16x3", choices=["f16x3", "gemm", "library"],
+                    help="1x1 convolutions: f16x3 kernels (weight gradient always, forward / data gradient below 64 MB)"
+                         " | batched fp32 library GEMMs | MIOpen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--amp", action="store_true", help="bf16 autocast for the model (loss stays fp32)")
     ap.add_argument("--channels-last", action="store_true")
@@ -380,6 +383,7 @@ def step_config(args, world):
         "parallel": world > 1, "batch_is_global": False, "channels_last": args.channels_last,
         "graph": {"model": "HRNet", "backbone": "hrnet48", "sync_bn": True, "out_stride": 4, "pretrained": False,
                   "align_corners": True, "branch_conv": args.branch_conv, "lazy_logits": not args.materialize_logits,
+                  "conv1x1": getattr(args, "conv1x1", "f16x3"),
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "before_context": True}},
         "data": {"dataset": "CITYSCAPES", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
                  "synthetic": True, "synthetic_length": args.batch * 2,
@@ -556,7 +560,7 @@ def eager_gpu_step_ms(args, dev, iters=3):
     from oracle import eager_torch
     S = args.scales
     graph = {"backbone": "hrnet48", "pretrained": False, "dataset": "CITYSCAPES", "align_corners": True,
-             "branch_conv": "library", "head_conv": "library", "fused_bn": False, "gemm_conv1x1": False,
+             "branch_conv": "library", "head_conv": "library", "fused_bn": False, "gemm_conv1x1": False, "conv1x1": "library",
              "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True}}
     torch.backends.cudnn.benchmark = False
     model = HRNet(graph, 1).to(dev).train()

@@ -58,6 +58,9 @@ SIGNATURES = {
     "dcl_absmax_multi": [_vp, _vp, _i, _vp],
     "dcl_conv3x3_pack_multi": [_vp, _vp, _i, _vp],
     "dcl_conv3x3_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "dcl_conv1x1_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "dcl_wgrad1x1_splits": [_i, _i, _i, _i, _i],
+    "dcl_wgrad1x1_f16x3": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "dcl_wgrad3x3_splits": [_i, _i, _i, _i, _i, _i],
     "dcl_wgrad3x3_set_stride2": [_i],
     "dcl_conv3x3_set_up2_phases": [_i],
@@ -105,6 +108,11 @@ def lib():
             fn.restype = ctypes.c_int
         l.dcl_last_error.restype = ctypes.c_char_p
         l.dcl_last_error.argtypes = []
+        # A/B switches for the tuning tools (same box, same process layout): kernel variants by environment variable
+        for env, fn in (("DCL_WGRAD_VARIANT", l.dcl_wgrad3x3_set_variant), ("DCL_WGRAD_S2", l.dcl_wgrad3x3_set_stride2),
+                        ("DCL_UP2_PHASES", l.dcl_conv3x3_set_up2_phases)):
+            if os.environ.get(env) is not None:
+                fn(int(os.environ[env]))
         _lib = l
     return _lib
 

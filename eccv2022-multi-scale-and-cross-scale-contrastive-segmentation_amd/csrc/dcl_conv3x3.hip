@@ -62,6 +62,7 @@ struct ConvArgs {
     int Ho, Wo;                     // output size (= H, W for stride 1)
     int tiles_x, tiles_y, nchunk, groups;
     int phases;                     // 1: data gradient of a stride-2 convolution, one output parity class per workgroup
+    int onetap;                     // 1: 1x1 convolution (weights packed with one tap)
 };
 
 constexpr float F16_TARGET = 16384.0f;      // operands are scaled so that their absmax lands in (2^13, 2^14]
@@ -81,10 +82,15 @@ __device__ __forceinline__ float pow2_scale(float amax)
 // workgroup takes ONE parity class: it runs the stride-1 tile over the STORED dy with the taps remapped (kernel tap
 // 1 -> ky 1 | 0, kernel tap 2 -> ky 2, kernel tap 0 unused), skips the others, and scatters its tile to the class's
 // pixels.  A quarter of the matrix work of the zero-inserted formulation (which spends 3/4 of it on zeros).
-template <int R, int P, int S, bool PH = false>
+//
+// MODE 2 ("one tap"): a 1x1 convolution -- the same tile, patch staging and epilogue with ONE MFMA group per chunk
+// (the centre pixel of the patch); the weights are packed with one tap per (tile, chunk) (pack_item, taps = 1) and
+// streamed one chunk ahead.
+template <int R, int P, int S, int MODE = 0>
 __device__ __forceinline__ void conv_body(const ConvArgs &a)
 {
-    static_assert(!PH || S == 1, "phases: stride-1 tile");
+    constexpr bool PH = MODE == 1, T1 = MODE == 2;
+    static_assert(MODE == 0 || S == 1, "phases / one tap: stride-1 tile");
     constexpr int LW = S * (TW - 1) + 3;          // patch width incl. halo: 34 | 65
     constexpr int ROWS = S * (4 * P - 1) + 3;     // 4P + 2 | 8P + 1
     constexpr int TP = ROWS * LW;
@@ -199,7 +205,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     const uint4 *wa[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        wa[r] = a.wp + (size_t)min(T0 + r, mtiles - 1) * a.nchunk * 9 * 2 * 64 + lane;
+        wa[r] = a.wp + (size_t)min(T0 + r, mtiles - 1) * a.nchunk * (T1 ? 1 : 9) * 2 * 64 + lane;
     auto load_A = [&](half8 (&A)[3][R][2], int c, int kx) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -226,17 +232,29 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     // kx (static indices, no copies): one step ahead when a step holds >= 54 MFMAs (R = 3), two steps ahead for
     // the smaller tiles, whose steps are shorter than an L2 round trip.
     constexpr int AD = (R >= 3 || (R == 2 && P == 2)) ? 1 : 2;   // (2, 2) must stay under 256 registers
-    constexpr bool O2 = S == 1 && R == 2 && P == 2;              // the tile that runs at two workgroups per CU
+    constexpr bool O2 = S == 1 && R == 2 && P == 2 && !T1;              // the tile that runs at two workgroups per CU
                                                                  // ((3, 1) was tried: its spills cost more than it gains)
     constexpr bool LA2 = !O2;                                    // two chunks of patch look-ahead (one for those)
     constexpr bool BPIPE = LA2 && !PH;                           // B fragments one group ahead (not for (2, 2): registers;
                                                                  // not with skipped taps: plain reads there)
     half8 Ab[3][3][R][2];
     const int nsteps = 3 * a.nchunk;
+    half8 A1[T1 ? 2 : 1][R][2];                                     // one tap: weight fragments of two chunks
+    auto load_A1 = [&](half8 (&A)[R][2], int c) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                A[r][part] = __builtin_bit_cast(half8, wa[r][((size_t)c * 2 + part) * 64]);
+    };
     load_items(0, gA);
-    load_A(Ab[0], 0, 0);
-    if (AD == 2)
-        load_A(Ab[1], 0, 1);
+    if constexpr (T1) {
+        load_A1(A1[0], 0);
+    } else {
+        load_A(Ab[0], 0, 0);
+        if (AD == 2)
+            load_A(Ab[1], 0, 1);
+    }
     // operand scale of x (max over the producer's partial maxima, exchanged between the waves through LDS) -- after
     // the first patch and weight fragments are in flight, so that its memory round trip hides behind theirs
     float xs;
@@ -265,6 +283,46 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     __syncthreads();
 
     const int brow = (S * P * wave) * LW + S * li;      // patch pixel of this lane's output pixel, tap (0, 0)
+    if constexpr (T1) {
+        // one tap: chunk c = P B fragments (patch pixel (p + 1, li + 1)) x R channel tiles x 3 passes; the weight
+        // fragments of chunk c + 1 are fetched while chunk c runs (two register sets, loop unrolled by two)
+        auto chunk = [&](auto PHASE, int c) {
+            constexpr int ph = decltype(PHASE)::value;
+            const unsigned char *cur = lds + (c & 1) * BUFB;
+            const bool more = c + 1 < a.nchunk;
+            __builtin_amdgcn_sched_barrier(0);
+            load_items(min(c + 2, a.nchunk - 1), gB);
+            load_A1(A1[ph ^ 1], min(c + 1, a.nchunk - 1));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const unsigned char *bp = cur + (brow + (p + 1) * LW + 1) * PIXB + h * 16;
+                const half8 bh = *(const half8 *)bp, bl = *(const half8 *)(bp + 32);
+#pragma unroll
+                for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[ph][r][pass == 2 ? 1 : 0],
+                                                                           pass == 1 ? bl : bh, acc[r][p], 0, 0, 0);
+                if (p == 0 && more)
+                    write_items(lds + ((c + 1) & 1) * BUFB, gA);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < NITEM; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    gA[m][e] = gB[m][e];
+        };
+        int c = 0;
+        for (; c + 2 <= a.nchunk; c += 2) {
+            chunk(std::integral_constant<int, 0>{}, c);
+            chunk(std::integral_constant<int, 1>{}, c + 1);
+        }
+        if (c < a.nchunk)
+            chunk(std::integral_constant<int, 0>{}, c);
+    } else {
     for (int c = 0; c < a.nchunk; ++c) {
         const unsigned char *cur = lds + (c & 1) * BUFB;
         const bool more = c + 1 < a.nchunk;
@@ -366,6 +424,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
         }
     }
 
+    }
     const float inv = 1.0f / (xs * pow2_scale(a.wamax[0]));
     const int col = PH ? 2 * (x0 + li) + px : x0 + li;
 #pragma unroll
@@ -412,7 +471,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
 template <int R, int P>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_phases(ConvArgs a)
 {
-    conv_body<R, P, 1, true>(a);
+    conv_body<R, P, 1, 1>(a);
+}
+
+template <int R, int P>
+__global__ __launch_bounds__(256, 1) void k_conv1x1(ConvArgs a)
+{
+    conv_body<R, P, 1, 2>(a);
 }
 
 // same body compiled for two workgroups per CU (<= 256 registers): the (2, 2) tile of the 48-channel shape, whose
@@ -426,16 +491,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_o2(ConvArgs a)
 // weights -> fragment order.  transposed = 0: value(m, k, ky, kx) = w[m][k][ky][kx], w is [M][K][3][3];
 // transposed = 1 (data gradient): value(m, k, ky, kx) = w[k][m][2 - ky][2 - kx], w is [K][M][3][3].
 // One thread per (fragment pair, lane): fragment (T, c, t) lane (hh, i) holds value(32 T + i, 16 c + 8 hh + e, t).
+// `transposed` bit 1 set: a 1x1 kernel, w is [M][K] ([K][M] transposed), ONE tap per (tile, chunk).
 __device__ __forceinline__ void pack_item(const float *__restrict__ w, int M, int K, int transposed, int gid,
                                           float s, uint4 *__restrict__ wp)
 {
     const int mtiles = (M + 31) / 32, nchunk = (K + 15) / 16;
-    if (gid >= mtiles * nchunk * 9 * 64)
+    const int taps = (transposed & 2) ? 1 : 9;
+    transposed &= 1;
+    if (gid >= mtiles * nchunk * taps * 64)
         return;
     const int lane = gid & 63;
     int f = gid >> 6;
-    const int t = f % 9;
-    f /= 9;
+    const int t = f % taps;
+    f /= taps;
     const int c = f % nchunk;
     const int T = f / nchunk;
     const int i = lane & 31, hh = lane >> 5;
@@ -446,14 +514,18 @@ __device__ __forceinline__ void pack_item(const float *__restrict__ w, int M, in
     for (int e = 0; e < 8; ++e) {
         const int k = 16 * c + 8 * hh + e;
         float v = 0.f;
-        if (m < M && k < K)
-            v = transposed ? w[(((size_t)k * M + m) * 3 + (2 - ky)) * 3 + (2 - kx)]
-                           : w[(((size_t)m * K + k) * 3 + ky) * 3 + kx];
+        if (m < M && k < K) {
+            if (taps == 1)
+                v = transposed ? w[(size_t)k * M + m] : w[(size_t)m * K + k];
+            else
+                v = transposed ? w[(((size_t)k * M + m) * 3 + (2 - ky)) * 3 + (2 - kx)]
+                               : w[(((size_t)m * K + k) * 3 + ky) * 3 + kx];
+        }
         v *= s;
         hi[e] = (_Float16)v;
         lo[e] = (_Float16)(v - (float)hi[e]);
     }
-    const size_t o = ((((size_t)T * nchunk + c) * 9 + t) * 2) * 64 + lane;
+    const size_t o = ((((size_t)T * nchunk + c) * taps + t) * 2) * 64 + lane;
     wp[o] = __builtin_bit_cast(uint4, hi);
     wp[o + 64] = __builtin_bit_cast(uint4, lo);
 }
@@ -571,8 +643,9 @@ extern "C" int dcl_conv3x3_pack(const float *w, int M, int K, int transposed, co
                                 void *stream)
 {
     DCL_CHECK_ARG(w && wamax && wp && M > 0 && K > 0, "bad arguments");
+    DCL_CHECK_ARG(transposed >= 0 && transposed <= 3, "transposed: bit 0 = data-gradient orientation, bit 1 = 1x1 kernel");
     const int mtiles = (M + 31) / 32, nchunk = (K + 15) / 16;
-    const int total = mtiles * nchunk * 9 * 64;
+    const int total = mtiles * nchunk * ((transposed & 2) ? 1 : 9) * 64;
     hipLaunchKernelGGL(k_pack_w3x3, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, M, K,
                        transposed, wamax, (uint4 *)wp);
     DCL_LAUNCH_CHECK();
@@ -612,6 +685,10 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
             hipLaunchKernelGGL((k_conv3x3_phases<R, P>), grid, dim3(256), 0, stream, a);
             return 0;
         }
+        if (a.onetap) {
+            hipLaunchKernelGGL((k_conv1x1<R, P>), grid, dim3(256), 0, stream, a);
+            return 0;
+        }
     }
     if constexpr (S == 1 && R == 2 && P == 2)
         hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);
@@ -628,10 +705,30 @@ extern "C" int dcl_conv3x3_set_up2_phases(int on)
     return 0;
 }
 
+static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout, const float *xamax,
+                      int xcount, const float *wamax, const float *addend, const float *bias, float *y, int stride,
+                      int in_up, int Hout, int Wout, int tile_r, int tile_p, int onetap, void *stream);
+
 extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
                                  const float *xamax, int xcount, const float *wamax, const float *addend,
                                  const float *bias, float *y, int stride, int in_up, int Hout, int Wout,
                                  int tile_r, int tile_p, void *stream)
+{
+    return conv_f16x3(x, N, Cin, H, W, wp, Cout, xamax, xcount, wamax, addend, bias, y, stride, in_up, Hout, Wout, tile_r,
+                      tile_p, 0, stream);
+}
+
+extern "C" int dcl_conv1x1_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
+                                 const float *xamax, int xcount, const float *wamax, const float *addend,
+                                 const float *bias, float *y, int tile_r, int tile_p, void *stream)
+{
+    return conv_f16x3(x, N, Cin, H, W, wp, Cout, xamax, xcount, wamax, addend, bias, y, 1, 1, 0, 0, tile_r, tile_p, 1,
+                      stream);
+}
+
+static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout, const float *xamax,
+                      int xcount, const float *wamax, const float *addend, const float *bias, float *y, int stride,
+                      int in_up, int Hout, int Wout, int tile_r, int tile_p, int onetap, void *stream)
 {
     DCL_CHECK_ARG(x && wp && xamax && wamax && y, "null pointer");
     DCL_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && xcount > 0, "bad shape");
@@ -654,6 +751,7 @@ extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, c
     a.Ws = W;
     a.up = in_up;
     a.phases = 0;
+    a.onetap = onetap;
     if (in_up == 2 && g_up2_phases) {
         // one parity class of the output per workgroup, over the stored input (see conv_body, PH)
         DCL_CHECK_ARG(Hout > 0 && Wout > 0 && (Hout - 1) / 2 + 1 == H && (Wout - 1) / 2 + 1 == W,

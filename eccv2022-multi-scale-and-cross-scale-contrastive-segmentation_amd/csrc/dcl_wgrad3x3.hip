@@ -437,9 +437,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
 static int g_tile_nco = 0, g_tile_nci = 0;      // tuning override (dcl_wgrad3x3_set_tile), 0 = automatic
 static int g_variant = -1;     // 1 = shared-dY workgroups (dcl_wgrad3x3s.hip), 0 = per-wave operands, -1 = by shape
 
-// measured (tools/wgrad_head.py): sharing dY through LDS pays from 12 input-channel tiles on (192 channels: 58.6 vs
-// 64.3 us, 384: 73.4 vs 89.3 us, 720: 10.1 vs 11.7 ms); below that the four-times larger slabs cost more than the loads
-static bool use_shared(int Cin) { return g_variant < 0 ? Cin / 16 >= 12 : g_variant == 1; }
+// The shared-dY kernel was the answer to the L1 tag rate of the MFMA-order loads (192 channels: 58.6 vs 64.3 us, 384: 73.4
+// vs 89.3 us).  With the operands staged by LDS-DMA the per-wave kernel reaches the same times (63 / 81 us, head 10.7 ms)
+// with slabs a quarter of the size -- in the training step, where the slab reduction competes with the neighbouring
+// kernels for HBM, that is what counts (k_wgrad_reduce_sk 38 us vs k_wgrad_reduce 9.5 us per launch in the step
+// profile).  So the shared kernel only runs when asked for.
+static bool use_shared(int Cin) { return g_variant == 1; }
 // per-wave kernel: operands staged by LDS-DMA (dcl_wgrad3x3d.hip) unless variant 0 asks for the direct loads
 static bool use_dma(int Cin, int H, int W) { return g_variant != 0 && (size_t)Cin * H * W * 4 < ((size_t)1 << 32); }
 

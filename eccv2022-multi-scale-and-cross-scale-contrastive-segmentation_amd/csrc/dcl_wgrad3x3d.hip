@@ -425,6 +425,321 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
                 }
 }
 
+
+// ---- 1x1 convolution: dw[co][ci] = sum_{n, y, x} dy[n, co, y, x] * x[n, ci, y, x] -----------------------------------
+// Same staging and work split with one tap: no halo pieces, no dY ring; a wave owns NCO x NCI tiles (up to 4 x 4) and per
+// row step issues 3 NCO NCI MFMAs on the fragments converted one step earlier while the next row is being split.
+struct Wgrad1Args {
+    const float *x, *dy;
+    float *part;                 // [nx][Cout][Cin]
+    const float *xamax, *gamax;
+    int xcount, gcount;
+    int N, Cin, Cout, H, W;
+    int strips, units, S, ncig, npairs, nx;
+};
+
+template <int NCO, int NCI>
+__global__ __launch_bounds__(256, 1) void k_wgrad1x1d(Wgrad1Args a)
+{
+    constexpr int NIA = (NCO * 16 * APIECES + 63) / 64, NIB = (NCI * 16 * APIECES + 63) / 64, NI = NIA + NIB;
+    // ring slots: rows are fetched NS - 1 steps ahead.  The steps are short (one tap) and the kernel is bound by HBM, not
+    // by the matrix pipe: what matters is the volume in flight, 4 waves x (NS - 1) x NI KiB per CU
+    constexpr int NS = NI > 13 ? 2 : 3, D = NS - 1;
+    constexpr int SLOTB = NI * 1024, STAGEB = 4 * NS * SLOTB;
+    constexpr int NREG = NCO * NCI * 4;
+    constexpr int REDB = 2 * NREG * 64 * 4;
+    constexpr int SMEMB = STAGEB > REDB ? STAGEB : REDB;
+    static_assert(SMEMB + 64 <= 160 * 1024, "LDS");
+    static_assert(D * NI < 64, "vmcnt");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEMB];
+    __shared__ float wm[8];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q4 = lane >> 4, j = lane & 15;
+
+    float sx, sg;
+    {
+        float mx = 0.f, mg = 0.f;
+        for (int i = tid; i < a.xcount; i += 256)
+            mx = fmaxf(mx, a.xamax[i]);
+        for (int i = tid; i < a.gcount; i += 256)
+            mg = fmaxf(mg, a.gamax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            mg = fmaxf(mg, __shfl_xor(mg, o, 64));
+        }
+        if (lane == 0) {
+            wm[wave] = mx;
+            wm[4 + wave] = mg;
+        }
+        __syncthreads();
+        sx = pow2_scale(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
+        sg = pow2_scale(fmaxf(fmaxf(wm[4], wm[5]), fmaxf(wm[6], wm[7])));
+    }
+    int pair, xsplit;
+    {
+        const int nx8 = a.nx & ~7, main_blocks = nx8 * a.npairs;
+        if ((int)blockIdx.x < main_blocks) {
+            const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+            pair = rest % a.npairs;
+            xsplit = (rest / a.npairs) * 8 + xcd;
+        } else {
+            const int rest = blockIdx.x - main_blocks;
+            pair = rest % a.npairs;
+            xsplit = nx8 + rest / a.npairs;
+        }
+    }
+    const int split = xsplit * 4 + wave;
+    const int cog = pair / a.ncig, cig = pair - cog * a.ncig;
+    const int co0 = cog * NCO * 16, ci0 = cig * NCI * 16;
+    const size_t plane = (size_t)a.H * a.W;
+
+    unsigned chanA[NIA], chanB[NIB];
+    int pieceA[NIA], pieceB[NIB];
+#pragma unroll
+    for (int m = 0; m < NIA; ++m) {
+        int P = 64 * m + lane;
+        if (P >= NCO * 16 * APIECES)
+            P = 0;
+        const int row = P / APIECES, pc = min(P - row * APIECES, APIECES - 2);
+        chanA[m] = (unsigned)((size_t)(co0 + row) * plane * 4);
+        pieceA[m] = 4 * pc;
+    }
+#pragma unroll
+    for (int m = 0; m < NIB; ++m) {
+        int P = 64 * m + lane;
+        if (P >= NCI * 16 * APIECES)
+            P = 0;
+        const int row = P / APIECES, pc = min(P - row * APIECES, APIECES - 2);
+        chanB[m] = (unsigned)((size_t)(ci0 + row) * plane * 4);
+        pieceB[m] = 4 * pc;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)smem +
+                          (unsigned)wave * (NS * SLOTB);
+    const unsigned char *my = smem + wave * (NS * SLOTB);
+    const unsigned ardo = (unsigned)(j * APIECES + 2 * q4) * 16;
+    const unsigned brdo = (unsigned)(NIA * 1024) + ardo;
+
+    f32x4 acc[NCO][NCI];
+#pragma unroll
+    for (int t = 0; t < NCO; ++t)
+#pragma unroll
+        for (int u = 0; u < NCI; ++u)
+            acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const long long T = (long long)a.units * a.H;
+    long long t = min(T, T * split / a.S);
+    const long long t1 = min(T, T * (split + 1) / a.S);
+    while (t < t1) {
+        const int col = (int)(t / a.H);
+        const int r0 = (int)(t - (long long)col * a.H);
+        const int r1 = (int)min((long long)a.H, r0 + (t1 - t));
+        t += r1 - r0;
+        const int strip = col % a.strips;
+        const int n = col / a.strips;
+        const int px0 = strip * 32, px = px0 + 8 * q4;
+        const bool oct_ok = px < a.W;
+        const float sx_c = oct_ok ? sx : 0.f, sg_c = oct_ok ? sg : 0.f;
+        unsigned offA[NIA], offB[NIB];
+#pragma unroll
+        for (int m = 0; m < NIA; ++m)
+            offA[m] = chanA[m] + 4u * (unsigned)min(px0 + pieceA[m], a.W - 4);
+#pragma unroll
+        for (int m = 0; m < NIB; ++m)
+            offB[m] = chanB[m] + 4u * (unsigned)min(px0 + pieceB[m], a.W - 4);
+        const float *dyn = a.dy + (size_t)n * a.Cout * plane, *xn = a.x + (size_t)n * a.Cin * plane;
+
+        auto dma_group = [&](int g, int s) {           // rows g of dY and X -> ring slot s
+            const size_t ro = (size_t)min(g, a.H - 1) * a.W;
+            const float *ab = uniform_ptr(dyn + ro), *bb = uniform_ptr(xn + ro);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)s * SLOTB);
+#pragma unroll
+            for (int m = 0; m < NIA; ++m)
+                dma16(ab, offA[m], dst + m * 1024);
+#pragma unroll
+            for (int m = 0; m < NIB; ++m)
+                dma16(bb, offB[m], dst + (NIA + m) * 1024);
+        };
+        auto read_rows = [&](int s, f32x4 (&da)[NCO][2], f32x4 (&db)[NCI][2]) {
+            const unsigned char *p = my + s * SLOTB;
+#pragma unroll
+            for (int t2 = 0; t2 < NCO; ++t2) {
+                da[t2][0] = *(const f32x4 *)(p + ardo + t2 * (16 * APIECES * 16));
+                da[t2][1] = *(const f32x4 *)(p + ardo + t2 * (16 * APIECES * 16) + 16);
+            }
+#pragma unroll
+            for (int u = 0; u < NCI; ++u) {
+                db[u][0] = *(const f32x4 *)(p + brdo + u * (16 * APIECES * 16));
+                db[u][1] = *(const f32x4 *)(p + brdo + u * (16 * APIECES * 16) + 16);
+            }
+        };
+        auto cvt8 = [&](const f32x4 (&src)[2], float scale, half8 (&dst)[2]) {
+            unsigned h[4], l[4];
+            split2(src[0].x, src[0].y, scale, h[0], l[0]);
+            split2(src[0].z, src[0].w, scale, h[1], l[1]);
+            split2(src[1].x, src[1].y, scale, h[2], l[2]);
+            split2(src[1].z, src[1].w, scale, h[3], l[3]);
+            dst[0] = as_half8(u32x4{h[0], h[1], h[2], h[3]});
+            dst[1] = as_half8(u32x4{l[0], l[1], l[2], l[3]});
+        };
+
+        half8 FA[2][NCO][2], FB[2][NCI][2];
+        dma_wait<0>();
+#pragma unroll
+        for (int g = 0; g <= D; ++g)
+            dma_group(r0 + g, g);
+        dma_wait<D * NI>();
+        {
+            f32x4 ra[NCO][2], rb[NCI][2];
+            read_rows(0, ra, rb);
+#pragma unroll
+            for (int t2 = 0; t2 < NCO; ++t2)
+                cvt8(ra[t2], sg_c, FA[0][t2]);
+#pragma unroll
+            for (int u = 0; u < NCI; ++u)
+                cvt8(rb[u], sx_c, FB[0][u]);
+        }
+        // step i (row r = r0 + i, ph = i % 6): fragments of row r are in set ph % 2; group r + 1 sits in slot
+        // (i + 1) % NS, group r + NS goes to slot i % NS (row r's, read one step ago)
+        auto step = [&](auto PH, int r) {
+            constexpr int ph = decltype(PH)::value, fs = ph % 2;
+            f32x4 ra[NCO][2], rb[NCI][2];
+            dma_wait<(D - 1) * NI>();
+            read_rows((ph + 1) % NS, ra, rb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // slot ph % NS was read a step ago; this one now
+            dma_group(r + NS, ph % NS);
+#pragma unroll
+            for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+                for (int t2 = 0; t2 < NCO; ++t2)
+#pragma unroll
+                    for (int u = 0; u < NCI; ++u)
+                        acc[t2][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FA[fs][t2][pass == 2 ? 1 : 0],
+                                                                            FB[fs][u][pass == 1 ? 1 : 0], acc[t2][u], 0, 0, 0);
+#pragma unroll
+            for (int t2 = 0; t2 < NCO; ++t2)
+                cvt8(ra[t2], sg_c, FA[fs ^ 1][t2]);
+#pragma unroll
+            for (int u = 0; u < NCI; ++u)
+                cvt8(rb[u], sx_c, FB[fs ^ 1][u]);
+        };
+        int r = r0;
+        for (; r + 6 <= r1; r += 6) {
+            step(std::integral_constant<int, 0>{}, r);
+            step(std::integral_constant<int, 1>{}, r + 1);
+            step(std::integral_constant<int, 2>{}, r + 2);
+            step(std::integral_constant<int, 3>{}, r + 3);
+            step(std::integral_constant<int, 4>{}, r + 4);
+            step(std::integral_constant<int, 5>{}, r + 5);
+        }
+        if (r < r1)
+            step(std::integral_constant<int, 0>{}, r);
+        if (r + 1 < r1)
+            step(std::integral_constant<int, 1>{}, r + 1);
+        if (r + 2 < r1)
+            step(std::integral_constant<int, 2>{}, r + 2);
+        if (r + 3 < r1)
+            step(std::integral_constant<int, 3>{}, r + 3);
+        if (r + 4 < r1)
+            step(std::integral_constant<int, 4>{}, r + 4);
+    }
+    dma_wait<0>();
+    __syncthreads();
+    {
+        float(*red)[NREG][64] = (float(*)[NREG][64])smem;
+        auto put = [&](int b) {
+#pragma unroll
+            for (int t2 = 0; t2 < NCO; ++t2)
+#pragma unroll
+                for (int u = 0; u < NCI; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        red[b][(t2 * NCI + u) * 4 + q][lane] = acc[t2][u][q];
+        };
+        auto add = [&](int b) {
+#pragma unroll
+            for (int t2 = 0; t2 < NCO; ++t2)
+#pragma unroll
+                for (int u = 0; u < NCI; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc[t2][u][q] += red[b][(t2 * NCI + u) * 4 + q][lane];
+        };
+        if (wave & 1)
+            put(wave >> 1);
+        __syncthreads();
+        if (!(wave & 1))
+            add(wave >> 1);
+        __syncthreads();
+        if (wave == 2)
+            put(0);
+        __syncthreads();
+        if (wave != 0)
+            return;
+        add(0);
+    }
+    const float inv = 1.0f / (sx * sg);
+    float *out = a.part + (size_t)xsplit * a.Cout * a.Cin;
+#pragma unroll
+    for (int t2 = 0; t2 < NCO; ++t2)
+#pragma unroll
+        for (int u = 0; u < NCI; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                out[(size_t)(co0 + 16 * t2 + 4 * q4 + q) * a.Cin + ci0 + 16 * u + j] = acc[t2][u][q] * inv;
+}
+
+// dw[i] = sum_s part[s][i], slabs added in fixed order (8 partial sums combined in order through LDS)
+__global__ __launch_bounds__(256) void k_slab_sum(const float *__restrict__ part, int S, int total, float *__restrict__ dw)
+{
+    __shared__ float sh[8][32];
+    const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (idx < total) {
+        int k = g;
+        for (; k + 8 < S; k += 16) {
+            s0 += part[(size_t)k * total + idx];
+            s1 += part[(size_t)(k + 8) * total + idx];
+        }
+        if (k < S)
+            s0 += part[(size_t)k * total + idx];
+    }
+    sh[g][lane] = s0 + s1;
+    __syncthreads();
+    if (g == 0 && idx < total) {
+        float s = sh[0][lane];
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+            s += sh[q][lane];
+        dw[idx] = s;
+    }
+}
+
+struct W1Plan {
+    int nco, nci, ncig, npairs, units, S, nx;
+};
+
+W1Plan w1_plan(int N, int Cin, int Cout, int H, int W)
+{
+    const int cot = Cout / 16, cit = Cin / 16;
+    W1Plan p;
+    p.nco = cot % 4 == 0 ? 4 : (cot % 3 == 0 ? 3 : (cot % 2 == 0 ? 2 : 1));
+    p.nci = cit % 4 == 0 ? 4 : (cit % 3 == 0 ? 3 : (cit % 2 == 0 ? 2 : 1));
+    if (p.nco == 4 && p.nci == 4)                   // the staging ring of a (4, 4) wave does not fit: 4 waves x 2 x 20 KiB
+        (cot >= cit ? p.nci : p.nco) = 2;
+    p.ncig = cit / p.nci;
+    p.npairs = (cot / p.nco) * p.ncig;
+    p.units = N * ((W + 31) / 32);
+    p.nx = 256 / p.npairs;
+    if (p.nx < 1)
+        p.nx = 1;
+    p.S = 4 * p.nx;
+    if ((long long)p.S > (long long)p.units * H)
+        p.S = p.units * H;
+    p.nx = (p.S + 3) / 4;
+    return p;
+}
+
 }  // namespace
 
 bool dcl_wgrad_dma_supported(int nco, int nci) { return nco >= 1 && nco <= 3 && nci >= 1 && nci <= 2; }
@@ -441,4 +756,49 @@ void dcl_wgrad_dma_launch(const WgradArgs &a, int nco, int nci, dim3 grid, hipSt
     DCL_WGD_CASE(2, 1)
     DCL_WGD_CASE(1, 1)
 #undef DCL_WGD_CASE
+}
+
+extern "C" int dcl_wgrad1x1_splits(int N, int Cin, int Cout, int H, int W)
+{
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cin & 15) || (Cout & 15) || (W & 7))
+        return 0;
+    return w1_plan(N, Cin, Cout, H, W).nx;
+}
+
+extern "C" int dcl_wgrad1x1_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W,
+                                  const float *xamax, int xcount, const float *gamax, int gcount, float *part, float *dw,
+                                  void *stream)
+{
+    DCL_CHECK_ARG(x && dy && xamax && gamax && part && dw, "null pointer");
+    DCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && xcount > 0 && gcount > 0, "bad shape");
+    DCL_CHECK_ARG(Cin > 0 && Cout > 0 && (Cin & 15) == 0 && (Cout & 15) == 0, "channel counts must be multiples of 16");
+    DCL_CHECK_ARG((W & 7) == 0, "W must be a multiple of 8");
+    DCL_CHECK_ARG((size_t)(Cin > Cout ? Cin : Cout) * H * W * 4 < ((size_t)1 << 32), "image too large");
+    DCL_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0, "tensors must be 16-byte aligned");
+    const W1Plan p = w1_plan(N, Cin, Cout, H, W);
+    Wgrad1Args a;
+    a.x = x; a.dy = dy; a.part = part; a.xamax = xamax; a.gamax = gamax; a.xcount = xcount; a.gcount = gcount;
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    a.strips = (W + 31) / 32;
+    a.units = p.units; a.S = p.S; a.ncig = p.ncig; a.npairs = p.npairs; a.nx = p.nx;
+    const dim3 grid((unsigned)(p.npairs * p.nx));
+    hipStream_t s = (hipStream_t)stream;
+#define DCL_W1_CASE(o, i)            \
+    if (p.nco == o && p.nci == i)    \
+        hipLaunchKernelGGL((k_wgrad1x1d<o, i>), grid, dim3(256), 0, s, a);
+#define DCL_W1_ROW(o) DCL_W1_CASE(o, 1) DCL_W1_CASE(o, 2) DCL_W1_CASE(o, 3)
+    DCL_W1_ROW(1)
+    DCL_W1_ROW(2)
+    DCL_W1_ROW(3)
+    DCL_W1_ROW(4)
+    DCL_W1_CASE(1, 4)
+    DCL_W1_CASE(2, 4)
+    DCL_W1_CASE(3, 4)
+#undef DCL_W1_ROW
+#undef DCL_W1_CASE
+    DCL_LAUNCH_CHECK();
+    const int total = Cout * Cin;
+    hipLaunchKernelGGL(k_slab_sum, dim3((total + 31) / 32), dim3(256), 0, s, part, p.nx, total, dw);
+    DCL_LAUNCH_CHECK();
+    return 0;
 }

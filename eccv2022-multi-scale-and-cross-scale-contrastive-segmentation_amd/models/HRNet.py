@@ -27,7 +27,8 @@ import torch.nn.functional as F
 
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
-from .ops import ConvPackGroup, DirectConv2d, GradToken, use_gemm_conv1x1, upsample_bilinear, use_direct_conv3x3
+from .ops import (ConvPackGroup, DirectConv2d, GradToken, use_gemm_conv1x1, upsample_bilinear, use_direct_conv3x3,
+                  use_direct_conv1x1)
 from .amax import record_stream as _amax_record_stream
 from .fused_bn import FusedBatchNorm2d, bn_act
 
@@ -457,12 +458,16 @@ class HRNet(nn.Module):
             use_direct_conv3x3(self.cls_head)
         if self.branch_conv == 'f16x3':
             use_direct_conv3x3(self.backbone)
-        if self.branch_conv == 'f16x3' or self.head_conv == 'direct':
-            self._conv_packs = ConvPackGroup(self)
-        # 1x1 convolutions (bottlenecks, fuse layers, projector, classifier) as plain batched GEMMs in all three
-        # directions: the library's weight gradient for them wraps an NHWC kernel in layout transposes
-        if config.get('gemm_conv1x1', True):
+        # 1x1 convolutions (bottlenecks, fuse layers, projector, classifier): 'f16x3' (default) = the same direct
+        # split-f16 kernels in their one-tap mode, all three directions; 'gemm' = plain batched fp32 library GEMMs (the
+        # library's own weight gradient for a 1x1 convolution wraps an NHWC kernel in layout transposes); 'library'
+        self.conv1x1 = config.get('conv1x1', 'f16x3' if config.get('gemm_conv1x1', True) else 'library')
+        if self.conv1x1 == 'f16x3':
+            use_direct_conv1x1(self)
+        elif self.conv1x1 == 'gemm':
             use_gemm_conv1x1(self)
+        if self.branch_conv == 'f16x3' or self.head_conv == 'direct' or self.conv1x1 == 'f16x3':
+            self._conv_packs = ConvPackGroup(self)
 
     def _head(self, x):
         return self.cls_head(x)

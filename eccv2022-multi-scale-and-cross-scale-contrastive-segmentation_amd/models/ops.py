@@ -90,16 +90,71 @@ def _stream(t):
 
 
 def conv3x3_pack(weight, wamax, transposed=False):
-    """Weights [Co, Ci, 3, 3] -> MFMA fragment order (f16 hi / lo), for the forward (M = Co, K = Ci) or, with
-    ``transposed``, for the data gradient (M = Ci, K = Co, taps flipped)."""
+    """Weights [Co, Ci, 3, 3] (or [Co, Ci, 1, 1]) -> MFMA fragment order (f16 hi / lo), for the forward (M = Co,
+    K = Ci) or, with ``transposed``, for the data gradient (M = Ci, K = Co, taps flipped)."""
     from .. import _lib
     co, ci = weight.shape[0], weight.shape[1]
+    taps = weight.shape[2] * weight.shape[3]
+    assert taps in (1, 9)
     m, k = (ci, co) if transposed else (co, ci)
-    nbytes = ((m + 31) // 32) * ((k + 15) // 16) * 9 * 2 * 64 * 16
+    nbytes = ((m + 31) // 32) * ((k + 15) // 16) * taps * 2 * 64 * 16
     wp = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    _lib.check(_lib.lib().dcl_conv3x3_pack(_lib.ptr(weight), m, k, 1 if transposed else 0, _lib.ptr(wamax),
-                                           _lib.ptr(wp), _stream(weight)), "dcl_conv3x3_pack")
+    _lib.check(_lib.lib().dcl_conv3x3_pack(_lib.ptr(weight), m, k, (1 if transposed else 0) | (2 if taps == 1 else 0),
+                                           _lib.ptr(wamax), _lib.ptr(wp), _stream(weight)), "dcl_conv3x3_pack")
     return wp
+
+
+def conv1x1_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0, addend=None, bias=None):
+    """1x1 convolution (or its data gradient, with transposed fragments) on the one-tap mode of the direct kernel."""
+    from .. import _lib
+    n, c, h, w = x.shape
+    _lib.check(_lib.lib().dcl_conv1x1_f16x3(_lib.ptr(x), n, c, h, w, _lib.ptr(wp), cout, _lib.ptr(xamax),
+                                            xamax.numel(), _lib.ptr(wamax), _lib.ptr(addend), _lib.ptr(bias),
+                                            _lib.ptr(out), tile_r, tile_p, _stream(x)), "dcl_conv1x1_f16x3")
+    return out
+
+
+def conv1x1_direct(x, weight, transposed=False):
+    """y = conv2d(x, weight [Co, Ci, 1, 1]) (or, ``transposed``, its data gradient applied to x) on the f16x3 kernel."""
+    from .amax import amax_of
+    x, weight = x.contiguous(), weight.contiguous()
+    wamax = amax_of(weight)
+    wp = conv3x3_pack(weight, wamax, transposed)
+    cout = weight.shape[1] if transposed else weight.shape[0]
+    out = torch.empty((x.shape[0], cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+    return conv1x1_launch(x, wp, cout, amax_of(x), wamax, out)
+
+
+def _conv1x1_by_library(x, y):
+    """Forward / data gradient of a 1x1 convolution: above 64 MB of input + output the layer is bound by HBM and the
+    library's streaming GEMM moves the bytes faster than the tile kernel, whose patch staging is built for the 3x3
+    case (tools/conv1x1_shapes.py: 64 -> 256 at 128 x 256, batch 12: 182 vs 226 us); below, the direct kernel wins or
+    ties and brings the absmax side channel and the fused bias / residual-gradient epilogue."""
+    return (x.numel() + y.numel()) * 4 > (64 << 20)
+
+
+def conv1x1_wgrad_supported(x, cout):
+    return x.shape[1] % 16 == 0 and cout % 16 == 0 and x.shape[3] % 8 == 0 \
+        and max(x.shape[1], cout) * x.shape[2] * x.shape[3] * 4 < (1 << 32)
+
+
+def conv1x1_wgrad(x, gy):
+    """dw [Co, Ci, 1, 1] of a 1x1 convolution, f16x3 (csrc/dcl_wgrad3x3d.hip, k_wgrad1x1d)."""
+    from .. import _lib
+    from .amax import amax_of
+    n, ci, h, w = x.shape
+    co = gy.shape[1]
+    L = _lib.lib()
+    splits = L.dcl_wgrad1x1_splits(n, ci, co, h, w)
+    if splits <= 0:
+        raise RuntimeError("conv1x1_wgrad: unsupported shape")
+    part = torch.empty(splits * co * ci, dtype=torch.float32, device=x.device)
+    dw = torch.empty((co, ci, 1, 1), dtype=torch.float32, device=x.device)
+    xa, ga = amax_of(x), amax_of(gy)
+    _lib.check(L.dcl_wgrad1x1_f16x3(_lib.ptr(x), _lib.ptr(gy), n, ci, co, h, w, _lib.ptr(xa), xa.numel(),
+                                    _lib.ptr(ga), ga.numel(), _lib.ptr(part), _lib.ptr(dw), _stream(x)),
+               "dcl_wgrad1x1_f16x3")
+    return dw
 
 
 def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0, addend=None, stride=1, in_up=1, bias=None):
@@ -182,10 +237,19 @@ class _Conv3x3Direct(torch.autograd.Function):
         ctx.token = token
         ctx.has_bias = bias is not None
         ctx.stride = st = mod.stride[0]
+        ctx.k1 = k1 = mod.kernel_size == (1, 1)
         wamax, wp, _ = mod.packed_weights()
         out = torch.empty((x.shape[0], weight.shape[0], (x.shape[2] - 1) // st + 1, (x.shape[3] - 1) // st + 1),
                           dtype=torch.float32, device=x.device)
-        conv3x3_launch(x, wp, weight.shape[0], amax_of(x), wamax, out, stride=st, bias=bias)
+        if k1 and _conv1x1_by_library(x, out):
+            n, ci, h, w = x.shape
+            torch.matmul(weight.view(-1, ci), x.view(n, ci, h * w), out=out.view(n, -1, h * w))
+            if bias is not None:
+                out += bias.view(1, -1, 1, 1)
+        elif k1:
+            conv1x1_launch(x, wp, weight.shape[0], amax_of(x), wamax, out, bias=bias)
+        else:
+            conv3x3_launch(x, wp, weight.shape[0], amax_of(x), wamax, out, stride=st, bias=bias)
         ctx.save_for_backward(x, weight)
         ctx.mod = mod
         return out
@@ -202,9 +266,23 @@ class _Conv3x3Direct(torch.autograd.Function):
             addend = None
             if ctx.token is not None and ctx.token.dres is not None:
                 addend, ctx.token.dres = ctx.token.dres, None        # gradient of the residual branch, fused in
-            conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend, in_up=ctx.stride)
+            if ctx.k1 and _conv1x1_by_library(x, gy):
+                n, ci, h, w = x.shape
+                torch.matmul(weight.view(-1, ci).t(), gy.view(n, -1, h * w), out=gx.view(n, ci, h * w))
+                if addend is not None:
+                    gx += addend
+            elif ctx.k1:
+                conv1x1_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend)
+            else:
+                conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend, in_up=ctx.stride)
         if ctx.needs_input_grad[1]:
-            if conv3x3_wgrad_supported(x, weight.shape[0]):
+            if ctx.k1:
+                if conv1x1_wgrad_supported(x, weight.shape[0]):
+                    gw = conv1x1_wgrad(x, gy)
+                else:
+                    n, ci, h, w = x.shape
+                    gw = torch.bmm(gy.view(n, -1, h * w), x.view(n, ci, h * w).transpose(1, 2)).sum(0).view_as(weight)
+            elif conv3x3_wgrad_supported(x, weight.shape[0]):
                 gw = conv3x3_wgrad(x, gy, ctx.stride)
             else:
                 st = ctx.stride
@@ -219,7 +297,8 @@ class DirectConv2d(torch.nn.Conv2d):
     kernels for contiguous fp32 CUDA inputs; every other configuration falls through to nn.Conv2d.forward."""
 
     def eligible(self, x):
-        return (self.kernel_size == (3, 3) and self.stride in ((1, 1), (2, 2)) and self.padding == (1, 1)
+        return (((self.kernel_size == (3, 3) and self.stride in ((1, 1), (2, 2)) and self.padding == (1, 1))
+                 or (self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)))
                 and self.dilation == (1, 1) and self.groups == 1
                 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
                 and self.weight.dtype == torch.float32 and not torch.is_autocast_enabled()
@@ -273,12 +352,13 @@ class ConvPackGroup:
             absjobs[i] = (w.data_ptr(), self.amax[i:i + 1].data_ptr(), w.numel(), len(ab2j), 0)
             ab2j += [i] * nblk
             pair = []
+            taps = w.shape[2] * w.shape[3]
             for tr in (0, 1):
                 mm, kk = (ci, co) if tr else (co, ci)
-                frags = ((mm + 31) // 32) * ((kk + 15) // 16) * 9
+                frags = ((mm + 31) // 32) * ((kk + 15) // 16) * taps
                 buf = torch.empty(frags * 2 * 64 * 16, dtype=torch.uint8, device=dev)
-                packjobs[2 * i + tr] = (w.data_ptr(), buf.data_ptr(), self.amax[i:i + 1].data_ptr(), mm, kk, tr,
-                                        len(pb2j))
+                packjobs[2 * i + tr] = (w.data_ptr(), buf.data_ptr(), self.amax[i:i + 1].data_ptr(), mm, kk,
+                                        tr | (2 if taps == 1 else 0), len(pb2j))
                 pb2j += [2 * i + tr] * ((frags * 64 + 255) // 256)
                 pair.append(buf)
             self.wp.append(pair)
@@ -316,6 +396,16 @@ def use_direct_conv3x3(module: torch.nn.Module) -> torch.nn.Module:
         if type(m) is torch.nn.Conv2d and m.kernel_size == (3, 3) and m.stride in ((1, 1), (2, 2)) \
                 and m.padding == (1, 1) \
                 and m.dilation == (1, 1) and m.groups == 1:
+            m.__class__ = DirectConv2d
+    return module
+
+
+def use_direct_conv1x1(module: torch.nn.Module) -> torch.nn.Module:
+    """Switch every plain (or GemmConv1x1) 1x1 / stride 1 / pad 0 / groups 1 nn.Conv2d to DirectConv2d in place: all
+    three directions on the f16x3 kernels (one-tap mode of csrc/dcl_conv3x3.hip, k_wgrad1x1d)."""
+    for m in module.modules():
+        if type(m) in (torch.nn.Conv2d, GemmConv1x1) and m.kernel_size == (1, 1) and m.stride == (1, 1) \
+                and m.padding == (0, 0) and m.dilation == (1, 1) and m.groups == 1:
             m.__class__ = DirectConv2d
     return module
 

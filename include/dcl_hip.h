@@ -281,7 +281,7 @@ int dcl_conv3x3_set_up2_phases(int on);
 int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W /* of x */, int stride);
 /* tuning hook: force the (co tiles, ci tiles) per wave of the weight-gradient kernel (0, 0 = automatic choice) */
 int dcl_wgrad3x3_set_tile(int nco, int nci);
-/* tuning hook: -1 (default) = by shape, 1 = workgroups that share the dY rows of a co group through LDS (csrc/dcl_wgrad3x3s.hip),
+/* tuning hook: -1 (default) = 2, 2 = per-wave kernel with LDS-DMA operand staging (csrc/dcl_wgrad3x3d.hip), 1 = workgroups that share the dY rows of a co group through LDS (csrc/dcl_wgrad3x3s.hip),
  * 0 = every wave loads both operands itself (csrc/dcl_wgrad3x3.hip).  Changes dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_variant(int variant);
 /* tuning hook (shared-dY variant): stream_k = -1 automatic, 0 equal pixel splits, 1 one contiguous (type, row step)
@@ -294,6 +294,20 @@ int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout
                        const float *xamax, int xcount, const float *gamax, int gcount,
                        int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,
                        void *stream);
+
+/* ---- 1x1 convolution on the same kernels ----------------------------------------------------------------------------
+ * Replaces nn.Conv2d(C_in, C_out, 1) forward / data gradient / weight gradient (reference models/HRNet.py:63-100
+ * Bottleneck, :236-262 fuse layers, models/Projector.py:46-51) at fp32-equivalent accuracy (f16x3).
+ * Weights: dcl_conv3x3_pack(w, M, K, transposed | 2, ...) -- bit 1 = 1x1 kernel, w is [M][K] (data gradient: [K][M],
+ * bit 0), M x ceil(K / 16) fragments of 2 KiB (a ninth of the 3x3 size). */
+int dcl_conv1x1_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout, const float *xamax,
+                      int xcount, const float *wamax, const float *addend /* optional, y's shape */,
+                      const float *bias /* optional [Cout] */, float *y, int tile_r, int tile_p, void *stream);
+/* dw[Cout,Cin] = sum_n dy_n x_n^T.  Cin % 16 == 0, Cout % 16 == 0, W % 8 == 0; part: workspace of
+ * dcl_wgrad1x1_splits(...) * Cout * Cin floats (slabs summed in fixed order: deterministic). */
+int dcl_wgrad1x1_splits(int N, int Cin, int Cout, int H, int W);
+int dcl_wgrad1x1_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax,
+                       int xcount, const float *gamax, int gcount, float *part, float *dw, void *stream);
 
 /* ---- per-step metrics -----------------------------------------------------
  * Confusion matrix of argmax(logits, dim=1) against the target, rows = predicted class, columns = target class:

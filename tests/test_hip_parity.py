@@ -923,7 +923,7 @@ def test_models_with_direct_kernels_match_library_kernels(dev, family):
     if family == "hrnet":
         g = {"backbone": "hrnet48", "pretrained": False, "dataset": "CITYSCAPES", "align_corners": True}
         a = M.HRNet(dict(g), 1).to(dev)
-        b = M.HRNet(dict(g, branch_conv="library", head_conv="library", fused_bn=False), 1).to(dev)
+        b = M.HRNet(dict(g, branch_conv="library", head_conv="library", fused_bn=False, conv1x1="library"), 1).to(dev)
     else:
         g = {"backbone": "swinT", "pretrained": False, "dataset": "ADE20K", "align_corners": False,
              "fpn_channels": 128}
@@ -939,6 +939,66 @@ def test_models_with_direct_kernels_match_library_kernels(dev, family):
         ya = ya[0] if isinstance(ya, (tuple, list)) else ya
         yb = yb[0] if isinstance(yb, (tuple, list)) else yb
         assert ((ya - yb).abs().max() / yb.abs().max()).item() < 1e-4, (family, mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(12, 64, 256, 16, 64), (2, 256, 64, 9, 32), (3, 48, 48, 17, 24), (1, 96, 256, 5, 8),
+                                   (2, 384, 48, 8, 16), (2, 720, 19, 6, 40), (1, 40, 72, 7, 23), (2, 192, 192, 4, 64)])
+def test_direct_conv1x1_matches_fp64(dev, shape):
+    """1x1 convolution on the one-tap mode of the direct kernel (forward, data gradient) and k_wgrad1x1d (weight
+    gradient) against float64 (3e-6 of max); the weight gradient is bitwise reproducible."""
+    from mscs_amd.models import ops
+    n, ci, co, h, w = shape
+    torch.manual_seed(sum(shape) + 3)
+    x = torch.randn(n, ci, h, w, device=dev).relu_() * 1.5
+    wt = torch.randn(co, ci, 1, 1, device=dev) * (2.0 / ci) ** 0.5
+    gy = torch.randn(n, co, h, w, device=dev) * 2e-4
+    x64, w64, g64 = x.double().cpu(), wt.double().cpu(), gy.double().cpu()
+    y64 = torch.nn.functional.conv2d(x64, w64)
+    gx64 = torch.nn.functional.conv_transpose2d(g64, w64)
+    gw64 = torch.einsum("nohw,nihw->oi", g64, x64).view(co, ci, 1, 1)
+    y = ops.conv1x1_direct(x, wt)
+    gx = ops.conv1x1_direct(gy, wt, transposed=True)
+    assert y.shape == y64.shape and gx.shape == gx64.shape
+    assert ((y.double().cpu() - y64).abs().max() / y64.abs().max()).item() < 3e-6
+    assert ((gx.double().cpu() - gx64).abs().max() / gx64.abs().max()).item() < 3e-6
+    if ops.conv1x1_wgrad_supported(x, co):
+        gw = ops.conv1x1_wgrad(x, gy)
+        assert ((gw.double().cpu() - gw64).abs().max() / gw64.abs().max()).item() < 3e-6
+        assert torch.equal(gw, ops.conv1x1_wgrad(x, gy))
+    # every tile configuration computes the same convolution
+    from mscs_amd.models.amax import amax_of
+    wamax, xamax = amax_of(wt), amax_of(x)
+    wp = ops.conv3x3_pack(wt, wamax)
+    for r in (1, 2, 3):
+        for p_ in (1, 2, 4):
+            out = torch.full_like(y, float("nan"))
+            ops.conv1x1_launch(x, wp, co, xamax, wamax, out, r, p_)
+            assert ((out.double().cpu() - y64).abs().max() / y64.abs().max()).item() < 3e-6, (r, p_)
+
+
+@pytest.mark.gpu
+def test_direct_conv1x1_module_autograd(dev):
+    """DirectConv2d for a 1x1 nn.Conv2d (with and without bias, channel counts with and without the weight-gradient
+    kernel's multiple-of-16 requirement): y, dx, dW, db against float64."""
+    from mscs_amd.models import ops
+    torch.manual_seed(21)
+    for (ci, co, bias) in ((64, 256, False), (96, 40, True), (720, 19, True)):
+        conv = torch.nn.Conv2d(ci, co, 1, bias=bias).to(dev)
+        ops.use_direct_conv1x1(conv)
+        assert isinstance(conv, ops.DirectConv2d)
+        x = (torch.randn(3, ci, 12, 24, device=dev)).requires_grad_(True)
+        gy = torch.randn(3, co, 12, 24, device=dev)
+        conv(x).backward(gy)
+        ref = torch.nn.Conv2d(ci, co, 1, bias=bias).double()
+        ref.load_state_dict({k: v.double().cpu() for k, v in conv.state_dict().items()})
+        x64 = x.detach().double().cpu().requires_grad_(True)
+        ref(x64).backward(gy.double().cpu())
+        pairs = [(conv(x), ref(x64)), (x.grad, x64.grad), (conv.weight.grad, ref.weight.grad)]
+        if bias:
+            pairs.append((conv.bias.grad, ref.bias.grad))
+        for got, want in pairs:
+            assert ((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max()).item() < 3e-6
 
 
 @pytest.mark.gpu

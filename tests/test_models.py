@@ -108,7 +108,7 @@ def _train_errors(name, dev, tag="", library=False):
     if float(z["drop_path_rate"]) >= 0:
         cfg["drop_path_rate"] = float(z["drop_path_rate"])
     if library:         # the same model code on stock PyTorch-ROCm kernels (MIOpen / ATen), for calibration
-        cfg.update(branch_conv="library", head_conv="library", fused_bn=False, gemm_conv1x1=False, direct_conv=False,
+        cfg.update(branch_conv="library", head_conv="library", fused_bn=False, gemm_conv1x1=False, conv1x1="library", direct_conv=False,
                    hip_attention=False, hip_decoder=False)
     model = _build(name.replace("G11_train_", ""), cfg, int(z["experiment"]))
     fill_state_dict_(model)

@@ -9,6 +9,7 @@ from mscs_amd.utils import set_verbosity
 set_verbosity(40)
 class A:
     batch, height, width, scales, no_cross, channels_last, branch_conv = 12, 512, 1024, 3, False, False, "f16x3"
+    materialize_logits, head_conv = False, "direct"
 mgr = HRNetManager(bench.step_config(A, 1), autostart=False); mgr.setup(); mgr.model.train()
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(0)
