@@ -63,6 +63,7 @@ SIGNATURES = {
     "dcl_wgrad1x1_f16x3": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "dcl_wgrad3x3_splits": [_i, _i, _i, _i, _i, _i],
     "dcl_wgrad3x3_set_stride2": [_i],
+    "dcl_wgrad3x3_set_splits": [_i],
     "dcl_conv3x3_set_up2_phases": [_i],
     "dcl_wgrad3x3_set_tile": [_i, _i],
     "dcl_wgrad3x3_set_variant": [_i],

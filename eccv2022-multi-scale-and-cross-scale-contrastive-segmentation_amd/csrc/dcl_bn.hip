@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
             }
     }
     if (amax)
-        block_amax(am, amax + plane);
+        block_amax(am, amax + (plane & (DCL_AMAX_SLOTS - 1)));
 }
 
 // part[(c*nslice + s)*2 + {0,1}] = {sum g, sum g * xhat},  g = dy * (y > 0 if RELU)
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
             }
     }
     if (amax)
-        block_amax(am, amax + plane);
+        block_amax(am, amax + (plane & (DCL_AMAX_SLOTS - 1)));
 }
 
 int pick_slices(int N, int C)

@@ -435,6 +435,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
 }  // namespace
 
 static int g_tile_nco = 0, g_tile_nci = 0;      // tuning override (dcl_wgrad3x3_set_tile), 0 = automatic
+static int g_force_nx = 0;                      // tuning override: pixel splits per tile pair (0 = automatic)
 static int g_variant = -1;     // 1 = shared-dY workgroups (dcl_wgrad3x3s.hip), 0 = per-wave operands, -1 = by shape
 
 // The shared-dY kernel was the answer to the L1 tag rate of the MFMA-order loads (192 channels: 58.6 vs 64.3 us, 384: 73.4
@@ -490,6 +491,8 @@ static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nc
     // One workgroup (4 waves = 4 splits of one pair) per CU is all that fits (a wave owns most of its SIMD's
     // registers): at most 256 workgroups, or the stragglers run as a second round and double the kernel time.
     int nx = 256 / pairs;
+    if (g_force_nx > 0)
+        nx = g_force_nx;
     if (nx < 1)
         nx = 1;         // more tile pairs than CUs (head convolution): one pixel split; finer splits were tried and
                         // lose (3 splits fill the last round better but take 26 ms against 12.5 ms)
@@ -520,6 +523,12 @@ extern "C" int dcl_wgrad3x3_set_partition(int stream_k, int nwg)
     if (stream_k < -1 || stream_k > 1 || nwg < 0)
         return DCL_EINVAL;
     dcl_wgrad_shared_tune(stream_k, nwg);
+    return 0;
+}
+
+extern "C" int dcl_wgrad3x3_set_splits(int nx)
+{
+    g_force_nx = nx > 0 ? nx : 0;
     return 0;
 }
 

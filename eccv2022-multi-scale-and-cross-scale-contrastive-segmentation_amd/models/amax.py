@@ -1,7 +1,7 @@
 """Absmax side-channel for the f16x3 convolution (csrc/dcl_conv3x3.hip).
 
 The direct convolution scales each operand by a power of two derived ON THE DEVICE from the operand's absmax.
-Producers that already stream the tensor (the fused BN kernels, forward and backward) emit per-plane maxima into
+Producers that already stream the tensor (the fused BN kernels, forward and backward) emit 64 partial maxima into
 a small zero-initialised buffer and tag their output with it; a consumer finds the tag through :func:`amax_of`
 and otherwise falls back to one `dcl_absmax` pass.  A tag carries the tensor's ``_version`` and is ignored once
 the tensor was modified in place (e.g. autograd's in-place gradient accumulation)."""
@@ -10,6 +10,8 @@ import ctypes
 import torch
 
 from .. import _lib
+
+SLOTS = 64        # DCL_AMAX_SLOTS (include/dcl_hip.h): partial maxima a fused BN kernel emits
 
 _POOL = {}
 _POOL_FLOATS = 1 << 20

@@ -113,8 +113,8 @@ class _FusedBNFunction(torch.autograd.Function):
         dx = torch.empty_like(x)
         want_res = ctx.has_res and (ctx.needs_input_grad[1] or ctx.token is not None)
         dres = torch.empty_like(x) if want_res else None
-        # per-plane max|dx| for the consumer (the data / weight gradient of the convolution in front of this norm)
-        amax = _amax.zeros(N * C, dev) if ctx.emit_amax else None
+        # partial max|dx| (64 slots) for the consumer (the data / weight gradient of the convolution in front of this norm)
+        amax = _amax.zeros(_amax.SLOTS, dev) if ctx.emit_amax else None
         _lib.check(L.dcl_bn_bwd_apply_fused(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(part_all),
                                             _lib.ptr(part), ctx.count, N, C, HW, relu, _lib.ptr(dx), _lib.ptr(dres),
@@ -143,8 +143,8 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
 
     def forward(self, x, residual=None, relu=False, grad_token=None):
         if self._fusable(x, residual):
-            # per-plane max|y| side output for the f16x3 convolutions that consume y (models/amax.py)
-            amax = _amax.zeros(x.shape[0] * x.shape[1], x.device) if self.emit_amax else None
+            # partial max|y| side output (64 slots) for the f16x3 convolutions that consume y (models/amax.py)
+            amax = _amax.zeros(_amax.SLOTS, x.device) if self.emit_amax else None
             y = _FusedBNFunction.apply(x, residual, self.weight, self.bias, self.running_mean,
                                        self.running_var, self.num_batches_tracked, float(self.eps),
                                        float(self.momentum), bool(relu), bool(self.sync), amax,

@@ -26,6 +26,8 @@
 
 #include <stdint.h>
 
+#define DCL_AMAX_SLOTS 64   /* partial absmax values a fused BN kernel emits (a power of two) */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -195,7 +197,7 @@ int dcl_bn_finalize(const float *sums, int C, double count, float eps, float mom
                     float *invstd, float *running_mean, float *running_var, void *stream);
 int dcl_bn_apply(const float *x, const float *res, const float *mean, const float *invstd,
                  const float *gamma, const float *beta, int N, int C, int HW, int relu, float *y,
-                 float *amax /* [N*C] zero-initialised: per-plane max|y| is max-ed in; or NULL */, void *stream);
+                 float *amax /* [DCL_AMAX_SLOTS] zero-initialised: max|y| of plane p is max-ed into slot p % DCL_AMAX_SLOTS; or NULL */, void *stream);
 int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y /* NULL with relu and no residual: the mask
                       y > 0 is recomputed from x, gamma, beta */, const float *mean, const float *invstd,
                       const float *gamma, const float *beta, int N, int C, int HW, int relu, float *part,
@@ -203,7 +205,7 @@ int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y /* NULL wi
 int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y /* as above */, const float *mean,
                      const float *invstd, const float *gamma, const float *beta, const float *sums, double count, int N,
                      int C, int HW, int relu, float *dx, float *dres,
-                     float *amax /* [N*C] zero-initialised: per-plane max|dx|; or NULL */, void *stream);
+                     float *amax /* [DCL_AMAX_SLOTS] zero-initialised: max|dx|, same slots; or NULL */, void *stream);
 
 /* Fused forms (what FusedBatchNorm2d uses): the per-slice partial sums `part` are combined in the prologue of the
  * apply kernels instead of by a separate launch.  Forward: dcl_bn_stats_part -> [all-reduce of part] ->
@@ -244,7 +246,8 @@ int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int w, int H, 
  * transposed, tap-flipped weights).  Arithmetic: both operands split into f16 (hi, lo) pairs after a
  * power-of-two scaling, products hi.hi + hi.lo + lo.hi on the f16 MFMA with f32 accumulation.
  * Operand scales are derived ON THE DEVICE from absmax values (s = 2^floor(log2(2^14 / max|v|))): the fused BN
- * kernels emit per-plane maxima of their outputs (dcl_bn_apply / dcl_bn_bwd_apply `amax`), dcl_absmax covers
+ * kernels emit partial maxima of their outputs (dcl_bn_apply / dcl_bn_bwd_apply `amax`, DCL_AMAX_SLOTS values: one
+ * load per lane in the consumer's prologue instead of a loop over N * C per-plane values), dcl_absmax covers
  * every other tensor.
  *   dcl_absmax      : out[0] = max(out[0], max|x|)  (out zero-initialised by the caller)
  *   dcl_conv3x3_pack: w [M][K][3][3] (transposed = 0) or [K][M][3][3] read as its data-gradient kernel
@@ -290,6 +293,8 @@ int dcl_wgrad3x3_set_partition(int stream_k, int nwg);
 /* tuning hook (stride 2): 1 (default) = GEMM over the output pixels (csrc/dcl_wgrad3x3_s2.hip, needs W % 16 == 0),
  * 0 = the stride-1 kernels on a zero-inserted dy.  Changes dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_stride2(int native);
+/* tuning hook (per-wave kernels): pixel splits per tile pair, 0 = automatic.  Changes dcl_wgrad3x3_splits(). */
+int dcl_wgrad3x3_set_splits(int nx);
 int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W /* of x */,
                        const float *xamax, int xcount, const float *gamax, int gcount,
                        int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,

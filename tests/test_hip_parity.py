@@ -671,7 +671,7 @@ def test_direct_conv_module_autograd_and_absmax_tags(dev):
     x = torch.randn(3, 32, 12, 40, device=dev, requires_grad=True)
     mid = bn_act(bn, c1(x))
     tag = mid._dcl_amax
-    assert tag[1].numel() == 3 * 48 and abs(tag[1].max().item() - mid.abs().max().item()) < 1e-6
+    assert tag[1].numel() == 64 and abs(tag[1].max().item() - mid.abs().max().item()) < 1e-6
     out = c2(mid)
     out.square().mean().backward()
     # float64 reference of the same graph
