@@ -211,7 +211,7 @@ def roofline_conv_kernels(args, dev, iters=20):
     gy = torch.randn(n, 48, h, w, device=dev, generator=gen) * 1e-4
     flops = 2.0 * n * 48 * 48 * 9 * h * w
     msw = _time_launches(lambda: ops.conv3x3_wgrad(x, gy), iters)
-    wg = {"bound": "mfma", "kernel": f"k_wgrad3x3<3,1> + k_wgrad_reduce (dcl_wgrad3x3_f16x3), {n}x48x{h}x{w}",
+    wg = {"bound": "mfma", "kernel": f"k_wgrad3x3d<3,1> + k_wgrad_reduce (dcl_wgrad3x3_f16x3), {n}x48x{h}x{w}",
           "achieved": round(flops / (msw * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
           "frac": round(flops / (msw * 1e-3) / 1e12 / peak, 4),
           "traffic": (2 * PMC_WGRAD48[0] + PMC_WGRAD48[1]) * 1024 if (default_shape and PMC_WGRAD48) else None,
