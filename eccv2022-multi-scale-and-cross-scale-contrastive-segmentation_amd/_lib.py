@@ -45,7 +45,7 @@ SIGNATURES = {
     "dcl_bn_stats_finalize": [_vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_stats_part": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "dcl_bn_apply_fused": [_vp, _vp, _vp, ctypes.c_double, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                           _vp, _vp],
+                           _vp, _vp, _vp],
     "dcl_bn_bwd_reduce_part": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "dcl_bn_bwd_apply_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp,
                                _vp, _vp, _vp],

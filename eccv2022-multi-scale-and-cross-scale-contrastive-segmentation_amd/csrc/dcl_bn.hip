@@ -193,7 +193,13 @@ struct BnFused {
     long long *batches_tracked;
     float *dbeta, *dgamma;      // backward outputs (may be NULL)
     const float *pivot;         // forward: [C] shift of the partial sums (k_bn_stats), NULL = 0
+    unsigned long long *mask_out;   // forward, RELU: packed y > 0 bits for the backward (see relu_mask_words), or NULL
 };
+
+// Packed ReLU mask of an [N*C, HW] tensor with HW % 256 == 0: the 64 consecutive 16-byte vectors a wave handles give
+// four 64-bit words, word k = the ballot of component k (bit = lane).  1/32 of the tensor's size: the backward of a
+// norm + residual + ReLU reads it instead of y (whose values it needs only for the sign).
+__device__ __forceinline__ size_t relu_mask_word(size_t plane, int hw4, int iv) { return (plane * (hw4 >> 6) + (iv >> 6)) * 4; }
 
 __device__ __forceinline__ void part_sums(const float *part, int c, int ns, float &a, float &b)
 {
@@ -269,6 +275,13 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
                 }
                 if (RELU) {
                     w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
+                    if (f.mask_out) {                           // (wave-uniform: HW % 256 == 0)
+                        const unsigned long long b0 = __ballot(w.x > 0.f), b1 = __ballot(w.y > 0.f),
+                                                 b2 = __ballot(w.z > 0.f), b3 = __ballot(w.w > 0.f);
+                        const int ln = threadIdx.x & 63;
+                        if (ln < 4)
+                            f.mask_out[relu_mask_word(plane, HW >> 2, i >> 2) + ln] = ln == 0 ? b0 : ln == 1 ? b1 : ln == 2 ? b2 : b3;
+                    }
                 }
                 *(f32x4 *)(y + base + i) = w;
                 am = fmaxf(am, fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
@@ -300,7 +313,8 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__res
                                                              const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, int N,
                                                              int C, int HW, int nslice,
-                                                             float *__restrict__ part)
+                                                             float *__restrict__ part,
+                                                             const unsigned long long *__restrict__ mask)
 {
     __shared__ float sh[8];
     const int c = blockIdx.x, s = blockIdx.y;
@@ -308,7 +322,8 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__res
     // y == NULL (ReLU without residual): the mask y > 0 is recomputed from x -- one tensor less to read
     float asc, ash;
     bn_affine(invstd, gamma, beta, mean, c, asc, ash);
-    const bool rec = RELU && y == nullptr;
+    const bool rec = RELU && y == nullptr && mask == nullptr;
+    const int ln = threadIdx.x & 63;
     float a = 0.f, b = 0.f;
     const int hw4 = (HW & 3) ? 0 : (HW >> 2);      // see k_bn_stats
     for (int n = s; n < N; n += nslice) {
@@ -316,6 +331,12 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__res
         const f32x4 *d4 = (const f32x4 *)(dy + base), *x4 = (const f32x4 *)(x + base),
                     *y4 = (const f32x4 *)(y + base);
         // one vector's contribution to (sum g, sum g (x - mean)); g = dy masked by y > 0 (y read, or recomputed)
+        // packed mask: the sign bits of vector iv as +1 / 0 "y values"
+        auto mask_y = [&](int iv) {
+            const unsigned long long *mw = mask + relu_mask_word((size_t)n * C + c, hw4, iv);
+            return f32x4{(float)((mw[0] >> ln) & 1), (float)((mw[1] >> ln) & 1), (float)((mw[2] >> ln) & 1),
+                         (float)((mw[3] >> ln) & 1)};
+        };
         auto accum = [&](f32x4 g, const f32x4 &xv, const f32x4 &ym) {
             if (RELU) {
                 f32x4 yv = ym;
@@ -334,7 +355,10 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__res
         for (; i + BN_THREADS < hw4; i += 2 * BN_THREADS) {
             const f32x4 g0 = d4[i], x0 = x4[i], g1 = d4[i + BN_THREADS], x1 = x4[i + BN_THREADS];
             f32x4 y0 = g0, y1 = g1;
-            if (RELU && !rec) {
+            if (RELU && mask) {
+                y0 = mask_y(i);
+                y1 = mask_y(i + BN_THREADS);
+            } else if (RELU && !rec) {
                 y0 = y4[i];
                 y1 = y4[i + BN_THREADS];
             }
@@ -342,7 +366,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce(const float *__res
             accum(g1, x1, y1);
         }
         if (i < hw4)
-            accum(d4[i], x4[i], (RELU && !rec) ? y4[i] : d4[i]);
+            accum(d4[i], x4[i], (RELU && mask) ? mask_y(i) : (RELU && !rec) ? y4[i] : d4[i]);
         for (int i = (hw4 << 2) + threadIdx.x; i < HW; i += BN_THREADS) {
             float g = dy[base + i];
             if (RELU)
@@ -372,14 +396,15 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                                                             float inv_count, int C, int HW,
                                                             float *__restrict__ dx,
                                                             float *__restrict__ dres,
-                                                            float *__restrict__ amax, BnFused f)
+                                                            float *__restrict__ amax, BnFused f,
+                                                            const unsigned long long *__restrict__ mask)
 {
     const int plane = blockIdx.y, c = plane % C;
     float am = 0.f;
     const float m = mean[c], is = invstd[c];
     float asc, ash;                                   // y == NULL: ReLU mask recomputed from x (see the reduce)
     bn_affine(invstd, gamma, beta, mean, c, asc, ash);
-    const bool rec = RELU && y == nullptr;
+    const bool rec = RELU && y == nullptr && mask == nullptr;
     const float k = is * (gamma ? gamma[c] : 1.f);
     float mg, mgx;
     if (f.part) {
@@ -410,7 +435,12 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
             if (i < HW) {
                 gv[u] = *(const f32x4 *)(dy + base + i);
                 xv[u] = *(const f32x4 *)(x + base + i);
-                if (RELU && !rec)
+                if (RELU && mask) {
+                    const unsigned long long *mw = mask + relu_mask_word(plane, HW >> 2, i >> 2);
+                    const int ln = threadIdx.x & 63;
+                    yv[u] = f32x4{(float)((mw[0] >> ln) & 1), (float)((mw[1] >> ln) & 1), (float)((mw[2] >> ln) & 1),
+                                  (float)((mw[3] >> ln) & 1)};
+                } else if (RELU && !rec)
                     yv[u] = *(const f32x4 *)(y + base + i);
             }
         }
@@ -542,10 +572,11 @@ extern "C" int dcl_bn_bwd_reduce(const float *dy, const float *x, const float *y
     DCL_CHECK_ARG(dy && x && mean && invstd && part && sums, "bad arguments");
     const int ns = pick_slices(N, C);
     hipStream_t st = (hipStream_t)stream;
+    const unsigned long long *mask = nullptr;
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part);
+        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part, mask);
     else
-        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part);
+        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part, mask);
     DCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_combine, dim3((C + 255) / 256), dim3(256), 0, st, part, C, ns, sums, dbeta,
                        dgamma, 0, 1.0, 0.f, 0.f, (float *)nullptr, (float *)nullptr, (float *)nullptr,
@@ -564,9 +595,9 @@ extern "C" int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y,
     hipStream_t st = (hipStream_t)stream;
     const float inv = (float)(1.0 / count);
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{});
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{}, (const unsigned long long *)nullptr);
     else
-        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{});
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{}, (const unsigned long long *)nullptr);
     DCL_LAUNCH_CHECK();
     return 0;
 }
@@ -589,12 +620,14 @@ extern "C" int dcl_bn_apply_fused(const float *x, const float *res, const float 
                                   float momentum, const float *gamma, const float *beta, int N, int C, int HW,
                                   int relu, float *y, float *mean, float *invstd, float *running_mean,
                                   float *running_var, int64_t *batches_tracked, float *amax, const float *pivot,
-                                  void *stream)
+                                  void *relu_mask, void *stream)
 {
     DCL_CHECK_ARG(x && part && y && mean && invstd && N > 0 && C > 0 && HW > 0 && count > 0, "bad arguments");
+    DCL_CHECK_ARG(!relu_mask || (relu && HW % 256 == 0), "relu_mask: ReLU and HW % 256 == 0 only");
     BnFused f{};
     f.part = part;
     f.pivot = pivot;
+    f.mask_out = (unsigned long long *)relu_mask;
     f.ns = pick_slices(N, C);
     f.count = count;
     f.eps = eps;
@@ -621,12 +654,16 @@ extern "C" int dcl_bn_bwd_reduce_part(const float *dy, const float *x, const flo
                                       int HW, int relu, float *part, void *stream)
 {
     DCL_CHECK_ARG(dy && x && mean && invstd && part, "bad arguments");
+    DCL_CHECK_ARG(relu != 2 || (y && HW % 256 == 0), "relu = 2: y is the packed mask, HW % 256 == 0");
+    const unsigned long long *mask = relu == 2 ? (const unsigned long long *)y : nullptr;
+    if (mask)
+        y = nullptr;
     const int ns = pick_slices(N, C);
     hipStream_t st = (hipStream_t)stream;
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part);
+        hipLaunchKernelGGL((k_bn_bwd_reduce<true>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part, mask);
     else
-        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part);
+        hipLaunchKernelGGL((k_bn_bwd_reduce<false>), dim3(C, ns), dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, N, C, HW, ns, part, mask);
     DCL_LAUNCH_CHECK();
     return 0;
 }
@@ -638,6 +675,10 @@ extern "C" int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const flo
                                       float *amax, void *stream)
 {
     DCL_CHECK_ARG(dy && x && mean && invstd && part && part_local && dx && count > 0, "bad arguments");
+    DCL_CHECK_ARG(relu != 2 || (y && HW % 256 == 0), "relu = 2: y is the packed mask, HW % 256 == 0");
+    const unsigned long long *mask = relu == 2 ? (const unsigned long long *)y : nullptr;
+    if (mask)
+        y = nullptr;
     BnFused f{};
     f.part = part;
     f.part_local = part_local;
@@ -649,9 +690,9 @@ extern "C" int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const flo
     hipStream_t st = (hipStream_t)stream;
     const float inv = (float)(1.0 / count);
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f);
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask);
     else
-        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f);
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask);
     DCL_LAUNCH_CHECK();
     return 0;
 }

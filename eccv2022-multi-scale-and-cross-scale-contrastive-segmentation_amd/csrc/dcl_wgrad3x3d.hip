@@ -90,8 +90,11 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
     __shared__ float wm[8];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q4 = lane >> 4, j = lane & 15;
 
-    float sx, sg;
-    {
+    // operand scales from the producers' partial maxima -- computed AFTER the first rows are in flight (a wave with an
+    // empty run does it right away: every wave passes the barrier inside exactly once)
+    float sx = 0.f, sg = 0.f;
+    bool have_scales = false;
+    auto scales = [&]() {
         float mx = 0.f, mg = 0.f;
         for (int i = tid; i < a.xcount; i += 256)
             mx = fmaxf(mx, a.xamax[i]);
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
         __syncthreads();
         sx = pow2_scale(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
         sg = pow2_scale(fmaxf(fmaxf(wm[4], wm[5]), fmaxf(wm[6], wm[7])));
-    }
+        have_scales = true;
+    };
     // workgroup -> (tile pair, pixel split): as k_wgrad3x3
     int pair, xsplit;
     if (a.rect_mode) {
@@ -187,6 +191,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
     const long long T = (long long)a.units * a.H;
     long long t = min(T, T * split / a.S);
     const long long t1 = min(T, T * (split + 1) / a.S);
+    if (t >= t1)
+        scales();
     while (t < t1) {
         const int col = (int)(t / a.H);
         const int r0 = (int)(t - (long long)col * a.H);
@@ -196,9 +202,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
         const int n = col / a.strips;
         const int px0 = strip * 32, px = px0 + 8 * q4;
         const bool oct_ok = px < a.W;
-        const float sx_c = oct_ok ? sx : 0.f;
-        const float sx_l = (oct_ok && px > 0) ? sx : 0.f;
-        const float sx_r = (px + 8 < a.W) ? sx : 0.f;
+        float sx_c, sx_l, sx_r;                                 // set once the scales are known (below)
         // per-lane source offsets of this column (pieces clamped into the row: what falls outside is masked by the scales)
         unsigned offA[NIA], offB[NIB];
 #pragma unroll
@@ -297,6 +301,11 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
         dma_group(r0 - 2, 0);
         dma_group(r0 - 1, 1);
         dma_group(r0, 2);
+        if (!have_scales)
+            scales();
+        sx_c = oct_ok ? sx : 0.f;
+        sx_l = (oct_ok && px > 0) ? sx : 0.f;
+        sx_r = (px + 8 < a.W) ? sx : 0.f;
         dma_wait<0>();
         {
             f32x4 ra[NCO][2], rb[NCI][2];
@@ -455,8 +464,11 @@ __global__ __launch_bounds__(256, 1) void k_wgrad1x1d(Wgrad1Args a)
     __shared__ float wm[8];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q4 = lane >> 4, j = lane & 15;
 
-    float sx, sg;
-    {
+    // operand scales from the producers' partial maxima -- computed AFTER the first rows are in flight (a wave with an
+    // empty run does it right away: every wave passes the barrier inside exactly once)
+    float sx = 0.f, sg = 0.f;
+    bool have_scales = false;
+    auto scales = [&]() {
         float mx = 0.f, mg = 0.f;
         for (int i = tid; i < a.xcount; i += 256)
             mx = fmaxf(mx, a.xamax[i]);
@@ -474,7 +486,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad1x1d(Wgrad1Args a)
         __syncthreads();
         sx = pow2_scale(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
         sg = pow2_scale(fmaxf(fmaxf(wm[4], wm[5]), fmaxf(wm[6], wm[7])));
-    }
+        have_scales = true;
+    };
     int pair, xsplit;
     {
         const int nx8 = a.nx & ~7, main_blocks = nx8 * a.npairs;
@@ -529,6 +542,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad1x1d(Wgrad1Args a)
     const long long T = (long long)a.units * a.H;
     long long t = min(T, T * split / a.S);
     const long long t1 = min(T, T * (split + 1) / a.S);
+    if (t >= t1)
+        scales();
     while (t < t1) {
         const int col = (int)(t / a.H);
         const int r0 = (int)(t - (long long)col * a.H);
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad1x1d(Wgrad1Args a)
         const int n = col / a.strips;
         const int px0 = strip * 32, px = px0 + 8 * q4;
         const bool oct_ok = px < a.W;
-        const float sx_c = oct_ok ? sx : 0.f, sg_c = oct_ok ? sg : 0.f;
+        float sx_c, sg_c;
         unsigned offA[NIA], offB[NIB];
 #pragma unroll
         for (int m = 0; m < NIA; ++m)
@@ -587,6 +602,10 @@ __global__ __launch_bounds__(256, 1) void k_wgrad1x1d(Wgrad1Args a)
 #pragma unroll
         for (int g = 0; g <= D; ++g)
             dma_group(r0 + g, g);
+        if (!have_scales)
+            scales();
+        sx_c = oct_ok ? sx : 0.f;
+        sg_c = oct_ok ? sg : 0.f;
         dma_wait<D * NI>();
         {
             f32x4 ra[NCO][2], rb[NCI][2];

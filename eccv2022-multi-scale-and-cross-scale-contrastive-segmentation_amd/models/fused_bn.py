@@ -29,6 +29,7 @@ def _world():
 
 
 _EQUAL_BATCH_CHECKED = set()
+_PACKED_RELU_MASK = __import__('os').environ.get('DCL_BN_MASK', '1') != '0'      # A/B switch for the tuning tools
 
 
 def _check_equal_batch(n, device):
@@ -74,14 +75,18 @@ class _FusedBNFunction(torch.autograd.Function):
             _check_equal_batch(N, dev)
             dist.all_reduce(part)
         y = torch.empty_like(x)
+        # The backward needs y only for the ReLU mask.  Without a residual it recomputes y > 0 from x (one tensor less
+        # to read, twice); with one, the apply kernel packs the sign bits (1/32 of y) and the backward reads those.
+        need_y = relu and res is not None
+        mask = torch.empty(N * C * HW // 64, dtype=torch.int64, device=dev) if need_y and HW % 256 == 0 and _PACKED_RELU_MASK else None
         _lib.check(L.dcl_bn_apply_fused(_lib.ptr(x), _lib.ptr(res), _lib.ptr(part), count, eps, momentum,
                                         _lib.ptr(weight), _lib.ptr(bias), N, C, HW, 1 if relu else 0, _lib.ptr(y),
                                         _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(running_mean),
-                                        _lib.ptr(running_var), _lib.ptr(nbt), _lib.ptr(amax), _lib.ptr(pivot), st),
+                                        _lib.ptr(running_var), _lib.ptr(nbt), _lib.ptr(amax), _lib.ptr(pivot),
+                                        _lib.ptr(mask), st),
                    "dcl_bn_apply_fused")
-        # y is only needed for the ReLU mask when a residual was added: without one the backward recomputes
-        # y > 0 from x (one tensor less to read, twice)
-        ctx.save_for_backward(x, y if (relu and res is not None) else None, weight, bias, mean, invstd)
+        ctx.save_for_backward(x, (mask if mask is not None else y) if need_y else None, weight, bias, mean, invstd)
+        ctx.packed_mask = mask is not None
         ctx.relu, ctx.world, ctx.count = relu, world, count
         ctx.has_res = res is not None
         ctx.emit_amax = amax is not None
@@ -98,7 +103,7 @@ class _FusedBNFunction(torch.autograd.Function):
         ns = L.dcl_bn_num_slices(N, C)
         part = torch.empty((C * ns * 2,), dtype=torch.float32, device=dev)
         st = _stream()
-        relu = 1 if ctx.relu else 0
+        relu = (2 if ctx.packed_mask else 1) if ctx.relu else 0         # 2: `y` is the packed sign mask
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         _lib.check(L.dcl_bn_bwd_reduce_part(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),

@@ -221,7 +221,12 @@ int dcl_bn_stats_part(const float *x, int N, int C, int HW, float *part,
 int dcl_bn_apply_fused(const float *x, const float *res, const float *part, double count, float eps, float momentum,
                        const float *gamma, const float *beta, int N, int C, int HW, int relu, float *y, float *mean,
                        float *invstd, float *running_mean, float *running_var, int64_t *batches_tracked,
-                       float *amax, const float *pivot /* pivot_out of dcl_bn_stats_part, or NULL */, void *stream);
+                       float *amax, const float *pivot /* pivot_out of dcl_bn_stats_part, or NULL */,
+                       void *relu_mask /* optional (relu, HW % 256 == 0): N * C * HW / 8 bytes, the sign bits of y packed
+                                          for the backward -- see below */,
+                       void *stream);
+/* relu = 2 in the two backward calls: `y` is the packed mask dcl_bn_apply_fused wrote (1/32 of y's size), not y
+ * itself -- what the backward of a norm + residual + ReLU needs from y is only y > 0. */
 int dcl_bn_bwd_reduce_part(const float *dy, const float *x, const float *y, const float *mean, const float *invstd,
                            const float *gamma, const float *beta, int N, int C, int HW, int relu, float *part,
                            void *stream);

@@ -942,6 +942,34 @@ def test_models_with_direct_kernels_match_library_kernels(dev, family):
 
 
 @pytest.mark.gpu
+def test_fused_bn_packed_relu_mask_is_bitwise_equivalent(dev):
+    """norm + residual + ReLU: the backward reads the packed sign bits the forward wrote (1/32 of y) instead of y; the
+    mask bit IS y > 0, so every gradient is bitwise the one of the y-reading path.  HW % 256 != 0 keeps reading y."""
+    import mscs_amd.models.fused_bn as fb
+    torch.manual_seed(33)
+    for shape in ((2, 48, 16, 32), (3, 20, 32, 64), (2, 16, 10, 12)):
+        outs = []
+        for packed in (True, False):
+            fb._PACKED_RELU_MASK = packed
+            try:
+                bn = fb.FusedBatchNorm2d(shape[1]).to(dev).train()
+                with torch.no_grad():
+                    bn.weight.copy_(torch.linspace(0.5, 1.5, shape[1]))
+                    bn.bias.copy_(torch.linspace(-0.3, 0.3, shape[1]))
+                g = torch.Generator(device=dev).manual_seed(5)
+                x = torch.randn(shape, device=dev, generator=g).requires_grad_(True)
+                r = torch.randn(shape, device=dev, generator=g).requires_grad_(True)
+                gy = torch.randn(shape, device=dev, generator=g)
+                y = bn(x, residual=r, relu=True)
+                y.backward(gy)
+                outs.append((y.detach(), x.grad, r.grad, bn.weight.grad, bn.bias.grad))
+            finally:
+                fb._PACKED_RELU_MASK = True
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), shape
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(12, 64, 256, 16, 64), (2, 256, 64, 9, 32), (3, 48, 48, 17, 24), (1, 96, 256, 5, 8),
                                    (2, 384, 48, 8, 16), (2, 720, 19, 6, 40), (1, 40, 72, 7, 23), (2, 192, 192, 4, 64)])
 def test_direct_conv1x1_matches_fp64(dev, shape):
