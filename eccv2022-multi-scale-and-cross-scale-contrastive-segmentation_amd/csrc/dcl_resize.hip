@@ -29,10 +29,18 @@ __device__ __forceinline__ void src_index(const Axis a, int dst, int in_size, in
     l0 = 1.f - l1;
 }
 
+// The high-resolution tensor may be a channel slice [c0, c0 + C) of a wider [N, ctot, H, W] tensor (the concatenation
+// the up-sampled maps go into): plane p = n * C + c of the low-resolution tensor <-> plane n * ctot + c0 + c there.
+struct Slice {
+    int C, ctot, c0;
+};
+__device__ __forceinline__ size_t wide_plane(const Slice &s, size_t p) { return (p / s.C) * s.ctot + s.c0 + p % s.C; }
+
 // one workgroup per output row (n, c, oy); each thread produces 4 consecutive ox
 __global__ __launch_bounds__(256) void k_upsample_fwd(const float *__restrict__ x,
                                                      const float *__restrict__ addend, int h, int w,
-                                                     int H, int W, Axis ay, Axis ax, int relu, float *__restrict__ y)
+                                                     int H, int W, Axis ay, Axis ax, int relu, float *__restrict__ y,
+                                                     Slice sl)
 {
     const int row = blockIdx.x;              // (n*C + c) * H + oy
     const int oy = row % H;
@@ -42,7 +50,7 @@ __global__ __launch_bounds__(256) void k_upsample_fwd(const float *__restrict__ 
     src_index(ay, oy, h, y0, y1, ly0, ly1);
     const float *r0 = x + (plane * h + y0) * (size_t)w;
     const float *r1 = x + (plane * h + y1) * (size_t)w;
-    float *out = y + (size_t)row * W;
+    float *out = y + (wide_plane(sl, plane) * H + oy) * (size_t)W;
     const float *add = addend ? addend + (size_t)row * W : nullptr;     // y = addend + upsample(x)
     const bool vec = (W & 3) == 0;
     for (int ox4 = threadIdx.x * 4; ox4 < W; ox4 += 256 * 4) {
@@ -113,7 +121,7 @@ __device__ __forceinline__ void out_range(const Axis a, int i, int in_size, int 
 // one thread per input element: dx[n,c,iy,ix] = sum_{oy,ox} wy(iy,oy) * wx(ix,ox) * dy[n,c,oy,ox]
 __global__ __launch_bounds__(256) void k_upsample_bwd(const float *__restrict__ dy, int h, int w, int H,
                                                      int W, Axis ay, Axis ax, size_t total,
-                                                     float *__restrict__ dx)
+                                                     float *__restrict__ dx, Slice sl)
 {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= total)
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float *__restrict__ 
     int oy_lo, oy_hi, ox_lo, ox_hi;
     out_range(ay, iy, h, H, oy_lo, oy_hi);
     out_range(ax, ix, w, W, ox_lo, ox_hi);
-    const float *g = dy + plane * (size_t)H * W;
+    const float *g = dy + wide_plane(sl, plane) * (size_t)H * W;
     // separable: the x-weights of this input column are evaluated once, not once per output row
     constexpr int MAXC = 16;
     float wxs[MAXC];
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(256) void k_upsample_bwd(const float *__restrict__ 
 constexpr int ROWS_MAXW = 4096;
 
 __global__ __launch_bounds__(256) void k_upsample_bwd_rows(const float *__restrict__ dy, int h, int w, int H, int W,
-                                                          Axis ay, Axis ax, float *__restrict__ dx)
+                                                          Axis ay, Axis ax, float *__restrict__ dx, Slice sl)
 {
     __shared__ __attribute__((aligned(16))) float tmp[ROWS_MAXW];
     const int row = blockIdx.x;              // plane * h + iy
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void k_upsample_bwd_rows(const float *__restri
     const size_t plane = row / h;
     int oy_lo, oy_hi;
     out_range(ay, iy, h, H, oy_lo, oy_hi);
-    const float *g = dy + plane * (size_t)H * W;
+    const float *g = dy + wide_plane(sl, plane) * (size_t)H * W;
     for (int ox4 = threadIdx.x * 4; ox4 < W; ox4 += blockDim.x * 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
@@ -212,19 +220,19 @@ Axis make_axis(int in_size, int out_size, int align)
 
 }  // namespace
 
-extern "C" int dcl_upsample_bilinear_fwd(const float *x, const float *addend, int planes, int h, int w,
-                                         int H, int W, int align_corners, int relu, float *y, void *stream)
+static int upsample_fwd(const float *x, const float *addend, int planes, int h, int w, int H, int W, int align_corners,
+                        int relu, float *y, Slice sl, void *stream)
 {
     DCL_CHECK_ARG(x && y && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad arguments");
     DCL_CHECK_ARG((long long)planes * H < 2147483647LL, "too many output rows");
     hipLaunchKernelGGL(k_upsample_fwd, dim3((unsigned)(planes * H)), dim3(256), 0, (hipStream_t)stream, x,
-                       addend, h, w, H, W, make_axis(h, H, align_corners), make_axis(w, W, align_corners), relu, y);
+                       addend, h, w, H, W, make_axis(h, H, align_corners), make_axis(w, W, align_corners), relu, y, sl);
     DCL_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int w, int H, int W,
-                                         int align_corners, float *dx, void *stream)
+static int upsample_bwd(const float *dy, int planes, int h, int w, int H, int W, int align_corners, float *dx, Slice sl,
+                        void *stream)
 {
     DCL_CHECK_ARG(dy && dx && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad arguments");
     const size_t total = (size_t)planes * h * w;
@@ -233,13 +241,41 @@ extern "C" int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int
         int threads = ((W / 4 + 63) / 64) * 64;
         threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
         hipLaunchKernelGGL(k_upsample_bwd_rows, dim3((unsigned)(planes * h)), dim3(threads), 0, (hipStream_t)stream, dy,
-                           h, w, H, W, make_axis(h, H, align_corners), make_axis(w, W, align_corners), dx);
+                           h, w, H, W, make_axis(h, H, align_corners), make_axis(w, W, align_corners), dx, sl);
         DCL_LAUNCH_CHECK();
         return 0;
     }
     hipLaunchKernelGGL(k_upsample_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, dy, h, w, H, W, make_axis(h, H, align_corners),
-                       make_axis(w, W, align_corners), total, dx);
+                       make_axis(w, W, align_corners), total, dx, sl);
     DCL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int dcl_upsample_bilinear_fwd(const float *x, const float *addend, int planes, int h, int w,
+                                         int H, int W, int align_corners, int relu, float *y, void *stream)
+{
+    return upsample_fwd(x, addend, planes, h, w, H, W, align_corners, relu, y, Slice{planes, planes, 0}, stream);
+}
+
+extern "C" int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int w, int H, int W,
+                                         int align_corners, float *dx, void *stream)
+{
+    return upsample_bwd(dy, planes, h, w, H, W, align_corners, dx, Slice{planes, planes, 0}, stream);
+}
+
+// Up-sampling straight into / out of a channel slice of a wider tensor (the concatenation of the four HRNet branches,
+// reference models/HRNet.py:549-553): y_wide[n, c0 + c] = up(x[n, c]); backward reads dy_wide[n, c0 + c] in place.
+extern "C" int dcl_upsample_bilinear_fwd_slice(const float *x, int N, int C, int h, int w, int H, int W,
+                                               int align_corners, float *y_wide, int ctot, int c0, void *stream)
+{
+    DCL_CHECK_ARG(N > 0 && C > 0 && ctot >= c0 + C && c0 >= 0, "bad slice");
+    return upsample_fwd(x, nullptr, N * C, h, w, H, W, align_corners, 0, y_wide, Slice{C, ctot, c0}, stream);
+}
+
+extern "C" int dcl_upsample_bilinear_bwd_slice(const float *dy_wide, int ctot, int c0, int N, int C, int h, int w, int H,
+                                               int W, int align_corners, float *dx, void *stream)
+{
+    DCL_CHECK_ARG(N > 0 && C > 0 && ctot >= c0 + C && c0 >= 0, "bad slice");
+    return upsample_bwd(dy_wide, N * C, h, w, H, W, align_corners, dx, Slice{C, ctot, c0}, stream);
 }

@@ -28,7 +28,7 @@ import torch.nn.functional as F
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
 from .ops import (ConvPackGroup, DirectConv2d, GradToken, use_gemm_conv1x1, upsample_bilinear, use_direct_conv3x3,
-                  use_direct_conv1x1)
+                  use_direct_conv1x1, upsample_concat)
 from .amax import record_stream as _amax_record_stream
 from .fused_bn import FusedBatchNorm2d, bn_act
 
@@ -354,9 +354,7 @@ class HighResolutionNet(nn.Module):
         y = self.stage3(self._enter_stage(self.transition2, y, self.stage2_cfg['NUM_BRANCHES']))
         y = self.stage4(self._enter_stage(self.transition3, y, self.stage3_cfg['NUM_BRANCHES']))
         assert self.use_as_backbone
-        size = y[0].shape[-2:]
-        ups = [y[0]] + [upsample_bilinear(t, size, self.align_corners) for t in y[1:]]
-        cat = torch.cat(ups, 1)
+        cat = upsample_concat(list(y), self.align_corners)
         if self.return_all_scales:
             return cat, [y[0], y[1], y[2], y[3]]
         return cat

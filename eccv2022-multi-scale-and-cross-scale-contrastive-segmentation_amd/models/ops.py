@@ -39,6 +39,65 @@ class _UpsampleBilinear(torch.autograd.Function):
         return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
+class _UpsampleConcat(torch.autograd.Function):
+    """cat([t0, up(t1), up(t2), ...], dim=1) with every up-sampled map written straight into its channel slice of the
+    result (no separate maps, no cat copy of them) and, backward, read straight out of the slice of the incoming
+    gradient (no .contiguous() copies of the narrow views torch.cat's backward hands out)."""
+
+    @staticmethod
+    def forward(ctx, align_corners, *ts):
+        from .. import _lib
+        L = _lib.lib()
+        n, _, H, W = ts[0].shape
+        ctot = sum(t.shape[1] for t in ts)
+        out = torch.empty((n, ctot, H, W), dtype=torch.float32, device=ts[0].device)
+        st = _lib.stream_ptr(out.device)
+        c0 = 0
+        for t in ts:
+            c, h, w = t.shape[1:]
+            if (h, w) == (H, W):
+                out[:, c0:c0 + c].copy_(t)
+            else:
+                _lib.check(L.dcl_upsample_bilinear_fwd_slice(_lib.ptr(t), n, c, h, w, H, W, 1 if align_corners else 0,
+                                                             _lib.ptr(out), ctot, c0, st),
+                           "dcl_upsample_bilinear_fwd_slice")
+            c0 += c
+        ctx.shapes, ctx.align = [tuple(t.shape) for t in ts], bool(align_corners)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _lib
+        L = _lib.lib()
+        dy = dy.contiguous()
+        n, ctot, H, W = dy.shape
+        st = _lib.stream_ptr(dy.device)
+        grads, c0 = [], 0
+        for i, (_, c, h, w) in enumerate(ctx.shapes):
+            g = None
+            if ctx.needs_input_grad[1 + i]:
+                if (h, w) == (H, W):
+                    g = dy[:, c0:c0 + c]
+                else:
+                    g = torch.empty((n, c, h, w), dtype=torch.float32, device=dy.device)
+                    _lib.check(L.dcl_upsample_bilinear_bwd_slice(_lib.ptr(dy), ctot, c0, n, c, h, w, H, W,
+                                                                 1 if ctx.align else 0, _lib.ptr(g), st),
+                               "dcl_upsample_bilinear_bwd_slice")
+            grads.append(g)
+            c0 += c
+        return (None, *grads)
+
+
+def upsample_concat(ts, align_corners):
+    """``torch.cat([ts[0]] + [F.interpolate(t, ts[0].shape[-2:], mode='bilinear', align_corners=...) for t in ts[1:]], 1)``
+    (reference models/HRNet.py:549-553) in one pass over the result for CUDA / float32 / contiguous maps."""
+    size = ts[0].shape[-2:]
+    if HIP_UPSAMPLE and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.is_contiguous() for t in ts) \
+            and not torch.is_autocast_enabled():
+        return _UpsampleConcat.apply(bool(align_corners), *ts)
+    return torch.cat([ts[0]] + [upsample_bilinear(t, size, align_corners) for t in ts[1:]], 1)
+
+
 HIP_UPSAMPLE = True        # False: F.interpolate everywhere (library_kernels_only(), the eager comparator of bench.py)
 
 

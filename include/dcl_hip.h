@@ -244,6 +244,13 @@ int dcl_upsample_bilinear_fwd(const float *x, const float *addend /* [planes,H,W
                               float *y, void *stream);
 int dcl_upsample_bilinear_bwd(const float *dy, int planes, int h, int w, int H, int W, int align_corners,
                               float *dx, void *stream);
+/* The same into / out of a channel slice [c0, c0 + C) of a wider [N, ctot, H, W] tensor: the concatenation of the four
+ * HRNet branches (reference models/HRNet.py:549-553) is written once, without separate up-sampled maps and a cat copy,
+ * and its gradient is read in place. */
+int dcl_upsample_bilinear_fwd_slice(const float *x, int N, int C, int h, int w, int H, int W, int align_corners,
+                                    float *y_wide, int ctot, int c0, void *stream);
+int dcl_upsample_bilinear_bwd_slice(const float *dy_wide, int ctot, int c0, int N, int C, int h, int w, int H, int W,
+                                    int align_corners, float *dx, void *stream);
 
 /* ---- direct f16x3 3x3 convolution (stride 1, pad 1, NCHW f32 in / out) --------------------------------------
  * Replaces the nn.Conv2d(C, C, 3, 1, 1, bias=False) of the reference's BasicBlock / Bottleneck

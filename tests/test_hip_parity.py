@@ -1045,4 +1045,25 @@ def test_gemm_conv1x1_matches_library(dev):
     a(x1).backward(gy)
     b(x2).backward(gy)
     for got, want in ((a(x1), b(x2)), (x1.grad, x2.grad), (a.weight.grad, b.weight.grad), (a.bias.grad, b.bias.grad)):
-        assert ((got - want).abs().max() / want.abs().max()).item() < 2e-5
+        assert ((got - want).abs().max() / want.abs().max()).item() < 2e-5@pytest.mark.gpu
+@pytest.mark.parametrize("align", [True, False])
+def test_upsample_concat_matches_cat_of_interpolates(dev, align):
+    """upsample_concat (every map written straight into its channel slice, gradient read in place) against
+    torch.cat of F.interpolate, forward and all input gradients."""
+    from mscs_amd.models import ops
+    torch.manual_seed(17)
+    shapes = [(2, 48, 32, 64), (2, 96, 16, 32), (2, 40, 8, 16), (2, 24, 5, 7)]
+    a = [torch.randn(s, device=dev, requires_grad=True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    y = ops.upsample_concat(a, align)
+    ref = torch.cat([b[0]] + [torch.nn.functional.interpolate(t, size=(32, 64), mode="bilinear", align_corners=align)
+                              for t in b[1:]], 1)
+    assert y.shape == ref.shape and (y - ref).abs().max().item() < 1e-5
+    gy = torch.randn_like(ref)
+    y.backward(gy)
+    ref.backward(gy)
+    for t, r in zip(a, b):
+        assert (t.grad - r.grad).abs().max().item() < 1e-4 * max(1.0, r.grad.abs().max().item())
+
+
+
