@@ -94,7 +94,11 @@ def upsample_concat(ts, align_corners):
     size = ts[0].shape[-2:]
     if HIP_UPSAMPLE and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.is_contiguous() for t in ts) \
             and not torch.is_autocast_enabled():
-        return _UpsampleConcat.apply(bool(align_corners), *ts)
+        from . import amax as _amax
+        out = _UpsampleConcat.apply(bool(align_corners), *ts)
+        # absmax side channel for the head convolution: bilinear interpolation is a convex combination, so max|up(t)|
+        # <= max|t| and the maxima of the (small, already tagged) inputs bound the result -- no pass over its 1.1 GB
+        return _amax.tag(out, torch.cat([_amax.amax_of(t) for t in ts]))
     return torch.cat([ts[0]] + [upsample_bilinear(t, size, align_corners) for t in ts[1:]], 1)
 
 
