@@ -1045,7 +1045,10 @@ def test_gemm_conv1x1_matches_library(dev):
     a(x1).backward(gy)
     b(x2).backward(gy)
     for got, want in ((a(x1), b(x2)), (x1.grad, x2.grad), (a.weight.grad, b.weight.grad), (a.bias.grad, b.bias.grad)):
-        assert ((got - want).abs().max() / want.abs().max()).item() < 2e-5@pytest.mark.gpu
+        assert ((got - want).abs().max() / want.abs().max()).item() < 2e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("align", [True, False])
 def test_upsample_concat_matches_cat_of_interpolates(dev, align):
     """upsample_concat (every map written straight into its channel slice, gradient read in place) against
