@@ -358,6 +358,7 @@ def step_config_upernet(args, world):
         "parallel": world > 1, "batch_is_global": False,
         "graph": {"model": "UPerNet", "backbone": "swinT", "sync_bn": True, "out_stride": 32, "pretrained": False,
                   "align_corners": False, "aux_head": {"in_index": 3, "dropout_rate": 0.1}, "dropout_rate": 0.1,
+                  "lazy_logits": not args.materialize_logits,
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "position": "fpn"}},
         "data": {"dataset": "ADE20K", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
                  "synthetic": True, "synthetic_length": args.batch * 2,

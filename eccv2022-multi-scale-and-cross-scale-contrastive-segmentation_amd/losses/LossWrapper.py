@@ -72,7 +72,8 @@ class LossWrapper(nn.Module):
         self.total_loss = self._zero()
         loss_list = list(self.loss_weightings.keys()) if loss_list is None else loss_list
         lazy = prediction if hasattr(prediction, 'materialize') else None     # models.ops.UpsampledLogits
-        if lazy is not None and any(k not in ('CrossEntropyLoss', 'DenseContrastiveLossV2', 'DenseContrastiveLossV2_ms')
+        if lazy is not None and any(k not in ('CrossEntropyLoss', 'DenseContrastiveLossV2', 'DenseContrastiveLossV2_ms',
+                                              'TwoScaleLoss')
                                     for k in self.loss_weightings if k in loss_list):
             prediction = lazy.materialize()           # a component without a fused path wants the full tensor
         for loss_class in self.loss_weightings:

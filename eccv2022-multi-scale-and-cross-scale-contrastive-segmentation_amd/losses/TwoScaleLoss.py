@@ -52,7 +52,17 @@ class TwoScaleLoss(nn.Module):
             raise NotImplementedError('different losses for interm {} and final {}'.format(
                 config['interm'], config['final']))
 
+    @staticmethod
+    def _apply(fn, logits, target):
+        """``fn(logits, target)``; logits kept at low resolution (models.ops.UpsampledLogits) go through the fused
+        up-sampling + cross-entropy kernel when fn is a plain mean-reduced nn.CrossEntropyLoss, else are materialised."""
+        if hasattr(logits, 'materialize'):
+            if type(fn) is nn.CrossEntropyLoss and fn.reduction == 'mean' and fn.label_smoothing == 0.0:
+                return logits.cross_entropy(target, weight=fn.weight, ignore_index=fn.ignore_index)
+            logits = logits.materialize()
+        return fn(logits, target)
+
     def forward(self, logits_interm, logits_final, target):
-        loss_final = self.loss_final(logits_final, target)
-        loss_interm = self.loss_interm(logits_interm, target)
+        loss_final = self._apply(self.loss_final, logits_final, target)
+        loss_interm = self._apply(self.loss_interm, logits_interm, target)
         return loss_final * self.w_final + loss_interm * self.w_interm

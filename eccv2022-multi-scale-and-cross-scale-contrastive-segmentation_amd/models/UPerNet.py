@@ -216,10 +216,19 @@ class UPerNet(nn.Module):
             self._conv_packs.refresh()
         feats = self.backbone(x)
         logits, fpn_feats, fused = self.fpn(feats)
-        logits = upsample_bilinear(logits, size, self.align_corners)
+        # graph key `lazy_logits` (extension, default off = the reference's return values): the logits of both heads stay
+        # at their own resolution; this repo's LossWrapper / TwoScaleLoss / metrics apply up-sampling + cross-entropy /
+        # arg-max in fused kernels (models/ops.py UpsampledLogits) -- 2 x 16 x 150 x 512 x 512 floats are never written
+        lazy = self.config.get('lazy_logits', False) and self.training and logits.is_cuda
+        if lazy:
+            from .ops import UpsampledLogits
+            up = lambda t: UpsampledLogits(t, size, self.align_corners)
+        else:
+            up = lambda t: upsample_bilinear(t, size, self.align_corners)
+        logits = up(logits)
         interm = None
         if self.get_intermediate and self.aux_head is not None:
-            interm = upsample_bilinear(self._aux(feats[self.aux_in_index]), size, self.align_corners)
+            interm = up(self._aux(feats[self.aux_in_index]))
         if self.projector_model is not None:
             if self.use_ms_projector:
                 if self.projector_position == 'backbone':

@@ -95,3 +95,50 @@ def test_lazy_logits_training_step_equals_materialised_step():
     gmax = max(g.abs().max().item() for g in a[3].values())
     for k in a[3]:
         assert (a[3][k] - b[3][k]).abs().max().item() <= 2e-3 * max(a[3][k].abs().max().item(), 1e-5 * gmax), k
+
+
+def test_lazy_logits_upernet_two_scale_step_equals_materialised_step():
+    """OCRNetManager step of UPerNet + Swin-T with TwoScaleLoss (auxiliary + final cross-entropy) and graph.lazy_logits:
+    both heads' logits stay at low resolution and go through the fused up-sampling + CE kernel; loss, loss_vals and
+    parameter gradients equal the step with materialised logits (eval-mode dropout so that both runs see one network)."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.managers import OCRNetManager
+    from mscs_amd.utils import set_verbosity
+    set_verbosity(40)
+    dev = torch.device("cuda:0")
+    res = {}
+    for lazy in (False, True):
+        cfg = {"name": "t4", "mode": "training", "manager": "OCRNet", "cuda": True, "parallel": False, "seed": 3,
+               "graph": {"model": "UPerNet", "backbone": "swinT", "sync_bn": False, "out_stride": 32, "pretrained": False,
+                         "align_corners": False, "aux_head": {"in_index": 3, "dropout_rate": 0.0}, "dropout_rate": 0.0,
+                         "drop_path_rate": 0.0, "fpn_channels": 64, "lazy_logits": lazy,
+                         "ms_projector": {"mlp": [[1, -1, 1]], "scales": 4, "d": 64, "use_bn": True, "position": "fpn"}},
+               "data": {"dataset": "ADE20K", "experiment": 1, "batch_size": 2, "synthetic": True,
+                        "synthetic_length": 4, "transform_values": {"crop_shape": [128, 128]}},
+               "loss": {"name": "LossWrapper", "temperature": 0.1, "scales": 4, "weights": [1.0, 0.7, 0.4, 0.1],
+                        "cross_scale_contrast": True, "min_views_per_class": 2, "max_features_total": 600,
+                        "interm": {"name": "CrossEntropyLoss", "args": [], "weight": 0.4},
+                        "final": {"name": "CrossEntropyLoss", "args": [], "weight": 1.0},
+                        "losses": {"TwoScaleLoss": 1.0, "DenseContrastiveLossV2_ms": 0.1}},
+               "train": {"learning_rate": 0.01, "lr_fct": "polynomial", "optim": "SGD", "lr_batchwise": True, "epochs": 1}}
+        mgr = OCRNetManager(cfg, autostart=False)
+        mgr.setup()
+        mgr.model.train()
+        gen = torch.Generator().manual_seed(0)
+        img = torch.randn(2, 3, 128, 128, generator=gen).to(dev)
+        lbl = torch.randint(0, 151, (2, 128, 128), generator=gen).to(dev)
+        torch.manual_seed(5)
+        ret = mgr.forward_step(img, lbl)
+        ret["loss"].backward()
+        res[lazy] = (ret["loss"].item(), {k: float(v) for k, v in mgr.loss.loss_vals.items()},
+                     {k: p.grad.clone() for k, p in mgr.model.named_parameters() if p.grad is not None},
+                     type(ret["output"]).__name__, type(ret["interm_output"]).__name__)
+    a, b = res[False], res[True]
+    assert a[3] == a[4] == "Tensor" and b[3] == b[4] == "UpsampledLogits"
+    assert abs(a[0] - b[0]) <= 1e-5 * abs(a[0])
+    for k in a[1]:
+        assert abs(a[1][k] - b[1][k]) <= 1e-5 * max(abs(a[1][k]), 1e-6), k
+    assert a[2].keys() == b[2].keys()
+    gmax = max(g.abs().max().item() for g in a[2].values())
+    for k in a[2]:
+        assert (a[2][k] - b[2][k]).abs().max().item() <= 2e-3 * max(a[2][k].abs().max().item(), 1e-5 * gmax), k
