@@ -279,3 +279,45 @@ extern "C" int dcl_upsample_bilinear_bwd_slice(const float *dy_wide, int ctot, i
     DCL_CHECK_ARG(N > 0 && C > 0 && ctot >= c0 + C && c0 >= 0, "bad slice");
     return upsample_bwd(dy_wide, N * C, h, w, H, W, align_corners, dx, Slice{C, ctot, c0}, stream);
 }
+
+// ---- out = a + b (+ c) (+ d): the gradient of a tensor with several consumers in ONE pass (models/ops.py _FanOut) instead of
+// autograd's chain of two-input adds (k + 1 tensor passes instead of 3 (k - 1))
+namespace {
+__global__ __launch_bounds__(256) void k_add_n(const float *__restrict__ a, const float *__restrict__ b,
+                                              const float *__restrict__ c, const float *__restrict__ d, size_t n4,
+                                              size_t n, float *__restrict__ out)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        f32x4 v = ((const f32x4 *)a)[i];
+        const f32x4 w = ((const f32x4 *)b)[i];
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        if (c) {
+            const f32x4 u = ((const f32x4 *)c)[i];
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        if (d) {
+            const f32x4 u = ((const f32x4 *)d)[i];
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        ((f32x4 *)out)[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256)
+            out[i] = a[i] + b[i] + (c ? c[i] : 0.f) + (d ? d[i] : 0.f);
+}
+}  // namespace
+
+extern "C" int dcl_add_n(const float *a, const float *b, const float *c, const float *d, int64_t n, float *out,
+                         void *stream)
+{
+    DCL_CHECK_ARG(a && b && out && n > 0 && (c || !d), "bad arguments (a, b required; d only with c)");
+    DCL_CHECK_ARG(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d) | ((uintptr_t)out)) & 15) == 0,
+                  "tensors must be 16-byte aligned");
+    const size_t n4 = (size_t)n / 4;
+    size_t blocks = (n4 + 256 * 4 - 1) / (256 * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks);
+    hipLaunchKernelGGL(k_add_n, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, d, n4, (size_t)n, out);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}

@@ -28,7 +28,7 @@ import torch.nn.functional as F
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
 from .ops import (ConvPackGroup, DirectConv2d, GradToken, use_gemm_conv1x1, upsample_bilinear, use_direct_conv3x3,
-                  use_direct_conv1x1, upsample_concat)
+                  use_direct_conv1x1, upsample_concat, fan_out)
 from .amax import record_stream as _amax_record_stream
 from .fused_bn import FusedBatchNorm2d, bn_act
 
@@ -220,8 +220,16 @@ class HighResolutionModule(nn.Module):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
         x = self._run_branches(x)
+        nrow = len(self.fuse_layers)
+        if nrow >= 3 and x[0].is_cuda:
+            # every branch output feeds every fuse row: hand each row its own alias, so that the nrow gradients of a
+            # branch output are summed by one kernel instead of nrow - 1 autograd adds (ops.fan_out)
+            al = [fan_out(t, nrow) for t in x]
+            xs = [[al[j][i] for j in range(self.num_branches)] for i in range(nrow)]
+        else:
+            xs = [x] * nrow
         if not (_BRANCH_STREAMS and x[0].is_cuda) or len(self.fuse_layers) == 1:
-            return [self._fuse_row(i, row, x) for i, row in enumerate(self.fuse_layers)]
+            return [self._fuse_row(i, row, xs[i]) for i, row in enumerate(self.fuse_layers)]
         # the fused outputs are independent of each other as well: output i on stream i
         main = torch.cuda.current_stream(x[0].device)
         side = _side_streams(x[0].device, len(self.fuse_layers) - 1)
@@ -232,8 +240,8 @@ class HighResolutionModule(nn.Module):
             with torch.cuda.stream(s):
                 for t in x:
                     _amax_record_stream(t, s)
-                fused[i] = self._fuse_row(i, self.fuse_layers[i], x)
-        fused[0] = self._fuse_row(0, self.fuse_layers[0], x)
+                fused[i] = self._fuse_row(i, self.fuse_layers[i], xs[i])
+        fused[0] = self._fuse_row(0, self.fuse_layers[0], xs[0])
         for i in range(1, len(self.fuse_layers)):
             main.wait_stream(side[i - 1])
             _amax_record_stream(fused[i], main)

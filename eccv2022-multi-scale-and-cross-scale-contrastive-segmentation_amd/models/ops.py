@@ -88,6 +88,50 @@ class _UpsampleConcat(torch.autograd.Function):
         return (None, *grads)
 
 
+class _FanOut(torch.autograd.Function):
+    """k aliases of one tensor for k consumers; the backward sums the k gradients in ONE kernel (k + 1 tensor passes)
+    where autograd's own accumulation chains k - 1 two-input adds (3 (k - 1) passes)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        from .. import _lib
+        L = _lib.lib()
+        gs = [g.contiguous() for g in gs]
+        while len(gs) > 1:
+            part, gs = gs[:4], gs[4:]
+            out = torch.empty_like(part[0])
+            p = [_lib.ptr(t) for t in part] + [None] * (4 - len(part))
+            _lib.check(L.dcl_add_n(p[0], p[1], p[2], p[3], out.numel(), _lib.ptr(out), _lib.stream_ptr(out.device)),
+                       "dcl_add_n")
+            gs = [out] + gs
+        return gs[0], None
+
+
+_FANOUT = __import__('os').environ.get('DCL_FANOUT', '1') != '0'        # A/B switch for the tuning tools
+
+
+def fan_out(x, k):
+    """k aliases of x whose gradients are summed by one kernel (see _FanOut); the absmax tag travels along."""
+    if k < 3 or not (_FANOUT and x.is_cuda and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled()):
+        return [x] * k
+    outs = _FanOut.apply(x, k)
+    tag = getattr(x, "_dcl_amax", None)
+    if tag is not None:
+        for o in outs:
+            o._dcl_amax = (o._version, tag[1])
+    return list(outs)
+
+
 def upsample_concat(ts, align_corners):
     """``torch.cat([ts[0]] + [F.interpolate(t, ts[0].shape[-2:], mode='bilinear', align_corners=...) for t in ts[1:]], 1)``
     (reference models/HRNet.py:549-553) in one pass over the result for CUDA / float32 / contiguous maps."""

@@ -252,6 +252,11 @@ int dcl_upsample_bilinear_fwd_slice(const float *x, int N, int C, int h, int w, 
 int dcl_upsample_bilinear_bwd_slice(const float *dy_wide, int ctot, int c0, int N, int C, int h, int w, int H, int W,
                                     int align_corners, float *dx, void *stream);
 
+/* out = a + b (+ c) (+ d), n floats: the gradient of a tensor with several consumers in one pass (HRNet exchange
+ * modules: every branch output feeds all fuse rows, reference models/HRNet.py:264-287). */
+int dcl_add_n(const float *a, const float *b, const float *c /* or NULL */, const float *d /* or NULL */, int64_t n,
+              float *out, void *stream);
+
 /* ---- direct f16x3 3x3 convolution (stride 1, pad 1, NCHW f32 in / out) --------------------------------------
  * Replaces the nn.Conv2d(C, C, 3, 1, 1, bias=False) of the reference's BasicBlock / Bottleneck
  * (models/HRNet.py:32-60, 63-100) -- ~80 % of HRNet-W48's FLOPs -- and its data gradient (same kernel on the

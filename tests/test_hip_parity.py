@@ -1070,3 +1070,24 @@ def test_upsample_concat_matches_cat_of_interpolates(dev, align):
 
 
 
+
+
+@pytest.mark.gpu
+def test_fan_out_sums_consumer_gradients_in_one_kernel(dev):
+    """ops.fan_out: k aliases of a tensor, backward = ONE fused sum of the k incoming gradients (None entries skipped),
+    bitwise equal to the left-to-right sum; the absmax tag travels with the aliases."""
+    from mscs_amd.models import ops, amax as _amax
+    torch.manual_seed(12)
+    for k in (3, 4, 6):
+        x = torch.randn(2, 5, 7, 9, device=dev, requires_grad=True)
+        _amax.tag(x, x.detach().abs().amax(dim=(2, 3)).flatten().contiguous())
+        outs = ops.fan_out(x, k)
+        assert len(outs) == k and all(o.data_ptr() == x.data_ptr() for o in outs)
+        assert all(_amax.amax_of(o) is _amax.amax_of(x) for o in outs)
+        ws = [torch.randn_like(x) for _ in range(k)]
+        used = [i for i in range(k) if i != 1]                          # consumer 1 contributes no gradient
+        sum((outs[i] * ws[i]).sum() for i in used).backward()
+        ref = ws[used[0]].clone()
+        for i in used[1:]:
+            ref = ref + ws[i]
+        assert (x.grad - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
