@@ -130,9 +130,17 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = bn_act(self.bn1, self.conv1(x))
+        # as in BasicBlock: x feeds conv1 AND the residual add; the token carries bn3's residual gradient into conv1's
+        # data-gradient epilogue instead of leaving the sum of two 400 MB tensors to an autograd add
+        tok = None
+        if _FUSE_RESIDUAL_GRAD and self.downsample is None and isinstance(self.conv1, DirectConv2d) \
+                and isinstance(self.bn3, FusedBatchNorm2d) and self.conv1.fuses_residual_grad(x):
+            tok = GradToken()
+            out = bn_act(self.bn1, self.conv1(x, grad_token=tok))
+        else:
+            out = bn_act(self.bn1, self.conv1(x))
         out = bn_act(self.bn2, self.conv2(out))
-        return bn_act(self.bn3, self.conv3(out), residual=identity)
+        return bn_act(self.bn3, self.conv3(out), residual=identity, grad_token=tok)
 
 
 blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck}

@@ -373,12 +373,12 @@ class _Conv3x3Direct(torch.autograd.Function):
             addend = None
             if ctx.token is not None and ctx.token.dres is not None:
                 addend, ctx.token.dres = ctx.token.dres, None        # gradient of the residual branch, fused in
-            if ctx.k1 and _conv1x1_by_library(x, gy):
+            if ctx.k1 and _conv1x1_by_library(x, gy) and addend is None:
                 n, ci, h, w = x.shape
                 torch.matmul(weight.view(-1, ci).t(), gy.view(n, -1, h * w), out=gx.view(n, ci, h * w))
-                if addend is not None:
-                    gx += addend
             elif ctx.k1:
+                # (with a residual gradient to add, the tile kernel's fused epilogue beats library GEMM + add kernel
+                # also above the size where the GEMM alone is faster)
                 conv1x1_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend)
             else:
                 conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend, in_up=ctx.stride)
