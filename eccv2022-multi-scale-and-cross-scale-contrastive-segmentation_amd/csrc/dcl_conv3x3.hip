@@ -627,6 +627,35 @@ __global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ x, siz
 
 }  // namespace
 
+// out[0] = max(a[0 .. na)) + max(b[0 .. nb)): an upper bound of max|a_tensor + b_tensor| from the two tensors' absmax
+// partials (one wave; the partial buffers hold 1 .. DCL_AMAX_SLOTS values)
+namespace {
+__global__ __launch_bounds__(64) void k_amax_sum2(const float *__restrict__ a, int na, const float *__restrict__ b, int nb,
+                                                 float *__restrict__ out)
+{
+    float ma = 0.f, mb = 0.f;
+    for (int i = threadIdx.x; i < na; i += 64)
+        ma = fmaxf(ma, a[i]);
+    for (int i = threadIdx.x; i < nb; i += 64)
+        mb = fmaxf(mb, b[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ma = fmaxf(ma, __shfl_xor(ma, o, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+    }
+    if (threadIdx.x == 0)
+        out[0] = ma + mb;
+}
+}  // namespace
+
+extern "C" int dcl_amax_sum2(const float *a, int na, const float *b, int nb, float *out, void *stream)
+{
+    DCL_CHECK_ARG(a && b && out && na > 0 && nb > 0, "bad arguments");
+    hipLaunchKernelGGL(k_amax_sum2, dim3(1), dim3(64), 0, (hipStream_t)stream, a, na, b, nb, out);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dcl_absmax(const float *x, int64_t n, float *out, void *stream)
 {
     DCL_CHECK_ARG(x && out && n > 0, "bad arguments");

@@ -35,6 +35,14 @@ def tag(t: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def tag_of(t: torch.Tensor):
+    """The valid absmax tag of t, or None (no fallback pass)."""
+    got = getattr(t, "_dcl_amax", None)
+    if got is not None and got[0] == t._version and got[1].device == t.device:
+        return got[1]
+    return None
+
+
 def amax_of(t: torch.Tensor) -> torch.Tensor:
     """1-D float tensor whose maximum is max|t| (per-plane maxima from the producer, or one value)."""
     got = getattr(t, "_dcl_amax", None)

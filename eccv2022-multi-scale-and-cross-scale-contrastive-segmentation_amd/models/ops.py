@@ -117,7 +117,8 @@ class _FanOut(torch.autograd.Function):
         return gs[0], None
 
 
-_FANOUT = __import__('os').environ.get('DCL_FANOUT', '1') != '0'        # A/B switch for the tuning tools
+_FANOUT = __import__('os').environ.get('DCL_FANOUT', '1') != '0'        # A/B switches for the tuning tools
+_UPSAMPLE_TAG = __import__('os').environ.get('DCL_UPSAMPLE_TAG', '1') != '0'
 
 
 def fan_out(x, k):
@@ -181,7 +182,22 @@ def upsample_bilinear(x, size, align_corners, add=None, relu=False):
             and not torch.is_autocast_enabled() and (H, W) != tuple(x.shape[-2:]) \
             and (add is None or (add.is_contiguous() and add.dtype == torch.float32
                                  and tuple(add.shape) == tuple(x.shape[:2]) + (H, W))):
-        return _UpsampleBilinear.apply(x, add, H, W, bool(align_corners), bool(relu))
+        y = _UpsampleBilinear.apply(x, add, H, W, bool(align_corners), bool(relu))
+        # absmax side channel without a pass over y: interpolation is a convex combination, so max|up(x)| <= max|x|;
+        # with an addend the sum of the two maxima bounds the result (a ReLU on top only shrinks it)
+        from . import amax as _amax
+        from .. import _lib
+        if not _UPSAMPLE_TAG:
+            return y
+        tx, ta = _amax.tag_of(x), (_amax.tag_of(add) if add is not None else None)
+        if tx is not None and add is None:
+            _amax.tag(y, tx)
+        elif tx is not None and ta is not None:
+            buf = torch.empty(1, dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().dcl_amax_sum2(_lib.ptr(tx), tx.numel(), _lib.ptr(ta), ta.numel(), _lib.ptr(buf),
+                                                _lib.stream_ptr(x.device)), "dcl_amax_sum2")
+            _amax.tag(y, buf)
+        return y
     y = x if (H, W) == tuple(x.shape[-2:]) else F.interpolate(x, size=(H, W), mode='bilinear',
                                                               align_corners=align_corners)
     y = y if add is None else add + y

@@ -274,6 +274,10 @@ int dcl_add_n(const float *a, const float *b, const float *c /* or NULL */, cons
  *                    tile_r / tile_p select the workgroup tile (channel tiles per wave / rows per wave),
  *                    0 = automatic */
 int dcl_absmax(const float *x, int64_t n, float *out, void *stream);
+/* out[0] = max(a[0..na)) + max(b[0..nb)): bound of max|A + B| from the absmax partials of A and B (the sum of an
+ * up-sampled map and its addend: interpolation is a convex combination, a ReLU on top only shrinks) -- saves the
+ * dcl_absmax pass over the sum. */
+int dcl_amax_sum2(const float *a, int na, const float *b, int nb, float *out, void *stream);
 /* Multi-tensor forms: ONE launch for all weights of a model.  Job tables live in device memory:
  *   absmax job {const float *x; float *out; int64 n; int32 first_block; int32 pad}   (4096 elements / workgroup)
  *   pack job   {const float *w; void *wp; const float *amax; int32 M, K, transposed, first_block}  (256 items / wg)

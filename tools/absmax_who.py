@@ -1,0 +1,35 @@
+import os, sys, collections, traceback, torch
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+import bench, mscs_amd
+from mscs_amd.managers import HRNetManager
+from mscs_amd.utils import set_verbosity
+from mscs_amd.models import amax as A
+set_verbosity(40)
+class Args:
+    batch, height, width, scales, no_cross, channels_last, branch_conv = 12, 512, 1024, 3, False, False, "f16x3"
+    materialize_logits, head_conv, conv1x1 = False, "direct", "f16x3"
+mgr = HRNetManager(bench.step_config(Args, 1), autostart=False); mgr.setup(); mgr.model.train()
+dev = torch.device("cuda:0")
+gen = torch.Generator().manual_seed(0)
+img = torch.randn(12, 3, 512, 1024, generator=gen).to(dev)
+lbl = torch.randint(0, 20, (12, 512, 1024), generator=gen).to(dev)
+def step():
+    mgr.optimiser.zero_grad(set_to_none=True)
+    ret = mgr.forward_step(img, lbl)
+    ret["loss"].backward()
+    mgr.optimiser.step()
+for _ in range(2): step()
+log = collections.Counter()
+orig = A.amax_of
+def spy(t):
+    got = getattr(t, "_dcl_amax", None)
+    if not (got is not None and got[0] == t._version and got[1].device == t.device):
+        fr = [f for f in traceback.extract_stack()[:-1] if "mscs_amd" in f.filename or "eccv2022" in f.filename][-3:]
+        log[(tuple(t.shape), " < ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(fr)))] += 1
+    return orig(t)
+A.amax_of = spy
+import mscs_amd.models.ops as O
+step()
+torch.cuda.synchronize()
+for k, v in sorted(log.items(), key=lambda kv: -kv[1]):
+    print(v, k)
