@@ -36,7 +36,7 @@ SIGNATURES = {
     "dcl_infonce_prep_stats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
     "dcl_infonce_bwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "dcl_normalize_bwd_scatter": [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
-                                  _i64, _i64, _i64, _vp],
+                                  _i64, _i64, _i64, _vp, _vp],
     "dcl_host_randperm_select": [_vp, _i64, _vp, _i, _i, _vp],
     "dcl_bn_num_slices": [_i, _i],
     "dcl_bn_stats": [_vp, _i, _i, _i, _vp, _vp, _vp],

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_normalize_bwd_scatter(
     SlabList slabs, int nslab, const float *__restrict__ bank, const float *__restrict__ nrm,
     const int32_t *__restrict__ pix, const int32_t *__restrict__ pair_b,
     const int32_t *__restrict__ slot_pair, int N, int V, int C, float *__restrict__ dfeat,
-    int64_t sn, int64_t sc, int64_t sp)
+    int64_t sn, int64_t sc, int64_t sp, float *__restrict__ amax)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -137,13 +137,24 @@ __global__ __launch_bounds__(256) void k_normalize_bwd_scatter(
     const int u = row / V, v = row - u * V;
     const int t = slot_pair[u];
     const int64_t base = (int64_t)pair_b[t] * sn + (int64_t)pix[(int64_t)t * V + v] * sp;
+    float am = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c = lane + 64 * q;
         if (c < C) {
             const float dx = clamped ? d[q] * inv : (d[q] - f[q] * inner) * inv;
             dfeat[base + (int64_t)c * sc] = dx;
+            am = fmaxf(am, fabsf(dx));
         }
+    }
+    // absmax side channel of the (otherwise zero) feature gradient, for the f16x3 convolutions of the projector's
+    // backward: DCL_AMAX_SLOTS partial maxima, integer atomicMax on the float bits (values >= 0: order independent)
+    if (amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            am = fmaxf(am, __shfl_xor(am, o, 64));
+        if (lane == 0)
+            atomicMax((unsigned int *)(amax + (row & (DCL_AMAX_SLOTS - 1))), __float_as_uint(am));
     }
 }
 
@@ -151,7 +162,7 @@ extern "C" int dcl_normalize_bwd_scatter(const float *const *slabs_host, int nsl
                                          const float *bank, const float *nrm, const int32_t *pix,
                                          const int32_t *pair_b, const int32_t *slot_pair, int T,
                                          int V, int C, float *dfeat, int64_t stride_n,
-                                         int64_t stride_c, int64_t stride_p, void *stream)
+                                         int64_t stride_c, int64_t stride_p, float *amax, void *stream)
 {
     DCL_CHECK_ARG(slabs_host && bank && nrm && pix && pair_b && slot_pair && dfeat, "null pointer");
     DCL_CHECK_ARG(nslab >= 0 && nslab <= DCL_MAX_SLABS, "too many slabs (max 64)");
@@ -162,7 +173,7 @@ extern "C" int dcl_normalize_bwd_scatter(const float *const *slabs_host, int nsl
     const int N = T * V;
     hipLaunchKernelGGL(k_normalize_bwd_scatter, dim3((N + 3) / 4), dim3(256), 0,
                        (hipStream_t)stream, sl, nslab, bank, nrm, pix, pair_b, slot_pair, N, V, C,
-                       dfeat, stride_n, stride_c, stride_p);
+                       dfeat, stride_n, stride_c, stride_p, amax);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from ..models import amax as _amax
 from .plan import HostPlan, build_host_plan, positive_ranges
 
 
@@ -753,11 +754,13 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
             arr = (ctypes.c_void_p * len(slabs[s]))(*[x.data_ptr() for x in slabs[s]])
             sn, scs, sp = sc.strides
             p = sc.plan
+            am = _amax.zeros(_amax.SLOTS, dev)
             _lib.check(L.dcl_normalize_bwd_scatter(arr, len(slabs[s]), _lib.ptr(sc.bank),
                                                    _lib.ptr(sc.nrm), _lib.ptr(sc.pix),
                                                    _lib.ptr(sc.pair_b), _lib.ptr(sc.slot_pair), p.T,
-                                                   p.V, sc.C, _lib.ptr(dfeat), sn, scs, sp, stream),
+                                                   p.V, sc.C, _lib.ptr(dfeat), sn, scs, sp, _lib.ptr(am), stream),
                        "dcl_normalize_bwd_scatter")
+            _amax.tag(dfeat, am)                # absmax of the (otherwise zero) map: no dcl_absmax pass in the projector
         grads.append(dfeat)
     return grads
 

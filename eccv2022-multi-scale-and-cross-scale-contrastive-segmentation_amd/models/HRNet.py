@@ -475,6 +475,12 @@ class HRNet(nn.Module):
         # 1x1 convolutions (bottlenecks, fuse layers, projector, classifier): 'f16x3' (default) = the same direct
         # split-f16 kernels in their one-tap mode, all three directions; 'gemm' = plain batched fp32 library GEMMs (the
         # library's own weight gradient for a 1x1 convolution wraps an NHWC kernel in layout transposes); 'library'
+        if config.get('fused_bn', True) and self.projector_model is not None:
+            # the projector's norms as well (class switch: same parameters / buffers / state_dict keys); their outputs
+            # and gradients then carry the absmax tags the projector's f16x3 1x1 convolutions need
+            for m in self.projector_model.modules():
+                if type(m) is nn.BatchNorm2d:
+                    m.__class__ = FusedBatchNorm2d
         self.conv1x1 = config.get('conv1x1', 'f16x3' if config.get('gemm_conv1x1', True) else 'library')
         if self.conv1x1 == 'f16x3':
             use_direct_conv1x1(self)

@@ -175,7 +175,9 @@ int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, int N2,
 int dcl_normalize_bwd_scatter(const float *const *slabs_host, int nslab, const float *bank,
                               const float *nrm, const int32_t *pix, const int32_t *pair_b,
                               const int32_t *slot_pair, int T, int V, int C, float *dfeat,
-                              int64_t stride_n, int64_t stride_c, int64_t stride_p, void *stream);
+                              int64_t stride_n, int64_t stride_c, int64_t stride_p,
+                              float *amax /* [DCL_AMAX_SLOTS] zero-initialised: max|dfeat| max-ed in; or NULL */,
+                              void *stream);
 
 /* ---- fused BatchNorm2d (+ residual) (+ ReLU), training mode, NCHW f32 ----
  * Replaces nn.BatchNorm2d -> (out += identity) -> nn.ReLU chains of the models (reference
