@@ -118,6 +118,8 @@ def lib():
                         ("DCL_UP2_PHASES", l.dcl_conv3x3_set_up2_phases)):
             if os.environ.get(env) is not None:
                 fn(int(os.environ[env]))
+        if os.environ.get("DCL_WGRAD_TILE"):
+            l.dcl_wgrad3x3_set_tile(*[int(v) for v in os.environ["DCL_WGRAD_TILE"].split(",")])
         _lib = l
     return _lib
 

@@ -464,23 +464,16 @@ static int g_s2_native = 1;     // stride 2: 1 = output-pixel formulation (dcl_w
 static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nci, int &S, int &units)
 {
     const int cot = Cout / 16, cit = Cin / 16;
-    nco = (cot % 3 == 0) ? 3 : (cot % 2 == 0) ? 2 : 1;        // (4 tiles would spill)
-    // pairs of ci tiles when that leaves no ragged group (for the head, cit = 45, the 6-tile variant with a ragged
-    // last group was tried: 27 ms against 12.5 ms -- it spills and writes per-wave slabs)
-    nci = (cit % 2 == 0) ? 2 : 1;
-    // measured on the HRNet-W48 branch shapes at batch 12 (tools/wgrad_tiles.py): the six-tile wave (3, 2) spills
-    // (70 registers) and only pays off when the tile-pair grid is large (384 channels); few pairs -> (3, 1) with many
-    // pixel splits (96 channels: 64.8 vs 75.6 us); otherwise the spill-free four-tile wave (2, 2) (192 channels: 66.9
-    // vs 71.3 us)
-    if (cot % 3 == 0 && cit % 2 == 0 && (cot / 3) * (cit / 2) >= 64) {
-        nco = 3;
-        nci = 2;
-    } else if (cot % 3 == 0 && (cot / 3) * cit <= 16) {
+    // Tiles per wave, measured on the HRNet-W48 shapes at batch 12 (tools/wgrad_tiles.py, and bench.py with
+    // DCL_WGRAD_TILE: the step decides, the slabs of the larger tiles cost HBM traffic that the standalone timing does not
+    // show): three co tiles x one ci tile wherever the co tiles divide by three (48 ... 720 channels: step 122.3 ms
+    // against 122.8 with (2, 2) at 192 and (3, 2) at 384 channels); else the four-tile wave (2, 2), (2, 1), (1, 2), (1, 1).
+    if (cot % 3 == 0) {
         nco = 3;
         nci = 1;
-    } else if (cot % 2 == 0 && cit % 2 == 0) {
-        nco = 2;
-        nci = 2;
+    } else {
+        nco = (cot % 2 == 0) ? 2 : 1;
+        nci = (cit % 2 == 0) ? 2 : 1;
     }
     if (g_tile_nco > 0 && g_tile_nco <= 3 && cot % g_tile_nco == 0)
         nco = g_tile_nco;
