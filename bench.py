@@ -434,10 +434,15 @@ def time_train_step(args, dev, rank, world):
     sync(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        ret = step()
     sync(world)
     dt = time.perf_counter() - t0
     mgr.flush_logging()
+    # a timing of a run whose numbers went bad is not a measurement (a chip multiplying NaNs even clocks higher):
+    # the last loss and every parameter must be finite after the timed steps
+    bad = [n for n, p in mgr.model.named_parameters() if not torch.isfinite(p).all()]
+    if bad or not torch.isfinite(ret["loss"]).item():
+        raise RuntimeError(f"benchmark step diverged: loss {float(ret['loss'])}, non-finite parameters {bad[:5]}")
     mod = mgr.loss.loss_classes["DenseContrastiveLossV2_ms"]
     extra = {"contrastive_loss_fwd_bwd_ms": round(loss_only_ms(mod, dev, args), 3),
              "metrics_in_step": not args.no_metrics,
