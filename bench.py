@@ -590,6 +590,8 @@ def eager_gpu_step_ms(args, dev, iters=3):
             torch.cuda.synchronize()
             if it:
                 times.append((time.perf_counter() - t0) * 1e3)
+    if not torch.isfinite(loss).item():
+        raise RuntimeError(f"eager comparator diverged: loss {float(loss)}")
     del model, opt
     torch.cuda.empty_cache()
     return sorted(times)[len(times) // 2]
