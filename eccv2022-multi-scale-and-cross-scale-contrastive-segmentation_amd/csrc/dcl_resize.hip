@@ -36,13 +36,17 @@ struct Slice {
 };
 __device__ __forceinline__ size_t wide_plane(const Slice &s, size_t p) { return (p / s.C) * s.ctot + s.c0 + p % s.C; }
 
-// one workgroup per output row (n, c, oy); each thread produces 4 consecutive ox
+// `tpr` threads (a power of two <= 256) per output row (n, c, oy), 256 / tpr rows per workgroup; each thread produces 4
+// consecutive ox (narrow maps: a 256-pixel row keeps 64 threads busy, so four rows share a workgroup)
 __global__ __launch_bounds__(256) void k_upsample_fwd(const float *__restrict__ x,
                                                      const float *__restrict__ addend, int h, int w,
                                                      int H, int W, Axis ay, Axis ax, int relu, float *__restrict__ y,
-                                                     Slice sl)
+                                                     Slice sl, int tpr, int nrows)
 {
-    const int row = blockIdx.x;              // (n*C + c) * H + oy
+    const int row = blockIdx.x * (256 / tpr) + threadIdx.x / tpr;              // (n*C + c) * H + oy
+    if (row >= nrows)
+        return;
+    const int tx = threadIdx.x & (tpr - 1);
     const int oy = row % H;
     const size_t plane = row / H;
     int y0, y1;
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256) void k_upsample_fwd(const float *__restrict__ 
     float *out = y + (wide_plane(sl, plane) * H + oy) * (size_t)W;
     const float *add = addend ? addend + (size_t)row * W : nullptr;     // y = addend + upsample(x)
     const bool vec = (W & 3) == 0;
-    for (int ox4 = threadIdx.x * 4; ox4 < W; ox4 += 256 * 4) {
+    for (int ox4 = tx * 4; ox4 < W; ox4 += tpr * 4) {
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -225,8 +229,13 @@ static int upsample_fwd(const float *x, const float *addend, int planes, int h, 
 {
     DCL_CHECK_ARG(x && y && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad arguments");
     DCL_CHECK_ARG((long long)planes * H < 2147483647LL, "too many output rows");
-    hipLaunchKernelGGL(k_upsample_fwd, dim3((unsigned)(planes * H)), dim3(256), 0, (hipStream_t)stream, x,
-                       addend, h, w, H, W, make_axis(h, H, align_corners), make_axis(w, W, align_corners), relu, y, sl);
+    int tpr = 1;
+    while (tpr < 256 && tpr * 4 < W)
+        tpr *= 2;
+    const int nrows = planes * H, rpb = 256 / tpr;
+    hipLaunchKernelGGL(k_upsample_fwd, dim3((unsigned)((nrows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x,
+                       addend, h, w, H, W, make_axis(h, H, align_corners), make_axis(w, W, align_corners), relu, y, sl, tpr,
+                       nrows);
     DCL_LAUNCH_CHECK();
     return 0;
 }
