@@ -1119,3 +1119,30 @@ def test_weight_gradient_kernel_variants_match_fp64(dev, variant):
     finally:
         L.dcl_wgrad3x3_set_variant(-1)
         L.dcl_wgrad3x3_set_partition(-1, 0)
+
+
+@pytest.mark.gpu
+def test_stride2_gradient_formulations_agree(dev):
+    """Stride-2 data gradient by output parity classes (default) against the stride-1 tile over the zero-inserted gradient
+    (dcl_conv3x3_set_up2_phases(0)), and the weight gradient over the output pixels against the zero-inserted dY operand
+    (dcl_wgrad3x3_set_stride2(0)): same results to f16x3 round-off, odd sizes included."""
+    from mscs_amd import _lib
+    from mscs_amd.models import ops
+    L = _lib.lib()
+    torch.manual_seed(77)
+    try:
+        for (n, ci, co, h, w) in [(2, 48, 96, 32, 64), (1, 32, 32, 9, 48), (2, 64, 48, 7, 16)]:
+            x = torch.randn(n, ci, h, w, device=dev).relu_()
+            wt = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+            gy = torch.randn(n, co, (h - 1) // 2 + 1, (w - 1) // 2 + 1, device=dev) * 1e-3
+            res = {}
+            for mode in (1, 0):
+                L.dcl_conv3x3_set_up2_phases(mode)
+                L.dcl_wgrad3x3_set_stride2(mode)
+                res[mode] = (ops.conv3x3_direct(gy, wt, transposed=True, stride=2, out_hw=(h, w)),
+                             ops.conv3x3_wgrad(x, gy, stride=2))
+            for a, b in zip(res[1], res[0]):
+                assert ((a - b).abs().max() / b.abs().max()).item() < 3e-6, (n, ci, co, h, w)
+    finally:
+        L.dcl_conv3x3_set_up2_phases(1)
+        L.dcl_wgrad3x3_set_stride2(1)
