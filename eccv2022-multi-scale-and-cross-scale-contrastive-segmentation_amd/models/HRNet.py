@@ -275,7 +275,12 @@ class HighResolutionModule(nn.Module):
                         t = step(t)
                     y = chain[-1](t, residual=y)
             return self.relu(y)
-        others = [j for j in range(self.num_branches) if j != i]
+        # coarser branches (up-sampling kernels) first, finer ones (stride-2 chains) last: the closing ReLU then rides on a
+        # norm kernel whenever the row has one -- its backward reads the packed sign mask, where an up-sampling with a
+        # fused ReLU needs a threshold pass over the full-resolution gradient (rows 1.. of every module: 14 passes less)
+        others = [j for j in range(self.num_branches) if j > i] + [j for j in range(self.num_branches) if j < i]
+        if os.environ.get('DCL_FUSE_ORDER', '1') == '0':      # A/B switch for the tuning tools
+            others = [j for j in range(self.num_branches) if j != i]
         y = x[i]
         for pos, j in enumerate(others):
             last = pos == len(others) - 1
