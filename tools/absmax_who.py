@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Which tensors of a training step reach a convolution WITHOUT an absmax tag (each costs a dcl_absmax pass over the
+tensor): shape and call site of every fallback in one steady-state step of the benchmark model."""
 import os, sys, collections, traceback, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
 import bench, mscs_amd
