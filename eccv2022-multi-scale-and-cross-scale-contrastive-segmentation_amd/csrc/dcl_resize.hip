@@ -179,7 +179,8 @@ constexpr int ROWS_MAXW = 4096;
 __global__ __launch_bounds__(256) void k_upsample_bwd_rows(const float *__restrict__ dy, int h, int w, int H, int W,
                                                           Axis ay, Axis ax, float *__restrict__ dx, Slice sl)
 {
-    __shared__ __attribute__((aligned(16))) float tmp[ROWS_MAXW];
+    // (dynamic: W floats -- a static 16-KiB row limited the CU to 10 of these one-wave workgroups)
+    extern __shared__ __attribute__((aligned(16))) float tmp[];
     const int row = blockIdx.x;              // plane * h + iy
     const int iy = row % h;
     const size_t plane = row / h;
@@ -249,7 +250,8 @@ static int upsample_bwd(const float *dy, int planes, int h, int w, int H, int W,
         (((uintptr_t)dy) & 15) == 0) {
         int threads = ((W / 4 + 63) / 64) * 64;
         threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
-        hipLaunchKernelGGL(k_upsample_bwd_rows, dim3((unsigned)(planes * h)), dim3(threads), 0, (hipStream_t)stream, dy,
+        hipLaunchKernelGGL(k_upsample_bwd_rows, dim3((unsigned)(planes * h)), dim3(threads), (size_t)W * sizeof(float),
+                           (hipStream_t)stream, dy,
                            h, w, H, W, make_axis(h, H, align_corners), make_axis(w, W, align_corners), dx, sl);
         DCL_LAUNCH_CHECK();
         return 0;

@@ -20,5 +20,5 @@ for (c, h, w, H, W) in [(48, 64, 128, 128, 256), (48, 32, 64, 128, 256), (48, 16
         y.backward(gy, retain_graph=True)
     tb = timeit(bwd, 20)
     mb = y.numel() * 4 / 1e6
-    print(f"{c:3d} ch {h}x{w} -> {H}x{W} ({mb:5.0f} MB out): fwd {tf * 1e3:6.1f} us ({(2 * mb + x.numel() * 4 / 1e6) / tf / 1e6:4.1f} TB/s r+w), "
+    print(f"{c:3d} ch {h}x{w} -> {H}x{W} ({mb:5.0f} MB out): fwd {tf * 1e3:6.1f} us ({(2 * mb + x.numel() * 4e-6) / (tf * 1e3):4.1f} TB/s r+w), "
           f"bwd (threshold + rows kernel) {tb * 1e3:6.1f} us", flush=True)
