@@ -220,11 +220,27 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, int C, int HW,
                                                         float *__restrict__ y, float *__restrict__ amax,
-                                                        BnFused f)
+                                                        BnFused f, int N)
 {
-    const int plane = blockIdx.y, c = plane % C;
+    // One grid row per CHANNEL; its N * HW elements (N segments of HW, C * HW apart) are one index space cut into
+    // workgroup-sized pieces -- with one grid row per (image, channel) plane the small maps (384 channels, 16 x 32)
+    // were 4 608 workgroups of half a vector per thread, bound by the workgroup dispatch rate (25 us for 19 MB).
+    // That layout is used when a plane is smaller than a workgroup's share (`flat`); large planes keep one grid row per
+    // plane (n0 fixed), which streams them in address order (the channel-major order cost the 48-channel, 128 x 256
+    // maps 30 %).
+    const bool flat = N > 0;
+    const int c = flat ? blockIdx.y : blockIdx.y % C, n0 = flat ? 0 : blockIdx.y / C;
+    const int hw4 = HW >> 2;
+    const unsigned nv = flat ? (unsigned)N * (unsigned)hw4 : (unsigned)hw4;      // vectors in this grid row
+    const unsigned j0 = blockIdx.x * (BN_UNROLL * BN_THREADS) + threadIdx.x;
     float am = 0.f;
-    float sc, sh;
+    float sc = 0.f, sh = 0.f;
+    // The per-channel constants are computed by ONE thread and handed to the others through LDS after the tensor loads
+    // have been issued: on the small planes (384 channels, 16 x 32: a single vector per thread) every thread running the
+    // slice loop, the double-precision square root and the division by itself made this prologue the whole kernel
+    // (25.7 us for 19 MB).  Same arithmetic, same order: bitwise the same statistics.
+    __shared__ float bc[2];
+    if (threadIdx.x == 0) {
     if (f.part) {
         // statistics of channel c from the partial sums (k_bn_combine's arithmetic), written out once per channel
         float a, b;
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
         var = var > 0.0 ? var : 0.0;
         const double m = ms + (f.pivot ? (double)f.pivot[c] : 0.0);
         const float mean_f = (float)m, invstd_f = (float)(1.0 / sqrt(var + (double)f.eps));
-        if (blockIdx.x == 0 && plane < C && threadIdx.x == 0) {
+        if (blockIdx.x == 0 && n0 == 0) {
             f.mean[c] = mean_f;
             f.invstd[c] = invstd_f;
             if (f.running_mean) {
@@ -250,24 +266,33 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
     } else {
         bn_affine(invstd, gamma, beta, mean, c, sc, sh);
     }
-    const size_t base = (size_t)plane * HW;
+    bc[0] = sc;
+    bc[1] = sh;
+    }
     // BN_UNROLL 16-byte vectors per thread, BN_THREADS apart (coalesced), all loads issued before the first use
-    const int i0 = (blockIdx.x * BN_UNROLL * BN_THREADS + threadIdx.x) << 2;
     if ((HW & 3) == 0) {
         f32x4 v[BN_UNROLL], r[BN_UNROLL];
+        size_t off[BN_UNROLL];                                  // element offset of the vector, per u
+        int pl[BN_UNROLL], ivv[BN_UNROLL];                      // its plane and vector index inside the plane
 #pragma unroll
         for (int u = 0; u < BN_UNROLL; ++u) {
-            const int i = i0 + u * BN_THREADS * 4;
-            if (i < HW) {
-                v[u] = *(const f32x4 *)(x + base + i);
+            const unsigned j = j0 + u * BN_THREADS;
+            const int n = flat ? (int)(j / (unsigned)hw4) : n0;
+            ivv[u] = flat ? (int)(j - (unsigned)n * (unsigned)hw4) : (int)j;
+            pl[u] = n * C + c;
+            off[u] = (size_t)pl[u] * HW + 4 * (size_t)ivv[u];
+            if (j < nv) {
+                v[u] = *(const f32x4 *)(x + off[u]);
                 if (RES)
-                    r[u] = *(const f32x4 *)(res + base + i);
+                    r[u] = *(const f32x4 *)(res + off[u]);
             }
         }
+        __syncthreads();
+        sc = bc[0];
+        sh = bc[1];
 #pragma unroll
         for (int u = 0; u < BN_UNROLL; ++u) {
-            const int i = i0 + u * BN_THREADS * 4;
-            if (i < HW) {
+            if (j0 + u * BN_THREADS < nv) {
                 f32x4 w = v[u];
                 w.x = bn_eval(w.x, sc, sh); w.y = bn_eval(w.y, sc, sh); w.z = bn_eval(w.z, sc, sh); w.w = bn_eval(w.w, sc, sh);
                 if (RES) {
@@ -280,27 +305,33 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
                                                  b2 = __ballot(w.z > 0.f), b3 = __ballot(w.w > 0.f);
                         const int ln = threadIdx.x & 63;
                         if (ln < 4)
-                            f.mask_out[relu_mask_word(plane, HW >> 2, i >> 2) + ln] = ln == 0 ? b0 : ln == 1 ? b1 : ln == 2 ? b2 : b3;
+                            f.mask_out[relu_mask_word(pl[u], hw4, ivv[u]) + ln] = ln == 0 ? b0 : ln == 1 ? b1 : ln == 2 ? b2 : b3;
                     }
                 }
-                *(f32x4 *)(y + base + i) = w;
+                *(f32x4 *)(y + off[u]) = w;
                 am = fmaxf(am, fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
             }
         }
     } else {
+        __syncthreads();
+        sc = bc[0];
+        sh = bc[1];
+        const unsigned ne = flat ? (unsigned)N * (unsigned)HW : (unsigned)HW;          // elements in this grid row
         for (int u = 0; u < BN_UNROLL; ++u)
-            for (int k = i0 + u * BN_THREADS * 4; k < HW && k < i0 + u * BN_THREADS * 4 + 4; ++k) {
-                float v = bn_eval(x[base + k], sc, sh);
+            for (unsigned e = (j0 + u * BN_THREADS) * 4; e < ne && e < (j0 + u * BN_THREADS) * 4 + 4; ++e) {
+                const int n = flat ? (int)(e / (unsigned)HW) : n0;
+                const size_t o = ((size_t)n * C + c) * HW + (size_t)(e - (flat ? (unsigned)n * (unsigned)HW : 0u));
+                float v = bn_eval(x[o], sc, sh);
                 if (RES)
-                    v += res[base + k];
+                    v += res[o];
                 if (RELU)
                     v = fmaxf(v, 0.f);
-                y[base + k] = v;
+                y[o] = v;
                 am = fmaxf(am, fabsf(v));
             }
     }
     if (amax)
-        block_amax(am, amax + (plane & (DCL_AMAX_SLOTS - 1)));
+        block_amax(am, amax + ((n0 * C + c) & (DCL_AMAX_SLOTS - 1)));
 }
 
 // part[(c*nslice + s)*2 + {0,1}] = {sum g, sum g * xhat},  g = dy * (y > 0 if RELU)
@@ -397,22 +428,28 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                                                             float *__restrict__ dx,
                                                             float *__restrict__ dres,
                                                             float *__restrict__ amax, BnFused f,
-                                                            const unsigned long long *__restrict__ mask)
+                                                            const unsigned long long *__restrict__ mask, int N)
 {
-    const int plane = blockIdx.y, c = plane % C;
+    const bool flat = N > 0;                            // one grid row per channel | per plane (see k_bn_apply)
+    const int c = flat ? blockIdx.y : blockIdx.y % C, n0 = flat ? 0 : blockIdx.y / C;
+    const int hw4 = HW >> 2;
+    const unsigned nv = flat ? (unsigned)N * (unsigned)hw4 : (unsigned)hw4;
+    const unsigned j0 = blockIdx.x * (BN_UNROLL * BN_THREADS) + threadIdx.x;
     float am = 0.f;
     const float m = mean[c], is = invstd[c];
     float asc, ash;                                   // y == NULL: ReLU mask recomputed from x (see the reduce)
     bn_affine(invstd, gamma, beta, mean, c, asc, ash);
     const bool rec = RELU && y == nullptr && mask == nullptr;
     const float k = is * (gamma ? gamma[c] : 1.f);
-    float mg, mgx;
+    float mg = 0.f, mgx = 0.f;
+    __shared__ float bc[2];                 // (one thread computes, see k_bn_apply)
+    if (threadIdx.x == 0) {
     if (f.part) {
         float a, b;
         part_sums(f.part, c, f.ns, a, b);
         mg = a * inv_count;
         mgx = b * inv_count;
-        if (blockIdx.x == 0 && plane < C && threadIdx.x == 0 && (f.dbeta || f.dgamma)) {
+        if (blockIdx.x == 0 && n0 == 0 && (f.dbeta || f.dgamma)) {
             float la = a, lb = b;
             if (f.part_local != f.part)
                 part_sums(f.part_local, c, f.ns, la, lb);       // this rank's sums: DDP averages the parameter grads
@@ -425,29 +462,36 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
         mg = sums[c * 2] * inv_count;
         mgx = sums[c * 2 + 1] * inv_count;
     }
-    const size_t base = (size_t)plane * HW;
-    const int i0 = (blockIdx.x * BN_UNROLL * BN_THREADS + threadIdx.x) << 2;
+    bc[0] = mg;
+    bc[1] = mgx;
+    }
     if ((HW & 3) == 0) {
         f32x4 gv[BN_UNROLL], xv[BN_UNROLL], yv[BN_UNROLL];
+        size_t off[BN_UNROLL];
 #pragma unroll
         for (int u = 0; u < BN_UNROLL; ++u) {
-            const int i = i0 + u * BN_THREADS * 4;
-            if (i < HW) {
-                gv[u] = *(const f32x4 *)(dy + base + i);
-                xv[u] = *(const f32x4 *)(x + base + i);
+            const unsigned j = j0 + u * BN_THREADS;
+            const int n = flat ? (int)(j / (unsigned)hw4) : n0;
+            const int iv = flat ? (int)(j - (unsigned)n * (unsigned)hw4) : (int)j, plane = n * C + c;
+            off[u] = (size_t)plane * HW + 4 * (size_t)iv;
+            if (j < nv) {
+                gv[u] = *(const f32x4 *)(dy + off[u]);
+                xv[u] = *(const f32x4 *)(x + off[u]);
                 if (RELU && mask) {
-                    const unsigned long long *mw = mask + relu_mask_word(plane, HW >> 2, i >> 2);
+                    const unsigned long long *mw = mask + relu_mask_word(plane, hw4, iv);
                     const int ln = threadIdx.x & 63;
                     yv[u] = f32x4{(float)((mw[0] >> ln) & 1), (float)((mw[1] >> ln) & 1), (float)((mw[2] >> ln) & 1),
                                   (float)((mw[3] >> ln) & 1)};
                 } else if (RELU && !rec)
-                    yv[u] = *(const f32x4 *)(y + base + i);
+                    yv[u] = *(const f32x4 *)(y + off[u]);
             }
         }
+        __syncthreads();
+        mg = bc[0];
+        mgx = bc[1];
 #pragma unroll
         for (int u = 0; u < BN_UNROLL; ++u) {
-            const int i = i0 + u * BN_THREADS * 4;
-            if (i < HW) {
+            if (j0 + u * BN_THREADS < nv) {
                 f32x4 g = gv[u];
                 const f32x4 xx = xv[u];
                 if (RELU) {
@@ -462,31 +506,37 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                     g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
                 }
                 if (dres)
-                    *(f32x4 *)(dres + base + i) = g;
+                    *(f32x4 *)(dres + off[u]) = g;
                 f32x4 o;
                 o.x = k * (g.x - mg - (xx.x - m) * is * mgx);
                 o.y = k * (g.y - mg - (xx.y - m) * is * mgx);
                 o.z = k * (g.z - mg - (xx.z - m) * is * mgx);
                 o.w = k * (g.w - mg - (xx.w - m) * is * mgx);
-                *(f32x4 *)(dx + base + i) = o;
+                *(f32x4 *)(dx + off[u]) = o;
                 am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
             }
         }
     } else {
+        __syncthreads();
+        mg = bc[0];
+        mgx = bc[1];
+        const unsigned ne = flat ? (unsigned)N * (unsigned)HW : (unsigned)HW;
         for (int u = 0; u < BN_UNROLL; ++u)
-            for (int q = i0 + u * BN_THREADS * 4; q < HW && q < i0 + u * BN_THREADS * 4 + 4; ++q) {
-                float g = dy[base + q];
+            for (unsigned e = (j0 + u * BN_THREADS) * 4; e < ne && e < (j0 + u * BN_THREADS) * 4 + 4; ++e) {
+                const int n = flat ? (int)(e / (unsigned)HW) : n0;
+                const size_t q = ((size_t)n * C + c) * HW + (size_t)(e - (flat ? (unsigned)n * (unsigned)HW : 0u));
+                float g = dy[q];
                 if (RELU)
-                    g = (rec ? bn_eval(x[base + q], asc, ash) : y[base + q]) > 0.f ? g : 0.f;
+                    g = (rec ? bn_eval(x[q], asc, ash) : y[q]) > 0.f ? g : 0.f;
                 if (dres)
-                    dres[base + q] = g;
-                const float o = k * (g - mg - (x[base + q] - m) * is * mgx);
-                dx[base + q] = o;
+                    dres[q] = g;
+                const float o = k * (g - mg - (x[q] - m) * is * mgx);
+                dx[q] = o;
                 am = fmaxf(am, fabsf(o));
             }
     }
     if (amax)
-        block_amax(am, amax + (plane & (DCL_AMAX_SLOTS - 1)));
+        block_amax(am, amax + ((n0 * C + c) & (DCL_AMAX_SLOTS - 1)));
 }
 
 int pick_slices(int N, int C)
@@ -552,9 +602,16 @@ extern "C" int dcl_bn_apply(const float *x, const float *res, const float *mean,
                             float *y, float *amax, void *stream)
 {
     DCL_CHECK_ARG(x && mean && invstd && y && N > 0 && C > 0 && HW > 0, "bad arguments");
-    dim3 grid((HW + BN_THREADS * 4 * BN_UNROLL - 1) / (BN_THREADS * 4 * BN_UNROLL), N * C);
+    DCL_CHECK_ARG((long long)N * HW < (1LL << 31) - 4 * BN_THREADS * BN_UNROLL, "N * H * W must stay below 2^31 per channel");
+    // planes smaller than a workgroup's share (4 vectors per thread): one grid row per channel over all N images
+    // (kernel argument N > 0); else one grid row per plane (N = 0)
+    const bool flat = (HW + 3) / 4 < BN_THREADS * BN_UNROLL;
+    const long long nvs = flat ? ((long long)N * HW + 3) / 4 : (HW + 3) / 4;
+    DCL_CHECK_ARG(flat || (long long)N * C <= 65535, "N * C must not exceed 65535 for planes of >= 4096 elements");
+    dim3 grid((unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL)), flat ? C : N * C);
+    const int Nk = flat ? N : 0;
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, mean, invstd, gamma, beta, C, HW, y, amax, BnFused{})
+#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, mean, invstd, gamma, beta, C, HW, y, amax, BnFused{}, Nk)
     if (relu && res) LAUNCH(true, true);
     else if (relu) LAUNCH(true, false);
     else if (res) LAUNCH(false, true);
@@ -591,13 +648,20 @@ extern "C" int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y,
                                 float *amax, void *stream)
 {
     DCL_CHECK_ARG(dy && x && mean && invstd && sums && dx && count > 0, "bad arguments");
-    dim3 grid((HW + BN_THREADS * 4 * BN_UNROLL - 1) / (BN_THREADS * 4 * BN_UNROLL), N * C);
+    DCL_CHECK_ARG((long long)N * HW < (1LL << 31) - 4 * BN_THREADS * BN_UNROLL, "N * H * W must stay below 2^31 per channel");
+    // planes smaller than a workgroup's share (4 vectors per thread): one grid row per channel over all N images
+    // (kernel argument N > 0); else one grid row per plane (N = 0)
+    const bool flat = (HW + 3) / 4 < BN_THREADS * BN_UNROLL;
+    const long long nvs = flat ? ((long long)N * HW + 3) / 4 : (HW + 3) / 4;
+    DCL_CHECK_ARG(flat || (long long)N * C <= 65535, "N * C must not exceed 65535 for planes of >= 4096 elements");
+    dim3 grid((unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL)), flat ? C : N * C);
+    const int Nk = flat ? N : 0;
     hipStream_t st = (hipStream_t)stream;
     const float inv = (float)(1.0 / count);
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{}, (const unsigned long long *)nullptr);
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{}, (const unsigned long long *)nullptr, Nk);
     else
-        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{}, (const unsigned long long *)nullptr);
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{}, (const unsigned long long *)nullptr, Nk);
     DCL_LAUNCH_CHECK();
     return 0;
 }
@@ -637,9 +701,16 @@ extern "C" int dcl_bn_apply_fused(const float *x, const float *res, const float 
     f.running_mean = running_mean;
     f.running_var = running_var;
     f.batches_tracked = (long long *)batches_tracked;
-    dim3 grid((HW + BN_THREADS * 4 * BN_UNROLL - 1) / (BN_THREADS * 4 * BN_UNROLL), N * C);
+    DCL_CHECK_ARG((long long)N * HW < (1LL << 31) - 4 * BN_THREADS * BN_UNROLL, "N * H * W must stay below 2^31 per channel");
+    // planes smaller than a workgroup's share (4 vectors per thread): one grid row per channel over all N images
+    // (kernel argument N > 0); else one grid row per plane (N = 0)
+    const bool flat = (HW + 3) / 4 < BN_THREADS * BN_UNROLL;
+    const long long nvs = flat ? ((long long)N * HW + 3) / 4 : (HW + 3) / 4;
+    DCL_CHECK_ARG(flat || (long long)N * C <= 65535, "N * C must not exceed 65535 for planes of >= 4096 elements");
+    dim3 grid((unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL)), flat ? C : N * C);
+    const int Nk = flat ? N : 0;
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, (const float *)nullptr, (const float *)nullptr, gamma, beta, C, HW, y, amax, f)
+#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, (const float *)nullptr, (const float *)nullptr, gamma, beta, C, HW, y, amax, f, Nk)
     if (relu && res) LAUNCH(true, true);
     else if (relu) LAUNCH(true, false);
     else if (res) LAUNCH(false, true);
@@ -686,13 +757,20 @@ extern "C" int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const flo
     f.count = count;
     f.dbeta = dbeta;
     f.dgamma = dgamma;
-    dim3 grid((HW + BN_THREADS * 4 * BN_UNROLL - 1) / (BN_THREADS * 4 * BN_UNROLL), N * C);
+    DCL_CHECK_ARG((long long)N * HW < (1LL << 31) - 4 * BN_THREADS * BN_UNROLL, "N * H * W must stay below 2^31 per channel");
+    // planes smaller than a workgroup's share (4 vectors per thread): one grid row per channel over all N images
+    // (kernel argument N > 0); else one grid row per plane (N = 0)
+    const bool flat = (HW + 3) / 4 < BN_THREADS * BN_UNROLL;
+    const long long nvs = flat ? ((long long)N * HW + 3) / 4 : (HW + 3) / 4;
+    DCL_CHECK_ARG(flat || (long long)N * C <= 65535, "N * C must not exceed 65535 for planes of >= 4096 elements");
+    dim3 grid((unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL)), flat ? C : N * C);
+    const int Nk = flat ? N : 0;
     hipStream_t st = (hipStream_t)stream;
     const float inv = (float)(1.0 / count);
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask);
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask, Nk);
     else
-        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask);
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask, Nk);
     DCL_LAUNCH_CHECK();
     return 0;
 }
