@@ -401,35 +401,54 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3(WgradArgs a)
 
 // dw[co][ci][tap] = sum_s part[s][tap][co][ci].  Block = 32 outputs x 8 slab groups: group g adds slabs g, g+8, ...
 // in order, the 8 partial sums are combined in order through LDS -> fixed summation tree, deterministic.
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ part, int S, int Cout, int Cin,
-                                                     float *__restrict__ dw)
+template <int K>
+__global__ __launch_bounds__(256) void k_wgrad_reduce_t(const float *__restrict__ part, int S, int Cout, int Cin,
+                                                       float *__restrict__ dw)
 {
-    __shared__ float sh[8][32];
+    // K groups of 32 outputs per workgroup: 1 for the narrow layers (many slabs, few outputs: parallelism over the
+    // outputs matters), 4 for the wide ones (with one, the 1.3 M outputs of a 384-channel layer were 41 k workgroups of
+    // a few loads each -- 16 us, bound by the workgroup dispatch rate)
+    __shared__ float sh[K][8][32];
     const int total = 9 * Cout * Cin;
     const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + lane;       // (tap, co, ci) in slab order
-    float s0 = 0.f, s1 = 0.f;
-    if (idx < total) {
-        int k = g;
-        for (; k + 8 < S; k += 16) {
-            s0 += part[(size_t)k * total + idx];
-            s1 += part[(size_t)(k + 8) * total + idx];
-        }
-        if (k < S)
-            s0 += part[(size_t)k * total + idx];
-    }
-    sh[g][lane] = s0 + s1;
-    __syncthreads();
-    if (g == 0 && idx < total) {
-        float s = sh[0][lane];
 #pragma unroll
-        for (int q = 1; q < 8; ++q)
-            s += sh[q][lane];
-        const int ci = idx % Cin;
-        const int co = (idx / Cin) % Cout;
-        const int tap = idx / (Cin * Cout);
-        dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+    for (int k = 0; k < K; ++k) {
+        const int idx = (blockIdx.x * K + k) * 32 + lane;       // (tap, co, ci) in slab order
+        float s0 = 0.f, s1 = 0.f;
+        if (idx < total) {
+            int q = g;
+            for (; q + 8 < S; q += 16) {
+                s0 += part[(size_t)q * total + idx];
+                s1 += part[(size_t)(q + 8) * total + idx];
+            }
+            if (q < S)
+                s0 += part[(size_t)q * total + idx];
+        }
+        sh[k][g][lane] = s0 + s1;
     }
+    __syncthreads();
+    if (g < K) {
+        const int idx = (blockIdx.x * K + g) * 32 + lane;
+        if (idx < total) {
+            float s = sh[g][0][lane];
+#pragma unroll
+            for (int q = 1; q < 8; ++q)
+                s += sh[g][q][lane];
+            const int ci = idx % Cin;
+            const int co = (idx / Cin) % Cout;
+            const int tap = idx / (Cin * Cout);
+            dw[((size_t)co * Cin + ci) * 9 + tap] = s;
+        }
+    }
+}
+
+static void launch_wgrad_reduce(const float *part, int S, int Cout, int Cin, float *dw, hipStream_t st)
+{
+    const int total = 9 * Cout * Cin;
+    if (total >= (1 << 18))
+        hipLaunchKernelGGL(k_wgrad_reduce_t<4>, dim3((total + 127) / 128), dim3(256), 0, st, part, S, Cout, Cin, dw);
+    else
+        hipLaunchKernelGGL(k_wgrad_reduce_t<1>, dim3((total + 31) / 32), dim3(256), 0, st, part, S, Cout, Cin, dw);
 }
 
 }  // namespace
@@ -560,8 +579,8 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
                             (hipStream_t)stream, &nslab);
         DCL_LAUNCH_CHECK();
         const int total = 9 * Cout * Cin;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nslab, Cout,
-                           Cin, dw);
+        (void)total;
+        launch_wgrad_reduce(part, nslab, Cout, Cin, dw, (hipStream_t)stream);
         DCL_LAUNCH_CHECK();
         return 0;
     }
@@ -607,8 +626,8 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
         dcl_wgrad_dma_launch(a, nco, nci, grid, s);
         DCL_LAUNCH_CHECK();
         const int total = 9 * Cout * Cin;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, s, part, nco * nci <= 4 ? a.nx : a.S, Cout,
-                           Cin, dw);
+        (void)total;
+        launch_wgrad_reduce(part, nco * nci <= 4 ? a.nx : a.S, Cout, Cin, dw, s);
         DCL_LAUNCH_CHECK();
         return 0;
     }
@@ -628,8 +647,8 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
 #undef DCL_WG_CASE
     DCL_LAUNCH_CHECK();
     const int total = 9 * Cout * Cin;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, s, part, nco * nci <= 4 ? a.nx : a.S, Cout,
-                       Cin, dw);
+    (void)total;
+    launch_wgrad_reduce(part, nco * nci <= 4 ? a.nx : a.S, Cout, Cin, dw, s);
     DCL_LAUNCH_CHECK();
     return 0;
 }
