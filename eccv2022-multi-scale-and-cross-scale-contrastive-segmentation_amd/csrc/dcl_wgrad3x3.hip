@@ -442,10 +442,38 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_t(const float *__restrict_
     }
 }
 
+// Wide layers (few slabs, many outputs): one workgroup per (co, 32 ci), thread = (tap, ci).  The slab layout
+// [tap][co][ci] is read in 128-byte runs as before, but dw[co][ci][tap] is written through an LDS tile as ONE contiguous
+// 1152-byte run -- the per-output form writes 4 bytes every 36 (a 32-byte sector per value: 42 MB of write traffic for the
+// 5 MB gradient of a 384-channel layer).  Same slab order: bitwise the same sums when S <= 8 (one group per output).
+__global__ __launch_bounds__(320) void k_wgrad_reduce_wide(const float *__restrict__ part, int S, int Cout, int Cin,
+                                                          float *__restrict__ dw)
+{
+    __shared__ float tile[32 * 9];
+    const int co = blockIdx.y, ci0 = blockIdx.x * 32;
+    const int t = threadIdx.x, tap = t >> 5, cl = t & 31;
+    const size_t total = (size_t)9 * Cout * Cin;
+    if (t < 288) {
+        float s0 = 0.f;
+        if (ci0 + cl < Cin) {
+            const float *p = part + ((size_t)tap * Cout + co) * Cin + ci0 + cl;
+            for (int q = 0; q < S; ++q)
+                s0 += p[(size_t)q * total];
+        }
+        tile[cl * 9 + tap] = s0;
+    }
+    __syncthreads();
+    const int nci = min(32, Cin - ci0);
+    if (t < nci * 9)
+        dw[((size_t)co * Cin + ci0) * 9 + t] = tile[t];
+}
+
 static void launch_wgrad_reduce(const float *part, int S, int Cout, int Cin, float *dw, hipStream_t st)
 {
     const int total = 9 * Cout * Cin;
-    if (total >= (1 << 18))
+    if (total >= (1 << 18) && S <= 8)
+        hipLaunchKernelGGL(k_wgrad_reduce_wide, dim3((Cin + 31) / 32, Cout), dim3(320), 0, st, part, S, Cout, Cin, dw);
+    else if (total >= (1 << 18))
         hipLaunchKernelGGL(k_wgrad_reduce_t<4>, dim3((total + 127) / 128), dim3(256), 0, st, part, S, Cout, Cin, dw);
     else
         hipLaunchKernelGGL(k_wgrad_reduce_t<1>, dim3((total + 31) / 32), dim3(256), 0, st, part, S, Cout, Cin, dw);
