@@ -69,6 +69,8 @@ SIGNATURES = {
     "dcl_wgrad3x3_set_stride2": [_i],
     "dcl_wgrad3x3_set_splits": [_i],
     "dcl_conv3x3_set_up2_phases": [_i],
+    "dcl_upsample_ce_set_bwd_chunk": [_i],
+    "dcl_upsample_ce_set_fwd_lds": [_i],
     "dcl_wgrad3x3_set_tile": [_i, _i],
     "dcl_wgrad3x3_set_variant": [_i],
     "dcl_wgrad3x3_set_partition": [_i, _i],
@@ -115,7 +117,9 @@ def lib():
         l.dcl_last_error.argtypes = []
         # A/B switches for the tuning tools (same box, same process layout): kernel variants by environment variable
         for env, fn in (("DCL_WGRAD_VARIANT", l.dcl_wgrad3x3_set_variant), ("DCL_WGRAD_S2", l.dcl_wgrad3x3_set_stride2),
-                        ("DCL_UP2_PHASES", l.dcl_conv3x3_set_up2_phases)):
+                        ("DCL_UP2_PHASES", l.dcl_conv3x3_set_up2_phases),
+                        ("DCL_UPCE_BWD_CHUNK", l.dcl_upsample_ce_set_bwd_chunk),
+                        ("DCL_UPCE_FWD_KIB", l.dcl_upsample_ce_set_fwd_lds)):
             if os.environ.get(env) is not None:
                 fn(int(os.environ[env]))
         if os.environ.get("DCL_WGRAD_TILE"):

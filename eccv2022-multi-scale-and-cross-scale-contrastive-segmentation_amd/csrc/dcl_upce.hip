@@ -89,12 +89,14 @@ struct UpceArgs {
     Axis ay, ax;
 };
 
-constexpr int FWD_LDS_FLOATS = 12288;       // 48 KiB: class chunk x 2 source rows x w
-constexpr int PIX = 4;                      // pixels per thread
-
+constexpr int FWD_LDS_FLOATS = 6144;        // 24 KiB: class chunk x 2 source rows x w (measured: 8-24 KiB 1.13 ms, 40-48 KiB
+                                            // 1.32 ms for 150 classes at 128^2 -> 512^2: more workgroups per CU)
+// PIX pixels per thread: 4 for rows of >= 1024 pixels, 2 below (a 512-pixel row would leave half the workgroup idle);
+// the class-chunk stage is sized by the launch (cc * 2 w floats)
+template <int PIX>
 __global__ __launch_bounds__(256) void k_upce_fwd(UpceArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float zs[FWD_LDS_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float zs[];
     __shared__ float red[2][4];
     const int row = blockIdx.x;                     // n * H + oy
     const int oy = row % a.H, n = row / a.H;
@@ -204,7 +206,9 @@ constexpr int BWD_LDS_FLOATS = 36864;       // 144 KiB: 3 staged low-res rows + 
 
 __global__ __launch_bounds__(256) void k_upce_bwd(UpceArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[BWD_LDS_FLOATS];
+    // dynamic: cc * (3 w + W) floats, sized by the launch so that two workgroups share a CU when the class count allows
+    // (the kernel is latency-bound: exp, gathers; a static 144-KiB array meant one workgroup per CU)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int row = blockIdx.x;                     // n * h + iy
     const int iy = row % a.h, n = row / a.h;
     const size_t plane = (size_t)a.h * a.w;
@@ -269,6 +273,14 @@ __global__ __launch_bounds__(256) void k_upce_bwd(UpceArgs a)
 
 }  // namespace
 
+static int g_upce_fwd_kb = 0;          // tuning override: KiB of LDS for the forward's class chunk (0 = 48)
+
+extern "C" int dcl_upsample_ce_set_fwd_lds(int kib)
+{
+    g_upce_fwd_kb = kib > 0 && kib <= 48 ? kib : 0;
+    return 0;
+}
+
 extern "C" int dcl_upsample_ce_fwd(const float *z, int N, int C, int h, int w, int H, int W, int align_corners,
                                    const int64_t *target, const float *weight, int ignore_index, float *lse,
                                    uint8_t *pred, float *partial, float *out2, void *stream)
@@ -281,14 +293,28 @@ extern "C" int dcl_upsample_ce_fwd(const float *z, int N, int C, int h, int w, i
     a.N = N; a.C = C; a.h = h; a.w = w; a.H = H; a.W = W; a.ignore = ignore_index;
     a.ay = make_axis(h, H, align_corners);
     a.ax = make_axis(w, W, align_corners);
-    a.cc = FWD_LDS_FLOATS / (2 * w);
+    a.cc = (g_upce_fwd_kb > 0 ? g_upce_fwd_kb * 256 : FWD_LDS_FLOATS) / (2 * w);
     if (a.cc > C)
         a.cc = C;
+    if (a.cc < 1)
+        a.cc = 1;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_upce_fwd, dim3((unsigned)(N * H)), dim3(256), 0, st, a);
+    const size_t lds_bytes = (size_t)a.cc * 2 * w * sizeof(float);
+    if (W >= 1024)
+        hipLaunchKernelGGL(k_upce_fwd<4>, dim3((unsigned)(N * H)), dim3(256), lds_bytes, st, a);
+    else
+        hipLaunchKernelGGL(k_upce_fwd<2>, dim3((unsigned)(N * H)), dim3(256), lds_bytes, st, a);
     DCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_upce_finish, dim3(1), dim3(256), 0, st, partial, N * H, out2);
     DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int g_upce_bwd_cc = 0;          // tuning override of the backward's class chunk (0 = automatic)
+
+extern "C" int dcl_upsample_ce_set_bwd_chunk(int cc)
+{
+    g_upce_bwd_cc = cc > 0 ? cc : 0;
     return 0;
 }
 
@@ -305,10 +331,21 @@ extern "C" int dcl_upsample_ce_bwd(const float *z, int N, int C, int h, int w, i
     a.N = N; a.C = C; a.h = h; a.w = w; a.H = H; a.W = W; a.ignore = ignore_index;
     a.ay = make_axis(h, H, align_corners);
     a.ax = make_axis(w, W, align_corners);
-    a.cc = BWD_LDS_FLOATS / (3 * w + W);
-    if (a.cc > C)
-        a.cc = C;
-    hipLaunchKernelGGL(k_upce_bwd, dim3((unsigned)(N * h)), dim3(256), 0, (hipStream_t)stream, a);
+    // class chunk: sized for 3-4 workgroups per CU, measured (tools/upce_time.py): 19 classes at 128 x 256 -> 512 x 1024:
+    // 7 per chunk 488 us, all 19 at one workgroup per CU 849 us; 150 classes at 128^2 -> 512^2: 7-10 per chunk 1.72 ms,
+    // 13: 2.03, 40 (one workgroup per CU): 3.84
+    const int per_class = 3 * w + W;
+    int cc = ((per_class * 4 > 4096 ? 50 : 36) * 1024 / 4) / per_class;
+    if (cc < 1)
+        cc = BWD_LDS_FLOATS / per_class;
+    a.cc = cc > C ? C : cc;
+    if (g_upce_bwd_cc > 0)
+        a.cc = g_upce_bwd_cc > C ? C : g_upce_bwd_cc;
+    DCL_CHECK_ARG(a.cc >= 1 && (size_t)a.cc * per_class <= BWD_LDS_FLOATS, "class chunk does not fit the LDS");
+    const size_t lds_bytes = (size_t)a.cc * per_class * sizeof(float);
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)k_upce_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(k_upce_bwd, dim3((unsigned)(N * h)), dim3(256), lds_bytes, (hipStream_t)stream, a);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -400,6 +400,10 @@ int dcl_upsample_ce_fwd(const float *z, int N, int C, int h, int w, int H, int W
 int dcl_upsample_ce_bwd(const float *z, int N, int C, int h, int w, int H, int W, int align_corners,
                         const int64_t *target, const float *weight, int ignore_index, const float *lse,
                         const float *gscale, float *dz, void *stream);
+/* tuning hook: class chunk of dcl_upsample_ce_bwd (0 = automatic: as many classes as fit half a CU's LDS) */
+int dcl_upsample_ce_set_bwd_chunk(int cc);
+/* tuning hook: KiB of LDS the forward stages a class chunk in (0 = default) */
+int dcl_upsample_ce_set_fwd_lds(int kib);
 
 /* Number of column splits the sweep kernels should use for an (N1 x N2) problem so that the
  * grid fills the 256 CUs evenly (host helper, no device work). */
