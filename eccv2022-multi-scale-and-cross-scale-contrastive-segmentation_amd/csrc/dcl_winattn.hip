@@ -26,7 +26,8 @@
 namespace {
 
 constexpr int WS = 7, NT = 49, HD = 32;
-constexpr int TS = 52;                 // row stride of the transposed 49 x 49 matrices in LDS
+constexpr int TS = 49;                 // row stride of the transposed 49 x 49 matrices in LDS (odd: lane-strided reads
+                                       // of pass 3 hit distinct banks)
 
 struct WaArgs {
     const float *qkv;       // [B, H*W, 3*C]
@@ -206,24 +207,26 @@ __global__ __launch_bounds__(256) void k_winattn_fwd(WaArgs a)
     }
 }
 
-// one wave per problem as in the forward, two waves per workgroup; LDS per wave: K, V, Q (scaled), dO as [49][32] and
-// three transposed 49 x 49 matrices [j][i]: P^T, dP^T -> dS^T, and the running bias-gradient accumulator
-constexpr int BWD_LDS = 4 * NT * HD + 3 * NT * TS;
+// one wave per problem as in the forward, one wave per workgroup; LDS: K, Q (scaled) and V as [49][32] -- dO takes V's
+// place once pass 1 is through with it -- and two transposed 49 x 49 matrices [j][i]: P^T and dP^T -> dS^T. 38 KB, so
+// four workgroups share a CU (one wave per SIMD: the kernel is VALU-bound and holds ~400 VGPRs). The running
+// bias-gradient row of query i lives in lane i's registers.
+constexpr int BWD_LDS = 3 * NT * HD + 2 * NT * TS;
 
-__global__ __launch_bounds__(128) void k_winattn_bwd(WaArgs a)
+__global__ __launch_bounds__(64) void k_winattn_bwd(WaArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2][BWD_LDS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gw = blockIdx.x * 2 + wave;                     // global wave id; its head is fixed: gw % heads
-    if (gw >= a.nwaves)
-        return;
+    __shared__ __attribute__((aligned(16))) float lds[BWD_LDS];
+    const int lane = threadIdx.x;
+    const int gw = blockIdx.x;                                // global wave id; its head is fixed: gw % heads
     const int hd = gw % a.heads;
-    float *Ks = lds[wave], *Vs = Ks + NT * HD, *Qs = Vs + NT * HD, *Gs = Qs + NT * HD;
-    float *PT = Gs + NT * HD, *DT = PT + NT * TS, *DB = DT + NT * TS;
+    float *Ks = lds, *Vs = Ks + NT * HD, *Qs = Vs + NT * HD, *Gs = Vs;
+    float *PT = Qs + NT * HD, *DT = PT + NT * TS;
     const int i = lane < NT ? lane : NT - 1;
     const bool act = lane < NT;
-    for (int idx = lane; idx < NT * TS; idx += 64)
-        DB[idx] = 0.f;
+    float db[WS][WS];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+        db[j / WS][j % WS] = 0.f;
     const long long nbw = (long long)a.B * a.nW;              // (image, window) pairs, strided over the waves of a head
     const int stride = a.nwaves / a.heads;
     for (long long bw = gw / a.heads; bw < nbw; bw += stride) {
@@ -252,7 +255,6 @@ __global__ __launch_bounds__(128) void k_winattn_bwd(WaArgs a)
         __builtin_amdgcn_wave_barrier();                      // previous iteration's LDS reads are done
         load_rows(Ks, lane, tok_ptr(1));
         load_rows(Vs, lane, tok_ptr(2));
-        load_rows(Gs, lane, dout_ptr);
         float q[HD], g[HD];
         {
             const float *qp = qkv_ptr(a, b, row_i, real_i, 0, hd);
@@ -310,7 +312,11 @@ __global__ __launch_bounds__(128) void k_winattn_bwd(WaArgs a)
                 }
             }
         }
-        // pass 2: dS = P (dP - D); dQ = scale * dS K; dS^T replaces dP^T; bias gradient accumulates in LDS
+        __builtin_amdgcn_wave_barrier();                      // V is done with: dO rows take its place
+        load_rows(Gs, lane, dout_ptr);
+        // pass 2: dS = P (dP - D); dQ = scale * dS K; dS^T replaces dP^T. The bias gradient accumulates in registers:
+        // the loop over key rows stays rolled, so the 7 x 7 accumulator rotates by one row per trip (49 moves against
+        // ~1100 FMAs) and every index is a constant; seven trips bring it back into place
         float dq[HD];
 #pragma unroll
         for (int k = 0; k < HD; ++k)
@@ -321,16 +327,23 @@ __global__ __launch_bounds__(128) void k_winattn_bwd(WaArgs a)
             for (int jj = 0; jj < WS; ++jj) {
                 const int j = jb * WS + jj;
                 const float ds = PT[j * TS + i] * (DT[j * TS + i] - D);
-                if (act) {
+                if (act)
                     DT[j * TS + lane] = ds;
-                    DB[j * TS + lane] += ds;
-                }
+                db[0][jj] += ds;
 #pragma unroll
                 for (int k4 = 0; k4 < 8; ++k4) {
                     const f32x4 kv = *(const f32x4 *)(Ks + j * HD + 4 * k4);
                     dq[4 * k4 + 0] += ds * kv.x; dq[4 * k4 + 1] += ds * kv.y;
                     dq[4 * k4 + 2] += ds * kv.z; dq[4 * k4 + 3] += ds * kv.w;
                 }
+            }
+#pragma unroll
+            for (int jj = 0; jj < WS; ++jj) {
+                const float t = db[0][jj];
+#pragma unroll
+                for (int r = 0; r + 1 < WS; ++r)
+                    db[r][jj] = db[r + 1][jj];
+                db[WS - 1][jj] = t;
             }
         }
         if (act) {
@@ -376,12 +389,11 @@ __global__ __launch_bounds__(128) void k_winattn_bwd(WaArgs a)
             }
         }
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (act) {                                               // dbias_part[gw][i][j] = DB[j][i]
+    if (act) {                                               // dbias_part[gw][i][:] = lane i's accumulator
         float *dst = a.dbias_part + ((size_t)gw * NT + lane) * NT;
+#pragma unroll
         for (int j = 0; j < NT; ++j)
-            dst[j] = DB[j * TS + lane];
+            dst[j] = db[j / WS][j % WS];
     }
 }
 
@@ -448,7 +460,7 @@ extern "C" int dcl_winattn_bwd(const float *qkv, const float *qkv_bias, const fl
     a.qkv = qkv; a.qkv_bias = qkv_bias; a.bias = bias; a.lse = const_cast<float *>(lse); a.dout = dout;
     a.dqkv = dqkv; a.dpad = dpad; a.dbias_part = dbias_part;
     a.nwaves = dcl_winattn_bwd_waves(B, H, W, heads);
-    hipLaunchKernelGGL(k_winattn_bwd, dim3((unsigned)((a.nwaves + 1) / 2)), dim3(128), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_winattn_bwd, dim3((unsigned)a.nwaves), dim3(64), 0, (hipStream_t)stream, a);
     DCL_LAUNCH_CHECK();
     return 0;
 }
