@@ -822,8 +822,11 @@ static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *
         P = stride == 2 ? 1 : 4;
         while (P > 1 && wgs(R, P) < 192)
             P >>= 1;
-        if (R == 2 && P == 4 && stride == 1 && !a.phases)
-            P = 2;              // the (2, 2) tile runs two workgroups per CU (k_conv3x3_o2): 81 vs 100 us at 48 channels
+        if (R == 2 && P == 4 && stride == 1 && !a.phases && a.nchunk <= 4)
+            P = 2;              // the (2, 2) tile runs two workgroups per CU (k_conv3x3_o2): 81 vs 100 us at 48 channels;
+                                // a short K loop is mostly prologue / epilogue, which two co-resident workgroups
+                                // hide.  With a long one (the 512-channel decoder convolutions of UPerNet) the (2, 4)
+                                // tile's reuse of the weight fragments wins: 415 vs 386 TFLOP/s
         if (P == 1 && wgs(R, P) < 128)
             R = 1;
     }
