@@ -477,12 +477,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = world > 1 and os.environ.get("DCL_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        # dress rehearsal of the N-rank launch on a box with ONE GPU: every rank on cuda:0, gloo instead of RCCL (which
+        # refuses two ranks on one device).  Exercises the launch contract, DDP, SyncBN and the max-over-ranks timing;
+        # the number it prints is not a measurement.
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         # one host core per rank is what the launch loop needs; leave the rest to the other ranks
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     workload = args.workload or "step"
