@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..utils import printlog
+from .ops import TokenLinear
 
 _COMMON = dict(window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
                drop_path_rate=0.3, ape=False, patch_norm=True, out_indices=[0, 1, 2, 3], pretrained=True)
@@ -62,9 +63,9 @@ class DropPath(nn.Module):
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
         super().__init__()
-        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc1 = TokenLinear(in_features, hidden_features or in_features)
         self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.fc2 = TokenLinear(hidden_features or in_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
@@ -98,9 +99,9 @@ class WindowAttention(nn.Module):
         rel[:, :, 1] += ww - 1
         rel[:, :, 0] *= 2 * ww - 1
         self.register_buffer("relative_position_index", rel.sum(-1))
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.qkv = TokenLinear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = TokenLinear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
         self.softmax = nn.Softmax(dim=-1)
@@ -185,7 +186,7 @@ class PatchMerging(nn.Module):
     def __init__(self, dim, norm_layer=nn.LayerNorm):
         super().__init__()
         self.dim = dim
-        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.reduction = TokenLinear(4 * dim, 2 * dim, bias=False)
         self.norm = norm_layer(4 * dim)
 
     def forward(self, x, H, W):

@@ -591,6 +591,64 @@ def use_gemm_conv1x1(module: torch.nn.Module) -> torch.nn.Module:
     return module
 
 
+# ---- token-major Linear (Swin: models/Swin.py qkv / proj / fc1 / fc2 / reduction) --------------------------------------
+
+def _token_slabs(m):
+    """Slabs of ~1024 tokens for the weight gradient of a token-major Linear; 0 = leave it to the library."""
+    if m < 32768:
+        return 0
+    for s in (256, 128, 64, 32, 16):
+        if m % s == 0 and m // s >= 1024:
+            return s
+    return 0
+
+
+class _TokenLinear(torch.autograd.Function):
+    """y = x W^T + b on [tokens, K] rows.  Forward and data gradient are the library's GEMMs; the weight gradient
+    dW = dY^T X reduces over 10^4..10^5 tokens into a tiny [N, K] output, a shape the library's fp32 kernels run at
+    10-40 TFLOP/s (one macro tile per output tile, the whole token axis serial: 450-1030 us where HBM allows 45-110,
+    tools/probes/linear_wgrad_split.py).  Here the token axis is cut into slabs of ~1024 rows, one batched GEMM
+    computes a partial dW per slab and a fixed-order sum adds them: 3-5x faster, deterministic."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        n, k = weight.shape
+        gy2 = gy.reshape(-1, n)
+        x2 = x.reshape(-1, k)
+        m = x2.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gy2.mm(weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            s = _token_slabs(m)
+            if s and gy2.is_contiguous() and x2.is_contiguous():
+                gw = torch.bmm(gy2.view(s, m // s, n).transpose(1, 2), x2.view(s, m // s, k)).sum(0)
+            else:
+                gw = gy2.t().mm(x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy2.sum(0)
+        return gx, gw, gb
+
+
+class TokenLinear(torch.nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose backward computes the weight gradient slab-wise
+    (_TokenLinear) for fp32 CUDA inputs with >= 32768 rows in training; anything else is nn.Linear.forward."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and self.weight.requires_grad
+                and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+                and _token_slabs(x.numel() // x.shape[-1])):
+            return _TokenLinear.apply(x, self.weight, self.bias)
+        return super().forward(x)
+
+
 # ---- Swin window attention (csrc/dcl_winattn.hip) -----------------------------------------------------------------
 
 class _WindowAttention(torch.autograd.Function):
