@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..utils import printlog
-from .ops import TokenLinear
+from .ops import FusedLayerNorm, TokenLinear
 
 _COMMON = dict(window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
                drop_path_rate=0.3, ape=False, patch_norm=True, out_indices=[0, 1, 2, 3], pretrained=True)
@@ -125,7 +125,7 @@ class WindowAttention(nn.Module):
 
 class SwinTransformerBlock(nn.Module):
     def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
-                 drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+                 drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=FusedLayerNorm):
         super().__init__()
         assert 0 <= shift_size < window_size, "shift_size must in 0-window_size"
         self.dim, self.num_heads, self.window_size, self.shift_size = dim, num_heads, window_size, shift_size
@@ -183,7 +183,7 @@ class SwinTransformerBlock(nn.Module):
 
 
 class PatchMerging(nn.Module):
-    def __init__(self, dim, norm_layer=nn.LayerNorm):
+    def __init__(self, dim, norm_layer=FusedLayerNorm):
         super().__init__()
         self.dim = dim
         self.reduction = TokenLinear(4 * dim, 2 * dim, bias=False)
@@ -201,7 +201,7 @@ class PatchMerging(nn.Module):
 
 class BasicLayer(nn.Module):
     def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0.,
-                 attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False):
+                 attn_drop=0., drop_path=0., norm_layer=FusedLayerNorm, downsample=None, use_checkpoint=False):
         super().__init__()
         self.window_size, self.shift_size, self.depth = window_size, window_size // 2, depth
         self.use_checkpoint = use_checkpoint
@@ -270,7 +270,7 @@ class PatchEmbed(nn.Module):
 class SwinTransformer(nn.Module):
     def __init__(self, pretrain_img_size=224, patch_size=4, in_chans=3, embed_dim=96, depths=[2, 2, 6, 2],
                  num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0.,
-                 attn_drop_rate=0., drop_path_rate=0.2, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 attn_drop_rate=0., drop_path_rate=0.2, norm_layer=FusedLayerNorm, ape=False, patch_norm=True,
                  out_indices=(0, 1, 2, 3), frozen_stages=-1, use_checkpoint=False, pretrained=True, name='swinT',
                  **kwargs):
         super().__init__()

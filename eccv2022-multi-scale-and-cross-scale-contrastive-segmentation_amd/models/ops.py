@@ -649,6 +649,54 @@ class TokenLinear(torch.nn.Linear):
         return super().forward(x)
 
 
+# ---- LayerNorm over token-major rows (csrc/dcl_layernorm.hip) -----------------------------------------------------
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        from .. import _lib
+        c = x.shape[-1]
+        m = x.numel() // c
+        y = torch.empty_like(x)
+        stats = torch.empty((2, m), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().dcl_layernorm_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, float(eps),
+                                                _lib.ptr(y), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _stream(x)),
+                   "dcl_layernorm_fwd")
+        ctx.save_for_backward(x, weight, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import _lib
+        x, weight, stats = ctx.saved_tensors
+        c = x.shape[-1]
+        m = x.numel() // c
+        gy = gy.contiguous()
+        L = _lib.lib()
+        gx = torch.empty_like(x)
+        parts = torch.empty((L.dcl_layernorm_bwd_parts(m, c), 2, c), dtype=torch.float32, device=x.device)
+        gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        _lib.check(L.dcl_layernorm_bwd(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(weight), _lib.ptr(stats[0]),
+                                       _lib.ptr(stats[1]), m, c, _lib.ptr(gx), _lib.ptr(parts), _lib.ptr(gwb),
+                                       _stream(x)), "dcl_layernorm_bwd")
+        return gx, gwb[0], gwb[1], None
+
+
+class FusedLayerNorm(torch.nn.LayerNorm):
+    """nn.LayerNorm over the last axis (same parameters / state_dict keys) on the HIP kernels of
+    csrc/dcl_layernorm.hip for contiguous fp32 CUDA rows of a supported length; anything else (CPU, autocast,
+    no affine, several normalised axes) is nn.LayerNorm.forward."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and len(self.normalized_shape) == 1 and self.weight is not None
+                and self.bias is not None and self.weight.dtype == torch.float32 and x.is_contiguous()
+                and not torch.is_autocast_enabled() and x.numel() > 0):
+            from .. import _lib
+            if _lib.lib().dcl_layernorm_supported(x.shape[-1]):
+                return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
 # ---- Swin window attention (csrc/dcl_winattn.hip) -----------------------------------------------------------------
 
 class _WindowAttention(torch.autograd.Function):

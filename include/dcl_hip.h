@@ -384,6 +384,21 @@ int dcl_winattn_bwd(const float *qkv, const float *qkv_bias, const float *bias, 
                     int B, int H, int W, int C, int heads, int shift, float scale, float *dqkv, float *dpad,
                     float *dbias_part, void *stream);
 
+/* ---- LayerNorm over the channel axis of token-major rows (the Swin backbone) --------
+ * Replaces nn.LayerNorm and its autograd in the Swin port (reference models/Swin.py:251-332 norm1 / norm2, :357-362
+ * PatchMerging.norm, :452-455 PatchEmbed.norm, :560-565 the per-stage output norms); csrc/dcl_layernorm.hip.
+ *   x, y, gy, gx f32 [M, C]      gamma, beta f32 [C]      mean, rstd f32 [M] (forward outputs, backward inputs)
+ *   supported row lengths: C = 4 V G with G a power of two in 8 .. 64 and V in {1, 2, 3, 4, 6, 8}
+ *   (dcl_layernorm_supported; Swin: 96 .. 1536)
+ * backward: parts f32 [dcl_layernorm_bwd_parts(M, C), 2, C] is workspace (one partial {dgamma, dbeta} row per
+ * workgroup); dgamma_dbeta f32 [2, C] receives their fixed-order sums (deterministic). */
+int dcl_layernorm_supported(int C);
+int dcl_layernorm_bwd_parts(long long M, int C);
+int dcl_layernorm_fwd(const float *x, const float *gamma, const float *beta, long long M, int C, float eps, float *y,
+                      float *mean, float *rstd, void *stream);
+int dcl_layernorm_bwd(const float *gy, const float *x, const float *gamma, const float *mean, const float *rstd,
+                      long long M, int C, float *gx, float *parts, float *dgamma_dbeta, void *stream);
+
 /* ---- fused bilinear up-sampling + class-weighted cross-entropy --------------------
  * loss = CrossEntropyLoss(weight, ignore_index)(F.interpolate(z, (H, W), 'bilinear', align_corners), target) without
  * materialising the up-sampled logits (reference models/HRNet.py:638 + losses/LossWrapper.py:26-30, :82); PyTorch's

@@ -163,3 +163,55 @@ def test_token_linear_slab_weight_gradient(M, K, N, bias):
     # below the row threshold and without grad it is nn.Linear itself
     small = torch.randn(8, 49, K, device=dev)
     assert torch.equal(lin(small), ref(small))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C", [(4 * 3137, 96), (2 * 1031, 192), (777, 384), (130, 768), (65, 1536), (50, 32), (9, 2048)])
+def test_fused_layernorm_matches_fp64(M, C):
+    """FusedLayerNorm (csrc/dcl_layernorm.hip; the Swin port's norm layers, reference Swin.py:251-332, :357-362,
+    :452-455, :560-565) against nn.LayerNorm in fp64: forward and all three gradients at ragged row counts, and at
+    least as close as ATen's fp32 kernels; unsupported row lengths fall through to nn.LayerNorm."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models.ops import FusedLayerNorm
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    ln = FusedLayerNorm(C).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        ln.bias.copy_(torch.randn(C, generator=g))
+    ref32 = torch.nn.LayerNorm(C).to(dev)
+    ref32.load_state_dict(ln.state_dict())
+    ref64 = torch.nn.LayerNorm(C).to(dev).double()
+    ref64.load_state_dict(ln.state_dict())
+    x = (torch.randn(M, C, generator=g) * 2.0 + 3.0).to(dev)
+    gy = torch.randn(M, C, generator=g).to(dev)
+    res = []
+    for mod, dt in ((ln, torch.float32), (ref32, torch.float32), (ref64, torch.float64)):
+        xi = x.detach().clone().to(dt).requires_grad_(True)
+        y = mod(xi)
+        y.backward(gy.to(dt))
+        res.append([t.double() for t in (y.detach(), xi.grad, mod.weight.grad, mod.bias.grad)])
+    for k, name in enumerate(("y", "dx", "dweight", "dbias")):
+        den = res[2][k].abs().max()
+        e_hip = ((res[0][k] - res[2][k]).abs().max() / den).item()
+        e_lib = ((res[1][k] - res[2][k]).abs().max() / den).item()
+        assert e_hip < 3e-6 and e_hip <= 3 * e_lib + 1e-7, (name, e_hip, e_lib)
+    # determinism of the partial-row reduction
+    xi = x.clone().requires_grad_(True)
+    ln.weight.grad = None
+    ln(xi).backward(gy)
+    assert torch.equal(ln.weight.grad.double(), res[0][2])
+    assert list(ln.state_dict().keys()) == list(ref32.state_dict().keys())
+
+
+@pytest.mark.gpu
+def test_fused_layernorm_fallbacks():
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models.ops import FusedLayerNorm
+    dev = torch.device("cuda:0")
+    ln = FusedLayerNorm(100).to(dev)            # 25 vectors: no (V, G) plan
+    x = torch.randn(7, 100, device=dev)
+    assert torch.equal(ln(x), F.layer_norm(x, (100,), ln.weight, ln.bias, ln.eps))
+    ln = FusedLayerNorm(96).to(dev)
+    xt = torch.randn(96, 64, device=dev).t()    # not contiguous
+    assert torch.equal(ln(xt), F.layer_norm(xt, (96,), ln.weight, ln.bias, ln.eps))
