@@ -16,6 +16,8 @@
 //             every low-res column gathers its x-footprint.  The upstream gradient and 1 / sum w are a device scalar.
 // Classes are processed in chunks that fit LDS (19 Cityscapes classes: one chunk; 150 ADE20K classes: several).
 // HBM-bound: reads z (30 MB), labels and lse; writes lse / prediction / dz.
+#include <type_traits>
+
 #include "dcl_common.h"
 
 namespace {
@@ -76,6 +78,19 @@ Axis make_axis(int in_size, int out_size, int align)
     return a;
 }
 
+// exp(t) = 2^(t log2 e) on v_exp_f32 (1 ulp) with the rounding error of the product folded back in: 7 instructions
+// against ~13 for expf, ~1e-7 relative.  t is clamped at -104 (the result is below the smallest denormal either way; a
+// comparison, so that NaN stays NaN), which also turns exp(-inf) into a plain 0 without the inf - inf of the remainder.
+__device__ __forceinline__ float exp_fast(float t)
+{
+    t = t < -104.f ? -104.f : t;
+    const float p = t * 1.44269502f;
+    float e = fmaf(t, 1.44269502f, -p);
+    e = fmaf(t, 1.92596299e-8f, e);
+    const float r = __builtin_amdgcn_exp2f(p);
+    return fmaf(r, e * 0.693147182f, r);
+}
+
 struct UpceArgs {
     const float *z;             // [N, C, h, w]
     const long long *target;    // [N, H, W]
@@ -125,25 +140,44 @@ __global__ __launch_bounds__(256) void k_upce_fwd(UpceArgs a)
         for (int c0 = 0; c0 < a.C; c0 += a.cc) {
             const int nc = min(a.cc, a.C - c0);
             __syncthreads();
-            for (int i = threadIdx.x; i < nc * 2 * a.w; i += 256) {      // stage rows y0, y1 of classes c0 .. c0 + nc
-                const int c = i / (2 * a.w), r = (i / a.w) & 1, x = i % a.w;
-                zs[i] = a.z[((size_t)n * a.C + c0 + c) * plane + (size_t)(r ? y1 : y0) * a.w + x];
+            // stage rows y0, y1 of classes c0 .. c0 + nc: one (class, row) per wave and trip, lanes along the row (no
+            // index divisions: they cost as much as the interpolation of a pixel)
+            for (int cr = threadIdx.x >> 6; cr < nc * 2; cr += 4) {
+                const float *src = a.z + ((size_t)n * a.C + c0 + (cr >> 1)) * plane + (size_t)((cr & 1) ? y1 : y0) * a.w;
+                for (int x = threadIdx.x & 63; x < a.w; x += 64)
+                    zs[cr * a.w + x] = src[x];
             }
             __syncthreads();
-            for (int c = 0; c < nc; ++c) {
-                const float *r0 = zs + (c * 2) * a.w, *r1 = r0 + a.w;
+            // four classes per trip: their 16 LDS gathers are in flight together, one rescale of the running sum per
+            // block (5 exponentials for 4 classes instead of 8), arg-max and target pick in class order, branch-free
+            for (int c = 0; c < nc; c += 4) {
+                float v[4][PIX];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cu = min(c + u, nc - 1);
+                    const float *r0 = zs + (cu * 2) * a.w, *r1 = r0 + a.w;
+#pragma unroll
+                    for (int k = 0; k < PIX; ++k) {
+                        const float t = ly0 * (lx0[k] * r0[x0[k]] + lx1[k] * r0[x1[k]]) +
+                                        ly1 * (lx0[k] * r1[x0[k]] + lx1[k] * r1[x1[k]]);
+                        v[u][k] = c + u < nc ? t : -INFINITY;
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < PIX; ++k) {
-                    const float v = ly0 * (lx0[k] * r0[x0[k]] + lx1[k] * r0[x1[k]]) +
-                                    ly1 * (lx0[k] * r1[x0[k]] + lx1[k] * r1[x1[k]]);
-                    const float mn = fmaxf(m[k], v);
-                    l[k] = l[k] * expf(m[k] - mn) + expf(v - mn);
+                    const float mn = fmaxf(m[k], fmaxf(fmaxf(v[0][k], v[1][k]), fmaxf(v[2][k], v[3][k])));
+                    l[k] = l[k] * exp_fast(m[k] - mn) + ((exp_fast(v[0][k] - mn) + exp_fast(v[1][k] - mn)) +
+                                                         (exp_fast(v[2][k] - mn) + exp_fast(v[3][k] - mn)));
                     m[k] = mn;
-                    if (c0 + c == tgt[k])
-                        vt[k] = v;
-                    const bool take = (v > best[k]) || (v != v && best[k] == best[k]);     // torch.argmax rule
-                    best[k] = take ? v : best[k];
-                    arg[k] = take ? c0 + c : arg[k];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float vv = v[u][k];
+                        vt[k] = ((c + u < nc) & (c0 + c + u == tgt[k])) ? vv : vt[k];
+                        // torch.argmax rule: the first maximum; a NaN beats everything that is not NaN
+                        const bool take = (vv > best[k]) | ((vv != vv) & (best[k] == best[k]));
+                        best[k] = take ? vv : best[k];
+                        arg[k] = take ? c0 + c + u : arg[k];
+                    }
                 }
             }
         }
@@ -202,6 +236,7 @@ __global__ __launch_bounds__(256) void k_upce_finish(const float *__restrict__ p
     }
 }
 
+constexpr int BWD_MAX_ROWS = 80;           // output rows in the footprint of a low-res row: scale factors up to ~36
 constexpr int BWD_LDS_FLOATS = 36864;       // 144 KiB: 3 staged low-res rows + the [classes][W] tile of a class chunk
 
 __global__ __launch_bounds__(256) void k_upce_bwd(UpceArgs a)
@@ -216,57 +251,115 @@ __global__ __launch_bounds__(256) void k_upce_bwd(UpceArgs a)
     out_range(a.ay, iy, a.h, a.H, oy_lo, oy_hi);
     const float gs = a.gscale[0];
     const int ya = max(iy - 1, 0);                  // staged rows ya .. ya + 2 (clamped to the image)
-    for (int c0 = 0; c0 < a.C; c0 += a.cc) {
+    // per output row of the footprint: {wy, weights of the three staged rows in its interpolation, times log2 e} --
+    // wave-uniform values the compiler would otherwise recompute on the vector ALU for every class block
+    __shared__ __attribute__((aligned(16))) float rowtab[BWD_MAX_ROWS][4];
+    for (int j = threadIdx.x; j <= oy_hi - oy_lo; j += 256) {
+        const int oy = oy_lo + j;
+        int y0, y1;
+        float ly0, ly1;
+        src_index(a.ay, oy, a.h, y0, y1, ly0, ly1);
+        const int r0 = y0 - ya, r1 = y1 - ya;        // both in 0 .. 2 for a row with a non-zero weight
+        rowtab[j][0] = axis_weight(a.ay, oy, a.h, iy);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            rowtab[j][1 + r] = ((r0 == r ? ly0 : 0.f) + (r1 == r ? ly1 : 0.f)) * 1.44269502f;
+    }
+    {                                               // one class chunk per workgroup (blockIdx.y)
+        const int c0 = blockIdx.y * a.cc;
         const int nc = min(a.cc, a.C - c0);
         float *zr = lds;                            // [nc][3][w]
         float *tile = lds + nc * 3 * a.w;           // [nc][W]
         __syncthreads();
-        for (int i = threadIdx.x; i < nc * 3 * a.w; i += 256) {
-            const int c = i / (3 * a.w), r = (i / a.w) % 3, x = i % a.w;
-            zr[i] = a.z[((size_t)n * a.C + c0 + c) * plane + (size_t)min(ya + r, a.h - 1) * a.w + x];
-        }
+        for (int c = threadIdx.x >> 6; c < nc; c += 4)             // one class per wave and trip, lanes along the rows
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float *src = a.z + ((size_t)n * a.C + c0 + c) * plane + (size_t)min(ya + r, a.h - 1) * a.w;
+                for (int x = threadIdx.x & 63; x < a.w; x += 64)
+                    zr[(c * 3 + r) * a.w + x] = src[x];
+            }
         __syncthreads();
-        // vertical pass: tile[c][ox] = sum_oy wy(oy -> iy) * w_t (softmax_c - [c = t])
+        // vertical pass: tile[c][ox] = sum_oy wy(oy -> iy) * w_t (softmax_c - [c = t]).  Eight (tail: four) classes at a time: their
+        // three staged rows are interpolated horizontally ONCE per column (6 LDS gathers per class and column instead of
+        // 4 per class and output pixel); an output row then costs three FMAs with wave-uniform row weights per class,
+        // one exponential, and the sums stay in registers until the block is done.
         for (int ox = threadIdx.x; ox < a.W; ox += 256) {
             int x0, x1;
             float lx0, lx1;
             src_index(a.ax, ox, a.w, x0, x1, lx0, lx1);
-            for (int c = 0; c < nc; ++c)
-                tile[c * a.W + ox] = 0.f;
-            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-                const float wy = axis_weight(a.ay, oy, a.h, iy);
-                if (wy == 0.f)
-                    continue;
-                const size_t p = ((size_t)n * a.H + oy) * a.W + ox;
-                const long long t = a.target[p];
-                if (t == a.ignore || t < 0 || t >= a.C)
-                    continue;
-                const float coef = wy * (a.weight ? a.weight[t] : 1.f) * gs;
-                const float lse = a.lse[p];
-                int y0, y1;
-                float ly0, ly1;
-                src_index(a.ay, oy, a.h, y0, y1, ly0, ly1);
-                const int r0 = y0 - ya, r1 = y1 - ya;           // both in 0 .. 2
-                for (int c = 0; c < nc; ++c) {
-                    const float *b0 = zr + (c * 3 + r0) * a.w, *b1 = zr + (c * 3 + r1) * a.w;
-                    const float v = ly0 * (lx0 * b0[x0] + lx1 * b0[x1]) + ly1 * (lx0 * b1[x0] + lx1 * b1[x1]);
-                    float g = expf(v - lse);
-                    if (c0 + c == (int)t)
-                        g -= 1.f;
-                    tile[c * a.W + ox] += coef * g;
+            auto block = [&](auto ubt, const int cb) {
+                constexpr int UB = decltype(ubt)::value;
+                float hl[UB][3], acc[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int cu = min(cb + u, nc - 1);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float *b = zr + (cu * 3 + r) * a.w;
+                        hl[u][r] = lx0 * b[x0] + lx1 * b[x1];
+                    }
+                    acc[u] = 0.f;
                 }
-            }
+                for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                    const f32x4 rt = *(const f32x4 *)rowtab[oy - oy_lo];
+                    if (rt.x == 0.f)                             // uniform
+                        continue;
+                    const size_t p = ((size_t)n * a.H + oy) * a.W + ox;
+                    const long long t = a.target[p];
+                    const bool valid = t != a.ignore && t >= 0 && t < a.C;
+                    const int ti = valid ? (int)t : -1;
+                    const float coef = valid ? rt.x * (a.weight ? a.weight[ti] : 1.f) * gs : 0.f;
+                    const float lse2 = a.lse[p] * 1.44269502f;
+                    // softmax_c = 2^((v - lse) log2 e), v <= lse: plain v_exp_f32 -- the rounding of the scaled argument
+                    // moves a probability by at most |t| e^t 6e-8 <= 2.2e-8 absolute
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const float v2 = rt.y * hl[u][0] + rt.z * hl[u][1] + rt.w * hl[u][2];
+                        const float g = __builtin_amdgcn_exp2f(v2 - lse2) - (c0 + cb + u == ti ? 1.f : 0.f);
+                        acc[u] += coef * g;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (cb + u < nc)
+                        tile[(cb + u) * a.W + ox] = acc[u];
+            };
+            int cb = 0;
+            for (; nc - cb > 4; cb += 8)
+                block(std::integral_constant<int, 8>{}, cb);
+            if (cb < nc)
+                block(std::integral_constant<int, 4>{}, cb);
         }
         __syncthreads();
         // horizontal pass: dz[n, c, iy, ix] = sum_ox wx(ox -> ix) * tile[c][ox]
-        for (int i = threadIdx.x; i < nc * a.w; i += 256) {
-            const int c = i / a.w, ix = i % a.w;
+        // (lanes along the low-res row, classes over the waves: the footprint and its <= 12 weights are computed once per
+        // column and serve every class of the chunk; wider footprints -- scale factors above 4 -- recompute them)
+        for (int ix = threadIdx.x & 63; ix < a.w; ix += 64) {
             int ox_lo, ox_hi;
             out_range(a.ax, ix, a.w, a.W, ox_lo, ox_hi);
-            float acc = 0.f;
-            for (int ox = ox_lo; ox <= ox_hi; ++ox)
-                acc += axis_weight(a.ax, ox, a.w, ix) * tile[c * a.W + ox];
-            a.dz[((size_t)n * a.C + c0 + c) * plane + (size_t)iy * a.w + ix] = acc;
+            const int cnt = ox_hi - ox_lo + 1;
+            float *dst = a.dz + ((size_t)n * a.C + c0) * plane + (size_t)iy * a.w + ix;
+            if (cnt <= 12) {
+                float wx[12];
+#pragma unroll
+                for (int j = 0; j < 12; ++j)
+                    wx[j] = j < cnt ? axis_weight(a.ax, ox_lo + j, a.w, ix) : 0.f;
+                for (int c = threadIdx.x >> 6; c < nc; c += 4) {
+                    const float *tr = tile + c * a.W + ox_lo;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 12; ++j)
+                        acc += wx[j] * tr[j < cnt ? j : 0];
+                    dst[(size_t)c * plane] = acc;
+                }
+            } else {
+                for (int c = threadIdx.x >> 6; c < nc; c += 4) {
+                    float acc = 0.f;
+                    for (int ox = ox_lo; ox <= ox_hi; ++ox)
+                        acc += axis_weight(a.ax, ox, a.w, ix) * tile[c * a.W + ox];
+                    dst[(size_t)c * plane] = acc;
+                }
+            }
         }
     }
 }
@@ -325,18 +418,20 @@ extern "C" int dcl_upsample_ce_bwd(const float *z, int N, int C, int h, int w, i
     DCL_CHECK_ARG(z && target && lse && gscale && dz, "null pointer");
     DCL_CHECK_ARG(N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H >= h && W >= w, "bad shape");
     DCL_CHECK_ARG(3 * w + W <= BWD_LDS_FLOATS, "rows too wide for the LDS tile");
+    DCL_CHECK_ARG(2 * ((H + h - 1) / h) + 8 <= BWD_MAX_ROWS, "vertical scale factor above 36");
     UpceArgs a = {};
     a.z = z; a.target = (const long long *)target; a.weight = weight; a.lse = const_cast<float *>(lse);
     a.gscale = gscale; a.dz = dz;
     a.N = N; a.C = C; a.h = h; a.w = w; a.H = H; a.W = W; a.ignore = ignore_index;
     a.ay = make_axis(h, H, align_corners);
     a.ax = make_axis(w, W, align_corners);
-    // class chunk: sized for 3-4 workgroups per CU, measured (tools/upce_time.py): 19 classes at 128 x 256 -> 512 x 1024:
-    // 7 per chunk 488 us, all 19 at one workgroup per CU 849 us; 150 classes at 128^2 -> 512^2: 7-10 per chunk 1.72 ms,
-    // 13: 2.03, 40 (one workgroup per CU): 3.84
+    // class chunk = classes per workgroup (grid.y walks the chunks): one register block of eight classes when that fits
+    // 36 KiB of LDS (3-4 workgroups per CU), else one of four; measured (tools/probes/upce_chunk_sweep.sh): 150 classes
+    // at 128^2 -> 512^2: 8 per chunk 817 us, 4: 1293, 12: 1251, 16: 1453; at 32^2 -> 512^2: 8: 534, 4: 898, 16: 604;
+    // 19 classes at 128 x 256 -> 512 x 1024 (7 KiB per class): 4 per chunk 280 us, 7: 293, 8: 380
     const int per_class = 3 * w + W;
-    int cc = ((per_class * 4 > 4096 ? 50 : 36) * 1024 / 4) / per_class;
-    if (cc < 1)
+    int cc = 8 * per_class * 4 <= 36 * 1024 ? 8 : 4;
+    if ((size_t)cc * per_class > BWD_LDS_FLOATS)
         cc = BWD_LDS_FLOATS / per_class;
     a.cc = cc > C ? C : cc;
     if (g_upce_bwd_cc > 0)
@@ -345,7 +440,8 @@ extern "C" int dcl_upsample_ce_bwd(const float *z, int N, int C, int h, int w, i
     const size_t lds_bytes = (size_t)a.cc * per_class * sizeof(float);
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)k_upce_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(k_upce_bwd, dim3((unsigned)(N * h)), dim3(256), lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_upce_bwd, dim3((unsigned)(N * h), (unsigned)((C + a.cc - 1) / a.cc)), dim3(256), lds_bytes,
+                       (hipStream_t)stream, a);
     DCL_LAUNCH_CHECK();
     return 0;
 }

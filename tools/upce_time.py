@@ -7,7 +7,8 @@ import mscs_amd  # noqa
 from mscs_amd.models.ops import UpsampledLogits
 from per_shape_roofline import timeit
 dev = torch.device("cuda:0")
-for (n, C, h, w, H, W, al) in [(12, 19, 128, 256, 512, 1024, True), (16, 150, 128, 128, 512, 512, False)]:
+for (n, C, h, w, H, W, al) in [(12, 19, 128, 256, 512, 1024, True), (16, 150, 128, 128, 512, 512, False),
+                              (16, 150, 32, 32, 512, 512, False)]:
     z = torch.randn(n, C, h, w, device=dev, requires_grad=True)
     t = torch.randint(0, C + 1, (n, H, W), device=dev)
     def fwd():
