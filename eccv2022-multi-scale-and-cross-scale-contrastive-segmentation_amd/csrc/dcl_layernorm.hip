@@ -165,20 +165,36 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float *__restrict__ gy, co
     }
 }
 
-// dgamma | dbeta [2][C] = fixed-order sum of the partial rows
+// dgamma | dbeta [2][C] = fixed-order sum of the partial rows: 16 columns x 16 row groups per workgroup (a thread adds
+// every 16th partial row, four independent chains; the groups meet in LDS) -- 3 workgroups walking 256 rows each took
+// 63 us per call
 __global__ __launch_bounds__(256) void k_ln_parts_sum(const float *__restrict__ parts, int nparts, int C2,
                                                       float *__restrict__ out)
 {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    float s = 0.f;
-    if (col < C2)
-        for (int p = q; p < nparts; p += 4)
-            s += parts[(size_t)p * C2 + col];
-    red[q][threadIdx.x & 63] = s;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < C2) {
+        int p = rg;
+        for (; p + 48 < nparts; p += 64) {
+            s0 += parts[(size_t)p * C2 + col];
+            s1 += parts[(size_t)(p + 16) * C2 + col];
+            s2 += parts[(size_t)(p + 32) * C2 + col];
+            s3 += parts[(size_t)(p + 48) * C2 + col];
+        }
+        for (; p < nparts; p += 16)
+            s0 += parts[(size_t)p * C2 + col];
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (q == 0 && col < C2)
-        out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rg == 0 && col < C2) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+            s += red[g][cl];
+        out[col] = s;
+    }
 }
 
 // C = 4 V G with G a power of two in 8 .. 64: the smallest V in {1, 2, 3, 4, 6, 8} that fits
@@ -280,7 +296,7 @@ extern "C" int dcl_layernorm_bwd(const float *gy, const float *x, const float *g
     const unsigned blocks = (unsigned)ln_blocks(M, G);
     DCL_LN_DISPATCH(k_ln_bwd, gy, x, gamma, mean, rstd, M, gx, parts);
     DCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ln_parts_sum, dim3((2 * C + 63) / 64), dim3(256), 0, s, parts, (int)blocks, 2 * C,
+    hipLaunchKernelGGL(k_ln_parts_sum, dim3((2 * C + 15) / 16), dim3(256), 0, s, parts, (int)blocks, 2 * C,
                        dgamma_dbeta);
     DCL_LAUNCH_CHECK();
     return 0;
