@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output for profiles/: per-kernel stats of ONE steady-state step of bench.py
-(delimited by consecutive k_label_hist launches) and PMC FETCH/WRITE averages per kernel.
+(delimited by the metrics kernel that closes a step on the main stream; runs without the metrics tail: by the
+label-stage launches) and PMC FETCH/WRITE averages per kernel.
 
-    python tools/summarize_profile.py trace <kernel_trace.csv> <scales> [step_index]
+    python tools/summarize_profile.py trace <kernel_trace.csv> <label-stage launches per step | steps=N> [step_index]
     python tools/summarize_profile.py pmc <counter_collection.csv>
 """
 import collections
@@ -15,7 +16,16 @@ def trace(path, scales=3, step=3):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_label_hist")]
-    s, e = idx[step * scales], idx[(step + 1) * scales]
+    if isinstance(scales, str) and scales.startswith("steps="):
+        # label-stage launches per step = all of them / the number of steps the traced command ran (warm-up included)
+        scales = len(idx) // int(scales[6:])
+    cm = [i for i, r in enumerate(rows) if "k_confusion_pred" in r["Kernel_Name"]]
+    if len(cm) > step + 1:
+        # the metrics tail closes a step on the MAIN stream (the label stage runs ahead on its own stream, so windows
+        # between label-stage launches follow the host's timeline, not the GPU's): step = (tail of step - 1, tail of step]
+        s, e = cm[step - 1] + 1, cm[step] + 1
+    else:
+        s, e = idx[step * scales], idx[(step + 1) * scales]
     sel = rows[s:e]
     t0, t1 = int(sel[0]["Start_Timestamp"]), int(rows[e]["Start_Timestamp"])
     agg = collections.defaultdict(lambda: [0, 0])
@@ -75,6 +85,7 @@ def pmc(path):
 
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
-        trace(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 3, int(sys.argv[4]) if len(sys.argv) > 4 else 3)
+        sc = sys.argv[3] if len(sys.argv) > 3 else "3"
+        trace(sys.argv[2], sc if sc.startswith("steps=") else int(sc), int(sys.argv[4]) if len(sys.argv) > 4 else 3)
     else:
         pmc(sys.argv[2])
