@@ -1,5 +1,7 @@
 """Operator-level replacements inside the models where the library's default kernel is far from the
 hardware roofline on MI355X (measured, see profiles/)."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -591,6 +593,24 @@ def use_gemm_conv1x1(module: torch.nn.Module) -> torch.nn.Module:
     return module
 
 
+# ---- token-major GEMM on the f16 matrix pipe (csrc/dcl_tokgemm.hip) ---------------------------------------------------
+
+def tok_gemm(x2, wp, n, xamax, wamax, bias=None, emit_amax=False):
+    """y [M, n] = x2 [M, K] W^T (+ bias) with W given as packed fragments (conv3x3_pack of W.view(n, K, 1, 1), or of its
+    transpose for the data gradient); ``emit_amax``: tag y with the partial maxima the epilogue collects."""
+    from .. import _lib
+    from . import amax as _amax
+    m, k = x2.shape
+    y = torch.empty((m, n), dtype=torch.float32, device=x2.device)
+    ybuf = _amax.zeros(_amax.SLOTS, x2.device) if emit_amax else None
+    _lib.check(_lib.lib().dcl_tok_gemm_f16x3(_lib.ptr(x2), m, k, _lib.ptr(wp), n, _lib.ptr(xamax), xamax.numel(),
+                                             _lib.ptr(wamax), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(ybuf), _stream(x2)),
+               "dcl_tok_gemm_f16x3")
+    if emit_amax:
+        _amax.tag(y, ybuf)
+    return y
+
+
 # ---- token-major Linear (Swin: models/Swin.py qkv / proj / fc1 / fc2 / reduction) --------------------------------------
 
 def _token_slabs(m):
@@ -604,16 +624,31 @@ def _token_slabs(m):
 
 
 class _TokenLinear(torch.autograd.Function):
-    """y = x W^T + b on [tokens, K] rows.  Forward and data gradient are the library's GEMMs; the weight gradient
-    dW = dY^T X reduces over 10^4..10^5 tokens into a tiny [N, K] output, a shape the library's fp32 kernels run at
-    10-40 TFLOP/s (one macro tile per output tile, the whole token axis serial: 450-1030 us where HBM allows 45-110,
-    tools/probes/linear_wgrad_split.py).  Here the token axis is cut into slabs of ~1024 rows, one batched GEMM
-    computes a partial dW per slab and a fixed-order sum adds them: 3-5x faster, deterministic."""
+    """y = x W^T + b on [tokens, K] rows.
+
+    Weight gradient: dW = dY^T X reduces over 10^4..10^5 tokens into a tiny [N, K] output, a shape the library's fp32
+    kernels run at 10-40 TFLOP/s (one macro tile per output tile, the whole token axis serial: 450-1030 us where HBM
+    allows 45-110, tools/probes/linear_wgrad_split.py).  Here the token axis is cut into slabs of ~1024 rows, one batched
+    GEMM computes a partial dW per slab and a fixed-order sum adds them: 3-5x faster, deterministic.
+
+    Forward and data gradient: the library's fp32 GEMMs, or -- ``mod.f16x3_rows`` >= the row count -- the f16x3 kernel
+    of csrc/dcl_tokgemm.hip on the module's packed fragments (operand maxima from the producers' tags where they
+    exist, else one absmax pass; its own outputs are tagged by the epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, mod):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.mod = mod
+        k = weight.shape[1]
+        ctx.f16x3 = mod is not None and mod.use_f16x3(x)
+        if ctx.f16x3:
+            from .amax import amax_of, tag_of
+            wamax, wp, _ = mod.packed_weights()
+            x2 = x.reshape(-1, k)
+            xamax = tag_of(x)
+            y = tok_gemm(x2, wp, weight.shape[0], amax_of(x2) if xamax is None else xamax, wamax, bias, True)
+            return _retag(y.view(x.shape[:-1] + (weight.shape[0],)), y)
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -625,7 +660,14 @@ class _TokenLinear(torch.autograd.Function):
         m = x2.shape[0]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = gy2.mm(weight).view(x.shape)
+            if ctx.f16x3 and gy2.is_contiguous():
+                from .amax import amax_of, tag_of
+                wamax, _, wpt = ctx.mod.packed_weights()
+                gamax = tag_of(gy)
+                g2 = tok_gemm(gy2, wpt, k, amax_of(gy2) if gamax is None else gamax, wamax, None, True)
+                gx = _retag(g2.view(x.shape), g2)
+            else:
+                gx = gy2.mm(weight).view(x.shape)
         if ctx.needs_input_grad[1]:
             s = _token_slabs(m)
             if s and gy2.is_contiguous() and x2.is_contiguous():
@@ -634,18 +676,52 @@ class _TokenLinear(torch.autograd.Function):
                 gw = gy2.t().mm(x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy2.sum(0)
-        return gx, gw, gb
+        return gx, gw, gb, None
+
+
+def _retag(view, base):
+    """Carry the absmax tag of ``base`` over to a view of it (same storage, same values)."""
+    from . import amax as _amax
+    buf = _amax.tag_of(base)
+    if buf is not None and view is not base:
+        _amax.tag(view, buf)
+    return view
 
 
 class TokenLinear(torch.nn.Linear):
-    """nn.Linear (same parameters / state_dict keys) whose backward computes the weight gradient slab-wise
-    (_TokenLinear) for fp32 CUDA inputs with >= 32768 rows in training; anything else is nn.Linear.forward."""
+    """nn.Linear (same parameters / state_dict keys) for token-major fp32 CUDA rows in training: slab-wise weight
+    gradient from 32768 rows on, and forward / data gradient on the f16x3 kernel for inputs of at most ``f16x3_rows``
+    rows (class default; 0 = library GEMMs); anything else is nn.Linear.forward."""
+
+    f16x3_rows = int(os.environ.get("DCL_LINEAR_F16X3_ROWS", "0"))
+
+    def use_f16x3(self, x):
+        from .. import _lib
+        n, k = self.weight.shape
+        m = x.numel() // k
+        return (0 < m <= self.f16x3_rows and m >= 512 and x.is_contiguous()
+                and bool(_lib.lib().dcl_tok_gemm_supported(k, n)))
+
+    def packed_weights(self):
+        """(max|w|, forward fragments, data-gradient fragments), rebuilt when the weight tensor was modified (or kept
+        fresh for all layers at once by ConvPackGroup.refresh)."""
+        from .amax import amax_of
+        w = self.weight
+        key = (w._version, w.data_ptr())
+        cache = getattr(self, "_packed", None)
+        if cache is None or cache[0] != key:
+            wd = w.detach().view(w.shape[0], w.shape[1], 1, 1)
+            wamax = amax_of(wd)
+            cache = (key, wamax, conv3x3_pack(wd, wamax, False), conv3x3_pack(wd, wamax, True))
+            self._packed = cache
+        return cache[1], cache[2], cache[3]
 
     def forward(self, x):
         if (x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and self.weight.requires_grad
-                and torch.is_grad_enabled() and not torch.is_autocast_enabled()
-                and _token_slabs(x.numel() // x.shape[-1])):
-            return _TokenLinear.apply(x, self.weight, self.bias)
+                and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
+            m = x.numel() // x.shape[-1]
+            if _token_slabs(m) or self.use_f16x3(x):
+                return _TokenLinear.apply(x, self.weight, self.bias, self)
         return super().forward(x)
 
 
