@@ -15,7 +15,7 @@ from torch import nn
 
 from ..utils import DATASETS_INFO, printlog
 from .fused_bn import FusedBatchNorm2d, bn_act
-from .ops import upsample_bilinear
+from .ops import upsample_bilinear, upsample_concat
 from .Projector import Projector
 from .Swin import SwinTransformer
 from .Swin import backbone_config as backbone_config_swin
@@ -94,11 +94,12 @@ class FPN(nn.Module):
             feature = upsample_bilinear(feature, lateral.shape[2:], self.align_corners, add=lateral)
             pyramid.append(self.fpn_out[-i + 1](feature))
         pyramid.reverse()                                       # [P2 .. P5]
-        out_size = pyramid[0].shape[2:]
         # concat order is [P2, P5, P4, P3]: the reference walks the reversed list from its END
         # (UPerNet.py:96-101), and conv_last's input channels are laid out accordingly
-        fused = torch.cat([pyramid[0]] + [upsample_bilinear(pyramid[-i + 1], out_size, self.align_corners)
-                                          for i in range(2, self.fpn_num_lvl + 1)], 1)
+        # (upsample_concat: the up-sampled levels are written straight into their channel slice of the fusion
+        # convolution's 2048-channel input and the gradient is read out of the slice in place -- no cat copy of 537 MB)
+        fused = upsample_concat([pyramid[0]] + [pyramid[-i + 1] for i in range(2, self.fpn_num_lvl + 1)],
+                                self.align_corners)
         x = self.conv_last(fused)
         if self.return_features:
             return x, pyramid, fused
