@@ -41,9 +41,10 @@ template <int V, int G>
 __global__ __launch_bounds__(256) void k_ln_fwd(const float *__restrict__ x, const float *__restrict__ gamma,
                                                 const float *__restrict__ beta, long long M, float eps,
                                                 float *__restrict__ y, float *__restrict__ mean,
-                                                float *__restrict__ rstd)
+                                                float *__restrict__ rstd, float *__restrict__ yamax)
 {
     constexpr int C = 4 * V * G, RW = 64 / G;                 // rows per wave and trip
+    float ymax = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % G, rl = lane / G;
     f32x4 gm[V], bt[V];
@@ -82,12 +83,20 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float *__restrict__ x, con
                 o.z = xv[v].z * rs * gm[v].z + bt[v].z;
                 o.w = xv[v].w * rs * gm[v].w + bt[v].w;
                 *(f32x4 *)(yp + 4 * (sub + v * G)) = o;
+                ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             }
             if (sub == 0) {
                 mean[row] = mu;
                 rstd[row] = rs;
             }
         }
+    }
+    if (yamax) {                                             // absmax side channel for an f16x3 consumer (dcl_tokgemm.hip)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+        if (lane == 0)
+            atomicMax((int *)yamax + (blockIdx.x & (DCL_AMAX_SLOTS - 1)), __float_as_int(ymax));
     }
 }
 
@@ -267,7 +276,7 @@ extern "C" int dcl_layernorm_bwd_parts(long long M, int C)
     } while (0)
 
 extern "C" int dcl_layernorm_fwd(const float *x, const float *gamma, const float *beta, long long M, int C, float eps,
-                                 float *y, float *mean, float *rstd, void *stream)
+                                 float *y, float *mean, float *rstd, float *yamax, void *stream)
 {
     DCL_CHECK_ARG(x && gamma && beta && y && mean && rstd, "null pointer");
     int V = 0, G = 0;
@@ -278,7 +287,7 @@ extern "C" int dcl_layernorm_fwd(const float *x, const float *gamma, const float
     const long long rows_per_block = 4 * (64 / G);
     long long nb = (M + rows_per_block - 1) / rows_per_block;
     const unsigned blocks = (unsigned)(nb < 8192 ? nb : 8192);
-    DCL_LN_DISPATCH(k_ln_fwd, x, gamma, beta, M, eps, y, mean, rstd);
+    DCL_LN_DISPATCH(k_ln_fwd, x, gamma, beta, M, eps, y, mean, rstd, yamax);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -41,6 +41,7 @@ struct TgArgs {
     float *yamax;               // optional: DCL_AMAX_SLOTS partial maxima of |y| (integer atomicMax on the float bits)
     long long M;
     int K, N, xcount, nchunk, ngroups;
+    int dbg;                    // timing experiments only: 1 = x always from chunk 0, 2 = weights always from chunk 0
 };
 
 template <int R, int P>
@@ -94,17 +95,18 @@ __global__ __launch_bounds__(256) void k_tok_gemm(TgArgs a)
         // the next chunk's loads are pinned above the MFMA block (left alone the scheduler sinks them to their use and
         // every trip waits for memory); the last trip re-loads its own chunk instead of branching
         const int cn = c + 1 < a.nchunk ? c + 1 : c;
+        const int cx = (a.dbg & 1) ? 0 : cn, cw = (a.dbg & 2) ? 0 : cn;
         f32x4 nxa[P], nxb[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            nxa[p] = *(const f32x4 *)(xp[p] + 16 * cn);
-            nxb[p] = *(const f32x4 *)(xp[p] + 16 * cn + 4);
+            nxa[p] = *(const f32x4 *)(xp[p] + 16 * cx);
+            nxb[p] = *(const f32x4 *)(xp[p] + 16 * cx + 4);
         }
         uint4 nbh[R], nbl[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-            nbh[t] = wp[t * tstride + (size_t)cn * 128];
-            nbl[t] = wp[t * tstride + (size_t)cn * 128 + 64];
+            nbh[t] = wp[t * tstride + (size_t)cw * 128];
+            nbl[t] = wp[t * tstride + (size_t)cw * 128 + 64];
         }
         __builtin_amdgcn_sched_barrier(0);
         half8 ah[P], al[P];
@@ -181,10 +183,13 @@ __global__ __launch_bounds__(256) void k_tok_gemm(TgArgs a)
 
 }  // namespace
 
+static int g_tok_dbg = 0;
 static int g_tok_p = 0;        // tuning override: row tiles per wave (0 = automatic)
 
 extern "C" int dcl_tok_gemm_set_rows(int p)
 {
+    g_tok_dbg = p >= 16 ? (p >> 4) : 0;          // timing experiments (results are wrong): 16 | 32 added to p
+    p &= 15;
     g_tok_p = p == 1 || p == 2 ? p : 0;
     return 0;
 }
@@ -203,7 +208,7 @@ extern "C" int dcl_tok_gemm_f16x3(const float *x, long long M, int K, const void
     DCL_CHECK_ARG((((uintptr_t)x) & 15) == 0, "16-byte alignment");
     TgArgs a;
     a.x = x; a.wp = (const uint4 *)wp; a.bias = bias; a.y = y; a.xamax = xamax; a.wamax = wamax; a.yamax = yamax;
-    a.M = M; a.K = K; a.N = N; a.xcount = xcount; a.nchunk = K / 16;
+    a.M = M; a.K = K; a.N = N; a.xcount = xcount; a.nchunk = K / 16; a.dbg = g_tok_dbg;
     const int ntile = N / 32;
     const int R = ntile % 3 == 0 ? 3 : (ntile % 2 == 0 ? 2 : 1);
     a.ngroups = ntile / R;

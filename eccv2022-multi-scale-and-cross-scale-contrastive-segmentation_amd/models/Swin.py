@@ -22,7 +22,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..utils import printlog
-from .ops import FusedLayerNorm, TokenLinear
+from .amax import tag, tag_of
+from .ops import FusedLayerNorm, TokenLinear, tagged_gelu
 
 _COMMON = dict(window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
                drop_path_rate=0.3, ape=False, patch_norm=True, out_indices=[0, 1, 2, 3], pretrained=True)
@@ -69,7 +70,11 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        h = self.fc1(x)
+        # (the absmax tag of an f16x3 fc1's output also bounds fc2's input, and the tag of fc2's data gradient the
+        # gradient GELU hands back to fc1)
+        a = tagged_gelu(h) if type(self.act) is nn.GELU and self.act.approximate == 'none' else self.act(h)
+        return self.drop(self.fc2(self.drop(a)))
 
 
 def window_partition(x, ws):
@@ -162,6 +167,9 @@ class SwinTransformerBlock(nn.Module):
             N = ws * ws
             bias = a.relative_position_bias_table[a.relative_position_index.view(-1)].view(N, N, a.num_heads)
             att = window_attention(qkv, qb, bias.permute(2, 0, 1), H, W, a.num_heads, self.shift_size, a.scale)
+            qbuf = tag_of(qkv)
+            if qbuf is not None:
+                tag(att, qbuf)              # a softmax-weighted mean of v rows (or of the bias row): |att| <= max|qkv|
             x = shortcut + self.drop_path(a.proj_drop(a.proj(att)))
             return x + self.drop_path(self.mlp(self.norm2(x)))
         x = self.norm1(x).view(B, H, W, C)

@@ -458,7 +458,10 @@ class ConvPackGroup:
     called at the start of the model's forward; it does nothing while no weight was modified."""
 
     def __init__(self, module: torch.nn.Module):
-        self.convs = [m for m in module.modules() if isinstance(m, DirectConv2d)]
+        # (TokenLinear layers that may run on the f16x3 kernel ride along: a [N, K] weight is a one-tap convolution)
+        self.convs = [m for m in module.modules()
+                      if isinstance(m, DirectConv2d) or (isinstance(m, TokenLinear) and m.f16x3_rows > 0
+                                                         and m.weight.shape[0] % 32 == 0 and m.weight.shape[1] % 16 == 0)]
         self.key = None
         self.tables = None
 
@@ -477,7 +480,7 @@ class ConvPackGroup:
             absjobs[i] = (w.data_ptr(), self.amax[i:i + 1].data_ptr(), w.numel(), len(ab2j), 0)
             ab2j += [i] * nblk
             pair = []
-            taps = w.shape[2] * w.shape[3]
+            taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
             for tr in (0, 1):
                 mm, kk = (ci, co) if tr else (co, ci)
                 frags = ((mm + 31) // 32) * ((kk + 15) // 16) * taps
@@ -727,17 +730,48 @@ class TokenLinear(torch.nn.Linear):
 
 # ---- LayerNorm over token-major rows (csrc/dcl_layernorm.hip) -----------------------------------------------------
 
+class _TaggedGELU(torch.autograd.Function):
+    """nn.GELU() (exact erf form) that hands the absmax tags of the f16x3 Linears through: |gelu(t)| <= |t| forward,
+    |gelu'(t)| <= 1.13 backward (inside the 4x headroom between the operand scale's target and the f16 range)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return torch.nn.functional.gelu(h)
+
+    @staticmethod
+    def backward(ctx, gy):
+        h, = ctx.saved_tensors
+        gh = torch.ops.aten.gelu_backward(gy, h)
+        buf = _amax_mod().tag_of(gy)
+        if buf is not None:
+            _amax_mod().tag(gh, buf)
+        return gh
+
+
+def tagged_gelu(h):
+    buf = _amax_mod().tag_of(h)
+    if buf is None:
+        return torch.nn.functional.gelu(h)
+    return _amax_mod().tag(_TaggedGELU.apply(h), buf)
+
+
+def _amax_mod():
+    from . import amax
+    return amax
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, ybuf=None):
         from .. import _lib
         c = x.shape[-1]
         m = x.numel() // c
         y = torch.empty_like(x)
         stats = torch.empty((2, m), dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().dcl_layernorm_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, float(eps),
-                                                _lib.ptr(y), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _stream(x)),
-                   "dcl_layernorm_fwd")
+                                                _lib.ptr(y), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(ybuf),
+                                                _stream(x)), "dcl_layernorm_fwd")
         ctx.save_for_backward(x, weight, stats)
         return y
 
@@ -755,7 +789,7 @@ class _LayerNormFn(torch.autograd.Function):
         _lib.check(L.dcl_layernorm_bwd(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(weight), _lib.ptr(stats[0]),
                                        _lib.ptr(stats[1]), m, c, _lib.ptr(gx), _lib.ptr(parts), _lib.ptr(gwb),
                                        _stream(x)), "dcl_layernorm_bwd")
-        return gx, gwb[0], gwb[1], None
+        return gx, gwb[0], gwb[1], None, None
 
 
 class FusedLayerNorm(torch.nn.LayerNorm):
@@ -769,7 +803,11 @@ class FusedLayerNorm(torch.nn.LayerNorm):
                 and not torch.is_autocast_enabled() and x.numel() > 0):
             from .. import _lib
             if _lib.lib().dcl_layernorm_supported(x.shape[-1]):
-                return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+                if TokenLinear.f16x3_rows <= 0:
+                    return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+                # absmax side channel for an f16x3 Linear behind the norm (csrc/dcl_tokgemm.hip)
+                ybuf = _amax_mod().zeros(_amax_mod().SLOTS, x.device)
+                return _amax_mod().tag(_LayerNormFn.apply(x, self.weight, self.bias, self.eps, ybuf), ybuf)
         return super().forward(x)
 
 

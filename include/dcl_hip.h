@@ -390,12 +390,13 @@ int dcl_winattn_bwd(const float *qkv, const float *qkv_bias, const float *bias, 
  *   x, y, gy, gx f32 [M, C]      gamma, beta f32 [C]      mean, rstd f32 [M] (forward outputs, backward inputs)
  *   supported row lengths: C = 4 V G with G a power of two in 8 .. 64 and V in {1, 2, 3, 4, 6, 8}
  *   (dcl_layernorm_supported; Swin: 96 .. 1536)
+ *   yamax        optional DCL_AMAX_SLOTS partial maxima of |y| (zero-initialised by the caller), NULL = not wanted
  * backward: parts f32 [dcl_layernorm_bwd_parts(M, C), 2, C] is workspace (one partial {dgamma, dbeta} row per
  * workgroup); dgamma_dbeta f32 [2, C] receives their fixed-order sums (deterministic). */
 int dcl_layernorm_supported(int C);
 int dcl_layernorm_bwd_parts(long long M, int C);
 int dcl_layernorm_fwd(const float *x, const float *gamma, const float *beta, long long M, int C, float eps, float *y,
-                      float *mean, float *rstd, void *stream);
+                      float *mean, float *rstd, float *yamax, void *stream);
 int dcl_layernorm_bwd(const float *gy, const float *x, const float *gamma, const float *mean, const float *rstd,
                       long long M, int C, float *gx, float *parts, float *dgamma_dbeta, void *stream);
 

@@ -4,18 +4,21 @@ tensor): shape and call site of every fallback in one steady-state step of the b
 import os, sys, collections, traceback, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
 import bench, mscs_amd
-from mscs_amd.managers import HRNetManager
+from mscs_amd.managers import HRNetManager, OCRNetManager
 from mscs_amd.utils import set_verbosity
 from mscs_amd.models import amax as A
 set_verbosity(40)
 class Args:
     batch, height, width, scales, no_cross, channels_last, branch_conv = 12, 512, 1024, 3, False, False, "f16x3"
-    materialize_logits, head_conv, conv1x1 = False, "direct", "f16x3"
-mgr = HRNetManager(bench.step_config(Args, 1), autostart=False); mgr.setup(); mgr.model.train()
+    materialize_logits, head_conv, conv1x1, config, classes = False, "direct", "f16x3", 2, 20
+C4 = "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "4"      # UPerNet + Swin-T
+if C4:
+    Args.batch, Args.height, Args.width, Args.scales, Args.config, Args.classes = 16, 512, 512, 4, 4, 151
+mgr = (OCRNetManager if C4 else HRNetManager)(bench.step_config(Args, 1), autostart=False); mgr.setup(); mgr.model.train()
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(0)
-img = torch.randn(12, 3, 512, 1024, generator=gen).to(dev)
-lbl = torch.randint(0, 20, (12, 512, 1024), generator=gen).to(dev)
+img = torch.randn(Args.batch, 3, Args.height, Args.width, generator=gen).to(dev)
+lbl = torch.randint(0, Args.classes, (Args.batch, Args.height, Args.width), generator=gen).to(dev)
 def step():
     mgr.optimiser.zero_grad(set_to_none=True)
     ret = mgr.forward_step(img, lbl)
