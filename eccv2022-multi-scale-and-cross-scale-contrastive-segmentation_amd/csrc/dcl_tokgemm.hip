@@ -181,6 +181,311 @@ __global__ __launch_bounds__(256) void k_tok_gemm(TgArgs a)
     }
 }
 
+// Variant with the weight fragments staged ONCE per workgroup in LDS (double-buffered, one barrier per chunk): the four
+// waves of a workgroup use the same R column tiles, and k_tok_gemm's per-wave copies of them are what saturates the L1
+// (8 KB of operands per 9 MFMAs and wave).  Each thread carries its share of chunk c + 2 in registers while chunk c + 1
+// sits in the other buffer.
+template <int R, int P>
+__global__ __launch_bounds__(256) void k_tok_gemm_s(TgArgs a)
+{
+    constexpr int RW = 32 * P, NB = 2 * R;                   // NB 1-KiB fragment blocks per chunk: [tile][hi | lo]
+    __shared__ __attribute__((aligned(16))) uint4 wl[2][NB * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.x % a.ngroups;
+    const long long row0 = (long long)(blockIdx.x / a.ngroups) * (4 * RW) + wave * RW;
+    float m = 0.f;
+    for (int i = lane; i < a.xcount; i += 64)
+        m = fmaxf(m, a.xamax[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float xs = pow2_scale(m);
+    const int li = lane & 31, h = lane >> 5;
+    const float *xp[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        long long r = row0 + 32 * p + li;
+        r = r < a.M ? r : a.M - 1;
+        xp[p] = a.x + r * a.K + 8 * h;
+    }
+    // staging share of this thread: blocks b0 (and b0 + 4 when it exists) of every chunk
+    const int b0 = wave;
+    constexpr bool TWO = NB > 4;
+    const bool has2 = TWO && b0 + 4 < NB;
+    const size_t tstride = (size_t)a.nchunk * 128;
+    auto wsrc = [&](int b, int c) {                           // block b = 2 * tile + part of chunk c
+        return a.wp + (size_t)(g * R + (b >> 1)) * tstride + (size_t)c * 128 + (b & 1) * 64 + lane;
+    };
+
+    f32x16 acc[P][R];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                acc[p][t][q] = 0.f;
+
+    // prologue: chunk 0 into buffer 0, chunk 1 into registers, x of chunk 0
+    const int c1 = a.nchunk > 1 ? 1 : 0;
+    if (b0 < NB)
+        wl[0][b0 * 64 + lane] = *wsrc(b0, 0);
+    if (has2)
+        wl[0][(b0 + 4) * 64 + lane] = *wsrc(b0 + 4, 0);
+    uint4 s0 = b0 < NB ? *wsrc(b0, c1) : uint4{0, 0, 0, 0}, s1 = has2 ? *wsrc(b0 + 4, c1) : uint4{0, 0, 0, 0};
+    // x fragments two chunks ahead as well (registers): a trip then waits for loads issued a full trip earlier, not for
+    // the ones it has just issued -- at ~300 matrix-pipe cycles per trip and 2-3 waves per SIMD one trip of look-ahead
+    // covers less than half of the memory latency
+    f32x4 xa[P], xb[P], n1a[P], n1b[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        xa[p] = *(const f32x4 *)xp[p];
+        xb[p] = *(const f32x4 *)(xp[p] + 4);
+        n1a[p] = *(const f32x4 *)(xp[p] + 16 * c1);
+        n1b[p] = *(const f32x4 *)(xp[p] + 16 * c1 + 4);
+    }
+    for (int c = 0; c < a.nchunk; ++c) {
+        __syncthreads();                                     // buffer c % 2 is complete, buffer (c + 1) % 2 is free
+        const int cur = c & 1;
+        if (b0 < NB)
+            wl[cur ^ 1][b0 * 64 + lane] = s0;
+        if (has2)
+            wl[cur ^ 1][(b0 + 4) * 64 + lane] = s1;
+        const int c2 = c + 2 < a.nchunk ? c + 2 : a.nchunk - 1;
+        if (b0 < NB)
+            s0 = *wsrc(b0, c2);
+        if (has2)
+            s1 = *wsrc(b0 + 4, c2);
+        f32x4 n2a[P], n2b[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            n2a[p] = *(const f32x4 *)(xp[p] + 16 * c2);
+            n2b[p] = *(const f32x4 *)(xp[p] + 16 * c2 + 4);
+        }
+        uint4 bh[R], bl[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            bh[t] = wl[cur][(2 * t) * 64 + lane];
+            bl[t] = wl[cur][(2 * t + 1) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        half8 ah[P], al[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            uint4 uh, ul;
+            split2(xa[p].x, xa[p].y, xs, uh.x, ul.x);
+            split2(xa[p].z, xa[p].w, xs, uh.y, ul.y);
+            split2(xb[p].x, xb[p].y, xs, uh.z, ul.z);
+            split2(xb[p].z, xb[p].w, xs, uh.w, ul.w);
+            ah[p] = __builtin_bit_cast(half8, uh);
+            al[p] = __builtin_bit_cast(half8, ul);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[p], __builtin_bit_cast(half8, bh[t]), acc[p][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[p], __builtin_bit_cast(half8, bl[t]), acc[p][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[p], __builtin_bit_cast(half8, bh[t]), acc[p][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            xa[p] = n1a[p];
+            xb[p] = n1b[p];
+            n1a[p] = n2a[p];
+            n1b[p] = n2b[p];
+        }
+    }
+
+    if (row0 >= a.M)
+        return;
+    const float inv = 1.0f / (xs * pow2_scale(a.wamax[0]));
+    float ymax = 0.f;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int col = (g * R + t) * 32 + li;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const long long row = row0 + 32 * p + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const float v = acc[p][t][q] * inv + bv;
+                if (row < a.M) {
+                    a.y[row * a.N + col] = v;
+                    ymax = fmaxf(ymax, fabsf(v));
+                }
+            }
+    }
+    if (a.yamax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+        if (lane == 0)
+            atomicMax((int *)a.yamax + (blockIdx.x & (DCL_AMAX_SLOTS - 1)), __float_as_int(ymax));
+    }
+}
+
+// Both operands through LDS: the counters say what bounds the two kernels above (tools/probes/tokgemm_one.py under
+// rocprofv3 --pmc): 43 % of a wave's lifetime in s_waitcnt, the matrix pipe busy 25 %, and pinning the loads to one chunk
+// (all L1 hits) changes nothing -- the x fragments are loaded in MFMA order, every lane its own 32 bytes of its own row,
+// and the vector-memory front end looks up one cache line per lane (the bound of the first weight-gradient kernel).
+// Here the workgroup's 128 rows x 32 k of x are fetched with eight lanes along each row's 128 bytes (one line per
+// eight lanes), parked in LDS with a 144-byte row stride (16 lanes of a ds_read_b128 pass -> 16 bank groups), and read
+// back in MFMA order; the weight fragments of the two chunks of a 32-wide k step sit next to them.  Double-buffered, one
+// barrier per k step, the next step's 7 loads per thread in flight over the 18 MFMAs of the current one.
+template <int R>
+__global__ __launch_bounds__(256) void k_tok_gemm_x(TgArgs a)
+{
+    constexpr int XROW = 144, XBUF = 128 * XROW, WBUF = 4 * R * 1024;     // bytes per buffer
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (XBUF + WBUF)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+    const int g = blockIdx.x % a.ngroups;
+    const long long blk0 = (long long)(blockIdx.x / a.ngroups) * 128;
+    const long long row0 = blk0 + wave * 32;
+    float m = 0.f;
+    for (int i = lane; i < a.xcount; i += 64)
+        m = fmaxf(m, a.xamax[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float xs = pow2_scale(m);
+    const int li = lane & 31, h = lane >> 5;
+    const int nstep = a.nchunk >> 1;                          // k steps of 32
+    const size_t tstride = (size_t)a.nchunk * 128;
+
+    // staging shares: x -- four rows (32 i + tid / 8), 16 bytes at tid % 8; weights -- R fragments
+    const float *xsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long long r = blk0 + 32 * i + (tid >> 3);
+        r = r < a.M ? r : a.M - 1;
+        xsrc[i] = a.x + r * a.K + 4 * (tid & 7);
+    }
+    const uint4 *wsrc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int u = i * 256 + tid, blk = u >> 6, j = blk / (2 * R), b = blk % (2 * R);
+        wsrc[i] = a.wp + (size_t)(g * R + (b >> 1)) * tstride + (size_t)j * 128 + (b & 1) * 64 + (u & 63);
+    }
+    const int xdst = (tid >> 3) * XROW + (tid & 7) * 16;     // + 32 i rows
+    // (named registers, not arrays: the compiler keeps arrays that live across the loop edge as allocas and "promotes"
+    // them to 16 KB of LDS plus scratch)
+#define TG_STAGE(buf)                                                          \
+    do {                                                                       \
+        unsigned char *base_ = lds + (buf) * (XBUF + WBUF);                    \
+        *(uint4 *)(base_ + xdst) = sx0;                                        \
+        *(uint4 *)(base_ + xdst + 32 * XROW) = sx1;                            \
+        *(uint4 *)(base_ + xdst + 64 * XROW) = sx2;                            \
+        *(uint4 *)(base_ + xdst + 96 * XROW) = sx3;                            \
+        *(uint4 *)(base_ + XBUF + tid * 16) = sw0;                             \
+        if constexpr (R > 1)                                                   \
+            *(uint4 *)(base_ + XBUF + (256 + tid) * 16) = sw1;                 \
+        if constexpr (R > 2)                                                   \
+            *(uint4 *)(base_ + XBUF + (512 + tid) * 16) = sw2;                 \
+    } while (0)
+#define TG_FETCH(st_)                                                          \
+    do {                                                                       \
+        sx0 = *(const uint4 *)(xsrc[0] + 32 * (st_));                          \
+        sx1 = *(const uint4 *)(xsrc[1] + 32 * (st_));                          \
+        sx2 = *(const uint4 *)(xsrc[2] + 32 * (st_));                          \
+        sx3 = *(const uint4 *)(xsrc[3] + 32 * (st_));                          \
+        sw0 = wsrc[0][(size_t)(st_) * 256];                                    \
+        if constexpr (R > 1)                                                   \
+            sw1 = wsrc[R > 1 ? 1 : 0][(size_t)(st_) * 256];                    \
+        if constexpr (R > 2)                                                   \
+            sw2 = wsrc[R > 2 ? 2 : 0][(size_t)(st_) * 256];                    \
+    } while (0)
+
+    f32x16 acc[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            acc[t][q] = 0.f;
+
+    uint4 sx0, sx1, sx2, sx3, sw0, sw1 = {0, 0, 0, 0}, sw2 = {0, 0, 0, 0};
+    TG_FETCH(0);
+    TG_STAGE(0);
+    TG_FETCH(nstep > 1 ? 1 : 0);
+    for (int st = 0; st < nstep; ++st) {
+        __syncthreads();                                     // buffer st % 2 is complete, the other one is free
+        const int cur = st & 1;
+        TG_STAGE(cur ^ 1);
+        TG_FETCH(st + 2 < nstep ? st + 2 : nstep - 1);
+        const unsigned char *xb = lds + cur * (XBUF + WBUF) + (wave * 32 + li) * XROW + h * 32;
+        const unsigned char *wb = lds + cur * (XBUF + WBUF) + XBUF + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 xa = *(const f32x4 *)(xb + j * 64), xc = *(const f32x4 *)(xb + j * 64 + 16);
+            uint4 bh[R], bl[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                bh[t] = *(const uint4 *)(wb + ((j * 2 * R + 2 * t) << 10));
+                bl[t] = *(const uint4 *)(wb + ((j * 2 * R + 2 * t + 1) << 10));
+            }
+            uint4 uh, ul;
+            split2(xa.x, xa.y, xs, uh.x, ul.x);
+            split2(xa.z, xa.w, xs, uh.y, ul.y);
+            split2(xc.x, xc.y, xs, uh.z, ul.z);
+            split2(xc.z, xc.w, xs, uh.w, ul.w);
+            const half8 ah = __builtin_bit_cast(half8, uh), al = __builtin_bit_cast(half8, ul);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, bh[t]), acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, bl[t]), acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(half8, bh[t]), acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+#undef TG_STAGE
+#undef TG_FETCH
+    if (row0 >= a.M)
+        return;
+    const float inv = 1.0f / (xs * pow2_scale(a.wamax[0]));
+    float ymax = 0.f;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const int col = (g * R + t) * 32 + li;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const long long row = row0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float v = acc[t][q] * inv + bv;
+            if (row < a.M) {
+                a.y[row * a.N + col] = v;
+                ymax = fmaxf(ymax, fabsf(v));
+            }
+        }
+    }
+    if (a.yamax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+        if (lane == 0)
+            atomicMax((int *)a.yamax + (blockIdx.x & (DCL_AMAX_SLOTS - 1)), __float_as_int(ymax));
+    }
+}
+
 }  // namespace
 
 static int g_tok_dbg = 0;
@@ -212,18 +517,34 @@ extern "C" int dcl_tok_gemm_f16x3(const float *x, long long M, int K, const void
     const int ntile = N / 32;
     const int R = ntile % 3 == 0 ? 3 : (ntile % 2 == 0 ? 2 : 1);
     a.ngroups = ntile / R;
-    // two row tiles per wave (every weight fragment feeds two MFMAs: the kernel is bound by the L1 path of the
-    // fragments) when that still leaves two workgroups per CU
+    hipStream_t s = (hipStream_t)stream;
+    if (K % 32 == 0 && !(g_tok_dbg & 12)) {
+        // both operands through LDS (k_tok_gemm_x); the two kernels above remain for K % 32 = 16 and as references
+        const long long rbx = (M + 127) / 128;
+        DCL_CHECK_ARG(rbx * a.ngroups < ((long long)1 << 31), "grid too large");
+        const dim3 gridx((unsigned)(rbx * a.ngroups));
+        if (R == 3)
+            hipLaunchKernelGGL(k_tok_gemm_x<3>, gridx, dim3(256), 0, s, a);
+        else if (R == 2)
+            hipLaunchKernelGGL(k_tok_gemm_x<2>, gridx, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_tok_gemm_x<1>, gridx, dim3(256), 0, s, a);
+        DCL_LAUNCH_CHECK();
+        return 0;
+    }
     int P = g_tok_p;
     if (P <= 0)
         P = ((M + 255) / 256) * a.ngroups >= 512 ? 2 : 1;
     const long long rb = (M + 128 * P - 1) / (128 * P);
     DCL_CHECK_ARG(rb * a.ngroups < ((long long)1 << 31), "grid too large");
     const dim3 grid((unsigned)(rb * a.ngroups));
-    hipStream_t s = (hipStream_t)stream;
 #define DCL_TG_CASE(r, p)                                                   \
-    if (R == r && P == p)                                                   \
-        hipLaunchKernelGGL((k_tok_gemm<r, p>), grid, dim3(256), 0, s, a);
+    if (R == r && P == p) {                                                 \
+        if (g_tok_dbg & 4)                                                  \
+            hipLaunchKernelGGL((k_tok_gemm<r, p>), grid, dim3(256), 0, s, a); \
+        else                                                                \
+            hipLaunchKernelGGL((k_tok_gemm_s<r, p>), grid, dim3(256), 0, s, a); \
+    }
     DCL_TG_CASE(3, 2) DCL_TG_CASE(3, 1) DCL_TG_CASE(2, 2) DCL_TG_CASE(2, 1) DCL_TG_CASE(1, 2) DCL_TG_CASE(1, 1)
 #undef DCL_TG_CASE
     DCL_LAUNCH_CHECK();
