@@ -345,15 +345,17 @@ __global__ __launch_bounds__(256) void k_tok_gemm_s(TgArgs a)
 // eight lanes), parked in LDS with a 144-byte row stride (16 lanes of a ds_read_b128 pass -> 16 bank groups), and read
 // back in MFMA order; the weight fragments of the two chunks of a 32-wide k step sit next to them.  Double-buffered, one
 // barrier per k step, the next step's 7 loads per thread in flight over the 18 MFMAs of the current one.
-template <int R>
+template <int R, int P>
 __global__ __launch_bounds__(256) void k_tok_gemm_x(TgArgs a)
 {
-    constexpr int XROW = 144, XBUF = 128 * XROW, WBUF = 4 * R * 1024;     // bytes per buffer
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (XBUF + WBUF)];
+    // P row tiles per wave (32 P rows; a workgroup = 128 P rows): every weight fragment read from LDS feeds P MFMAs
+    // (P = 2 moves 10 KB of operands per 18 MFMAs instead of 8 KB per 9, but leaves one wave per SIMD: slower, measured).
+    constexpr int XROW = 144, XBUF = 128 * P * XROW, WBUF = 4 * R * 1024;     // bytes per buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 2 x (XBUF + WBUF)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
     const int g = blockIdx.x % a.ngroups;
-    const long long blk0 = (long long)(blockIdx.x / a.ngroups) * 128;
-    const long long row0 = blk0 + wave * 32;
+    const long long blk0 = (long long)(blockIdx.x / a.ngroups) * (128 * P);
+    const long long row0 = blk0 + wave * 32 * P;
     float m = 0.f;
     for (int i = lane; i < a.xcount; i += 64)
         m = fmaxf(m, a.xamax[i]);
@@ -365,10 +367,10 @@ __global__ __launch_bounds__(256) void k_tok_gemm_x(TgArgs a)
     const int nstep = a.nchunk >> 1;                          // k steps of 32
     const size_t tstride = (size_t)a.nchunk * 128;
 
-    // staging shares: x -- four rows (32 i + tid / 8), 16 bytes at tid % 8; weights -- R fragments
-    const float *xsrc[4];
+    // staging shares: x -- 4 P rows (32 i + tid / 8), 16 bytes at tid % 8; weights -- R fragments
+    const float *xsrc[4 * P];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * P; ++i) {
         long long r = blk0 + 32 * i + (tid >> 3);
         r = r < a.M ? r : a.M - 1;
         xsrc[i] = a.x + r * a.K + 4 * (tid & 7);
@@ -389,6 +391,12 @@ __global__ __launch_bounds__(256) void k_tok_gemm_x(TgArgs a)
         *(uint4 *)(base_ + xdst + 32 * XROW) = sx1;                            \
         *(uint4 *)(base_ + xdst + 64 * XROW) = sx2;                            \
         *(uint4 *)(base_ + xdst + 96 * XROW) = sx3;                            \
+        if constexpr (P > 1) {                                                 \
+            *(uint4 *)(base_ + xdst + 128 * XROW) = sx4;                       \
+            *(uint4 *)(base_ + xdst + 160 * XROW) = sx5;                       \
+            *(uint4 *)(base_ + xdst + 192 * XROW) = sx6;                       \
+            *(uint4 *)(base_ + xdst + 224 * XROW) = sx7;                       \
+        }                                                                      \
         *(uint4 *)(base_ + XBUF + tid * 16) = sw0;                             \
         if constexpr (R > 1)                                                   \
             *(uint4 *)(base_ + XBUF + (256 + tid) * 16) = sw1;                 \
@@ -401,6 +409,12 @@ __global__ __launch_bounds__(256) void k_tok_gemm_x(TgArgs a)
         sx1 = *(const uint4 *)(xsrc[1] + 32 * (st_));                          \
         sx2 = *(const uint4 *)(xsrc[2] + 32 * (st_));                          \
         sx3 = *(const uint4 *)(xsrc[3] + 32 * (st_));                          \
+        if constexpr (P > 1) {                                                 \
+            sx4 = *(const uint4 *)(xsrc[P > 1 ? 4 : 0] + 32 * (st_));          \
+            sx5 = *(const uint4 *)(xsrc[P > 1 ? 5 : 0] + 32 * (st_));          \
+            sx6 = *(const uint4 *)(xsrc[P > 1 ? 6 : 0] + 32 * (st_));          \
+            sx7 = *(const uint4 *)(xsrc[P > 1 ? 7 : 0] + 32 * (st_));          \
+        }                                                                      \
         sw0 = wsrc[0][(size_t)(st_) * 256];                                    \
         if constexpr (R > 1)                                                   \
             sw1 = wsrc[R > 1 ? 1 : 0][(size_t)(st_) * 256];                    \
@@ -408,54 +422,94 @@ __global__ __launch_bounds__(256) void k_tok_gemm_x(TgArgs a)
             sw2 = wsrc[R > 2 ? 2 : 0][(size_t)(st_) * 256];                    \
     } while (0)
 
-    f32x16 acc[R];
+    f32x16 acc[P][R];
 #pragma unroll
-    for (int t = 0; t < R; ++t)
+    for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-            acc[t][q] = 0.f;
+        for (int t = 0; t < R; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                acc[p][t][q] = 0.f;
 
-    uint4 sx0, sx1, sx2, sx3, sw0, sw1 = {0, 0, 0, 0}, sw2 = {0, 0, 0, 0};
+    uint4 sx0, sx1, sx2, sx3, sx4 = {0, 0, 0, 0}, sx5 = {0, 0, 0, 0}, sx6 = {0, 0, 0, 0}, sx7 = {0, 0, 0, 0};
+    uint4 sw0, sw1 = {0, 0, 0, 0}, sw2 = {0, 0, 0, 0};
+    // fragments of sub-chunk (st, j) out of buffer st % 2, into named register sets (no arrays across the loop edge)
+    const int xoff = (wave * 32 * P + li) * XROW + h * 32, woff = XBUF + lane * 16;
+#define TG_READ(buf, j, XA, XC, XA2, XC2, BH, BL)                                              \
+    do {                                                                                       \
+        const unsigned char *b_ = lds + (buf) * (XBUF + WBUF);                                 \
+        XA = *(const f32x4 *)(b_ + xoff + (j) * 64);                                           \
+        XC = *(const f32x4 *)(b_ + xoff + (j) * 64 + 16);                                      \
+        if constexpr (P > 1) {                                                                 \
+            XA2 = *(const f32x4 *)(b_ + xoff + 32 * XROW + (j) * 64);                          \
+            XC2 = *(const f32x4 *)(b_ + xoff + 32 * XROW + (j) * 64 + 16);                     \
+        }                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < R; ++t) {                                        \
+            BH[t] = *(const uint4 *)(b_ + woff + (((j) * 2 * R + 2 * t) << 10));               \
+            BL[t] = *(const uint4 *)(b_ + woff + (((j) * 2 * R + 2 * t + 1) << 10));           \
+        }                                                                                      \
+    } while (0)
+#define TG_SPLIT(XA, XC, AH, AL)                                                               \
+    do {                                                                                       \
+        uint4 uh_, ul_;                                                                        \
+        split2(XA.x, XA.y, xs, uh_.x, ul_.x);                                                  \
+        split2(XA.z, XA.w, xs, uh_.y, ul_.y);                                                  \
+        split2(XC.x, XC.y, xs, uh_.z, ul_.z);                                                  \
+        split2(XC.z, XC.w, xs, uh_.w, ul_.w);                                                  \
+        AH = __builtin_bit_cast(half8, uh_);                                                   \
+        AL = __builtin_bit_cast(half8, ul_);                                                   \
+    } while (0)
+#define TG_MFMA(XA, XC, XA2, XC2, BH, BL)                                                      \
+    do {                                                                                       \
+        half8 ah[P], al[P];                                                                    \
+        TG_SPLIT(XA, XC, ah[0], al[0]);                                                        \
+        if constexpr (P > 1)                                                                   \
+            TG_SPLIT(XA2, XC2, ah[P - 1], al[P - 1]);                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        _Pragma("unroll") for (int p = 0; p < P; ++p)                                          \
+            _Pragma("unroll") for (int t = 0; t < R; ++t)                                      \
+                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[p], __builtin_bit_cast(half8, BH[t]), acc[p][t], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        _Pragma("unroll") for (int p = 0; p < P; ++p)                                          \
+            _Pragma("unroll") for (int t = 0; t < R; ++t)                                      \
+                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[p], __builtin_bit_cast(half8, BL[t]), acc[p][t], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        _Pragma("unroll") for (int p = 0; p < P; ++p)                                          \
+            _Pragma("unroll") for (int t = 0; t < R; ++t)                                      \
+                acc[p][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[p], __builtin_bit_cast(half8, BH[t]), acc[p][t], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+
+    // Schedule of a k step (two sub-chunks of 16): the fragment reads run ONE sub-chunk ahead of the MFMAs, so each MFMA
+    // block covers the LDS latency of the next one's operands, and the workgroup barrier sits between the two blocks:
+    //   read F(st, 1) | MFMA(st, 0) | park step st + 1 in the other buffer, fetch step st + 2 | barrier |
+    //   read F(st + 1, 0) | MFMA(st, 1)
+    // (a raw barrier behind an LDS-only wait: __syncthreads() also drains vmcnt, i.e. waits at every step for the global
+    // loads that were issued just before it)
+#define TG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     TG_FETCH(0);
     TG_STAGE(0);
     TG_FETCH(nstep > 1 ? 1 : 0);
+    f32x4 xa0, xc0, xa1, xc1, ya0 = {0.f, 0.f, 0.f, 0.f}, yc0 = ya0, ya1 = ya0, yc1 = ya0;
+    uint4 bh0[R], bl0[R], bh1[R], bl1[R];
+    TG_BARRIER();
+    TG_READ(0, 0, xa0, xc0, ya0, yc0, bh0, bl0);
     for (int st = 0; st < nstep; ++st) {
-        __syncthreads();                                     // buffer st % 2 is complete, the other one is free
         const int cur = st & 1;
+        TG_READ(cur, 1, xa1, xc1, ya1, yc1, bh1, bl1);
+        __builtin_amdgcn_sched_barrier(0);
+        TG_MFMA(xa0, xc0, ya0, yc0, bh0, bl0);
         TG_STAGE(cur ^ 1);
         TG_FETCH(st + 2 < nstep ? st + 2 : nstep - 1);
-        const unsigned char *xb = lds + cur * (XBUF + WBUF) + (wave * 32 + li) * XROW + h * 32;
-        const unsigned char *wb = lds + cur * (XBUF + WBUF) + XBUF + lane * 16;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const f32x4 xa = *(const f32x4 *)(xb + j * 64), xc = *(const f32x4 *)(xb + j * 64 + 16);
-            uint4 bh[R], bl[R];
-#pragma unroll
-            for (int t = 0; t < R; ++t) {
-                bh[t] = *(const uint4 *)(wb + ((j * 2 * R + 2 * t) << 10));
-                bl[t] = *(const uint4 *)(wb + ((j * 2 * R + 2 * t + 1) << 10));
-            }
-            uint4 uh, ul;
-            split2(xa.x, xa.y, xs, uh.x, ul.x);
-            split2(xa.z, xa.w, xs, uh.y, ul.y);
-            split2(xc.x, xc.y, xs, uh.z, ul.z);
-            split2(xc.z, xc.w, xs, uh.w, ul.w);
-            const half8 ah = __builtin_bit_cast(half8, uh), al = __builtin_bit_cast(half8, ul);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < R; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, bh[t]), acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < R; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, bl[t]), acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < R; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(half8, bh[t]), acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        TG_BARRIER();                          // the other buffer is complete; nobody reads this one any more
+        TG_READ(cur ^ 1, 0, xa0, xc0, ya0, yc0, bh0, bl0);      // (after the last step: a harmless re-read)
+        __builtin_amdgcn_sched_barrier(0);
+        TG_MFMA(xa1, xc1, ya1, yc1, bh1, bl1);
     }
+#undef TG_READ
+#undef TG_SPLIT
+#undef TG_MFMA
+#undef TG_BARRIER
 
 #undef TG_STAGE
 #undef TG_FETCH
@@ -468,14 +522,16 @@ __global__ __launch_bounds__(256) void k_tok_gemm_x(TgArgs a)
         const int col = (g * R + t) * 32 + li;
         const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const long long row = row0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-            const float v = acc[t][q] * inv + bv;
-            if (row < a.M) {
-                a.y[row * a.N + col] = v;
-                ymax = fmaxf(ymax, fabsf(v));
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const long long row = row0 + 32 * p + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const float v = acc[p][t][q] * inv + bv;
+                if (row < a.M) {
+                    a.y[row * a.N + col] = v;
+                    ymax = fmaxf(ymax, fabsf(v));
+                }
             }
-        }
     }
     if (a.yamax) {
 #pragma unroll
@@ -520,15 +576,24 @@ extern "C" int dcl_tok_gemm_f16x3(const float *x, long long M, int K, const void
     hipStream_t s = (hipStream_t)stream;
     if (K % 32 == 0 && !(g_tok_dbg & 12)) {
         // both operands through LDS (k_tok_gemm_x); the two kernels above remain for K % 32 = 16 and as references
-        const long long rbx = (M + 127) / 128;
+        // one row tile per wave: two (98 KB of LDS, one workgroup = one wave per SIMD) are 25-50 % slower on every shape
+        // (tools/probes/tokgemm_bound.py); kept for dcl_tok_gemm_set_rows(2)
+        int PX = g_tok_p;
+        if (PX <= 0)
+            PX = 1;
+        const long long rbx = (M + 128 * PX - 1) / (128 * PX);
         DCL_CHECK_ARG(rbx * a.ngroups < ((long long)1 << 31), "grid too large");
         const dim3 gridx((unsigned)(rbx * a.ngroups));
-        if (R == 3)
-            hipLaunchKernelGGL(k_tok_gemm_x<3>, gridx, dim3(256), 0, s, a);
-        else if (R == 2)
-            hipLaunchKernelGGL(k_tok_gemm_x<2>, gridx, dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL(k_tok_gemm_x<1>, gridx, dim3(256), 0, s, a);
+        const size_t ldsx = 2 * ((size_t)128 * PX * 144 + 4 * R * 1024);
+#define DCL_TGX_CASE(r, p)                                                                              \
+    if (R == r && PX == p) {                                                                            \
+        if (ldsx > 64 * 1024)                                                                           \
+            (void)hipFuncSetAttribute((const void *)k_tok_gemm_x<r, p>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)ldsx);                                                       \
+        hipLaunchKernelGGL((k_tok_gemm_x<r, p>), gridx, dim3(256), ldsx, s, a);                         \
+    }
+        DCL_TGX_CASE(3, 2) DCL_TGX_CASE(3, 1) DCL_TGX_CASE(2, 2) DCL_TGX_CASE(2, 1) DCL_TGX_CASE(1, 2) DCL_TGX_CASE(1, 1)
+#undef DCL_TGX_CASE
         DCL_LAUNCH_CHECK();
         return 0;
     }
