@@ -9,8 +9,7 @@ M, K, N = 16384, 384, 1152
 x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
 sw, sx = amax_of(w), amax_of(x)
 wp = ops.conv3x3_pack(w.view(N, K, 1, 1), sw, False)
-_lib.lib().dcl_tok_gemm_set_rows(1)
-for _ in range(5): ops.tok_gemm(x, wp, N, sx, sw)
-_lib.lib().dcl_tok_gemm_set_rows(1 + 16 * 4)
-for _ in range(5): ops.tok_gemm(x, wp, N, sx, sw)
+for mode in (1, 1 + 16 * 8, 1 + 16 * 4):       # both operands in LDS | weights in LDS | per-wave operands
+    _lib.lib().dcl_tok_gemm_set_rows(mode)
+    for _ in range(5): ops.tok_gemm(x, wp, N, sx, sw)
 torch.cuda.synchronize()
