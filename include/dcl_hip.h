@@ -410,7 +410,10 @@ int dcl_layernorm_bwd(const float *gy, const float *x, const float *gamma, const
  *   yamax   optional DCL_AMAX_SLOTS partial maxima of |y| (zero-initialised by the caller)
  *   shapes  K % 16 == 0 and N % 32 == 0 (dcl_tok_gemm_supported) */
 int dcl_tok_gemm_supported(int K, int N);
-int dcl_tok_gemm_set_rows(int p);   /* tuning: row tiles per wave, 1 | 2 (0 = automatic) */
+int dcl_tok_gemm_set_rows(int p);   /* tuning: row tiles per wave, 1 | 2 (0 = automatic); + 64: operands per wave from
+                                       global memory, + 128: weight fragments only through LDS (the two earlier
+                                       stagings, kept for tools/probes/tokgemm_bound.py; + 16 / + 32 pin their x /
+                                       weight loads to one chunk: timing only, wrong results) */
 int dcl_tok_gemm_f16x3(const float *x, long long M, int K, const void *wp, int N, const float *xamax, int xcount,
                        const float *wamax, const float *bias, float *y, float *yamax, void *stream);
 
