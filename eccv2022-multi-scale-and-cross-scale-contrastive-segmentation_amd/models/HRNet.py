@@ -73,6 +73,8 @@ def _conv_bn(cin, cout, k, stride=1, relu=False, norm=nn.BatchNorm2d):
 _FUSE_RESIDUAL_GRAD = os.environ.get('DCL_FUSE_RESIDUAL_GRAD', '1') != '0'
 _BRANCH_STREAMS = os.environ.get('DCL_BRANCH_STREAMS', '1') != '0'
 _SIDE_STREAMS = {}
+# experiment switch: stream per branch (0 = the main stream), e.g. "0,1,1,0"; default: one stream per branch
+_BRANCH_STREAM_MAP = [int(v) for v in os.environ.get('DCL_BRANCH_STREAM_MAP', '').split(',') if v != '']
 
 
 def _side_streams(device, n):
@@ -212,16 +214,25 @@ class HighResolutionModule(nn.Module):
         main = torch.cuda.current_stream(x[0].device)
         side = _side_streams(x[0].device, self.num_branches - 1)
         outs = [None] * self.num_branches
-        for i in range(self.num_branches - 1, 0, -1):          # smallest branch first: it has the most to gain
-            s = side[i - 1]
-            s.wait_stream(main)
+        smap = _BRANCH_STREAM_MAP[:self.num_branches] if _BRANCH_STREAM_MAP else list(range(self.num_branches))
+        used = sorted({k for k in smap if k > 0})
+        for k in used:
+            side[k - 1].wait_stream(main)
+        for i in range(self.num_branches - 1, -1, -1):         # smallest branch first: it has the most to gain
+            if smap[i] == 0:
+                continue
+            s = side[smap[i] - 1]
             with torch.cuda.stream(s):
                 _amax_record_stream(x[i], s)
                 outs[i] = self.branches[i](x[i])
-        outs[0] = self.branches[0](x[0])
-        for i in range(1, self.num_branches):
-            main.wait_stream(side[i - 1])
-            _amax_record_stream(outs[i], main)
+        for i in range(self.num_branches - 1, -1, -1):
+            if smap[i] == 0:
+                outs[i] = self.branches[i](x[i])
+        for k in used:
+            main.wait_stream(side[k - 1])
+        for i in range(self.num_branches):
+            if smap[i] > 0:
+                _amax_record_stream(outs[i], main)
         return outs
 
     def forward(self, x):
