@@ -73,6 +73,7 @@ def _conv_bn(cin, cout, k, stride=1, relu=False, norm=nn.BatchNorm2d):
 _FUSE_RESIDUAL_GRAD = os.environ.get('DCL_FUSE_RESIDUAL_GRAD', '1') != '0'
 _BRANCH_STREAMS = os.environ.get('DCL_BRANCH_STREAMS', '1') != '0'
 _SIDE_STREAMS = {}
+_DEFER_JOIN = os.environ.get('DCL_DEFER_JOIN', '1') != '0'
 # experiment switch: stream per branch (0 = the main stream), e.g. "0,1,1,0"; default: one stream per branch
 _BRANCH_STREAM_MAP = [int(v) for v in os.environ.get('DCL_BRANCH_STREAM_MAP', '').split(',') if v != '']
 
@@ -216,8 +217,10 @@ class HighResolutionModule(nn.Module):
         outs = [None] * self.num_branches
         smap = _BRANCH_STREAM_MAP[:self.num_branches] if _BRANCH_STREAM_MAP else list(range(self.num_branches))
         used = sorted({k for k in smap if k > 0})
-        for k in used:
-            side[k - 1].wait_stream(main)
+        if not (_DEFER_JOIN and getattr(self, 'inputs_on_streams', False) and not _BRANCH_STREAM_MAP):
+            for k in used:
+                side[k - 1].wait_stream(main)
+        # (else: x[i] is the previous module's fused output i, produced on side stream i - 1 itself)
         for i in range(self.num_branches - 1, -1, -1):         # smallest branch first: it has the most to gain
             if smap[i] == 0:
                 continue
@@ -261,6 +264,12 @@ class HighResolutionModule(nn.Module):
                     _amax_record_stream(t, s)
                 fused[i] = self._fuse_row(i, self.fuse_layers[i], xs[i])
         fused[0] = self._fuse_row(0, self.fuse_layers[0], xs[0])
+        if _DEFER_JOIN and not getattr(self, 'join_output', True) and not _BRANCH_STREAM_MAP \
+                and len(self.fuse_layers) == self.num_branches:
+            # the next module of the stage runs branch i on the stream that produced fused[i]: no join here and no fork
+            # there -- its branches start as soon as THEIR row is done instead of after the slowest one (the rows cost
+            # between three up-sampling + add kernels and six stride-2 convolution + norm pairs)
+            return fused
         for i in range(1, len(self.fuse_layers)):
             main.wait_stream(side[i - 1])
             _amax_record_stream(fused[i], main)
@@ -368,6 +377,10 @@ class HighResolutionNet(nn.Module):
                                                 num_inchannels, scfg['NUM_CHANNELS'], scfg['FUSE_METHOD'],
                                                 ms_out, norm_layer=self.norm_layer))
             num_inchannels = modules[-1].get_num_inchannels()
+        # between two modules of a stage output i stays on stream i (see HighResolutionModule.forward)
+        for m, mod in enumerate(modules):
+            mod.join_output = m == len(modules) - 1
+            mod.inputs_on_streams = m > 0
         return nn.Sequential(*modules), num_inchannels
 
     @staticmethod
