@@ -74,6 +74,7 @@ _FUSE_RESIDUAL_GRAD = os.environ.get('DCL_FUSE_RESIDUAL_GRAD', '1') != '0'
 _BRANCH_STREAMS = os.environ.get('DCL_BRANCH_STREAMS', '1') != '0'
 _SIDE_STREAMS = {}
 _DEFER_JOIN = os.environ.get('DCL_DEFER_JOIN', '1') != '0'
+_FANOUT_ON_BRANCH_STREAM = os.environ.get('DCL_FANOUT_STREAM', '1') != '0'
 # experiment switch: stream per branch (0 = the main stream), e.g. "0,1,1,0"; default: one stream per branch
 _BRANCH_STREAM_MAP = [int(v) for v in os.environ.get('DCL_BRANCH_STREAM_MAP', '').split(',') if v != '']
 
@@ -246,7 +247,17 @@ class HighResolutionModule(nn.Module):
         if nrow >= 3 and x[0].is_cuda:
             # every branch output feeds every fuse row: hand each row its own alias, so that the nrow gradients of a
             # branch output are summed by one kernel instead of nrow - 1 autograd adds (ops.fan_out)
-            al = [fan_out(t, nrow) for t in x]
+            if _FANOUT_ON_BRANCH_STREAM and _BRANCH_STREAMS and not _BRANCH_STREAM_MAP:
+                # the alias node of branch j is recorded on branch j's stream: its backward (the sum of the rows'
+                # gradients) then runs there, in parallel with the other branches' sums and in order with the branch's
+                # own backward, instead of all four on the main stream
+                side_f = _side_streams(x[0].device, self.num_branches - 1)
+                al = [fan_out(x[0], nrow)]
+                for j in range(1, self.num_branches):
+                    with torch.cuda.stream(side_f[j - 1]):
+                        al.append(fan_out(x[j], nrow))
+            else:
+                al = [fan_out(t, nrow) for t in x]
             xs = [[al[j][i] for j in range(self.num_branches)] for i in range(nrow)]
         else:
             xs = [x] * nrow
