@@ -74,6 +74,7 @@ _FUSE_RESIDUAL_GRAD = os.environ.get('DCL_FUSE_RESIDUAL_GRAD', '1') != '0'
 _BRANCH_STREAMS = os.environ.get('DCL_BRANCH_STREAMS', '1') != '0'
 _SIDE_STREAMS = {}
 _DEFER_JOIN = os.environ.get('DCL_DEFER_JOIN', '1') != '0'
+_STAGE_CONTINUITY = os.environ.get('DCL_STAGE_CONTINUITY', '1') != '0'
 _FANOUT_ON_BRANCH_STREAM = os.environ.get('DCL_FANOUT_STREAM', '1') != '0'
 # experiment switch: stream per branch (0 = the main stream), e.g. "0,1,1,0"; default: one stream per branch
 _BRANCH_STREAM_MAP = [int(v) for v in os.environ.get('DCL_BRANCH_STREAM_MAP', '').split(',') if v != '']
@@ -218,10 +219,11 @@ class HighResolutionModule(nn.Module):
         outs = [None] * self.num_branches
         smap = _BRANCH_STREAM_MAP[:self.num_branches] if _BRANCH_STREAM_MAP else list(range(self.num_branches))
         used = sorted({k for k in smap if k > 0})
-        if not (_DEFER_JOIN and getattr(self, 'inputs_on_streams', False) and not _BRANCH_STREAM_MAP):
-            for k in used:
+        for k in used:
+            # x[k] carrying the mark of side stream k - 1 is the previous module's fused output k (or a transition's
+            # output), produced on that very stream: nothing to wait for
+            if not (_DEFER_JOIN and not _BRANCH_STREAM_MAP and getattr(x[k], '_dcl_stream', None) is side[k - 1]):
                 side[k - 1].wait_stream(main)
-        # (else: x[i] is the previous module's fused output i, produced on side stream i - 1 itself)
         for i in range(self.num_branches - 1, -1, -1):         # smallest branch first: it has the most to gain
             if smap[i] == 0:
                 continue
@@ -280,6 +282,8 @@ class HighResolutionModule(nn.Module):
             # the next module of the stage runs branch i on the stream that produced fused[i]: no join here and no fork
             # there -- its branches start as soon as THEIR row is done instead of after the slowest one (the rows cost
             # between three up-sampling + add kernels and six stride-2 convolution + norm pairs)
+            for i in range(1, len(self.fuse_layers)):
+                fused[i]._dcl_stream = side[i - 1]
             return fused
         for i in range(1, len(self.fuse_layers)):
             main.wait_stream(side[i - 1])
@@ -366,6 +370,10 @@ class HighResolutionNet(nn.Module):
             setattr(self, f'transition{idx - 1}', self._transition(pre, cur))
             stage, pre = self._make_stage(scfg, cur)
             setattr(self, f'stage{idx}', stage)
+        # stream continuity across the stage transitions as well (forward() / _enter_stage): the last module of stages
+        # 2 and 3 leaves its outputs on their streams (marked), the transition and the next stage's first module pick them up
+        for idx in (2, 3):
+            getattr(self, f'stage{idx}')[-1].join_output = not _STAGE_CONTINUITY
 
     def _transition(self, pre, cur):
         layers = []
@@ -391,15 +399,40 @@ class HighResolutionNet(nn.Module):
         # between two modules of a stage output i stays on stream i (see HighResolutionModule.forward)
         for m, mod in enumerate(modules):
             mod.join_output = m == len(modules) - 1
-            mod.inputs_on_streams = m > 0
         return nn.Sequential(*modules), num_inchannels
 
     @staticmethod
     def _enter_stage(transition, prev, n_prev):
+        on_streams = (_DEFER_JOIN and _BRANCH_STREAMS and not _BRANCH_STREAM_MAP and n_prev > 1 and prev[0].is_cuda
+                      and all(getattr(t, '_dcl_stream', None) is not None for t in prev[1:]))
+        if not on_streams:
+            out = []
+            for i, t in enumerate(transition):
+                src = prev[i] if i < n_prev else prev[-1]
+                out.append(src if t is None else t(src))
+            return out
+        # prev[i] was left on stream i by the previous stage's last module (branch 0: the current stream): a transition
+        # layer of an existing branch runs there, a new branch on the next free stream behind the branch it derives from;
+        # the first module of the next stage continues on the same streams and joins after its branches
+        main = torch.cuda.current_stream(prev[0].device)
+        side = _side_streams(prev[0].device, len(transition) - 1)
         out = []
         for i, t in enumerate(transition):
-            src = prev[i] if i < n_prev else prev[-1]
-            out.append(src if t is None else t(src))
+            s = main if i == 0 else side[i - 1]
+            if i < n_prev:
+                if t is None:
+                    out.append(prev[i])
+                else:
+                    with torch.cuda.stream(s):
+                        out.append(t(prev[i]))
+            else:
+                src_stream = main if n_prev == 1 else side[n_prev - 2]
+                s.wait_stream(src_stream)
+                with torch.cuda.stream(s):
+                    _amax_record_stream(prev[-1], s)
+                    out.append(t(prev[-1]))
+            if i > 0:
+                out[-1]._dcl_stream = s
         return out
 
     def forward(self, x):

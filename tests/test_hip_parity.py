@@ -863,7 +863,7 @@ def test_stage_without_joins_between_modules_matches_joined(dev):
     graph = {"backbone": "hrnet48", "pretrained": False, "dataset": "CITYSCAPES", "align_corners": True}
     torch.manual_seed(10)
     stage = hm.HRNet(graph, 1).backbone.stage4.to(dev).train()
-    assert [m.join_output for m in stage] == [False, False, True] and [m.inputs_on_streams for m in stage] == [False, True, True]
+    assert [m.join_output for m in stage] == [False, False, True]
     xs0 = [torch.randn(3, 48 * 2 ** i, 64 // 2 ** i, 96 // 2 ** i, device=dev) for i in range(4)]
 
     def run(flag):
