@@ -78,6 +78,11 @@ def parse():
     ap.add_argument("--miopen-benchmark", action="store_true",
                     help="cudnn.benchmark=True like the reference (BaseManager.py:122). OFF by default: on a fresh box "
                          "MIOpen's exhaustive fp32 solver search for HRNet-W48's ~300 conv shapes takes > 20 minutes")
+    ap.add_argument("--eager-miopen-benchmark", action="store_true",
+                    help="time the eager-structure comparator a second time with torch.backends.cudnn.benchmark = True "
+                         "(the reference's setting, BaseManager.py:122: MIOpen searches its solvers per shape during "
+                         "the warm-up step -- many minutes for HRNet-W48's ~300 convolution shapes on a cold find-db) "
+                         "and print both ratios")
     ap.add_argument("--eager-baseline", action="store_true",
                     help="also time the eager-structure restatement of the loss alone on the GPU")
     ap.add_argument("--no-eager-step", action="store_true",
@@ -203,7 +208,8 @@ def roofline_conv_kernels(args, dev, iters=20):
                 "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_note": note,
                 "traffic": (2 * pmc[0] + pmc[1]) * 1024 if (default_shape and pmc) else None,
-                "traffic_source": "profiles/r02_conv_pmc_fetch.csv, r02_conv_pmc_write.csv (FETCH_SIZE x 2 + WRITE_SIZE)",
+                "traffic_source": "constant from profiles/r02_conv_pmc_fetch.csv, r02_conv_pmc_write.csv (FETCH_SIZE x 2 + "
+                                  "WRITE_SIZE of a separate rocprofv3 --pmc run; not read live)",
                 "algorithmic_bytes": 2 * n * c * h * w * 4, "launch_ms": round(ms, 4)}, x
     main, _ = conv_entry(720, "k_conv3x3<3,4,1>", PMC_CONV720, 5)
     torch.cuda.empty_cache()
@@ -265,12 +271,14 @@ def roofline_bwd_kernel(mod, iters=10):
             "peak_note": ("f32 MFMA 157.3 TFLOP/s" if mode == "f32" else
                           "4NMC algorithmic FLOP issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): "
                           "2.5 PFLOP/s / 3 = 833.3 TFLOP/s"),
-            "traffic": traffic, "traffic_source": "profiles/r02_loss_pmc_fetch.csv, r02_loss_pmc_write.csv",
+            "traffic": traffic, "traffic_source": "constant from " + PMC_SOURCE + " (separate rocprofv3 --pmc run; "
+                                                                   "not read live)",
             "algorithmic_bytes": 3 * N * 256 * 4, "launch_ms": round(ms, 4), "N1": N, "N2": N, "C": 256,
             "nsplit": ns}
 
 
 PMC_F16X3 = (104540.5, 128128.0)      # KiB per launch (FETCH_SIZE, WRITE_SIZE), profiles/r02_loss_pmc_*.csv
+PMC_SOURCE = "profiles/r02_loss_pmc_fetch.csv, r02_loss_pmc_write.csv"
 
 
 def cpu_baseline_loss(args, n_terms):
@@ -446,6 +454,10 @@ def time_train_step(args, dev, rank, world):
     mod = mgr.loss.loss_classes["DenseContrastiveLossV2_ms"]
     extra = {"contrastive_loss_fwd_bwd_ms": round(loss_only_ms(mod, dev, args), 3),
              "metrics_in_step": not args.no_metrics,
+             # graph key of THIS repo (default off in models/HRNet.py; the reference has no such key): the logits stay
+             # at 1/4 resolution and up-sampling + cross-entropy / arg-max run in fused kernels.  --materialize-logits
+             # gives the reference's return value (a full-resolution logits tensor); worth ~0.8 ms of the step
+             "lazy_logits": not args.materialize_logits,
              "model_dtype": "bf16-autocast" if args.amp else "f32",
              "memory_format": "channels_last" if args.channels_last else "contiguous",
              "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
@@ -470,11 +482,38 @@ def loss_only_ms(mod, dev, args, iters=5):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` (N > 1) started WITHOUT a launcher (no WORLD_SIZE in the environment): start the N
+    ranks ourselves -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` on
+    this very command line, as a CHILD process and before anything in this process has touched the GPU -- forward
+    rank 0's single JSON line and exit with the child's code.  (Under the driver's own torch.distributed.run launch
+    WORLD_SIZE is set and this is skipped.)"""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    rehearsal = os.environ.get("DCL_BENCH_REHEARSAL") == "1"
+    if have < args.gpus and not rehearsal:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node "
+                         f"(DCL_BENCH_REHEARSAL=1 rehearses the {args.gpus}-rank launch on one GPU over gloo; "
+                         f"its number is not a measurement)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     global MFMA_MODE
     MFMA_MODE = args.mfma
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the two must agree")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     rehearsal = world > 1 and os.environ.get("DCL_BENCH_REHEARSAL") == "1"
@@ -552,14 +591,23 @@ def main():
             out["speedup_vs_eager_gpu_step"] = round(eager_ms / ms_per_step, 2)
             out["eager_gpu_step_note"] = ("same architecture on stock PyTorch-ROCm kernels (MIOpen / ATen, one stream) + "
                                           "eager-structure contrastive loss (oracle/eager_torch.py) + SGD, same GPU, "
-                                          "median of 3 after 1 warm-up; BASELINE.json target: >= 5x")
+                                          "median of 3 after 1 warm-up; BASELINE.json target: >= 5x; "
+                                          "torch.backends.cudnn.benchmark off (MIOpen's immediate-mode solvers) -- "
+                                          "--eager-miopen-benchmark adds the reference's benchmark=True setting; the "
+                                          "comparator has no per-step metrics tail, the timed step does")
+            if args.eager_miopen_benchmark:
+                t0 = time.perf_counter()
+                tuned_ms = eager_gpu_step_ms(args, dev, miopen_benchmark=True)
+                out["eager_gpu_step_ms_miopen_find"] = round(tuned_ms, 1)
+                out["speedup_vs_eager_gpu_step_miopen_find"] = round(tuned_ms / ms_per_step, 2)
+                out["eager_miopen_find_total_s"] = round(time.perf_counter() - t0, 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def eager_gpu_step_ms(args, dev, iters=3):
+def eager_gpu_step_ms(args, dev, iters=3, miopen_benchmark=False):
     """The "reference PyTorch-eager GPU step" of BASELINE.json's >= 5x target (SURVEY.md section 8 row d), measured
     on THIS MI355X in the same run: the same HRNet-W48 + projector architecture on stock PyTorch-ROCm kernels only
     (MIOpen convolutions and batch norm, ATen interpolate, one stream; mscs_amd.models.ops.library_kernels_only),
@@ -575,7 +623,7 @@ def eager_gpu_step_ms(args, dev, iters=3):
     graph = {"backbone": "hrnet48", "pretrained": False, "dataset": "CITYSCAPES", "align_corners": True,
              "branch_conv": "library", "head_conv": "library", "fused_bn": False, "gemm_conv1x1": False, "conv1x1": "library",
              "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True}}
-    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.benchmark = bool(miopen_benchmark)
     model = HRNet(graph, 1).to(dev).train()
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
     gen = torch.Generator().manual_seed(0)
@@ -601,6 +649,7 @@ def eager_gpu_step_ms(args, dev, iters=3):
         raise RuntimeError(f"eager comparator diverged: loss {float(loss)}")
     del model, opt
     torch.cuda.empty_cache()
+    torch.backends.cudnn.benchmark = False
     return sorted(times)[len(times) // 2]
 
 

@@ -73,7 +73,6 @@ SIGNATURES = {
     "dcl_upsample_ce_set_fwd_lds": [_i],
     "dcl_wgrad3x3_set_tile": [_i, _i],
     "dcl_wgrad3x3_set_variant": [_i],
-    "dcl_wgrad3x3_set_partition": [_i, _i],
     "dcl_wgrad3x3_f16x3": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],
     "dcl_confusion_matrix": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp],
     "dcl_metrics_from_cm": [_vp, _i, _i, _vp, _vp],
@@ -122,15 +121,8 @@ def lib():
             fn.restype = ctypes.c_int
         l.dcl_last_error.restype = ctypes.c_char_p
         l.dcl_last_error.argtypes = []
-        # A/B switches for the tuning tools (same box, same process layout): kernel variants by environment variable
-        for env, fn in (("DCL_WGRAD_VARIANT", l.dcl_wgrad3x3_set_variant), ("DCL_WGRAD_S2", l.dcl_wgrad3x3_set_stride2),
-                        ("DCL_UP2_PHASES", l.dcl_conv3x3_set_up2_phases),
-                        ("DCL_UPCE_BWD_CHUNK", l.dcl_upsample_ce_set_bwd_chunk),
-                        ("DCL_UPCE_FWD_KIB", l.dcl_upsample_ce_set_fwd_lds)):
-            if os.environ.get(env) is not None:
-                fn(int(os.environ[env]))
-        if os.environ.get("DCL_WGRAD_TILE"):
-            l.dcl_wgrad3x3_set_tile(*[int(v) for v in os.environ["DCL_WGRAD_TILE"].split(",")])
+        from .debug import cfg as _dbg       # A/B switches of the tuning tools: one object, read once
+        _dbg.apply_to_library(l)
         _lib = l
     return _lib
 

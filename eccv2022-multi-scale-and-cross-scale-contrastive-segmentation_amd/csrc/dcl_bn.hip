@@ -147,7 +147,7 @@ __global__ void k_bn_finalize(const float *__restrict__ sums, int C, double coun
     }
 }
 
-// grid (ceil(HW/1024), N*C)
+// grid: ceil(row vectors / 1024) chunks x rows, linearised (see k_bn_apply)
 // per-plane (image, channel) absmax side output (consumed by the f16x3 convolution to pick its power-of-two
 // operand scale; one slot per plane keeps the atomics per address at HW / 1024):
 // block maximum -> one integer atomicMax on the float bits (values are >= 0, so uint order == float order and
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, int C, int HW,
                                                         float *__restrict__ y, float *__restrict__ amax,
-                                                        BnFused f, int N)
+                                                        BnFused f, int N, unsigned nchunk)
 {
     // One grid row per CHANNEL; its N * HW elements (N segments of HW, C * HW apart) are one index space cut into
     // workgroup-sized pieces -- with one grid row per (image, channel) plane the small maps (384 channels, 16 x 32)
@@ -228,11 +228,14 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
     // That layout is used when a plane is smaller than a workgroup's share (`flat`); large planes keep one grid row per
     // plane (n0 fixed), which streams them in address order (the channel-major order cost the 48-channel, 128 x 256
     // maps 30 %).
+    // 1-D grid: (chunk of the row, row) linearised with the chunk fastest -- a 2-D grid would cap the rows (N * C
+    // planes) at 65 535
+    const unsigned bx = blockIdx.x % nchunk, by = blockIdx.x / nchunk;
     const bool flat = N > 0;
-    const int c = flat ? blockIdx.y : blockIdx.y % C, n0 = flat ? 0 : blockIdx.y / C;
+    const int c = flat ? (int)by : (int)(by % (unsigned)C), n0 = flat ? 0 : (int)(by / (unsigned)C);
     const int hw4 = HW >> 2;
     const unsigned nv = flat ? (unsigned)N * (unsigned)hw4 : (unsigned)hw4;      // vectors in this grid row
-    const unsigned j0 = blockIdx.x * (BN_UNROLL * BN_THREADS) + threadIdx.x;
+    const unsigned j0 = bx * (BN_UNROLL * BN_THREADS) + threadIdx.x;
     float am = 0.f;
     float sc = 0.f, sh = 0.f;
     // The per-channel constants are computed by ONE thread and handed to the others through LDS after the tensor loads
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
         var = var > 0.0 ? var : 0.0;
         const double m = ms + (f.pivot ? (double)f.pivot[c] : 0.0);
         const float mean_f = (float)m, invstd_f = (float)(1.0 / sqrt(var + (double)f.eps));
-        if (blockIdx.x == 0 && n0 == 0) {
+        if (bx == 0 && n0 == 0) {
             f.mean[c] = mean_f;
             f.invstd[c] = invstd_f;
             if (f.running_mean) {
@@ -428,13 +431,17 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                                                             float *__restrict__ dx,
                                                             float *__restrict__ dres,
                                                             float *__restrict__ amax, BnFused f,
-                                                            const unsigned long long *__restrict__ mask, int N)
+                                                            const unsigned long long *__restrict__ mask, int N,
+                                                            unsigned nchunk)
 {
+    // 1-D grid: (chunk of the row, row) linearised with the chunk fastest -- a 2-D grid would cap the rows (N * C
+    // planes) at 65 535
+    const unsigned bx = blockIdx.x % nchunk, by = blockIdx.x / nchunk;
     const bool flat = N > 0;                            // one grid row per channel | per plane (see k_bn_apply)
-    const int c = flat ? blockIdx.y : blockIdx.y % C, n0 = flat ? 0 : blockIdx.y / C;
+    const int c = flat ? (int)by : (int)(by % (unsigned)C), n0 = flat ? 0 : (int)(by / (unsigned)C);
     const int hw4 = HW >> 2;
     const unsigned nv = flat ? (unsigned)N * (unsigned)hw4 : (unsigned)hw4;
-    const unsigned j0 = blockIdx.x * (BN_UNROLL * BN_THREADS) + threadIdx.x;
+    const unsigned j0 = bx * (BN_UNROLL * BN_THREADS) + threadIdx.x;
     float am = 0.f;
     const float m = mean[c], is = invstd[c];
     float asc, ash;                                   // y == NULL: ReLU mask recomputed from x (see the reduce)
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
         part_sums(f.part, c, f.ns, a, b);
         mg = a * inv_count;
         mgx = b * inv_count;
-        if (blockIdx.x == 0 && n0 == 0 && (f.dbeta || f.dgamma)) {
+        if (bx == 0 && n0 == 0 && (f.dbeta || f.dgamma)) {
             float la = a, lb = b;
             if (f.part_local != f.part)
                 part_sums(f.part_local, c, f.ns, la, lb);       // this rank's sums: DDP averages the parameter grads
@@ -607,11 +614,12 @@ extern "C" int dcl_bn_apply(const float *x, const float *res, const float *mean,
     // (kernel argument N > 0); else one grid row per plane (N = 0)
     const bool flat = (HW + 3) / 4 < BN_THREADS * BN_UNROLL;
     const long long nvs = flat ? ((long long)N * HW + 3) / 4 : (HW + 3) / 4;
-    DCL_CHECK_ARG(flat || (long long)N * C <= 65535, "N * C must not exceed 65535 for planes of >= 4096 elements");
-    dim3 grid((unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL)), flat ? C : N * C);
+    const unsigned nchunk = (unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL));
+    DCL_CHECK_ARG((long long)nchunk * (flat ? C : (long long)N * C) < (1LL << 31), "tensor too large for one launch");
+    dim3 grid(nchunk * (unsigned)(flat ? C : N * C));
     const int Nk = flat ? N : 0;
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, mean, invstd, gamma, beta, C, HW, y, amax, BnFused{}, Nk)
+#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, mean, invstd, gamma, beta, C, HW, y, amax, BnFused{}, Nk, nchunk)
     if (relu && res) LAUNCH(true, true);
     else if (relu) LAUNCH(true, false);
     else if (res) LAUNCH(false, true);
@@ -653,15 +661,16 @@ extern "C" int dcl_bn_bwd_apply(const float *dy, const float *x, const float *y,
     // (kernel argument N > 0); else one grid row per plane (N = 0)
     const bool flat = (HW + 3) / 4 < BN_THREADS * BN_UNROLL;
     const long long nvs = flat ? ((long long)N * HW + 3) / 4 : (HW + 3) / 4;
-    DCL_CHECK_ARG(flat || (long long)N * C <= 65535, "N * C must not exceed 65535 for planes of >= 4096 elements");
-    dim3 grid((unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL)), flat ? C : N * C);
+    const unsigned nchunk = (unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL));
+    DCL_CHECK_ARG((long long)nchunk * (flat ? C : (long long)N * C) < (1LL << 31), "tensor too large for one launch");
+    dim3 grid(nchunk * (unsigned)(flat ? C : N * C));
     const int Nk = flat ? N : 0;
     hipStream_t st = (hipStream_t)stream;
     const float inv = (float)(1.0 / count);
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{}, (const unsigned long long *)nullptr, Nk);
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{}, (const unsigned long long *)nullptr, Nk, nchunk);
     else
-        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{}, (const unsigned long long *)nullptr, Nk);
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, sums, inv, C, HW, dx, dres, amax, BnFused{}, (const unsigned long long *)nullptr, Nk, nchunk);
     DCL_LAUNCH_CHECK();
     return 0;
 }
@@ -706,11 +715,12 @@ extern "C" int dcl_bn_apply_fused(const float *x, const float *res, const float 
     // (kernel argument N > 0); else one grid row per plane (N = 0)
     const bool flat = (HW + 3) / 4 < BN_THREADS * BN_UNROLL;
     const long long nvs = flat ? ((long long)N * HW + 3) / 4 : (HW + 3) / 4;
-    DCL_CHECK_ARG(flat || (long long)N * C <= 65535, "N * C must not exceed 65535 for planes of >= 4096 elements");
-    dim3 grid((unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL)), flat ? C : N * C);
+    const unsigned nchunk = (unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL));
+    DCL_CHECK_ARG((long long)nchunk * (flat ? C : (long long)N * C) < (1LL << 31), "tensor too large for one launch");
+    dim3 grid(nchunk * (unsigned)(flat ? C : N * C));
     const int Nk = flat ? N : 0;
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, (const float *)nullptr, (const float *)nullptr, gamma, beta, C, HW, y, amax, f, Nk)
+#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply<R, S>), grid, dim3(BN_THREADS), 0, st, x, res, (const float *)nullptr, (const float *)nullptr, gamma, beta, C, HW, y, amax, f, Nk, nchunk)
     if (relu && res) LAUNCH(true, true);
     else if (relu) LAUNCH(true, false);
     else if (res) LAUNCH(false, true);
@@ -762,15 +772,16 @@ extern "C" int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const flo
     // (kernel argument N > 0); else one grid row per plane (N = 0)
     const bool flat = (HW + 3) / 4 < BN_THREADS * BN_UNROLL;
     const long long nvs = flat ? ((long long)N * HW + 3) / 4 : (HW + 3) / 4;
-    DCL_CHECK_ARG(flat || (long long)N * C <= 65535, "N * C must not exceed 65535 for planes of >= 4096 elements");
-    dim3 grid((unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL)), flat ? C : N * C);
+    const unsigned nchunk = (unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL));
+    DCL_CHECK_ARG((long long)nchunk * (flat ? C : (long long)N * C) < (1LL << 31), "tensor too large for one launch");
+    dim3 grid(nchunk * (unsigned)(flat ? C : N * C));
     const int Nk = flat ? N : 0;
     hipStream_t st = (hipStream_t)stream;
     const float inv = (float)(1.0 / count);
     if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask, Nk);
+        hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask, Nk, nchunk);
     else
-        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask, Nk);
+        hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask, Nk, nchunk);
     DCL_LAUNCH_CHECK();
     return 0;
 }

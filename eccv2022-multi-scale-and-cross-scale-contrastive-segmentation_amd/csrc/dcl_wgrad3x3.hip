@@ -483,23 +483,15 @@ static void launch_wgrad_reduce(const float *part, int S, int Cout, int Cin, flo
 
 static int g_tile_nco = 0, g_tile_nci = 0;      // tuning override (dcl_wgrad3x3_set_tile), 0 = automatic
 static int g_force_nx = 0;                      // tuning override: pixel splits per tile pair (0 = automatic)
-static int g_variant = -1;     // 1 = shared-dY workgroups (dcl_wgrad3x3s.hip), 0 = per-wave operands, -1 = by shape
+static int g_variant = -1;     // 0 = MFMA-order operand loads (this file), -1 / 2 = LDS-DMA staging (dcl_wgrad3x3d.hip)
 
-// The shared-dY kernel was the answer to the L1 tag rate of the MFMA-order loads (192 channels: 58.6 vs 64.3 us, 384: 73.4
-// vs 89.3 us).  With the operands staged by LDS-DMA the per-wave kernel reaches the same times (63 / 81 us, head 10.7 ms)
-// with slabs a quarter of the size -- in the training step, where the slab reduction competes with the neighbouring
-// kernels for HBM, that is what counts (k_wgrad_reduce_sk 38 us vs k_wgrad_reduce 9.5 us per launch in the step
-// profile).  So the shared kernel only runs when asked for.
-static bool use_shared(int Cin) { return g_variant == 1; }
-// per-wave kernel: operands staged by LDS-DMA (dcl_wgrad3x3d.hip) unless variant 0 asks for the direct loads
+// (A third variant -- workgroups handing the dY rows of a co group to each other through LDS, optional stream-K partition
+// -- reached the same kernel times as the LDS-DMA kernel with slabs four times the size and lost in the training step; it
+// was retired from the library in round 3: tools/probes/retired/dcl_wgrad3x3s.hip.)
+// per-wave kernel: operands staged by LDS-DMA (dcl_wgrad3x3d.hip) unless variant 0 asks for the direct loads; the direct
+// loads also serve tensors beyond the DMA kernel's 32-bit offsets and the zero-inserted stride-2 form
 static bool use_dma(int Cin, int H, int W) { return g_variant != 0 && (size_t)Cin * H * W * 4 < ((size_t)1 << 32); }
 
-// dcl_wgrad3x3s.hip
-int dcl_wgrad_shared_slabs(int N, int Cin, int Cout, int H, int W, int force_nco, int force_nci);
-void dcl_wgrad_shared_launch(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax,
-                             int xcount, const float *gamax, int gcount, int stride, float *part, float *dw, int force_nco,
-                             int force_nci, hipStream_t s);
-void dcl_wgrad_shared_tune(int sk_mode, int nwg);
 // dcl_wgrad3x3_s2.hip
 bool dcl_wgrad_s2_supported(int H, int W);
 int dcl_wgrad_s2_slabs(int N, int Cin, int Cout, int H, int W, int force_nco, int force_nci);
@@ -552,17 +544,9 @@ extern "C" int dcl_wgrad3x3_set_tile(int nco, int nci)
 
 extern "C" int dcl_wgrad3x3_set_variant(int variant)
 {
-    if (variant < -1 || variant > 2)
+    if (variant < -1 || variant > 2 || variant == 1)     // 1 was the retired kernel
         return DCL_EINVAL;
     g_variant = variant;
-    return 0;
-}
-
-extern "C" int dcl_wgrad3x3_set_partition(int stream_k, int nwg)
-{
-    if (stream_k < -1 || stream_k > 1 || nwg < 0)
-        return DCL_EINVAL;
-    dcl_wgrad_shared_tune(stream_k, nwg);
     return 0;
 }
 
@@ -585,8 +569,6 @@ extern "C" int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W, int s
     if (stride == 2 && g_s2_native && dcl_wgrad_s2_supported(H, W))
         return dcl_wgrad_s2_slabs(N, Cin, Cout, H, W, g_tile_nco, g_tile_nci);
     int nco, nci, S, units;
-    if (use_shared(Cin))
-        return dcl_wgrad_shared_slabs(N, Cin, Cout, H, W, g_tile_nco, g_tile_nci);
     wgrad_plan(N, Cin, Cout, H, W, nco, nci, S, units);
     return nco * nci <= 4 ? (S + 3) / 4 : S;      // one slab per workgroup (4 splits), or per wave (6-tile variant)
 }
@@ -609,12 +591,6 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
         const int total = 9 * Cout * Cin;
         (void)total;
         launch_wgrad_reduce(part, nslab, Cout, Cin, dw, (hipStream_t)stream);
-        DCL_LAUNCH_CHECK();
-        return 0;
-    }
-    if (use_shared(Cin)) {
-        dcl_wgrad_shared_launch(x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, stride, part, dw, g_tile_nco,
-                                g_tile_nci, (hipStream_t)stream);
         DCL_LAUNCH_CHECK();
         return 0;
     }

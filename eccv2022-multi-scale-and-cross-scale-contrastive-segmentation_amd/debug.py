@@ -1,0 +1,65 @@
+"""The ONE place where tuning / A-B switches enter the package.
+
+Every switch of the tuning tools (tools/*.py, bench.py A/B runs on one box) is a field of ``cfg`` below, read from
+the environment ONCE at import; product modules read ``debug.cfg.<field>`` and never touch ``os.environ``.  All
+defaults are the shipped configuration; nothing here changes results beyond fp32 round-off (kernel variants, stream
+layout), and none of it is part of the reference's surface."""
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+
+def _flag(name: str, default: bool = True) -> bool:
+    v = os.environ.get(name)
+    return default if v is None else v != '0'
+
+
+def _int(name: str) -> Optional[int]:
+    v = os.environ.get(name)
+    return None if v is None or v == '' else int(v)
+
+
+@dataclass
+class DebugConfig:
+    # ---- model graph (models/HRNet.py, models/ops.py, models/fused_bn.py)
+    fuse_residual_grad: bool = field(default_factory=lambda: _flag('DCL_FUSE_RESIDUAL_GRAD'))   # GradToken path
+    branch_streams: bool = field(default_factory=lambda: _flag('DCL_BRANCH_STREAMS'))           # one HIP stream per branch
+    defer_join: bool = field(default_factory=lambda: _flag('DCL_DEFER_JOIN'))                   # no join between modules
+    stage_continuity: bool = field(default_factory=lambda: _flag('DCL_STAGE_CONTINUITY'))       # ... nor between stages
+    fanout_on_branch_stream: bool = field(default_factory=lambda: _flag('DCL_FANOUT_STREAM'))
+    branch_stream_map: List[int] = field(default_factory=lambda: [
+        int(v) for v in os.environ.get('DCL_BRANCH_STREAM_MAP', '').split(',') if v != ''])     # e.g. "0,1,1,0"
+    fuse_order: bool = field(default_factory=lambda: _flag('DCL_FUSE_ORDER'))                   # stride-2 chains last
+    fanout: bool = field(default_factory=lambda: _flag('DCL_FANOUT'))                           # one-kernel gradient sums
+    upsample_tag: bool = field(default_factory=lambda: _flag('DCL_UPSAMPLE_TAG'))               # absmax tags of up-sampled maps
+    packed_relu_mask: bool = field(default_factory=lambda: _flag('DCL_BN_MASK'))                # packed sign mask in the BN backward
+    coalesced_sync_bn: bool = field(default_factory=lambda: _flag('DCL_SYNCBN_COALESCE'))       # stacked SyncBN exchanges
+    bn_fold: bool = field(default_factory=lambda: _flag('DCL_BN_FOLD'))                         # norm + ReLU folded into the next conv
+    linear_f16x3_rows: int = field(default_factory=lambda: _int('DCL_LINEAR_F16X3_ROWS') or 0)  # TokenLinear on the f16x3 kernel
+    # ---- loss
+    mfma_mode: Optional[str] = field(default_factory=lambda: os.environ.get('DCL_MFMA'))        # 'f32' | 'f16x3' override
+    sweep_streamk: Optional[int] = field(default_factory=lambda: _int('DCL_SWEEP_STREAMK'))     # 0 = column-split slabs
+    # ---- kernel variants set on the library at load (include/dcl_hip.h "tuning hook" entries)
+    wgrad_variant: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_VARIANT'))
+    wgrad_stride2: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_S2'))
+    up2_phases: Optional[int] = field(default_factory=lambda: _int('DCL_UP2_PHASES'))
+    upce_bwd_chunk: Optional[int] = field(default_factory=lambda: _int('DCL_UPCE_BWD_CHUNK'))
+    upce_fwd_kib: Optional[int] = field(default_factory=lambda: _int('DCL_UPCE_FWD_KIB'))
+    wgrad_tile: Optional[Tuple[int, int]] = field(default_factory=lambda: (
+        tuple(int(v) for v in os.environ['DCL_WGRAD_TILE'].split(',')) if os.environ.get('DCL_WGRAD_TILE') else None))
+
+    def apply_to_library(self, l) -> None:
+        """Hand the kernel-variant switches to a freshly loaded libdcl_hip.so."""
+        for val, fn in ((self.wgrad_variant, l.dcl_wgrad3x3_set_variant), (self.wgrad_stride2, l.dcl_wgrad3x3_set_stride2),
+                        (self.up2_phases, l.dcl_conv3x3_set_up2_phases),
+                        (self.upce_bwd_chunk, l.dcl_upsample_ce_set_bwd_chunk),
+                        (self.upce_fwd_kib, l.dcl_upsample_ce_set_fwd_lds)):
+            if val is not None:
+                fn(int(val))
+        if self.wgrad_tile:
+            l.dcl_wgrad3x3_set_tile(*self.wgrad_tile)
+        if self.sweep_streamk is not None and hasattr(l, 'dcl_infonce_set_streamk'):
+            l.dcl_infonce_set_streamk(int(self.sweep_streamk))
+
+
+cfg = DebugConfig()

@@ -65,9 +65,9 @@ class DenseContrastiveLossV2(nn.Module):
         # (RCCL all-gather of the sampled embeddings; gradients stay rank-local)
         self.global_negatives = bool(config.get('global_negatives', False))
         # similarity-product arithmetic: 'f32' (exact fp32 MFMA) or 'f16x3' (split-f16 MFMA, fp32-equivalent);
-        # config key 'mfma_mode', overridable with the DCL_MFMA environment variable
-        import os
-        self.mfma_mode = os.environ.get('DCL_MFMA', config.get('mfma_mode', 'f16x3'))
+        # config key 'mfma_mode', overridable through the debug configuration (mscs_amd/debug.py: DCL_MFMA)
+        from ..debug import cfg as _dbg
+        self.mfma_mode = _dbg.mfma_mode or config.get('mfma_mode', 'f16x3')
         assert self.mfma_mode in ('f32', 'f16x3'), f"mfma_mode must be 'f32' or 'f16x3', got {self.mfma_mode}"
         if self.label_scaling_mode == 'nn':
             assert self.dominant_mode == 'all', \

@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from ..utils import DATASETS_INFO, is_distributed, printlog
 from .DenseContrastiveLossV2 import DenseContrastiveLossV2 as DCV2
-from .engine import dense_contrast_terms, presample
+from .engine import PreSampleFailed, dense_contrast_terms, presample
 
 
 class DenseContrastiveLossV2_ms(nn.Module):
@@ -54,7 +54,13 @@ class DenseContrastiveLossV2_ms(nn.Module):
         plan (the reference's randperm draws, same order) and the pixel selection kernel -- on a side stream, so
         that none of it waits behind the model forward and the forward pass is not followed by ~1.5 ms of host work
         with the GPU idle.  A no-op until one forward has been seen for this label shape (the strides come from the
-        feature maps).  Does not touch the RNG; forward() ignores the staged result if the label changed."""
+        feature maps).  It DOES consume the CPU generator: the randperm draws of this step happen here, in the
+        reference's order, instead of inside forward() -- so call it only for a step whose forward() will evaluate
+        this loss on the same label tensor (LossWrapper.prepare skips components that are not in ``loss_list``).
+        A planning error (e.g. no (image, class) pair with ``min_views_per_class`` pixels) is not raised here: it is
+        kept and re-raised by forward() from inside the autograd function, i.e. behind the all-rank agreement of the
+        shared negative bank (engine.agree_or_raise) -- raising here would leave the other ranks waiting in their
+        first collective."""
         geoms = self._geoms.get(tuple(label.shape))
         if geoms is None or not label.is_cuda:
             return False
@@ -62,9 +68,16 @@ class DenseContrastiveLossV2_ms(nn.Module):
             # high priority: its own hardware queue, so that the label stage is not queued behind the previous step's
             # backward (HIP maps the ordinary streams of a process onto a few shared hardware queues)
             self._side_stream = torch.cuda.Stream(device=label.device, priority=-1)
-        self._staged = presample(self._engine_cfg(), label, geoms, bool(self.cross_scale_contrast),
-                                 self._side_stream, ready_event=ready_event)
+        try:
+            self._staged = presample(self._engine_cfg(), label, geoms, bool(self.cross_scale_contrast),
+                                     self._side_stream, ready_event=ready_event)
+        except Exception as e:  # noqa: BLE001 -- surfaces in forward(), see the docstring
+            self._staged = PreSampleFailed(e, label)
         return True
+
+    def discard_prepared(self):
+        """Drop what prepare() staged (the step turned out not to evaluate this loss)."""
+        self._staged = None
 
     def _engine_cfg(self):
         return self.DCV2_scale0.engine_config(weights=tuple(float(w) for w in self.weights),

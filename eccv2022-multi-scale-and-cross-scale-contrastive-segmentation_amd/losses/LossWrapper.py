@@ -46,13 +46,15 @@ class LossWrapper(nn.Module):
         self.info_string = self.info_string[:-2]
         self.dc_off = True if 'dc_off_at_epoch' in self.config else False
 
-    def prepare(self, labels: torch.Tensor, ready_event=None):
+    def prepare(self, labels: torch.Tensor, ready_event=None, loss_list: list = None):
         """Forward the label tensor to components that can start work before the model forward
-        (DenseContrastiveLossV2_ms.prepare).  Optional; not part of the reference surface."""
+        (DenseContrastiveLossV2_ms.prepare).  Optional; not part of the reference surface.  ``loss_list``: the list
+        forward() will be called with -- a component that is left out of it is not prepared (its preparation would
+        consume the step's randperm draws for nothing)."""
         if labels.dtype != torch.int64:       # forward() would see a different (converted) tensor
             return
-        for fn in self.loss_classes.values():
-            if hasattr(fn, 'prepare'):
+        for name, fn in self.loss_classes.items():
+            if hasattr(fn, 'prepare') and (loss_list is None or name in loss_list):
                 fn.prepare(labels, ready_event=ready_event)
 
     def _zero(self):
@@ -104,6 +106,8 @@ class LossWrapper(nn.Module):
                     loss = self._zero()
             else:
                 loss = self._zero()
+                if hasattr(self.loss_classes[loss_class], 'discard_prepared'):
+                    self.loss_classes[loss_class].discard_prepared()     # prepared for a step that leaves it out
 
             loss = loss * self.loss_weightings[loss_class]
             self.loss_vals[loss_class] = loss.detach()

@@ -363,6 +363,15 @@ class PreSampled:
         self.st, self.key, self.geoms, self.cfg_key, self.stream, self.event = st, key, geoms, cfg_key, stream, event
 
 
+class PreSampleFailed:
+    """prepare() ran the sampling plan ahead of the model forward and it raised (its RNG draws, if any, are spent).
+    The error is re-raised by ``plan_and_sample`` -- inside DenseContrastFunction.forward, i.e. behind
+    ``agree_or_raise`` when the shared negative bank is on, so that every rank leaves the step together."""
+
+    def __init__(self, error: BaseException, label: torch.Tensor):
+        self.error, self.key = error, _label_key(label)
+
+
 def _cfg_key(cfg: EngineConfig, with_cross: bool):
     return (cfg.num_all_classes, cfg.min_views_per_class, cfg.max_views_per_class, cfg.max_features_total,
             tuple(cfg.weights), bool(with_cross), cfg.temperature, cfg.cross_scale_temperature, bool(cfg.detach_deepest),
@@ -409,6 +418,10 @@ def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torc
     n, H, W = label.shape
     K = cfg.num_all_classes
     geoms = feature_geometry((n, H, W), feats)
+    if isinstance(staged, PreSampleFailed):
+        if staged.key == _label_key(label):
+            raise staged.error                       # planning of THIS step already failed in prepare()
+        staged = None
     if isinstance(staged, PreSampled):
         pre, staged = staged, None
         if pre.key == _label_key(label) and pre.geoms == geoms and pre.cfg_key == _cfg_key(cfg, with_cross):

@@ -29,7 +29,7 @@ from ..losses import LossWrapper
 from ..utils import DATASETS_INFO, printlog
 from ..utils.config import parse_config
 from ..utils.lr_functions import LRFcts
-from ..utils.metrics import (out_of_range, t_get_confusion_matrix, t_get_mean_iou, t_get_pixel_accuracy,
+from ..utils.metrics import (out_of_range, take_out_of_range, t_get_confusion_matrix, t_get_mean_iou, t_get_pixel_accuracy,
                              t_metrics_from_confusion_matrix)
 
 
@@ -207,7 +207,9 @@ class BaseManager:
         keys = tcfg.get('opt_keys')
         if not keys:
             return self.model.parameters()
-        base_lr, base_wd = tcfg['learning_rate'], tcfg.get('weight_decay', 0.0)
+        # like the reference (optimizer_utils.py:38): opt_keys without train.weight_decay is a KeyError, not a silent
+        # run with zero weight decay (every group carries an explicit value, so the optimiser's default never applies)
+        base_lr, base_wd = tcfg['learning_rate'], tcfg['weight_decay']
         groups = {}
         for name, p in self.model.named_parameters():
             if not p.requires_grad:
@@ -320,7 +322,7 @@ class BaseManager:
                     vals.append(v.float())
         if loss.is_cuda:          # targets outside the class range, counted by the confusion-matrix kernel
             keys.append('_oob')
-            vals.append(out_of_range(loss.device).float())
+            vals.append(take_out_of_range(loss.device))           # this step's count; the counter restarts at 0
         dev_vals = torch.stack([v.reshape(()) for v in vals])
         self.flush_logging()                                        # the PREVIOUS step's record
         if loss.is_cuda:
@@ -369,6 +371,11 @@ class BaseManager:
             if i + 1 >= self.config.get('max_valid_imgs', 10):
                 break
         miou = float(t_get_mean_iou(cm).item())
+        if torch.is_tensor(cm) and cm.is_cuda and int(take_out_of_range(cm.device).item()) > 0:
+            # a validation label outside the class range: F.one_hot's error in the reference's confusion matrix
+            # (utils/torch_utils.py:172-177), raised here instead of by the next training epoch's first flush
+            self.model.train()
+            raise RuntimeError('Class values must be smaller than num_classes.')
         self.metrics['final_miou'] = miou
         self.metrics['final_miou_step'] = self.global_step - 1
         is_best = miou > self.best_miou

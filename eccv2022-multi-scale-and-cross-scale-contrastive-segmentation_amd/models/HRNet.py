@@ -19,12 +19,11 @@ Reference quirks kept on purpose: exchange modules interpola
 concat and the logits up-sampling use the configured value; ``HRNet`` always builds the W48 backbone
 unless ``config['backbone']`` names another factory (an extension: the reference hard-codes it).
 """
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..debug import cfg as _dbg
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
 from .ops import (ConvPackGroup, DirectConv2d, GradToken, use_gemm_conv1x1, upsample_bilinear, use_direct_conv3x3,
@@ -70,14 +69,15 @@ def _conv_bn(cin, cout, k, stride=1, relu=False, norm=nn.BatchNorm2d):
     return _ConvBN(*layers)
 
 
-_FUSE_RESIDUAL_GRAD = os.environ.get('DCL_FUSE_RESIDUAL_GRAD', '1') != '0'
-_BRANCH_STREAMS = os.environ.get('DCL_BRANCH_STREAMS', '1') != '0'
+# A/B switches of the tuning tools: fields of the one debug configuration object (mscs_amd/debug.py); module-level
+# names so that library_kernels_only() and the tools can flip them on one box
+_FUSE_RESIDUAL_GRAD = _dbg.fuse_residual_grad
+_BRANCH_STREAMS = _dbg.branch_streams
 _SIDE_STREAMS = {}
-_DEFER_JOIN = os.environ.get('DCL_DEFER_JOIN', '1') != '0'
-_STAGE_CONTINUITY = os.environ.get('DCL_STAGE_CONTINUITY', '1') != '0'
-_FANOUT_ON_BRANCH_STREAM = os.environ.get('DCL_FANOUT_STREAM', '1') != '0'
-# experiment switch: stream per branch (0 = the main stream), e.g. "0,1,1,0"; default: one stream per branch
-_BRANCH_STREAM_MAP = [int(v) for v in os.environ.get('DCL_BRANCH_STREAM_MAP', '').split(',') if v != '']
+_DEFER_JOIN = _dbg.defer_join
+_STAGE_CONTINUITY = _dbg.stage_continuity
+_FANOUT_ON_BRANCH_STREAM = _dbg.fanout_on_branch_stream
+_BRANCH_STREAM_MAP = list(_dbg.branch_stream_map)     # stream per branch (0 = the main stream); default: one each
 
 
 def _side_streams(device, n):
@@ -314,7 +314,7 @@ class HighResolutionModule(nn.Module):
         # norm kernel whenever the row has one -- its backward reads the packed sign mask, where an up-sampling with a
         # fused ReLU needs a threshold pass over the full-resolution gradient (rows 1.. of every module: 14 passes less)
         others = [j for j in range(self.num_branches) if j > i] + [j for j in range(self.num_branches) if j < i]
-        if os.environ.get('DCL_FUSE_ORDER', '1') == '0':      # A/B switch for the tuning tools
+        if not _dbg.fuse_order:                                # A/B switch for the tuning tools
             others = [j for j in range(self.num_branches) if j != i]
         y = x[i]
         for pos, j in enumerate(others):

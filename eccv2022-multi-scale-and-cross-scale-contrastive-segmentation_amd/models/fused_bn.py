@@ -29,7 +29,8 @@ def _world():
 
 
 _EQUAL_BATCH_CHECKED = set()
-_PACKED_RELU_MASK = __import__('os').environ.get('DCL_BN_MASK', '1') != '0'      # A/B switch for the tuning tools
+from ..debug import cfg as _dbg      # noqa: E402
+_PACKED_RELU_MASK = _dbg.packed_relu_mask       # A/B switch for the tuning tools
 
 
 def _check_equal_batch(n, device):
@@ -140,7 +141,6 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
 
     def _fusable(self, x, residual):
         return (self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-                and x.shape[0] * x.shape[1] <= 65535        # the element-wise kernels put the (n, c) plane on grid.y
                 and x.is_contiguous() and self.affine and self.track_running_stats
                 and self.momentum is not None and not torch.is_autocast_enabled()
                 and (residual is None or (residual.shape == x.shape and residual.is_contiguous()
@@ -155,6 +155,12 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                                        float(self.momentum), bool(relu), bool(self.sync), amax,
                                        grad_token if residual is not None else None)
             return _amax.tag(y, amax) if amax is not None else y
+        if self.sync and self.training and _world() > 1:
+            # convert_sync_batchnorm only flips the flag of a FusedBatchNorm2d: nn.BatchNorm2d.forward below would
+            # silently normalise with THIS rank's statistics
+            raise RuntimeError("FusedBatchNorm2d(sync=True): input not supported by the fused SyncBatchNorm path "
+                               f"(shape {tuple(x.shape)}, dtype {x.dtype}, device {x.device}, contiguous "
+                               f"{x.is_contiguous()}); it needs contiguous float32 NCHW CUDA tensors outside autocast")
         y = super().forward(x)
         if residual is not None:
             y = y + residual

@@ -119,8 +119,9 @@ class _FanOut(torch.autograd.Function):
         return gs[0], None
 
 
-_FANOUT = __import__('os').environ.get('DCL_FANOUT', '1') != '0'        # A/B switches for the tuning tools
-_UPSAMPLE_TAG = __import__('os').environ.get('DCL_UPSAMPLE_TAG', '1') != '0'
+from ..debug import cfg as _dbg      # noqa: E402  (A/B switches of the tuning tools: one object, mscs_amd/debug.py)
+_FANOUT = _dbg.fanout
+_UPSAMPLE_TAG = _dbg.upsample_tag
 
 
 def fan_out(x, k):
@@ -696,7 +697,7 @@ class TokenLinear(torch.nn.Linear):
     gradient from 32768 rows on, and forward / data gradient on the f16x3 kernel for inputs of at most ``f16x3_rows``
     rows (class default; 0 = library GEMMs); anything else is nn.Linear.forward."""
 
-    f16x3_rows = int(os.environ.get("DCL_LINEAR_F16X3_ROWS", "0"))
+    f16x3_rows = _dbg.linear_f16x3_rows
 
     def use_f16x3(self, x):
         from .. import _lib

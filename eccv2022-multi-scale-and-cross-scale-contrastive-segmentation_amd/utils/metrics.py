@@ -23,8 +23,19 @@ def _oob_counter(device):
 
 
 def out_of_range(device):
-    """int32 [1] device counter of targets outside the class range seen by t_get_confusion_matrix so far."""
+    """int32 [1] device counter of targets outside the class range seen by t_get_confusion_matrix since the last
+    ``take_out_of_range`` (the fused up-sampling + CE kernels treat such targets as ignored; the confusion-matrix
+    kernel of the same step is what counts them)."""
     return _oob_counter(torch.device(device))
+
+
+def take_out_of_range(device):
+    """The counter's current value as a new float32 [1] device tensor, and the counter reset to zero (both
+    stream-ordered, no host sync): one bad batch is reported once, not by every later flush."""
+    c = _oob_counter(torch.device(device))
+    v = c.float()
+    c.zero_()
+    return v
 
 
 def _cols(C, dataset, no_ignore_class):

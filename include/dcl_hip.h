@@ -307,12 +307,10 @@ int dcl_conv3x3_set_up2_phases(int on);
 int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W /* of x */, int stride);
 /* tuning hook: force the (co tiles, ci tiles) per wave of the weight-gradient kernel (0, 0 = automatic choice) */
 int dcl_wgrad3x3_set_tile(int nco, int nci);
-/* tuning hook: -1 (default) = 2, 2 = per-wave kernel with LDS-DMA operand staging (csrc/dcl_wgrad3x3d.hip), 1 = workgroups that share the dY rows of a co group through LDS (csrc/dcl_wgrad3x3s.hip),
- * 0 = every wave loads both operands itself (csrc/dcl_wgrad3x3.hip).  Changes dcl_wgrad3x3_splits(). */
+/* tuning hook: -1 (default) = 2 = per-wave kernel with LDS-DMA operand staging (csrc/dcl_wgrad3x3d.hip), 0 = every wave
+ * loads both operands itself in MFMA order (csrc/dcl_wgrad3x3.hip; also the fallback for tensors beyond 4 GiB per
+ * image and for the zero-inserted stride-2 form).  Changes dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_variant(int variant);
-/* tuning hook (shared-dY variant): stream_k = -1 automatic, 0 equal pixel splits, 1 one contiguous (type, row step)
- * range per workgroup; nwg = workgroups of that partition (0 = 256, one per CU).  Changes dcl_wgrad3x3_splits(). */
-int dcl_wgrad3x3_set_partition(int stream_k, int nwg);
 /* tuning hook (stride 2): 1 (default) = GEMM over the output pixels (csrc/dcl_wgrad3x3_s2.hip, needs W % 16 == 0),
  * 0 = the stride-1 kernels on a zero-inserted dy.  Changes dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_stride2(int native);

@@ -1,6 +1,9 @@
-"""Two ranks on ONE GPU (gloo backend moving CUDA tensors through the host) -- exercises the multi-rank
-code paths that a single-GPU box can reach: SyncBatchNorm semantics of FusedBatchNorm2d, the DDP training
-step of the manager with the HIP loss, and the shared-negative-bank all-gather."""
+"""Two ranks, either on two GPUs over RCCL (backend "nccl", one device per rank: what an 8-GPU node runs) when the box
+has at least two devices, or on ONE GPU over gloo (CUDA tensors moved through the host; RCCL refuses two ranks on one
+device): SyncBatchNorm semantics of FusedBatchNorm2d, the DDP training step of the manager with the HIP loss, and the
+shared-negative-bank all-gather.  gloo's host-staged copies synchronise the issuing stream, so only the nccl variant
+can expose a missing stream dependency around a collective; every collective of the package is issued on the CURRENT
+stream of the calling code (the branch's stream inside HighResolutionModule), never on a hidden one."""
 import os
 import socket
 
@@ -19,14 +22,25 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bn_worker(rank, world, port, out_dir):
+def _backend():
+    """("nccl", one device per rank) when the box has >= 2 GPUs, else ("gloo", every rank on cuda:0).  Counting devices
+    does not initialise the GPU, so this is safe in the pytest parent before mp.spawn."""
+    return "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+
+
+def _device_of(rank, backend):
+    return rank if backend == "nccl" else 0
+
+
+def _bn_worker(rank, world, port, out_dir, backend):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import mscs_amd  # noqa: F401
     from mscs_amd.models.fused_bn import FusedBatchNorm2d
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", _device_of(rank, backend))
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     g = torch.Generator().manual_seed(5)
     shape = (4, 24, 12, 20)
     x = torch.randn(shape, generator=g) * 1.5 + 0.3
@@ -53,7 +67,7 @@ def _bn_worker(rank, world, port, out_dir):
 @pytest.mark.timeout(300)
 def test_fused_bn_sync_two_ranks_one_gpu(tmp_path):
     port = _free_port()
-    mp.spawn(_bn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_bn_worker, args=(2, port, str(tmp_path), _backend()), nprocs=2, join=True)
     g = torch.Generator().manual_seed(5)
     shape = (4, 24, 12, 20)
     x = (torch.randn(shape, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
@@ -78,15 +92,17 @@ def test_fused_bn_sync_two_ranks_one_gpu(tmp_path):
     assert torch.allclose((outs[0]["db"] + outs[1]["db"]).double(), ref.bias.grad, atol=2e-4)
 
 
-def _train_worker(rank, world, port, out_dir, global_negatives, backbone="hrnet18", scales=2):
+def _train_worker(rank, world, port, out_dir, global_negatives, backbone="hrnet18", scales=2, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import mscs_amd  # noqa: F401
     from mscs_amd.managers import HRNetManager
     from mscs_amd.utils import set_verbosity
     set_verbosity(40)
     cfg = {"name": "t", "mode": "training", "manager": "HRNet", "cuda": True, "parallel": True,
-           "gpu_device": [0, 0], "seed": 3, "log_every_n_steps": 1000, "dist_backend": "gloo",
+           "gpu_device": [_device_of(q, backend) for q in range(world)], "seed": 3, "log_every_n_steps": 1000,
+           "dist_backend": backend,
            "graph": {"model": "HRNet", "backbone": backbone, "sync_bn": True, "pretrained": False,
                      "align_corners": True,
                      "ms_projector": {"mlp": [[1, -1, 1]], "scales": scales, "d": 64, "use_bn": True}},
@@ -101,7 +117,7 @@ def _train_worker(rank, world, port, out_dir, global_negatives, backbone="hrnet1
                      "epochs": 1}}
     mgr = HRNetManager(cfg, autostart=False)
     mgr.world_size = mgr.n_gpus = world
-    mgr._worker_setup(0, rank)
+    mgr._worker_setup(_device_of(rank, backend), rank)
     mgr.train_one_epoch()
     flat = torch.cat([p.detach().flatten() for p in mgr.model.parameters()]).cpu()
     from mscs_amd.models.ops import DirectConv2d
@@ -117,7 +133,8 @@ def _train_worker(rank, world, port, out_dir, global_negatives, backbone="hrnet1
 @pytest.mark.parametrize("global_negatives", [False, True])
 def test_ddp_training_step_two_ranks_one_gpu(tmp_path, global_negatives):
     port = _free_port()
-    mp.spawn(_train_worker, args=(2, port, str(tmp_path), global_negatives), nprocs=2, join=True)
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path), global_negatives, "hrnet18", 2, _backend()), nprocs=2,
+             join=True)
     a, b = [torch.load(os.path.join(str(tmp_path), f"train{q}.pt")) for q in range(2)]
     assert torch.equal(a["params"], b["params"]), "parameters diverged across ranks"
     assert np.isfinite(a["metrics"]["loss"]) and np.isfinite(b["metrics"]["loss"])
@@ -132,7 +149,7 @@ def test_ddp_hrnet48_direct_kernels_and_branch_streams_two_ranks_one_gpu(tmp_pat
     that runs on an 8-GPU node (there over RCCL; gloo here because both ranks share the one GPU of this box).
     Shared negative bank on: the overlapped per-scale bank gathers run too."""
     port = _free_port()
-    mp.spawn(_train_worker, args=(2, port, str(tmp_path), True, "hrnet48", 3), nprocs=2, join=True)
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path), True, "hrnet48", 3, _backend()), nprocs=2, join=True)
     a, b = [torch.load(os.path.join(str(tmp_path), f"train{q}.pt")) for q in range(2)]
     assert a["direct_convs"] > 250                                   # every 3x3 convolution of W48 is a DirectConv2d
     assert torch.equal(a["params"], b["params"]), "parameters diverged across ranks"
