@@ -242,11 +242,22 @@ def roofline_bwd_kernel(mod, iters=10):
     _lib.check(L.dcl_infonce_prep_stats(p(t.Z), p(t.W), p(t.rng_lo), p(t.rng_hi), None, N, A.plan.V, 1, 1.0,
                                         1.0 / t.tau, None, p(stat), stream), "prep")
     ns = int(L.dcl_suggest_nsplit(N, N))
-    dpart = torch.empty((ns, Npad, 256), device=dev)
+    G = int(L.dcl_infonce_bwd_streamk_workgroups(N, N)) if A.bank_h is not None else 0
+    if G > 0:        # what the step runs in f16x3 mode: the stream-K partition (finished tiles, no slabs)
+        dout = torch.empty((Npad, 256), device=dev)
+        ws = torch.empty((G, 128, 256), device=dev)
+        flags = torch.zeros(G, dtype=torch.int32, device=dev)
 
-    def launch():
-        _lib.check(L.dcl_infonce_bwd(p(A.bank), N, A.plan.V, p(A.bank), N, p(t.rng_lo), p(t.rng_hi),
-                                     1.0 / t.tau, 1, 1, 1, p(stat), p(stat), ns, p(dpart), p(A.bank_h), p(A.bank_h), stream), "bwd")
+        def launch():
+            _lib.check(L.dcl_infonce_bwd_streamk(p(A.bank), N, A.plan.V, p(A.bank), N, p(t.rng_lo), p(t.rng_hi),
+                                                 1.0 / t.tau, 1, 1, 1, p(stat), p(stat), p(dout), p(ws), p(flags),
+                                                 p(A.bank_h), p(A.bank_h), stream), "bwd_streamk")
+    else:
+        dpart = torch.empty((ns, Npad, 256), device=dev)
+
+        def launch():
+            _lib.check(L.dcl_infonce_bwd(p(A.bank), N, A.plan.V, p(A.bank), N, p(t.rng_lo), p(t.rng_hi),
+                                         1.0 / t.tau, 1, 1, 1, p(stat), p(stat), ns, p(dpart), p(A.bank_h), p(A.bank_h), stream), "bwd")
     launch()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -264,8 +275,11 @@ def roofline_bwd_kernel(mod, iters=10):
     # (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH doubled per the gfx950 correction in MI355X_MICROARCH.md;
     # only valid for the benchmark shape, else null
     pmc = {"f32": (102168.7, 128128.0), "f16x3": PMC_F16X3}.get(mode)       # f32 pair: round-1 f32 passes
-    traffic = (2 * pmc[0] + pmc[1]) * 1024 if (pmc and N == 9804 and ns == 13) else None
-    return {"bound": "mfma", "kernel": f"k_sweep<MODE_BWD> (dcl_infonce_bwd), both products in {mode}",
+    traffic = (2 * pmc[0] + pmc[1]) * 1024 if (pmc and N == 9804 and ns == 13 and G == 0) else None
+    if G > 0 and N == 9804 and PMC_F16X3_SK:
+        traffic = (2 * PMC_F16X3_SK[0] + PMC_F16X3_SK[1]) * 1024
+    return {"bound": "mfma", "kernel": (f"k_sweep<MODE_BWD, stream-K> (dcl_infonce_bwd_streamk, {G} persistent workgroups)"
+                                        if G > 0 else "k_sweep<MODE_BWD> (dcl_infonce_bwd)") + f", both products in {mode}",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "peak_note": ("f32 MFMA 157.3 TFLOP/s" if mode == "f32" else
@@ -274,10 +288,11 @@ def roofline_bwd_kernel(mod, iters=10):
             "traffic": traffic, "traffic_source": "constant from " + PMC_SOURCE + " (separate rocprofv3 --pmc run; "
                                                                    "not read live)",
             "algorithmic_bytes": 3 * N * 256 * 4, "launch_ms": round(ms, 4), "N1": N, "N2": N, "C": 256,
-            "nsplit": ns}
+            "nsplit": ns if G == 0 else None, "streamk_workgroups": G}
 
 
 PMC_F16X3 = (104540.5, 128128.0)      # KiB per launch (FETCH_SIZE, WRITE_SIZE), profiles/r02_loss_pmc_*.csv
+PMC_F16X3_SK = None                   # stream-K kernel: filled from profiles/r03_loss_pmc_*.csv once collected
 PMC_SOURCE = "profiles/r02_loss_pmc_fetch.csv, r02_loss_pmc_write.csv"
 
 

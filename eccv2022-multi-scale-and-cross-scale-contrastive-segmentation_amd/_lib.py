@@ -35,6 +35,9 @@ SIGNATURES = {
     "dcl_infonce_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "dcl_infonce_prep_stats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
     "dcl_infonce_bwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "dcl_infonce_bwd_streamk_workgroups": [_i, _i],
+    "dcl_infonce_set_streamk": [_i],
+    "dcl_infonce_bwd_streamk": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_normalize_bwd_scatter": [ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
                                   _i64, _i64, _i64, _vp, _vp],
     "dcl_host_randperm_select": [_vp, _i64, _vp, _i, _i, _vp],

@@ -62,7 +62,12 @@ struct SweepArgs {
     float *Z, *rowloss, *W;        // MODE_POS out: [N1pad]
     const float *rstat, *cstat;    // MODE_BWD in: [N1pad,4], [N2pad,4] = {Z, cW, cZ, 0}
     int use_row, use_col;
-    float *dpart;          // MODE_BWD out: [nsplit, N1pad, CP]
+    float *dpart;          // MODE_BWD out: [nsplit, N1pad, CP]  (stream-K: [N1pad, CP], the finished gradient)
+    // stream-K backward (SK): gridDim.x persistent workgroups share the (row block, chunk) sequence
+    int N1pad;             // rows of the padded anchor bank
+    float *sk_ws;          // [gridDim.x][BM][CP] partial tiles of the workgroups whose range ends inside a row block
+    int *sk_flags;         // [gridDim.x] 0 on entry and on exit; 1 = workgroup g's partial tile is in sk_ws
+    int sk_probe;          // timing probe (dcl_infonce_set_streamk(2)): no flag traffic, no waiting -- WRONG results
 };
 
 // One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to the wave-uniform LDS address
@@ -137,9 +142,24 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_sched_group_barrier(0x100, (n_ds), 0);      \
     __builtin_amdgcn_sched_group_barrier(0x008, (n_mfma) - 1, 0)
 
-template <int MODE, bool USE_COL, bool F16>
+// SK (backward, f16x3): "stream-K" partition.  The (row block, chunk) units of the launch form ONE sequence, row block
+// major; gridDim.x persistent workgroups (one per CU) take equal contiguous ranges of it.  A range covers at most the tail
+// of one row block, whole row blocks, and the head of another: per piece ("segment") the workgroup loads that row block's A
+// panel and runs the chunk pipeline.  The workgroup that finishes a row block (its segment contains the last chunk)
+// owns the result: it waits for the partial tiles of the workgroups that covered the earlier chunks of the row block --
+// always LOWER workgroup ids, which the dispatcher starts first, so the wait cannot deadlock -- adds them in ascending id
+// order (fixed order: bitwise reproducible) and writes the finished 128 x 256 tile.  Every other segment is the last one of
+// its workgroup and leaves one partial tile in sk_ws[g].  Against one slab per (row block, column split) that is
+// <= 255 partial tiles of 128 KiB instead of 13 x 77 (131 MB written, then read again by K6), one or two A-panel
+// prologues per CU instead of four, and no tail round.
+// PF (pipelined f16x3 backward): how many steps ahead of the MFMAs that consume them the LDS operand reads are issued.
+// At one wave per SIMD nothing hides an LDS read that is not back when its MFMAs are due, and a step is only 96
+// matrix-pipe cycles (3 MFMAs): with PF = 1 the reads of step q + 1 have those 96 cycles, less than the LDS round trip
+// while four waves keep the LDS pipe ~70 % busy.
+template <int MODE, bool USE_COL, bool F16, bool SK = false, int PF = 1>
 __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepArgs p)
 {
+    static_assert(!SK || (MODE == MODE_BWD && F16), "stream-K: f16x3 backward only");
     // per buffer: one 32-row chunk of the contrast bank, f32 rows or (hi | lo) half rows (same 1040-B stride);
     // in f16x3 mode both products of the backward read the half rows
     constexpr int BUF = BUF_FLOATS;
@@ -152,11 +172,38 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
     constexpr int PBUF = CJ * CP;                  // floats per PIPE buffer (32 KiB)
     __shared__ __attribute__((aligned(1024))) float lds[PIPE ? NBUF * PBUF + (USE_COL ? NBUF * CSTF : 0) : NBUF * BUF];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    // (SK: the wave index as a scalar, so that what the compiler derives from it and hoists out of the segment loop sits
+    // in SGPRs; the other instantiations keep the code they were tuned with)
+    const int wave = SK ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+    // stream-K: this workgroup's range [su, su1) of the unit sequence (unit = (row block, chunk), row block major)
+    const int sk_nchunk = (p.N2 + CJ - 1) / CJ;
+    long long su = 0, su1 = 0;
+    if (SK) {
+        const long long U = (long long)(p.N1pad / BM) * sk_nchunk;
+        su = U * blockIdx.x / gridDim.x;
+        su1 = U * (blockIdx.x + 1) / gridDim.x;
+        if (su >= su1)
+            return;
+    }
+    for (bool sk_first = true;; sk_first = false) {      // one trip unless SK: one trip per segment of the range
+    // SK: the lane id is laundered through an empty asm in every trip -- as loop invariants, the lane-dependent addresses
+    // of the prologue, the fragment reads and the 128 tile stores would be hoisted out of the segment loop, kept live
+    // across it and spilled (this kernel has no register to spare)
+    int lane = lane0;
+    if (SK)
+        asm volatile("" : "+v"(lane));
     const int h = lane >> 5, li = lane & 31;
-    const int rb = blockIdx.x, split = blockIdx.y;
-    const int N1pad = gridDim.x * BM;
+    // SK: the segments of the range are taken LAST FIRST.  The last segment is the one that may end inside a row block,
+    // i.e. the partial tile other workgroups wait for: it is published before anything else, and the one segment that may
+    // have to wait for other workgroups' tiles (the first: the tail of a row block) comes at the very end.  In range
+    // order every owner would sit in its wait before it even started the tile the NEXT owner waits for -- a dependency
+    // chain through all row blocks (measured: 9.6 ms instead of 0.3).
+    const int rb = SK ? (int)((su1 - 1) / sk_nchunk) : blockIdx.x, split = SK ? 0 : blockIdx.y;
+    const int N1pad = SK ? p.N1pad : gridDim.x * BM;
     const int i = rb * BM + wave * 32 + li;     // this lane's anchor row (both lane halves)
+    if (SK && !sk_first)
+        dma_wait_barrier<0>();                  // every wave has left the previous segment's chunk buffers
 
     // ---- A panel -> registers.  Lane half h holds k in {8q + 4h .. 8q + 4h + 3}: the MFMA sums over
     // all k, so any k order works as long as both operands use the same one.
@@ -232,6 +279,9 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
         } else {
             c0 = c1 = 0;
         }
+    } else if (SK) {
+        c0 = (int)max(0LL, su - (long long)rb * sk_nchunk);
+        c1 = (int)(su1 - (long long)rb * sk_nchunk);
     } else {
         const int nchunk = (p.N2 + CJ - 1) / CJ;
         c0 = (int)((long long)split * nchunk / p.nsplit);
@@ -343,16 +393,18 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                 hi8 = *(const half8 *)a;
                 lo8 = *(const half8 *)(a + 512);
             };
-            half8 bh, bl;
-            rd(0, bh, bl);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            half8 qh[PF + 1], ql[PF + 1];          // ring of operand fragments, static indices after unrolling
+#pragma unroll
+            for (int q = 0; q < PF; ++q)
+                rd(q, qh[q], ql[q]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 accN[r] = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) {
-                half8 nh, nl;
-                rd(kb < 15 ? kb + 1 : 15, nh, nl);
+                rd(kb + PF < 16 ? kb + PF : 15, qh[(kb + PF) % (PF + 1)], ql[(kb + PF) % (PF + 1)]);
+                const half8 bh = qh[kb % (PF + 1)], bl = ql[kb % (PF + 1)];
                 accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ahi[kb], accN, 0, 0, 0);
                 accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, alo[kb], accN, 0, 0, 0);
                 accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ahi[kb], accN, 0, 0, 0);
@@ -382,8 +434,6 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                     }
                     DCL_SCHED_MFMA_DS_MFMA(2, 3);
                 }
-                bh = nh;
-                bl = nl;
             }
         };
         const int nck = c1 - c0;
@@ -453,21 +503,21 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                 bl.q[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_FP16X4 *)(pa + 512));
                 bl.q[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_FP16X4 *)(pb + 512));
             };
-            TR bh, bl;
-            read_b(0, bh, bl);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            TR th[PF + 1], tl[PF + 1];
+#pragma unroll
+            for (int q = 0; q < PF; ++q)
+                read_b(q, th[q], tl[q]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * PF, 0);
 #pragma unroll
             for (int st = 0; st < 16; ++st) {
                 const int kb = st >> 3, ct = st & 7;
                 const half8 hh = __builtin_bit_cast(half8, hhv[kb]), hl = __builtin_bit_cast(half8, hlv[kb]);
-                TR nh, nl;
-                read_b(st < 15 ? st + 1 : 15, nh, nl);
-                dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh, bh.v, dacc[ct], 0, 0, 0);
-                dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh, bl.v, dacc[ct], 0, 0, 0);
-                dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl, bh.v, dacc[ct], 0, 0, 0);
+                read_b(st + PF < 16 ? st + PF : 15, th[(st + PF) % (PF + 1)], tl[(st + PF) % (PF + 1)]);
+                const half8 bhv = th[st % (PF + 1)].v, blv = tl[st % (PF + 1)].v;
+                dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh, bhv, dacc[ct], 0, 0, 0);
+                dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hh, blv, dacc[ct], 0, 0, 0);
+                dacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hl, bhv, dacc[ct], 0, 0, 0);
                 DCL_SCHED_MFMA_DS_MFMA(4, 3);
-                bh = nh;
-                bl = nl;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the loop
@@ -671,7 +721,83 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             p.W[i] = wsum;
         }
     } else {
-        if (F16) {
+        if (SK) {
+            // natural channel order (column li of MFMA ct <-> channel 32 ct + li), unscaled by 1 / (G * 2^10)
+            const int g = blockIdx.x;
+            // element (r, ct) of this lane sits at toff + KOFF(r, ct) of a 128 x 256 tile, KOFF a compile-time constant.
+            // toff is laundered through an empty asm: as a loop invariant of the segment loop the compiler would hoist all
+            // 128 (64-bit) store addresses out of it and spill them (1 KiB of scratch per lane)
+            unsigned toff = (unsigned)((wave * 32 + 4 * h) * CP + li);
+            asm volatile("" : "+v"(toff));
+#define DCL_KOFF(r, ct) ((unsigned)(jrow((r), 0) * CP + 32 * (ct)))
+            if (c1 == sk_nchunk) {
+                // owner of row block rb: the earlier chunks (if any) were covered by workgroups gf .. g - 1, each of
+                // which leaves exactly one partial tile (its last segment) in sk_ws
+                float *out = p.dpart + (size_t)rb * BM * CP;
+                if (c0 > 0) {
+                    const long long U = (long long)(p.N1pad / BM) * sk_nchunk, ub = (long long)rb * sk_nchunk;
+                    int gf = g - 1;                              // first contributor: the workgroup holding unit (rb, 0)
+                    while (gf > 0 && U * gf / gridDim.x > ub)
+                        --gf;
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            dacc[ct][r] *= hInv;
+                    // Everything that crosses workgroups -- the flags and the partial tiles -- moves as relaxed AGENT-scope
+                    // atomic accesses (sc1: served by memory, not by this XCD's L2) and is ordered by hand (the writer
+                    // waits for its stores, then a barrier, then the flag).  Acquire / release fences at agent scope
+                    // would do it too, but on this multi-XCD part they invalidate / write back the WHOLE L2 of the XCD
+                    // each time: with the owners spinning on acquire loads the launch took 10 ms instead of 0.3.
+                    if (tid == 0 && p.sk_probe == 0) {
+                        for (int gp = gf; gp < g; ++gp)
+                            while (__hip_atomic_load(p.sk_flags + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                                __builtin_amdgcn_s_sleep(8);
+                    }
+                    __syncthreads();
+                    for (int gp = gf; gp < g; ++gp) {
+                        const float *pt = p.sk_ws + (size_t)gp * BM * CP;
+#pragma unroll
+                        for (int ct = 0; ct < 8; ++ct) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                dacc[ct][r] += __hip_atomic_load(pt + toff + DCL_KOFF(r, ct), __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+                            __builtin_amdgcn_sched_barrier(0);       // 16 loads in flight, not 128 (registers)
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();                             // everyone has read the tiles: their flags go back to 0
+                    if (tid == 0)
+                        for (int gp = gf; gp < g; ++gp)
+                            __hip_atomic_store(p.sk_flags + gp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            out[toff + DCL_KOFF(r, ct)] = dacc[ct][r];
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            out[toff + DCL_KOFF(r, ct)] = dacc[ct][r] * hInv;
+                }
+            } else {
+                float *out = p.sk_ws + (size_t)g * BM * CP;
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __hip_atomic_store(out + toff + DCL_KOFF(r, ct), dacc[ct][r] * hInv, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's tile rows have reached memory
+                __syncthreads();
+                if (tid == 0 && p.sk_probe == 0)
+                    __hip_atomic_store(p.sk_flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#undef DCL_KOFF
+        } else if (F16) {
             // natural channel order (column li of MFMA ct <-> channel 32 ct + li), unscaled by 1 / (G * 2^10)
             float *out = p.dpart + ((size_t)split * N1pad + (size_t)rb * BM + wave * 32) * CP + li;
 #pragma unroll
@@ -694,6 +820,12 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                 }
         }
     }
+    if (!SK)
+        break;
+    su1 -= c1 - c0;
+    if (su >= su1)
+        break;
+    }   // segments
 }
 
 // loss = -(1/N1) sum_i rowloss_i / P_i     (DenseContrastiveLossV2.py:188-189; ms:148-156)
@@ -908,6 +1040,70 @@ extern "C" int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, i
         else
             hipLaunchKernelGGL((k_sweep<MODE_BWD, false, false>), grid, dim3(256), 0, st, p);
     }
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- stream-K backward (f16x3 operands) ----------------------------------------------------------------------------
+static int g_streamk = 1;
+static int g_sk_prefetch = 2;      // operand read-ahead of the pipelined backward (tuning hook: 1, 2 or 3 steps)
+
+extern "C" int dcl_infonce_set_streamk(int on)
+{
+    // 0 off, 1 on, 2 = timing probe without the inter-workgroup hand-over (results invalid); + 16 * read-ahead steps
+    // (1..3, 0 = keep): tuning hook for the operand prefetch depth of the pipelined kernel
+    g_streamk = on & 15;
+    if ((on >> 4) >= 1 && (on >> 4) <= 3)
+        g_sk_prefetch = on >> 4;
+    return 0;
+}
+
+// 0 = the column-split form should be used (switch off, or fewer units than workgroups would make empty ranges pointless)
+extern "C" int dcl_infonce_bwd_streamk_workgroups(int N1, int N2)
+{
+    if (!g_streamk || N1 <= 0 || N2 <= 0)
+        return 0;
+    const long long units = (long long)(dcl_round_up(N1, BM) / BM) * ((N2 + CJ - 1) / CJ);
+    return units >= 256 ? 256 : (int)units;          // one persistent workgroup per CU
+}
+
+extern "C" int dcl_infonce_bwd_streamk(const float *A, int N1, int V1, const float *B, int N2,
+                                       const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int intra,
+                                       int use_row, int use_col, const float *rstat, const float *cstat, float *dout,
+                                       float *ws, int32_t *flags, const void *Ah, const void *Bh, void *stream)
+{
+    int rc = check_common(A, N1, V1, B, N2, rng_lo, rng_hi, 1);
+    if (rc)
+        return rc;
+    DCL_CHECK_ARG(dout && ws && flags, "null output / workspace pointer");
+    DCL_CHECK_ARG(Ah && Bh, "the stream-K backward takes the (hi | lo) half rows of both banks");
+    DCL_CHECK_ARG(!use_row || rstat, "use_row needs rstat");
+    DCL_CHECK_ARG(!use_col || cstat, "use_col needs cstat");
+    const int G = dcl_infonce_bwd_streamk_workgroups(N1, N2);
+    DCL_CHECK_ARG(G > 0, "stream-K is switched off (dcl_infonce_set_streamk)");
+    SweepArgs p = fwd_args(A, N1, V1, B, N2, rng_lo, rng_hi, inv_tau, intra, Ah, Bh);
+    p.nsplit = 1;
+    p.rstat = rstat; p.cstat = cstat; p.use_row = use_row; p.use_col = use_col;
+    p.dpart = dout;
+    p.N1pad = dcl_round_up(N1, BM);
+    p.sk_ws = ws;
+    p.sk_flags = flags;
+    p.sk_probe = g_streamk == 2 ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+#define DCL_SK_LAUNCH(PFV)                                                                                    \
+    do {                                                                                                      \
+        if (use_col)                                                                                          \
+            hipLaunchKernelGGL((k_sweep<MODE_BWD, true, true, true, PFV>), dim3(G), dim3(256), 0, st, p);     \
+        else                                                                                                  \
+            hipLaunchKernelGGL((k_sweep<MODE_BWD, false, true, true, PFV>), dim3(G), dim3(256), 0, st, p);    \
+    } while (0)
+    if (g_sk_prefetch == 1)
+        DCL_SK_LAUNCH(1);
+    else if (g_sk_prefetch == 3)
+        DCL_SK_LAUNCH(3);
+    else
+        DCL_SK_LAUNCH(2);
+#undef DCL_SK_LAUNCH
     DCL_LAUNCH_CHECK();
     return 0;
 }

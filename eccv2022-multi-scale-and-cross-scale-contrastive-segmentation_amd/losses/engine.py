@@ -708,6 +708,22 @@ class DenseContrastFunction(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+_SK_WS = {}
+
+
+def _streamk_workspace(dev, G: int):
+    """(partial-tile workspace f32 [G, 128, 256], flags int32 [G]) of the stream-K backward for the CURRENT stream of
+    ``dev``.  The flags are zero between launches (the kernel resets what it sets) and the launches of one stream run one
+    after the other, so one persistent pair per (device, stream) serves every term of every step."""
+    key = (dev.index, _lib.stream_ptr(dev))
+    got = _SK_WS.get(key)
+    if got is None or got[1].numel() < G:
+        got = (torch.empty((G, _lib.ROW_TILE, _lib.CP), dtype=torch.float32, device=dev),
+               torch.zeros((G,), dtype=torch.int32, device=dev))
+        _SK_WS[key] = got
+    return got
+
+
 def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_meta, need):
     """The Function outputs the RAW per-term losses; the module forms the weighted sum with torch
     ops, so autograd hands us d total / d term_i = weight_i * upstream.  Each term's kernels read
@@ -735,6 +751,19 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
         if want_a:
             for sg in t.segs:
                 sym = t.intra and sg.own            # own rows are anchors AND contrast columns
+                G = int(L.dcl_infonce_bwd_streamk_workgroups(N1, sg.N)) if sg.bank_h is not None else 0
+                if G > 0:
+                    # f16x3: stream-K partition, ONE finished [N1pad, 256] tile array per launch instead of nsplit slabs
+                    dout = torch.empty((N1pad, _lib.CP), dtype=torch.float32, device=dev)
+                    ws, flags = _streamk_workspace(dev, G)
+                    _lib.check(L.dcl_infonce_bwd_streamk(_lib.ptr(A.bank), N1, A.plan.V, _lib.ptr(sg.bank), sg.N,
+                                                         _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi), inv_tau,
+                                                         1 if sym else 0, 1, 1 if sym else 0, _lib.ptr(stat),
+                                                         _lib.ptr(stat) if sym else None, _lib.ptr(dout), _lib.ptr(ws),
+                                                         _lib.ptr(flags), _lib.ptr(A.bank_h), _lib.ptr(sg.bank_h), stream),
+                               "dcl_infonce_bwd_streamk")
+                    slabs[t.a].append(dout)
+                    continue
                 dpart = torch.empty((sg.nsplit, N1pad, _lib.CP), dtype=torch.float32, device=dev)
                 _lib.check(L.dcl_infonce_bwd(_lib.ptr(A.bank), N1, A.plan.V, _lib.ptr(sg.bank), sg.N,
                                              _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi), inv_tau,
@@ -746,6 +775,17 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
                 slabs[t.a] += [dpart[i] for i in range(sg.nsplit)]
         if want_b:
             # G^T F1 restricted to this rank's rows of bank b (they are columns of the own segment)
+            G = int(L.dcl_infonce_bwd_streamk_workgroups(N2, N1)) if (B.bank_h is not None and A.bank_h is not None) else 0
+            if G > 0:
+                dout = torch.empty((N2pad, _lib.CP), dtype=torch.float32, device=dev)
+                ws, flags = _streamk_workspace(dev, G)
+                _lib.check(L.dcl_infonce_bwd_streamk(_lib.ptr(B.bank), N2, B.plan.V, _lib.ptr(A.bank), N1,
+                                                     _lib.ptr(t.rev_lo), _lib.ptr(t.rev_hi), inv_tau, 0, 0, 1, None,
+                                                     _lib.ptr(stat), _lib.ptr(dout), _lib.ptr(ws), _lib.ptr(flags),
+                                                     _lib.ptr(B.bank_h), _lib.ptr(A.bank_h), stream),
+                           "dcl_infonce_bwd_streamk")
+                slabs[t.b].append(dout)
+                continue
             ns = int(L.dcl_suggest_nsplit(N2, N1))
             dpart = torch.empty((ns, N2pad, _lib.CP), dtype=torch.float32, device=dev)
             _lib.check(L.dcl_infonce_bwd(_lib.ptr(B.bank), N2, B.plan.V, _lib.ptr(A.bank), N1,

@@ -165,6 +165,22 @@ int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, int N2,
                     float *dpart, const void *Ah /* f16x3 banks, see dcl_infonce_zsweep */,
                     const void *Bh, void *stream);
 
+/* Stream-K form of dcl_infonce_bwd for f16x3 banks (Ah, Bh required): same sum, but dout f32 [N1pad, DCL_CP] is the
+ * FINISHED gradient tile of every row block instead of nsplit partial slabs.  G = dcl_infonce_bwd_streamk_workgroups(N1,
+ * N2) persistent workgroups (one per CU; 0 = switched off with dcl_infonce_set_streamk(0), use dcl_infonce_bwd) share the
+ * (row block, 32-column chunk) sequence in equal contiguous ranges; the workgroup that reaches the end of a row block
+ * adds the partial tiles of the (lower-numbered) workgroups that covered its earlier chunks in ascending order --
+ * bitwise reproducible -- and writes the tile.  ws f32 [G, DCL_ROW_TILE, DCL_CP] partial tiles; flags int32 [G], must be
+ * ZERO on entry and is zero again when the kernel has finished (one buffer can serve every launch of a stream).
+ * Replaces the same reference lines as dcl_infonce_bwd (autograd of losses/DenseContrastiveLossV2.py:150-192 and
+ * losses/DenseContrastiveLossV2_ms.py:84-161). */
+int dcl_infonce_bwd_streamk_workgroups(int N1, int N2);
+int dcl_infonce_set_streamk(int on);
+int dcl_infonce_bwd_streamk(const float *A, int N1, int V1, const float *B, int N2,
+                            const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int intra,
+                            int use_row, int use_col, const float *rstat, const float *cstat, float *dout,
+                            float *ws, int32_t *flags, const void *Ah, const void *Bh, void *stream);
+
 /* ---- K6 ---------------------------------------------------------------------------------
  * Sum the partial dF slabs of a bank in a fixed order, apply the VJP of F.normalize
  * (dx = (dF - f (f.dF)) / max(|x|, 1e-12)) and scatter into the dense feature gradient

@@ -191,6 +191,62 @@ def test_deterministic_bitwise(dev):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n,H,W,cap", [(2, 128, 256, 10000), (3, 64, 128, 700), (12, 256, 512, 10000), (2, 128, 128, 90)])
+def test_streamk_backward_equals_column_split_backward(dev, n, H, W, cap):
+    """dcl_infonce_bwd_streamk (persistent workgroups over the (row block, chunk) sequence, finished tiles) against
+    dcl_infonce_bwd (one slab per column split, summed here) on the banks of a real step: intra-scale (H = G + G^T),
+    cross-scale dF1 (rows) and dF2 (columns, rectangular, other bank's statistics); ragged row blocks, fewer units than
+    workgroups, ranges that span several row blocks.  Same products, different summation order: 2e-6 of max.  Bitwise
+    reproducible, and the flags are back to zero."""
+    from mscs_amd import _lib
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    L = _lib.lib()
+    label, feats = _random_case(21, n, H, W, 20, 64, (4, 16))
+    cfg = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": 2, "weights": [1.0, 0.5],
+           "cross_scale_contrast": True, "max_features_total": cap, "mfma_mode": "f16x3"}
+    mod = DenseContrastiveLossV2_ms(cfg)
+    fs = [f.to(dev).requires_grad_(True) for f in feats]
+    torch.manual_seed(2)
+    mod(label.to(dev), fs).backward()
+    st = mod.last_state
+    p = _lib.ptr
+    stream = _lib.stream_ptr(dev)
+    for t in st.terms:
+        A, B = st.scales[t.a], st.scales[t.b]
+        N1, N2 = A.plan.N, B.plan.N
+        N1pad, N2pad = A.bank.shape[0], B.bank.shape[0]
+        stat = torch.empty((N1pad + 1, 4), device=dev)
+        _lib.check(L.dcl_infonce_prep_stats(p(t.Z), p(t.W), p(t.rng_lo), p(t.rng_hi), None, N1, A.plan.V,
+                                            1 if t.intra else 0, 1.0, 1.0 / t.tau, None, p(stat), stream), "prep")
+        cases = [(A, B, N1, N2, N1pad, t.rng_lo, t.rng_hi, 1 if t.intra else 0, 1, 1 if t.intra else 0,
+                  stat, stat if t.intra else None)]
+        if not t.intra:
+            cases.append((B, A, N2, N1, N2pad, t.rev_lo, t.rev_hi, 0, 0, 1, None, stat))
+        for (X, Y, n1, n2, n1pad, lo, hi, intra, use_row, use_col, rstat, cstat) in cases:
+            ns = int(L.dcl_suggest_nsplit(n1, n2))
+            dpart = torch.empty((ns, n1pad, 256), device=dev)
+            _lib.check(L.dcl_infonce_bwd(p(X.bank), n1, X.plan.V, p(Y.bank), n2, p(lo), p(hi), 1.0 / t.tau, intra,
+                                         use_row, use_col, p(rstat), p(cstat), ns, p(dpart), p(X.bank_h), p(Y.bank_h),
+                                         stream), "bwd")
+            want = dpart.sum(0)
+            G = int(L.dcl_infonce_bwd_streamk_workgroups(n1, n2))
+            assert 0 < G <= 256
+            ws = torch.full((G, 128, 256), float("nan"), device=dev)
+            flags = torch.zeros(G, dtype=torch.int32, device=dev)
+            outs = []
+            for _ in range(2):
+                dout = torch.full((n1pad, 256), float("nan"), device=dev)
+                _lib.check(L.dcl_infonce_bwd_streamk(p(X.bank), n1, X.plan.V, p(Y.bank), n2, p(lo), p(hi), 1.0 / t.tau,
+                                                     intra, use_row, use_col, p(rstat), p(cstat), p(dout), p(ws), p(flags),
+                                                     p(X.bank_h), p(Y.bank_h), stream), "bwd_streamk")
+                outs.append(dout)
+                assert int(flags.abs().sum().item()) == 0
+            assert torch.equal(outs[0], outs[1])
+            scale = want[:n1].abs().max().item()
+            assert torch.isfinite(outs[0][:n1]).all()
+            assert (outs[0][:n1] - want[:n1]).abs().max().item() <= 2e-6 * scale, (t.a, t.b, n1, n2, G)
+
+
 @pytest.mark.parametrize("mfma", ["f16x3", "f32"])
 def test_properties_at_baseline_config2_size(dev, mfma, monkeypatch):
     """BASELINE config 2 (n=12, 512x1024, K=20, C=256, 3 scales + cross-scale), size-independent checks:
