@@ -56,10 +56,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=["step", "loss"])
-    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
                     help="BASELINE.json configs[] index of the timed workload: 2 = HRNet-W48 Cityscapes 512x1024 (the "
                          "headline metric, default), 4 = UPerNet + Swin-T ADE20K 512x512 with per-GPU batch 16 "
-                         "(SURVEY.md Appendix C case 4': the whole global batch of configs[3] on one GPU)")
+                         "(SURVEY.md Appendix C case 4': the whole global batch of configs[3] on one GPU), 5 = UPerNet + "
+                         "Swin-L 640x640 + cross-scale contrastive (configs[4]) with per-GPU batch 16")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 12 / 16 by config")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
@@ -93,7 +94,7 @@ def parse():
     ap.add_argument("--no-metrics", action="store_true",
                     help="leave the per-step metrics tail (confusion matrix, accuracies, mIoU, logging) out of the step")
     a = ap.parse_args()
-    d = {2: (12, 512, 1024, 3), 4: (16, 512, 512, 4)}[a.config]
+    d = {2: (12, 512, 1024, 3), 4: (16, 512, 512, 4), 5: (16, 640, 640, 4)}[a.config]
     a.batch = a.batch or d[0]
     a.height = a.height or d[1]
     a.width = a.width or d[2]
@@ -364,8 +365,10 @@ def workload_name(args, workload):
     if workload == "loss":
         return (f"DenseContrastiveLossV2_ms fwd+bwd, {args.scales} scales{cross}, n={args.batch} "
                 f"{args.height}x{args.width} iid labels K={args.classes}, C=256, per GPU")
-    if args.config == 4:
-        return (f"BASELINE configs[3] on one GPU (SURVEY App. C 4'): UPerNet + Swin-T + LossWrapper(TwoScaleLoss + "
+    if args.config in (4, 5):
+        which = "configs[3] on one GPU (SURVEY App. C 4'): UPerNet + Swin-T" if args.config == 4 else \
+            "configs[4] on one GPU: UPerNet + Swin-L"
+        return (f"BASELINE {which} + LossWrapper(TwoScaleLoss + "
                 f"0.1*DenseContrastiveLossV2_ms, {args.scales} scales{cross}, fpn projector) train step (fwd+bwd+AdamW), "
                 f"synthetic ADE20K {args.height}x{args.width}, batch {args.batch} per GPU, iid labels")
     return (f"HRNet-W48 + LossWrapper(CE + 0.1*DenseContrastiveLossV2_ms, {args.scales} scales{cross}) train step "
@@ -379,7 +382,7 @@ def step_config_upernet(args, world):
     return {
         "name": "bench4", "mode": "training", "manager": "OCRNet", "cuda": True, "seed": 0,
         "parallel": world > 1, "batch_is_global": False,
-        "graph": {"model": "UPerNet", "backbone": "swinT", "sync_bn": True, "out_stride": 32, "pretrained": False,
+        "graph": {"model": "UPerNet", "backbone": "swinL" if args.config == 5 else "swinT", "sync_bn": True, "out_stride": 32, "pretrained": False,
                   "align_corners": False, "aux_head": {"in_index": 3, "dropout_rate": 0.1}, "dropout_rate": 0.1,
                   "lazy_logits": not args.materialize_logits,
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "position": "fpn"}},
@@ -399,7 +402,7 @@ def step_config_upernet(args, world):
 
 
 def step_config(args, world):
-    if getattr(args, "config", 2) == 4:
+    if getattr(args, "config", 2) in (4, 5):
         return step_config_upernet(args, world)
     S = args.scales
     return {
@@ -426,7 +429,7 @@ def time_train_step(args, dev, rank, world):
     from mscs_amd.utils import set_verbosity
     set_verbosity(40)
     torch.backends.cudnn.benchmark = bool(args.miopen_benchmark)
-    mgr = (OCRNetManager if args.config == 4 else HRNetManager)(step_config(args, world), autostart=False)
+    mgr = (OCRNetManager if args.config in (4, 5) else HRNetManager)(step_config(args, world), autostart=False)
     mgr.setup()
     mgr.model.train()
     gen = torch.Generator().manual_seed(1000 * rank)
