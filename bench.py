@@ -79,11 +79,11 @@ def parse():
     ap.add_argument("--miopen-benchmark", action="store_true",
                     help="cudnn.benchmark=True like the reference (BaseManager.py:122). OFF by default: on a fresh box "
                          "MIOpen's exhaustive fp32 solver search for HRNet-W48's ~300 conv shapes takes > 20 minutes")
-    ap.add_argument("--eager-miopen-benchmark", action="store_true",
-                    help="time the eager-structure comparator a second time with torch.backends.cudnn.benchmark = True "
-                         "(the reference's setting, BaseManager.py:122: MIOpen searches its solvers per shape during "
-                         "the warm-up step -- many minutes for HRNet-W48's ~300 convolution shapes on a cold find-db) "
-                         "and print both ratios")
+    ap.add_argument("--no-eager-miopen-benchmark", dest="eager_miopen_benchmark", action="store_false",
+                    help="do not time the eager-structure comparator a second time with torch.backends.cudnn.benchmark "
+                         "= True (the reference's setting, BaseManager.py:122).  On this image the solver search of the "
+                         "warm-up step takes ~4 s (profiles/r03_bench_miopen_find.json), so both ratios are printed by "
+                         "default")
     ap.add_argument("--eager-baseline", action="store_true",
                     help="also time the eager-structure restatement of the loss alone on the GPU")
     ap.add_argument("--no-eager-step", action="store_true",

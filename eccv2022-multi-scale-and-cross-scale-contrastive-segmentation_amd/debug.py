@@ -35,7 +35,6 @@ class DebugConfig:
     packed_relu_mask: bool = field(default_factory=lambda: _flag('DCL_BN_MASK'))                # packed sign mask in the BN backward
     coalesced_sync_bn: bool = field(default_factory=lambda: _flag('DCL_SYNCBN_COALESCE'))       # stacked SyncBN exchanges
     bn_fold: bool = field(default_factory=lambda: _flag('DCL_BN_FOLD'))                         # norm + ReLU folded into the next conv
-    linear_f16x3_rows: int = field(default_factory=lambda: _int('DCL_LINEAR_F16X3_ROWS') or 0)  # TokenLinear on the f16x3 kernel
     # ---- loss
     mfma_mode: Optional[str] = field(default_factory=lambda: os.environ.get('DCL_MFMA'))        # 'f32' | 'f16x3' override
     sweep_streamk: Optional[int] = field(default_factory=lambda: _int('DCL_SWEEP_STREAMK'))     # 0 = column-split slabs

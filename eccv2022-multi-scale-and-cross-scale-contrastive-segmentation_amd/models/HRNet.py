@@ -19,6 +19,8 @@ Reference quirks kept on purpose: exchange modules interpola
 concat and the logits up-sampling use the configured value; ``HRNet`` always builds the W48 backbone
 unless ``config['backbone']`` names another factory (an extension: the reference hard-codes it).
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -29,7 +31,7 @@ from .Projector import Projector
 from .ops import (ConvPackGroup, DirectConv2d, GradToken, use_gemm_conv1x1, upsample_bilinear, use_direct_conv3x3,
                   use_direct_conv1x1, upsample_concat, fan_out)
 from .amax import record_stream as _amax_record_stream
-from .fused_bn import FusedBatchNorm2d, bn_act
+from .fused_bn import FusedBatchNorm2d, bn_act, bn_act_group, can_group
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
 
@@ -207,11 +209,73 @@ class HighResolutionModule(nn.Module):
     def get_num_inchannels(self):
         return self.num_inchannels
 
+    def _groupable(self, x):
+        """SyncBatchNorm on several ranks: the norms of the branches at one block depth can share ONE statistics exchange
+        per direction (fused_bn.bn_act_group) when every branch is a chain of plain BasicBlocks of equal length."""
+        if not (x[0].is_cuda and self.num_branches > 1):
+            return False
+        chains = [list(br) for br in self.branches]
+        if len({len(c) for c in chains}) != 1:
+            return False
+        if not all(type(blk) is BasicBlock and blk.downsample is None and isinstance(blk.bn1, FusedBatchNorm2d)
+                   for c in chains for blk in c):
+            return False
+        first = [c[0] for c in chains]
+        return can_group([b.bn1 for b in first], x)
+
+    def _run_branches_grouped(self, x):
+        """Depth-major schedule of the branches for SyncBatchNorm on several ranks: at every block depth the branches'
+        convolutions run on their own streams as usual, but the 2 x num_branches statistics exchanges of the depth (bn1
+        and bn2 of every branch, forward, and again backward) become 2 stacked all-reduces (reference semantics:
+        nn.SyncBatchNorm over the process group, BaseManager.py:450-451 -- 208 of HRNet-W48's 310 norms sit in these
+        chains).  Same kernels and arithmetic as the free-running schedule."""
+        nb = self.num_branches
+        main = torch.cuda.current_stream(x[0].device)
+        side = _side_streams(x[0].device, nb - 1)
+        streams = [None] + list(side) if _BRANCH_STREAMS else [None] * nb
+        for k in range(1, nb):
+            if streams[k] is not None and getattr(x[k], '_dcl_stream', None) is not streams[k]:
+                streams[k].wait_stream(main)
+        cur = list(x)
+        for k in range(1, nb):
+            if streams[k] is not None:
+                _amax_record_stream(cur[k], streams[k])
+
+        def on(k):
+            return torch.cuda.stream(streams[k]) if streams[k] is not None else contextlib.nullcontext()
+
+        depth = len(self.branches[0])
+        for d in range(depth):
+            blocks = [self.branches[b][d] for b in range(nb)]
+            toks, z = [], []
+            for b, blk in enumerate(blocks):
+                with on(b):
+                    tok = None
+                    if _FUSE_RESIDUAL_GRAD and isinstance(blk.conv1, DirectConv2d) and blk.conv1.fuses_residual_grad(cur[b]):
+                        tok = GradToken()
+                        z.append(blk.conv1(cur[b], grad_token=tok))
+                    else:
+                        z.append(blk.conv1(cur[b]))
+                    toks.append(tok)
+            a = bn_act_group([blk.bn1 for blk in blocks], z, relu=True, streams=streams)
+            z2 = []
+            for b, blk in enumerate(blocks):
+                with on(b):
+                    z2.append(blk.conv2(a[b]))
+            cur = bn_act_group([blk.bn2 for blk in blocks], z2, residuals=cur, relu=True, tokens=toks, streams=streams)
+        for k in range(1, nb):
+            if streams[k] is not None:
+                main.wait_stream(streams[k])
+                _amax_record_stream(cur[k], main)
+        return cur
+
     def _run_branches(self, x):
         """The branches of a module are independent until the fuse layers: on CUDA each runs on its own HIP stream
         (the low-resolution branches launch far fewer workgroups than the chip has CUs, so their kernels overlap
         with each other and with the high-resolution branch); autograd replays the same streams in the backward.
         Tensors that cross streams are registered with the caching allocator (record_stream)."""
+        if self._groupable(x):
+            return self._run_branches_grouped(x)
         if not (_BRANCH_STREAMS and x[0].is_cuda):
             return [branch(xi) for branch, xi in zip(self.branches, x)]
         main = torch.cuda.current_stream(x[0].device)

@@ -74,7 +74,7 @@ class _FusedBNFunction(torch.autograd.Function):
         if world > 1:
             import torch.distributed as dist
             _check_equal_batch(N, dev)
-            dist.all_reduce(part)
+            _all_reduce(part)
         y = torch.empty_like(x)
         # The backward needs y only for the ReLU mask.  Without a residual it recomputes y > 0 from x (one tensor less
         # to read, twice); with one, the apply kernel packs the sign bits (1/32 of y) and the backward reads those.
@@ -115,7 +115,7 @@ class _FusedBNFunction(torch.autograd.Function):
         if ctx.world > 1:
             import torch.distributed as dist
             part_all = part.clone()
-            dist.all_reduce(part_all)
+            _all_reduce(part_all)
         dx = torch.empty_like(x)
         want_res = ctx.has_res and (ctx.needs_input_grad[1] or ctx.token is not None)
         dres = torch.empty_like(x) if want_res else None
@@ -132,6 +132,199 @@ class _FusedBNFunction(torch.autograd.Function):
             # the residual's gradient travels through the token to the convolution that shares the input
             ctx.token.dres, dres = dres, None
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+COLLECTIVES = {"count": 0}        # SyncBatchNorm exchanges issued by this process (tests / tools read it)
+FORCE_GROUP = False               # tests: take the grouped schedule on ONE rank too (the exchange itself is skipped)
+
+
+def _all_reduce(t):
+    import torch.distributed as dist
+    COLLECTIVES["count"] += 1
+    dist.all_reduce(t)
+
+
+class _FusedBNGroupFunction(torch.autograd.Function):
+    """SyncBatchNorm of SEVERAL independent norm layers (the branches of an exchange module at one block depth) with ONE
+    stacked statistics exchange per direction: every member's per-slice partial sums land in one buffer, one all-reduce
+    moves it, every member's apply kernel reads its slice.  Same kernels and arithmetic as ``_FusedBNFunction``; member
+    k's kernels run on ``meta[k]['stream']`` (its branch's HIP stream), the collective on the calling stream, with the
+    joins / forks in between.  A single autograd node: in the backward it runs once all members' gradients are there."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        L = _lib.lib()
+        nm = len(meta)
+        xs, ress, ws, bs = tensors[0::4], tensors[1::4], tensors[2::4], tensors[3::4]
+        dev = xs[0].device
+        main = torch.cuda.current_stream(dev)
+        world = _world() if any(m['sync'] for m in meta) else 1
+        if world > 1:
+            _check_equal_batch(xs[0].shape[0], dev)
+        sizes = [x.shape[1] * L.dcl_bn_num_slices(x.shape[0], x.shape[1]) * 2 for x in xs]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        stack = torch.empty((offs[-1],), dtype=torch.float32, device=dev)
+        saved, ys, masks = [], [], []
+        for k, m in enumerate(meta):
+            st = m['stream'] or main
+            x = xs[k]
+            N, C, H, W = x.shape
+            with torch.cuda.stream(st):
+                if st is not main:
+                    stack.record_stream(st)
+                wsb = torch.empty((3 * C,), dtype=torch.float32, device=dev)
+                m['ws'] = wsb
+                _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, H * W, _lib.ptr(stack[offs[k]:]),
+                                               _lib.ptr(m['running_mean']), _lib.ptr(wsb[2 * C:]), _lib.stream_ptr(dev)),
+                           "dcl_bn_stats_part")
+        for m in meta:
+            if m['stream'] is not None and m['stream'] is not main:
+                main.wait_stream(m['stream'])
+        if world > 1:
+            _all_reduce(stack)
+        for k, m in enumerate(meta):
+            st = m['stream'] or main
+            x, res = xs[k], ress[k]
+            N, C, H, W = x.shape
+            HW = H * W
+            relu = m['relu']
+            if st is not main:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                wsb = m['ws']
+                y = torch.empty_like(x)
+                need_y = relu and res is not None
+                mask = torch.empty(N * C * HW // 64, dtype=torch.int64, device=dev) \
+                    if need_y and HW % 256 == 0 and _PACKED_RELU_MASK else None
+                _lib.check(L.dcl_bn_apply_fused(_lib.ptr(x), _lib.ptr(res), _lib.ptr(stack[offs[k]:]),
+                                                float(N * HW * world), m['eps'], m['momentum'], _lib.ptr(ws[k]),
+                                                _lib.ptr(bs[k]), N, C, HW, 1 if relu else 0, _lib.ptr(y),
+                                                _lib.ptr(wsb[:C]), _lib.ptr(wsb[C:2 * C]), _lib.ptr(m['running_mean']),
+                                                _lib.ptr(m['running_var']), _lib.ptr(m['nbt']), _lib.ptr(m['amax']),
+                                                _lib.ptr(wsb[2 * C:]), _lib.ptr(mask), _lib.stream_ptr(dev)),
+                           "dcl_bn_apply_fused")
+            ys.append(y)
+            saved += [x, (mask if mask is not None else y) if need_y else None, ws[k], bs[k], wsb]
+            masks.append(mask is not None)
+        ctx.save_for_backward(*saved)
+        ctx.meta, ctx.masks, ctx.world = meta, masks, world
+        ctx.has_res = [r is not None for r in ress]
+        ctx.keep = stack
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        L = _lib.lib()
+        meta = ctx.meta
+        sv = ctx.saved_tensors
+        dev = sv[0].device
+        main = torch.cuda.current_stream(dev)
+        nm = len(meta)
+        sizes = [sv[5 * k].shape[1] * L.dcl_bn_num_slices(sv[5 * k].shape[0], sv[5 * k].shape[1]) * 2 for k in range(nm)]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        local = torch.empty((offs[-1],), dtype=torch.float32, device=dev)
+        dys = [dy.contiguous() for dy in dys]
+        relus = []
+        for k, m in enumerate(meta):
+            st = m['stream'] or main
+            x, ym, w, b, wsb = sv[5 * k:5 * k + 5]
+            N, C, H, W = x.shape
+            relu = (2 if ctx.masks[k] else 1) if m['relu'] else 0
+            relus.append(relu)
+            if st is not main:
+                st.wait_stream(main)               # the engine has made `main` wait for the producers of dys
+                local.record_stream(st)
+                dys[k].record_stream(st)
+            with torch.cuda.stream(st):
+                _lib.check(L.dcl_bn_bwd_reduce_part(_lib.ptr(dys[k]), _lib.ptr(x), _lib.ptr(ym), _lib.ptr(wsb[:C]),
+                                                    _lib.ptr(wsb[C:2 * C]), _lib.ptr(w), _lib.ptr(b), N, C, H * W, relu,
+                                                    _lib.ptr(local[offs[k]:]), _lib.stream_ptr(dev)),
+                           "dcl_bn_bwd_reduce_part")
+        for m in meta:
+            if m['stream'] is not None and m['stream'] is not main:
+                main.wait_stream(m['stream'])
+        total = local
+        if ctx.world > 1:
+            total = local.clone()
+            _all_reduce(total)
+        grads = []
+        for k, m in enumerate(meta):
+            st = m['stream'] or main
+            x, ym, w, b, wsb = sv[5 * k:5 * k + 5]
+            N, C, H, W = x.shape
+            tok = m.get('token')
+            if st is not main:
+                st.wait_stream(main)
+                total.record_stream(st)
+            with torch.cuda.stream(st):
+                dx = torch.empty_like(x)
+                want_res = ctx.has_res[k] and (ctx.needs_input_grad[1 + 4 * k + 1] or tok is not None)
+                dres = torch.empty_like(x) if want_res else None
+                dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1 + 4 * k + 2] else None
+                dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1 + 4 * k + 3] else None
+                amax = _amax.zeros(_amax.SLOTS, dev) if m['amax'] is not None else None
+                _lib.check(L.dcl_bn_bwd_apply_fused(_lib.ptr(dys[k]), _lib.ptr(x), _lib.ptr(ym), _lib.ptr(wsb[:C]),
+                                                    _lib.ptr(wsb[C:2 * C]), _lib.ptr(w), _lib.ptr(b),
+                                                    _lib.ptr(total[offs[k]:]), _lib.ptr(local[offs[k]:]),
+                                                    float(N * H * W * ctx.world), N, C, H * W, relus[k], _lib.ptr(dx),
+                                                    _lib.ptr(dres), _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(amax),
+                                                    _lib.stream_ptr(dev)), "dcl_bn_bwd_apply_fused")
+                if amax is not None:
+                    _amax.tag(dx, amax)
+                if tok is not None:
+                    tok.dres, dres = dres, None
+            if st is not main:                      # the node's results belong to `main` as far as the engine knows
+                main.wait_stream(st)
+                for t in (dx, dres, dgamma, dbeta, amax):
+                    if t is not None:
+                        t.record_stream(main)
+            grads += [dx, dres, dgamma, dbeta]
+        return (None, *grads)
+
+
+def bn_act_group(bns, xs, residuals=None, relu=True, tokens=None, streams=None):
+    """``[bn_act(bn_k, x_k, residual_k, relu, token_k)]`` for independent FusedBatchNorm2d layers in SyncBatchNorm mode
+    with one stacked statistics exchange per direction instead of one per layer (see _FusedBNGroupFunction); member k's
+    kernels run on ``streams[k]`` (None: the current stream), its input must have been produced there."""
+    n = len(bns)
+    residuals = residuals or [None] * n
+    tokens = tokens or [None] * n
+    streams = streams or [None] * n
+    meta, tensors = [], []
+    for k, bn in enumerate(bns):
+        amax = None
+        if bn.emit_amax:
+            st = streams[k]
+            if st is not None:
+                with torch.cuda.stream(st):
+                    amax = _amax.zeros(_amax.SLOTS, xs[k].device)
+            else:
+                amax = _amax.zeros(_amax.SLOTS, xs[k].device)
+        meta.append(dict(stream=streams[k], sync=bool(bn.sync), running_mean=bn.running_mean, running_var=bn.running_var,
+                         nbt=bn.num_batches_tracked, eps=float(bn.eps), momentum=float(bn.momentum), relu=bool(relu),
+                         amax=amax, token=tokens[k] if residuals[k] is not None else None))
+        tensors += [xs[k], residuals[k], bn.weight, bn.bias]
+    ys = _FusedBNGroupFunction.apply(meta, *tensors)
+    out = []
+    for k, y in enumerate(ys):
+        out.append(_amax.tag(y, meta[k]['amax']) if meta[k]['amax'] is not None else y)
+    return out
+
+
+def can_group(bns, xs, residuals=None):
+    """True when ``bn_act_group`` applies: several fused norms in SyncBatchNorm mode on more than one rank."""
+    if len(bns) < 2 or not _dbg.coalesced_sync_bn:
+        return False
+    if not all(isinstance(bn, FusedBatchNorm2d) for bn in bns):
+        return False
+    if not FORCE_GROUP and (_world() < 2 or not all(bn.sync for bn in bns)):
+        return False
+    residuals = residuals or [None] * len(bns)
+    return all(bn._fusable(x, r) for bn, x, r in zip(bns, xs, residuals))
 
 
 class FusedBatchNorm2d(nn.BatchNorm2d):

@@ -459,10 +459,7 @@ class ConvPackGroup:
     called at the start of the model's forward; it does nothing while no weight was modified."""
 
     def __init__(self, module: torch.nn.Module):
-        # (TokenLinear layers that may run on the f16x3 kernel ride along: a [N, K] weight is a one-tap convolution)
-        self.convs = [m for m in module.modules()
-                      if isinstance(m, DirectConv2d) or (isinstance(m, TokenLinear) and m.f16x3_rows > 0
-                                                         and m.weight.shape[0] % 32 == 0 and m.weight.shape[1] % 16 == 0)]
+        self.convs = [m for m in module.modules() if isinstance(m, DirectConv2d)]
         self.key = None
         self.tables = None
 
@@ -597,24 +594,6 @@ def use_gemm_conv1x1(module: torch.nn.Module) -> torch.nn.Module:
     return module
 
 
-# ---- token-major GEMM on the f16 matrix pipe (csrc/dcl_tokgemm.hip) ---------------------------------------------------
-
-def tok_gemm(x2, wp, n, xamax, wamax, bias=None, emit_amax=False):
-    """y [M, n] = x2 [M, K] W^T (+ bias) with W given as packed fragments (conv3x3_pack of W.view(n, K, 1, 1), or of its
-    transpose for the data gradient); ``emit_amax``: tag y with the partial maxima the epilogue collects."""
-    from .. import _lib
-    from . import amax as _amax
-    m, k = x2.shape
-    y = torch.empty((m, n), dtype=torch.float32, device=x2.device)
-    ybuf = _amax.zeros(_amax.SLOTS, x2.device) if emit_amax else None
-    _lib.check(_lib.lib().dcl_tok_gemm_f16x3(_lib.ptr(x2), m, k, _lib.ptr(wp), n, _lib.ptr(xamax), xamax.numel(),
-                                             _lib.ptr(wamax), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(ybuf), _stream(x2)),
-               "dcl_tok_gemm_f16x3")
-    if emit_amax:
-        _amax.tag(y, ybuf)
-    return y
-
-
 # ---- token-major Linear (Swin: models/Swin.py qkv / proj / fc1 / fc2 / reduction) --------------------------------------
 
 def _token_slabs(m):
@@ -628,31 +607,19 @@ def _token_slabs(m):
 
 
 class _TokenLinear(torch.autograd.Function):
-    """y = x W^T + b on [tokens, K] rows.
+    """y = x W^T + b on [tokens, K] rows with a slab-wise weight gradient.
 
-    Weight gradient: dW = dY^T X reduces over 10^4..10^5 tokens into a tiny [N, K] output, a shape the library's fp32
-    kernels run at 10-40 TFLOP/s (one macro tile per output tile, the whole token axis serial: 450-1030 us where HBM
-    allows 45-110, tools/probes/linear_wgrad_split.py).  Here the token axis is cut into slabs of ~1024 rows, one batched
-    GEMM computes a partial dW per slab and a fixed-order sum adds them: 3-5x faster, deterministic.
-
-    Forward and data gradient: the library's fp32 GEMMs, or -- ``mod.f16x3_rows`` >= the row count -- the f16x3 kernel
-    of csrc/dcl_tokgemm.hip on the module's packed fragments (operand maxima from the producers' tags where they
-    exist, else one absmax pass; its own outputs are tagged by the epilogue)."""
+    dW = dY^T X reduces over 10^4..10^5 tokens into a tiny [N, K] output, a shape the library's fp32 kernels run at
+    10-40 TFLOP/s (one macro tile per output tile, the whole token axis serial: 450-1030 us where HBM allows 45-110,
+    tools/probes/linear_wgrad_split.py).  Here the token axis is cut into slabs of ~1024 rows, one batched GEMM computes
+    a partial dW per slab and a fixed-order sum adds them: 3-5x faster, deterministic.  Forward and data gradient are the
+    library's fp32 GEMMs.  (An f16x3 token GEMM on the direct convolutions' arithmetic was built in round 2, came out
+    within noise in the step and was retired in round 3: tools/probes/retired/dcl_tokgemm.hip.)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mod):
+    def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        ctx.mod = mod
-        k = weight.shape[1]
-        ctx.f16x3 = mod is not None and mod.use_f16x3(x)
-        if ctx.f16x3:
-            from .amax import amax_of, tag_of
-            wamax, wp, _ = mod.packed_weights()
-            x2 = x.reshape(-1, k)
-            xamax = tag_of(x)
-            y = tok_gemm(x2, wp, weight.shape[0], amax_of(x2) if xamax is None else xamax, wamax, bias, True)
-            return _retag(y.view(x.shape[:-1] + (weight.shape[0],)), y)
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -664,14 +631,7 @@ class _TokenLinear(torch.autograd.Function):
         m = x2.shape[0]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            if ctx.f16x3 and gy2.is_contiguous():
-                from .amax import amax_of, tag_of
-                wamax, _, wpt = ctx.mod.packed_weights()
-                gamax = tag_of(gy)
-                g2 = tok_gemm(gy2, wpt, k, amax_of(gy2) if gamax is None else gamax, wamax, None, True)
-                gx = _retag(g2.view(x.shape), g2)
-            else:
-                gx = gy2.mm(weight).view(x.shape)
+            gx = gy2.mm(weight).view(x.shape)
         if ctx.needs_input_grad[1]:
             s = _token_slabs(m)
             if s and gy2.is_contiguous() and x2.is_contiguous():
@@ -680,81 +640,27 @@ class _TokenLinear(torch.autograd.Function):
                 gw = gy2.t().mm(x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy2.sum(0)
-        return gx, gw, gb, None
-
-
-def _retag(view, base):
-    """Carry the absmax tag of ``base`` over to a view of it (same storage, same values)."""
-    from . import amax as _amax
-    buf = _amax.tag_of(base)
-    if buf is not None and view is not base:
-        _amax.tag(view, buf)
-    return view
+        return gx, gw, gb
 
 
 class TokenLinear(torch.nn.Linear):
     """nn.Linear (same parameters / state_dict keys) for token-major fp32 CUDA rows in training: slab-wise weight
-    gradient from 32768 rows on, and forward / data gradient on the f16x3 kernel for inputs of at most ``f16x3_rows``
-    rows (class default; 0 = library GEMMs); anything else is nn.Linear.forward."""
-
-    f16x3_rows = _dbg.linear_f16x3_rows
-
-    def use_f16x3(self, x):
-        from .. import _lib
-        n, k = self.weight.shape
-        m = x.numel() // k
-        return (0 < m <= self.f16x3_rows and m >= 512 and x.is_contiguous()
-                and bool(_lib.lib().dcl_tok_gemm_supported(k, n)))
-
-    def packed_weights(self):
-        """(max|w|, forward fragments, data-gradient fragments), rebuilt when the weight tensor was modified (or kept
-        fresh for all layers at once by ConvPackGroup.refresh)."""
-        from .amax import amax_of
-        w = self.weight
-        key = (w._version, w.data_ptr())
-        cache = getattr(self, "_packed", None)
-        if cache is None or cache[0] != key:
-            wd = w.detach().view(w.shape[0], w.shape[1], 1, 1)
-            wamax = amax_of(wd)
-            cache = (key, wamax, conv3x3_pack(wd, wamax, False), conv3x3_pack(wd, wamax, True))
-            self._packed = cache
-        return cache[1], cache[2], cache[3]
+    gradient from 32768 rows on; anything else is nn.Linear.forward."""
 
     def forward(self, x):
         if (x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and self.weight.requires_grad
                 and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
-            m = x.numel() // x.shape[-1]
-            if _token_slabs(m) or self.use_f16x3(x):
-                return _TokenLinear.apply(x, self.weight, self.bias, self)
+            if _token_slabs(x.numel() // x.shape[-1]):
+                return _TokenLinear.apply(x, self.weight, self.bias)
         return super().forward(x)
 
 
 # ---- LayerNorm over token-major rows (csrc/dcl_layernorm.hip) -----------------------------------------------------
 
-class _TaggedGELU(torch.autograd.Function):
-    """nn.GELU() (exact erf form) that hands the absmax tags of the f16x3 Linears through: |gelu(t)| <= |t| forward,
-    |gelu'(t)| <= 1.13 backward (inside the 4x headroom between the operand scale's target and the f16 range)."""
-
-    @staticmethod
-    def forward(ctx, h):
-        ctx.save_for_backward(h)
-        return torch.nn.functional.gelu(h)
-
-    @staticmethod
-    def backward(ctx, gy):
-        h, = ctx.saved_tensors
-        gh = torch.ops.aten.gelu_backward(gy, h)
-        buf = _amax_mod().tag_of(gy)
-        if buf is not None:
-            _amax_mod().tag(gh, buf)
-        return gh
-
-
 def tagged_gelu(h):
-    buf = _amax_mod().tag_of(h)
-    if buf is None:
-        return torch.nn.functional.gelu(h)
-    return _amax_mod().tag(_TaggedGELU.apply(h), buf)
+    """nn.GELU() (exact erf form).  (Kept under its round-2 name: it used to hand absmax tags through for the retired
+    f16x3 token GEMM.)"""
+    return torch.nn.functional.gelu(h)
 
 
 def _amax_mod():
@@ -804,11 +710,7 @@ class FusedLayerNorm(torch.nn.LayerNorm):
                 and not torch.is_autocast_enabled() and x.numel() > 0):
             from .. import _lib
             if _lib.lib().dcl_layernorm_supported(x.shape[-1]):
-                if TokenLinear.f16x3_rows <= 0:
-                    return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
-                # absmax side channel for an f16x3 Linear behind the norm (csrc/dcl_tokgemm.hip)
-                ybuf = _amax_mod().zeros(_amax_mod().SLOTS, x.device)
-                return _amax_mod().tag(_LayerNormFn.apply(x, self.weight, self.bias, self.eps, ybuf), ybuf)
+                return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return super().forward(x)
 
 

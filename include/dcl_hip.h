@@ -414,23 +414,6 @@ int dcl_layernorm_fwd(const float *x, const float *gamma, const float *beta, lon
 int dcl_layernorm_bwd(const float *gy, const float *x, const float *gamma, const float *mean, const float *rstd,
                       long long M, int C, float *gx, float *parts, float *dgamma_dbeta, void *stream);
 
-/* ---- token-major Linear on the f16 matrix pipe (the Swin backbone) ------------------
- * y[M, N] = x[M, K] W^T (+ bias), fp32-equivalent (split-f16, three MFMA passes, f32 accumulation; the scheme of the
- * direct convolutions): nn.Linear of the Swin port (reference models/Swin.py:62-76, :198-230, :357-362) and -- on the
- * transposed fragments, with x = dy -- its data gradient; csrc/dcl_tokgemm.hip.
- *   wp      weight fragments from dcl_conv3x3_pack(w, M = N, K, transposed | 2 (one tap), wamax, wp): forward from
- *           W [N, K] as stored; data gradient: transposed = 1 with (M, K) = (in features, out features)
- *   xamax   xcount partial maxima of |x| (a producer's side channel or one dcl_absmax pass), wamax max|W| (1 value)
- *   yamax   optional DCL_AMAX_SLOTS partial maxima of |y| (zero-initialised by the caller)
- *   shapes  K % 16 == 0 and N % 32 == 0 (dcl_tok_gemm_supported) */
-int dcl_tok_gemm_supported(int K, int N);
-int dcl_tok_gemm_set_rows(int p);   /* tuning: row tiles per wave, 1 | 2 (0 = automatic); + 64: operands per wave from
-                                       global memory, + 128: weight fragments only through LDS (the two earlier
-                                       stagings, kept for tools/probes/tokgemm_bound.py; + 16 / + 32 pin their x /
-                                       weight loads to one chunk: timing only, wrong results) */
-int dcl_tok_gemm_f16x3(const float *x, long long M, int K, const void *wp, int N, const float *xamax, int xcount,
-                       const float *wamax, const float *bias, float *y, float *yamax, void *stream);
-
 /* ---- fused bilinear up-sampling + class-weighted cross-entropy --------------------
  * loss = CrossEntropyLoss(weight, ignore_index)(F.interpolate(z, (H, W), 'bilinear', align_corners), target) without
  * materialising the up-sampled logits (reference models/HRNet.py:638 + losses/LossWrapper.py:26-30, :82); PyTorch's

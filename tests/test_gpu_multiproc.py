@@ -57,9 +57,32 @@ def _bn_worker(rank, world, port, out_dir, backend):
     ri = r[half].to(dev).requires_grad_(True)
     y = bn(xi, residual=ri, relu=True)
     y.backward(gy[half].to(dev))
-    torch.save({"y": y.detach().cpu(), "dx": xi.grad.cpu(), "dr": ri.grad.cpu(), "dw": bn.weight.grad.cpu(),
-                "db": bn.bias.grad.cpu(), "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu()},
-               os.path.join(out_dir, f"bn{rank}.pt"))
+    out = {"y": y.detach().cpu(), "dx": xi.grad.cpu(), "dr": ri.grad.cpu(), "dw": bn.weight.grad.cpu(),
+           "db": bn.bias.grad.cpu(), "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu()}
+    # the same layer twice more as the two members of ONE stacked exchange (models/fused_bn.bn_act_group), the second
+    # member on a side stream: must give the single-layer results
+    from mscs_amd.models import fused_bn
+    side = torch.cuda.Stream(device=dev)
+    bns = []
+    for _ in range(2):
+        b2 = FusedBatchNorm2d(24).to(dev)
+        b2.sync = True
+        with torch.no_grad():
+            b2.weight.copy_(w); b2.bias.copy_(b)
+        bns.append(b2)
+    xs = [x[half].to(dev).requires_grad_(True) for _ in range(2)]
+    rs = [r[half].to(dev).requires_grad_(True) for _ in range(2)]
+    before = fused_bn.COLLECTIVES["count"]
+    torch.cuda.synchronize()
+    ys = fused_bn.bn_act_group(bns, xs, residuals=rs, relu=True, streams=[None, side])
+    torch.cuda.current_stream().wait_stream(side)
+    ((ys[0] * gy[half].to(dev)).sum() + (ys[1] * gy[half].to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    out["group_collectives"] = fused_bn.COLLECTIVES["count"] - before
+    for k in range(2):
+        out[f"g{k}"] = {"y": ys[k].detach().cpu(), "dx": xs[k].grad.cpu(), "dr": rs[k].grad.cpu(),
+                        "dw": bns[k].weight.grad.cpu(), "rm": bns[k].running_mean.cpu()}
+    torch.save(out, os.path.join(out_dir, f"bn{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,6 +110,10 @@ def test_fused_bn_sync_two_ranks_one_gpu(tmp_path):
             assert (outs[q][key].double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), key
         assert torch.allclose(outs[q]["rm"].double(), ref.running_mean, atol=1e-5)
         assert torch.allclose(outs[q]["rv"].double(), ref.running_var, atol=1e-5)
+        assert outs[q]["group_collectives"] == 2            # one stacked exchange forward, one backward
+        for k in range(2):                   # the grouped (stacked-exchange) form: identical to the single layer
+            for key in ("y", "dx", "dr", "dw", "rm"):
+                assert torch.equal(outs[q][f"g{k}"][key], outs[q][key]), (k, key)
     # weight / bias grads are per-rank partial sums (DDP averages them): they add up to the full-batch grads
     assert torch.allclose((outs[0]["dw"] + outs[1]["dw"]).double(), ref.weight.grad, atol=2e-4)
     assert torch.allclose((outs[0]["db"] + outs[1]["db"]).double(), ref.bias.grad, atol=2e-4)
@@ -122,7 +149,9 @@ def _train_worker(rank, world, port, out_dir, global_negatives, backbone="hrnet1
     flat = torch.cat([p.detach().flatten() for p in mgr.model.parameters()]).cpu()
     from mscs_amd.models.ops import DirectConv2d
     direct = sum(isinstance(m, DirectConv2d) for m in mgr.model.modules())
-    torch.save({"params": flat, "metrics": mgr.metrics, "direct_convs": direct,
+    from mscs_amd.models import fused_bn
+    torch.save({"params": flat, "metrics": mgr.metrics, "direct_convs": direct, "syncbn_collectives": fused_bn.COLLECTIVES["count"],
+                "steps": mgr.global_step,
                 "segs": [len(t.segs) for t in mgr.loss.loss_classes["DenseContrastiveLossV2_ms"].last_state.terms]},
                os.path.join(out_dir, f"train{rank}.pt"))
     dist.barrier()
@@ -155,3 +184,7 @@ def test_ddp_hrnet48_direct_kernels_and_branch_streams_two_ranks_one_gpu(tmp_pat
     assert torch.equal(a["params"], b["params"]), "parameters diverged across ranks"
     assert np.isfinite(a["metrics"]["loss"]) and np.isfinite(b["metrics"]["loss"])
     assert a["segs"] == [2] * 5                                      # 3 intra + 2 cross terms, 2 segments each
+    # SyncBatchNorm exchanges per step: 310 norms x 2 directions = 620 one by one; the branch chains' 208 norms share one
+    # exchange per block depth (64 instead of 208 per direction)
+    per_step = a["syncbn_collectives"] / max(1, a["steps"])
+    assert per_step <= 340, per_step

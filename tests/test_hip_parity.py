@@ -863,6 +863,44 @@ def test_kernels_stay_inside_their_tensors(dev, where):
 
 
 @pytest.mark.gpu
+def test_grouped_syncbn_schedule_is_bitwise_the_free_running_one(dev):
+    """The depth-major schedule of an exchange module's branches (one stacked SyncBatchNorm statistics exchange per block
+    depth and direction, models/fused_bn.bn_act_group) runs the same kernels on the same data as the free-running
+    per-branch schedule: outputs, input gradients and parameter gradients bitwise equal (one rank: the exchange itself is
+    skipped; two ranks: tests/test_gpu_multiproc.py)."""
+    import importlib
+    from mscs_amd.models import fused_bn
+    from mscs_amd.models.ops import use_direct_conv1x1, use_direct_conv3x3
+    hm = importlib.import_module("mscs_amd.models.HRNet")
+    torch.manual_seed(5)
+    ch = [48, 96, 192, 384]
+    mod = hm.HighResolutionModule(4, hm.BasicBlock, [4] * 4, ch, ch, 'SUM', True, norm_layer=fused_bn.FusedBatchNorm2d)
+    use_direct_conv3x3(mod)
+    use_direct_conv1x1(mod)
+    mod.to(dev).train()
+    state = {k: v.clone() for k, v in mod.state_dict().items()}
+    xs0 = [torch.randn(2, c, 64 >> i, 96 >> i, device=dev) for i, c in enumerate(ch)]
+    res = []
+    for grouped in (False, True):
+        mod.load_state_dict(state)
+        mod.zero_grad(set_to_none=True)
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        fused_bn.FORCE_GROUP = grouped
+        try:
+            assert mod._groupable(xs) == grouped
+            outs = mod(list(xs))
+            sum((o * torch.cos(torch.arange(o.numel(), device=dev).view(o.shape) * 0.37)).mean() for o in outs).backward()
+        finally:
+            fused_bn.FORCE_GROUP = False
+        torch.cuda.synchronize()
+        res.append(([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
+                    [p.grad.clone() for p in mod.parameters()], [b.clone() for b in mod.buffers()]))
+    for a, b in zip(res[0], res[1]):
+        for t, u in zip(a, b):
+            assert torch.equal(t, u)
+
+
+@pytest.mark.gpu
 def test_fuse_layer_streams_match_single_stream(dev):
     """A whole HighResolutionModule (branches + fuse layers, one stream per branch / per fused output) against its
     single-stream execution, to within 10x the measured run-to-run noise of the library convolutions that the

@@ -217,39 +217,3 @@ def test_fused_layernorm_fallbacks():
     assert torch.equal(ln(xt), F.layer_norm(xt, (96,), ln.weight, ln.bias, ln.eps))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("M,K,N,bias", [(4096, 96, 288, True), (2 * 1000, 384, 96, False), (33 * 32 + 5, 192, 64, True),
-                                        (16384, 768, 3072, True)])
-def test_token_linear_f16x3_kernel(M, K, N, bias, monkeypatch):
-    """The f16x3 token GEMM (csrc/dcl_tokgemm.hip) behind TokenLinear: forward and data gradient against fp64 at ragged
-    row counts and all three column-tile groupings, at least as close as the library's fp32 GEMM; outputs tagged with
-    their absmax."""
-    import mscs_amd  # noqa: F401
-    from mscs_amd.models import ops
-    from mscs_amd.models.amax import tag_of
-    monkeypatch.setattr(ops.TokenLinear, "f16x3_rows", 1 << 20)
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(5)
-    lin = ops.TokenLinear(K, N, bias=bias).to(dev)
-    x = (torch.randn(2, M // 2, K, generator=g) * 3.0).to(dev).requires_grad_(True)
-    gy = (torch.randn(2, M // 2, N, generator=g) * 1e-4).to(dev)
-    assert lin.use_f16x3(x)
-    y = lin(x)
-    y.backward(gy)
-    buf = tag_of(y)
-    assert buf is not None and abs(buf.max().item() - y.detach().abs().max().item()) <= 1e-6 * y.detach().abs().max().item()
-    w64, x64 = lin.weight.detach().double(), x.detach().double()
-    y64 = F.linear(x64, w64, lin.bias.detach().double() if bias else None)
-    dx64 = gy.double() @ w64
-    ylib = F.linear(x.detach(), lin.weight.detach(), lin.bias.detach() if bias else None)
-    dxlib = gy @ lin.weight.detach()
-    err = lambda a, ref: ((a.double() - ref).abs().max() / ref.abs().max()).item()
-    assert err(y.detach(), y64) < 3e-6 and err(y.detach(), y64) <= 2 * err(ylib, y64) + 1e-7
-    assert err(x.grad, dx64) < 3e-6 and err(x.grad, dx64) <= 2 * err(dxlib, dx64) + 1e-7
-    gw64 = gy.double().view(-1, N).t() @ x64.view(-1, K)
-    assert err(lin.weight.grad, gw64) < 1e-5          # the library's fp32 GEMM (slab-wise from 32768 rows on)
-    # modified weights are re-packed
-    with torch.no_grad():
-        lin.weight.mul_(0.5)
-    y2 = lin(x.detach())
-    assert err(y2, F.linear(x64, w64 * 0.5, lin.bias.detach().double() if bias else None)) < 3e-6
