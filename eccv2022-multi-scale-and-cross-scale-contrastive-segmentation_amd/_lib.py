@@ -72,6 +72,7 @@ SIGNATURES = {
     "dcl_wgrad3x3_set_stride2": [_i],
     "dcl_wgrad3x3_set_splits": [_i],
     "dcl_conv3x3_set_up2_phases": [_i],
+    "dcl_conv3x3_set_interleave": [_i],
     "dcl_upsample_ce_set_bwd_chunk": [_i],
     "dcl_upsample_ce_set_fwd_lds": [_i],
     "dcl_wgrad3x3_set_tile": [_i, _i],
@@ -114,7 +115,8 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found. The dense contrastive loss has no fallback path: build the HIP "
                 f"library first (python -c 'import __graft_entry__ as g; g.build()' or make -C {CSRC_DIR}).")
-        l = ctypes.CDLL(LIB_PATH)
+        from .debug import cfg as _dbg0
+        l = ctypes.CDLL(_dbg0.lib_path or LIB_PATH)      # (lib_path: probe builds, tools/probes/conv_bounds.sh)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = argtypes

@@ -31,6 +31,14 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+// Bound probes (tools/probes/conv_bounds.sh builds the library with -DDCL_CONV_PROBE=<bits>; 0 in the product): 1 = no
+// MFMAs, 2 = no patch loads, 4 = no output stores, 8 = no weight-fragment loads.  Results are wrong, times tell which part
+// of a launch bounds it.
+#ifndef DCL_CONV_PROBE
+#define DCL_CONV_PROBE 0
+#endif
+#define DCL_MFMA(A, B, C) ((DCL_CONV_PROBE & 1) ? (C) : __builtin_amdgcn_mfma_f32_32x32x16_f16((A), (B), (C), 0, 0, 0))
+
 constexpr int TW = 32;          // tile width in pixels (one MFMA pixel tile = 1 row x 32 columns)
 constexpr int PIXB = 80;        // bytes per LDS pixel record
 
@@ -86,10 +94,19 @@ __device__ __forceinline__ float pow2_scale(float amax)
 // MODE 2 ("one tap"): a 1x1 convolution -- the same tile, patch staging and epilogue with ONE MFMA group per chunk
 // (the centre pixel of the patch); the weights are packed with one tap per (tile, chunk) (pack_item, taps = 1) and
 // streamed one chunk ahead.
-template <int R, int P, int S, int MODE = 0>
+//
+// IL ("interleaved", stride-1 3x3 tiles with two chunks of look-ahead, Cin % 16 == 0): the staging of the NEXT chunks --
+// the global loads of chunk c + 2, the split + LDS write of chunk c + 1, the weight fragments of the next kx step -- is
+// spread over chunk c's MFMAs by scheduling groups (after every MFMA: <= V loads, <= A VALU, <= 1 LDS write) instead of
+// sitting in blocks between fences.  Probe builds of this file (DCL_CONV_PROBE) showed the blocks do NOT overlap the
+// matrix work: on every shape time(no MFMAs) + time(no loads, no stores) = time(product), e.g. head 2.2 + 6.5 = 8.8 ms,
+// 96 channels 21 + 45 = 63 us -- at one wave per SIMD the 40-94 vector-memory instructions and ~160 VALU of a chunk's
+// staging are issued while the matrix pipe idles.
+template <int R, int P, int S, int MODE = 0, bool IL = false>
 __device__ __forceinline__ void conv_body(const ConvArgs &a)
 {
     constexpr bool PH = MODE == 1, T1 = MODE == 2;
+    static_assert(!IL || (S == 1 && MODE == 0), "interleaved staging: stride-1 3x3 tiles");
     static_assert(MODE == 0 || S == 1, "phases / one tap: stride-1 tile");
     constexpr int LW = S * (TW - 1) + 3;          // patch width incl. halo: 34 | 65
     constexpr int ROWS = S * (4 * P - 1) + 3;     // 4P + 2 | 8P + 1
@@ -168,7 +185,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     // MFMAs run), gB receives the loads of the chunk after that
     float gA[NITEM][8], gB[NITEM][8];
     auto load_items = [&](int c, float (&g)[NITEM][8]) {
-        if (!ragged || c + 1 < a.nchunk) {
+        if (DCL_CONV_PROBE & 2) {
+#pragma unroll
+            for (int m = 0; m < NITEM; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    g[m][e] = 1.0f;
+        } else if (!ragged || c + 1 < a.nchunk) {
 #pragma unroll
             for (int m = 0; m < NITEM; ++m) {
                 const float *xc = xb + (size_t)(16 * c + 8 * (tid + 256 * m >= TP ? 1 : 0)) * plane + goff[m];
@@ -214,7 +237,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
 #pragma unroll
                 for (int part = 0; part < 2; ++part) {
                     const int tap = PH ? (ky == 1 ? kyo1 : ky) * 3 + (kx == 1 ? kxo1 : kx) : ky * 3 + kx;
-                    const uint4 v = wa[r][(((size_t)c * 9 + tap) * 2 + part) * 64];
+                    const uint4 v = (DCL_CONV_PROBE & 8) ? make_uint4(tap, c, r, part)
+                                                         : wa[r][(((size_t)c * 9 + tap) * 2 + part) * 64];
                     A[ky][r][part] = __builtin_bit_cast(half8, v);
                 }
     };
@@ -278,7 +302,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     for (int m = 0; m < NITEM; ++m)
         gsc[m] = gok[m] ? xs : 0.f;
     write_items(lds, gA);
-    if (LA2)
+    // (IL with P = 4: ONE register set -- a chunk's items are loaded during the first half of the previous chunk's slices
+    // and split + written during its second half; the two-set scheme spills at (3, 4))
+    constexpr bool ONESET = IL && (P == 4 || O2);
+    if (LA2 && !ONESET)
         load_items(min(1, a.nchunk - 1), gA);
     __syncthreads();
 
@@ -302,8 +329,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
                 for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[ph][r][pass == 2 ? 1 : 0],
-                                                                           pass == 1 ? bl : bh, acc[r][p], 0, 0, 0);
+                        acc[r][p] = DCL_MFMA(A1[ph][r][pass == 2 ? 1 : 0],
+                                                                           pass == 1 ? bl : bh, acc[r][p]);
                 if (p == 0 && more)
                     write_items(lds + ((c + 1) & 1) * BUFB, gA);
             }
@@ -322,6 +349,100 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
         }
         if (c < a.nchunk)
             chunk(std::integral_constant<int, 0>{}, c);
+    } else if constexpr (IL) {
+    // A chunk's MFMAs form 3 (kx) x (P + 2) (tile row) x 3 (pass) slices, fenced from each other (sched_barrier), so the
+    // staging work dealt out to a slice stays there: the weight fragments of the next kx step go to the three slices of
+    // the step's first tile row, item m's loads (chunk c + 2) and its split + LDS write (chunk c + 1) to slices spread
+    // evenly over the chunk.  (Scheduling groups were tried first -- "1 MFMA, <= V loads, <= A VALU, <= 1 LDS write" 324
+    // times per chunk -- and the scheduler ignored them: the staging still sat in front of each kx step.)
+    constexpr int NS = 9 * (P + 2);                                // slices per chunk
+    auto load_item = [&](int c, int m, float (&g)[NITEM][8]) {
+        const float *xc = xb + (size_t)(16 * c + 8 * (tid + 256 * m >= TP ? 1 : 0)) * plane + goff[m];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            g[m][e] = xc[e * plane];
+    };
+    auto write_item = [&](unsigned char *buf, int m, const float (&g)[NITEM][8]) {
+        unsigned hh[4], ll[4];
+        split2(g[m][0], g[m][1], gsc[m], hh[0], ll[0]);
+        split2(g[m][2], g[m][3], gsc[m], hh[1], ll[1]);
+        split2(g[m][4], g[m][5], gsc[m], hh[2], ll[2]);
+        split2(g[m][6], g[m][7], gsc[m], hh[3], ll[3]);
+        *(uint4 *)(buf + loff[m]) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+        *(uint4 *)(buf + loff[m] + 32) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+    };
+    for (int c = 0; c < a.nchunk; ++c) {
+        const unsigned char *cur = lds + (c & 1) * BUFB;
+        unsigned char *nxt = lds + ((c + 1) & 1) * BUFB;            // (past the last chunk: written, never read)
+        const int c2 = min(c + (ONESET ? 1 : 2), a.nchunk - 1);
+        half8 bq[2][2];
+        auto read_b = [&](int g, half8 (&dst)[2]) {
+            const unsigned char *bp = cur + (brow + (g % (P + 2)) * LW + g / (P + 2)) * PIXB + h * 16;
+            dst[0] = *(const half8 *)bp;
+            dst[1] = *(const half8 *)(bp + 32);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(0, bq[0]);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int s2 = min(3 * c + kx + AD, nsteps - 1);          // step whose weight fragments are fetched in this one
+#pragma unroll
+            for (int rr = 0; rr < P + 2; ++rr) {
+                const int g = kx * (P + 2) + rr;
+                const half8 bh = bq[g & 1][0], bl = bq[g & 1][1];
+#pragma unroll
+                for (int pass = 0; pass < 3; ++pass) {
+                    const int sl = g * 3 + pass;                        // slice index, 0 .. NS - 1
+                    if (pass == 0 && g + 1 < 3 * (P + 2))
+                        read_b(g + 1, bq[(g + 1) & 1]);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int p = rr - ky;
+                        if (p >= 0 && p < P) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+                                acc[r][p] = DCL_MFMA(Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p]);
+                        }
+                    }
+                    // ---- this slice's share of the staging
+                    if (rr == 0) {                                      // weights of the next step: tap row `pass`
+                        const int c3 = s2 / 3, kx3 = s2 % 3;
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+#pragma unroll
+                            for (int part = 0; part < 2; ++part) {
+                                const uint4 v = (DCL_CONV_PROBE & 8) ? make_uint4(pass, c3, r, part)
+                                    : wa[r][(((size_t)c3 * 9 + pass * 3 + kx3) * 2 + part) * 64];
+                                Ab[(kx + AD) % 3][pass][r][part] = __builtin_bit_cast(half8, v);
+                            }
+                    }
+#pragma unroll
+                    for (int m = 0; m < NITEM; ++m) {
+                        if (ONESET) {
+                            if (sl == m * (NS / 2) / NITEM)               // loads of chunk c + 1, item m: first half
+                                load_item(c2, m, gA);
+                            if (sl == NS / 2 + m * (NS / 2) / NITEM)      // its split + write: half a chunk later
+                                write_item(nxt, m, gA);
+                        } else {
+                            if (sl == (2 * m + 1) * NS / (2 * NITEM))     // loads of chunk c + 2, item m
+                                load_item(c2, m, gB);
+                            if (sl == (2 * m) * NS / (2 * NITEM) + 1)     // split + write of chunk c + 1, item m
+                                write_item(nxt, m, gA);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();
+        if (!ONESET) {
+#pragma unroll
+            for (int m = 0; m < NITEM; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    gA[m][e] = gB[m][e];
+        }
+    }
     } else {
     for (int c = 0; c < a.nchunk; ++c) {
         const unsigned char *cur = lds + (c & 1) * BUFB;
@@ -374,8 +495,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
                             if (p >= 0 && p < P && (!PH || ((kym >> ky) & 1))) {
 #pragma unroll
                                 for (int r = 0; r < R; ++r)
-                                    acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                        Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p], 0, 0, 0);
+                                    acc[r][p] = DCL_MFMA(Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p]);
                             }
                         }
                     // number of (p, ky) pairs of this tile row
@@ -404,8 +524,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
                         for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
                             for (int r = 0; r < R; ++r)
-                                acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                    Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p], 0, 0, 0);
+                                acc[r][p] = DCL_MFMA(Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p]);
                     }
             }
             if (LA2 && kx == 0 && more)
@@ -433,7 +552,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
         for (int p = 0; p < P; ++p) {
             const int row = PH ? 2 * (y0 + P * wave + p) + py : y0 + P * wave + p;
             const int cob = (T0 + r) * 32 + 4 * h;
-            if (row < a.Ho && col < a.Wo && cob < a.Cout) {
+            if (row < a.Ho && col < a.Wo && cob < a.Cout && !((DCL_CONV_PROBE & 4) && acc[r][p][0] != 12345.f)) {
                 const size_t o0 = (((size_t)n * a.Cout + cob) * a.Ho + row) * a.Wo + col;
                 float *yp = a.y + o0;
                 if (a.addend || a.bias) {
@@ -466,6 +585,18 @@ template <int R, int P, int S>
 __global__ __launch_bounds__(256, 1) void k_conv3x3(ConvArgs a)
 {
     conv_body<R, P, S>(a);
+}
+
+template <int R, int P>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_il(ConvArgs a)
+{
+    conv_body<R, P, 1, 0, true>(a);
+}
+
+template <int R, int P>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_il_o2(ConvArgs a)
+{
+    conv_body<R, P, 1, 0, true>(a);
 }
 
 template <int R, int P>
@@ -699,6 +830,14 @@ extern "C" int dcl_conv3x3_pack_multi(const void *jobs, const int32_t *blk2job, 
     return 0;
 }
 
+static int g_conv_interleave = 1;      // staging interleaved with the MFMAs (k_conv3x3_il); 0 = the fenced blocks
+
+extern "C" int dcl_conv3x3_set_interleave(int on)
+{
+    g_conv_interleave = on ? 1 : 0;
+    return 0;
+}
+
 template <int R, int P, int S>
 static int launch_conv(const ConvArgs &a0, hipStream_t stream)
 {
@@ -719,10 +858,19 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
             return 0;
         }
     }
-    if constexpr (S == 1 && R == 2 && P == 2)
-        hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);
-    else
+    if constexpr (S == 1 && R == 2 && P == 2) {
+        if (g_conv_interleave && (a.Cin & 15) == 0 && a.up == 1)
+            hipLaunchKernelGGL((k_conv3x3_il_o2<R, P>), grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);
+    } else if constexpr (S == 1) {
+        if (g_conv_interleave && (a.Cin & 15) == 0 && a.up == 1)
+            hipLaunchKernelGGL((k_conv3x3_il<R, P>), grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
+    } else {
         hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
+    }
     return 0;
 }
 

@@ -19,6 +19,12 @@
 #include "dcl_common.h"
 #include "dcl_wgrad.h"
 
+// Bound probes (tools/probes/conv_bounds.sh; 0 in the product): 1 = no MFMAs, 2 = no LDS-DMA.  Results are wrong.
+#ifndef DCL_WG_PROBE
+#define DCL_WG_PROBE 0
+#endif
+#define DCL_WMFMA(A, B, C) ((DCL_WG_PROBE & 1) ? (C) : __builtin_amdgcn_mfma_f32_16x16x32_f16((A), (B), (C), 0, 0, 0))
+
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -59,6 +65,8 @@ __device__ __forceinline__ const float *uniform_ptr(const float *p)
 // gbase and lds_dst must be wave-uniform (scalar registers)
 __device__ __forceinline__ void dma16(const void *gbase, unsigned voff, unsigned lds_dst)
 {
+    if (DCL_WG_PROBE & 2)
+        return;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
@@ -74,6 +82,10 @@ __device__ __forceinline__ void dma_wait()
 }
 
 constexpr int APIECES = 9, BPIECES = 11;          // 16-byte pieces per staged row: 8 (+ 2 halo) + 1 pad
+#ifndef DCL_WG_SPREAD
+#define DCL_WG_SPREAD 1
+#endif
+constexpr bool g_wgrad_spread = DCL_WG_SPREAD != 0;      // LDS-DMA instructions dealt out among the MFMAs (see step())
 
 template <int NCO, int NCI>
 __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
@@ -333,9 +345,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
                     for (int t2 = 0; t2 < NCO; ++t2)
 #pragma unroll
                         for (int u = 0; u < NCI; ++u)
-                            acc[t2][u][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                                A[slot][t2][pass == 2 ? 1 : 0], B[bs][kx][u][pass == 1 ? 1 : 0],
-                                acc[t2][u][ky * 3 + kx], 0, 0, 0);
+                            acc[t2][u][ky * 3 + kx] = DCL_WMFMA(A[slot][t2][pass == 2 ? 1 : 0], B[bs][kx][u][pass == 1 ? 1 : 0],
+                                acc[t2][u][ky * 3 + kx]);
         };
         auto step = [&](auto PH, int r) {
             constexpr int ph = decltype(PH)::value;
@@ -351,11 +362,43 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
             mfma_row(I{}, BS{}, std::integral_constant<int, 2>{});
             cvt_A(r + 2, ra, A[ph % 3]);
             cvt_B(rb, rl, rr, B[(ph + 1) % 2]);
+            // Group r + 3 goes into slot ph % 3 (group r's, read one step ago).  Its NI LDS-DMA instructions are dealt out
+            // one per (pass, kx) sub-block of the remaining two tap rows (18 sub-blocks of NCO x NCI MFMAs), each fenced
+            // so that it stays there: as ONE block between the tap rows (~5 NI scalar + vector-memory instructions) they were
+            // issued with the matrix pipe idle -- probe builds: time(no DMA) = 0.80 x time(product) on the BasicBlock shapes.
             __builtin_amdgcn_sched_barrier(0);
-            dma_group(r + 3, ph % 3);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(I1{}, BS{}, std::integral_constant<int, 1>{});
-            mfma_row(I2{}, BS{}, std::integral_constant<int, 0>{});
+            if (!g_wgrad_spread) {
+                dma_group(r + 3, ph % 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_row(I1{}, BS{}, std::integral_constant<int, 1>{});
+                mfma_row(I2{}, BS{}, std::integral_constant<int, 0>{});
+            } else {
+                const int g3 = r + 3;
+                const float *ab = uniform_ptr(dyn + (size_t)min(max(g3 + 1, 0), a.H - 1) * a.W);
+                const float *bb = uniform_ptr(xn + (size_t)min(max(g3, 0), a.H - 1) * a.W);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(ph % 3) * SLOTB);
+                static_assert(NI <= 18, "one DMA instruction per sub-block");
+#pragma unroll
+                for (int sb = 0; sb < 18; ++sb) {
+                    const int kyi = sb / 9, pass = (sb % 9) / 3, kx = sb % 3;      // tap row ky = 1, then ky = 0
+#pragma unroll
+                    for (int t2 = 0; t2 < NCO; ++t2)
+#pragma unroll
+                        for (int u = 0; u < NCI; ++u) {
+                            if (kyi == 0)
+                                acc[t2][u][3 + kx] = DCL_WMFMA(A[(ph + 1) % 3][t2][pass == 2 ? 1 : 0],
+                                                               B[ph % 2][kx][u][pass == 1 ? 1 : 0], acc[t2][u][3 + kx]);
+                            else
+                                acc[t2][u][kx] = DCL_WMFMA(A[(ph + 2) % 3][t2][pass == 2 ? 1 : 0],
+                                                           B[ph % 2][kx][u][pass == 1 ? 1 : 0], acc[t2][u][kx]);
+                        }
+                    if (sb < NIA)
+                        dma16(ab, offA[sb], dst + sb * 1024);
+                    else if (sb < NI)
+                        dma16(bb, offB[sb - NIA], dst + sb * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         };
         int r = r0;
         for (; r + 6 <= r1; r += 6) {
@@ -632,8 +675,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad1x1d(Wgrad1Args a)
                 for (int t2 = 0; t2 < NCO; ++t2)
 #pragma unroll
                     for (int u = 0; u < NCI; ++u)
-                        acc[t2][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FA[fs][t2][pass == 2 ? 1 : 0],
-                                                                            FB[fs][u][pass == 1 ? 1 : 0], acc[t2][u], 0, 0, 0);
+                        acc[t2][u] = DCL_WMFMA(FA[fs][t2][pass == 2 ? 1 : 0],
+                                                                            FB[fs][u][pass == 1 ? 1 : 0], acc[t2][u]);
 #pragma unroll
             for (int t2 = 0; t2 < NCO; ++t2)
                 cvt8(ra[t2], sg_c, FA[fs ^ 1][t2]);

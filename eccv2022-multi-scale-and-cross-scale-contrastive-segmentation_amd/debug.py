@@ -38,10 +38,12 @@ class DebugConfig:
     # ---- loss
     mfma_mode: Optional[str] = field(default_factory=lambda: os.environ.get('DCL_MFMA'))        # 'f32' | 'f16x3' override
     sweep_streamk: Optional[int] = field(default_factory=lambda: _int('DCL_SWEEP_STREAMK'))     # 0 = column-split slabs
+    lib_path: Optional[str] = field(default_factory=lambda: os.environ.get('DCL_LIB_PATH'))     # probe builds of the library
     # ---- kernel variants set on the library at load (include/dcl_hip.h "tuning hook" entries)
     wgrad_variant: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_VARIANT'))
     wgrad_stride2: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_S2'))
     up2_phases: Optional[int] = field(default_factory=lambda: _int('DCL_UP2_PHASES'))
+    conv_interleave: Optional[int] = field(default_factory=lambda: _int('DCL_CONV_IL'))
     upce_bwd_chunk: Optional[int] = field(default_factory=lambda: _int('DCL_UPCE_BWD_CHUNK'))
     upce_fwd_kib: Optional[int] = field(default_factory=lambda: _int('DCL_UPCE_FWD_KIB'))
     wgrad_tile: Optional[Tuple[int, int]] = field(default_factory=lambda: (
@@ -51,6 +53,7 @@ class DebugConfig:
         """Hand the kernel-variant switches to a freshly loaded libdcl_hip.so."""
         for val, fn in ((self.wgrad_variant, l.dcl_wgrad3x3_set_variant), (self.wgrad_stride2, l.dcl_wgrad3x3_set_stride2),
                         (self.up2_phases, l.dcl_conv3x3_set_up2_phases),
+                        (self.conv_interleave, l.dcl_conv3x3_set_interleave),
                         (self.upce_bwd_chunk, l.dcl_upsample_ce_set_bwd_chunk),
                         (self.upce_fwd_kib, l.dcl_upsample_ce_set_fwd_lds)):
             if val is not None:

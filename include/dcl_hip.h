@@ -316,6 +316,9 @@ int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored inp
 /* tuning hook: in_up = 2 (data gradient of a stride-2 convolution) -- 1 (default): every workgroup computes one parity
  * class of the output pixels with the 1, 2 or 4 taps that class sees; 0: stride-1 tile over the zero-inserted input */
 int dcl_conv3x3_set_up2_phases(int on);
+/* tuning hook: 1 (default) = stride-1 3x3 tiles stage the next chunks interleaved with the MFMAs (k_conv3x3_il), 0 = in
+ * fenced blocks between them (k_conv3x3) */
+int dcl_conv3x3_set_interleave(int on);
 
 /* Weight gradient of the same convolution, dw[Cout,Cin,3,3] = sum_n dy (*) x, on the f16x3 MFMA path with no LDS
  * staging (csrc/dcl_wgrad3x3.hip).  Cin % 16 == 0, Cout % 16 == 0, W % 8 == 0.  part: workspace of

@@ -7,6 +7,7 @@
 #   <tag>_loss_pmc_{fetch,write,sq}.csv               FETCH_SIZE / WRITE_SIZE / SQ counters, separate passes
 #   <tag>_conv_pmc_{fetch,write}.csv                  same for the direct convolution kernels (per-shape tool)
 #   <tag>_conv_per_shape.csv                          HIP-event time per launch and roofline fraction per shape
+#   <tag>_conv_per_shape_rocprof.csv                  rocprofv3 kernel trace of the same tool, one row per (kernel, grid)
 set -e
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -35,4 +36,8 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 $S pmc $(find $D -name '*counter_collection.csv' | head -1) > $OUT/${TAG}_loss_pmc_sq.csv; rm -rf $D $OUT/*.log
 
 python3 $ROOT/tools/per_shape_roofline.py --out $OUT/${TAG}_conv_per_shape.csv > /dev/null
+# the same tool under the kernel trace: one rocprof row per (kernel, grid) = per shape (the head launch among them)
+D=$OUT/${TAG}_shape_trace; rm -rf $D
+rocprofv3 --kernel-trace --output-format csv -d $D -- python3 $ROOT/tools/per_shape_roofline.py > $D.log 2>&1
+$S bygrid $(find $D -name '*kernel_trace.csv' | head -1) > $OUT/${TAG}_conv_per_shape_rocprof.csv; rm -rf $D $D.log
 ls -la $OUT | grep ${TAG}_

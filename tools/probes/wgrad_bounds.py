@@ -1,0 +1,30 @@
+"""Times the weight-gradient kernel (+ slab reduction) on the BasicBlock shapes and the head (see conv_bounds.sh wrun)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import mscs_amd  # noqa: E402,F401
+from mscs_amd.models import ops  # noqa: E402
+from mscs_amd.models.amax import amax_of  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+for (n, c, h, w) in [(12, 48, 128, 256), (12, 96, 64, 128), (12, 192, 32, 64), (12, 384, 16, 32), (12, 720, 128, 256)]:
+    x = torch.randn(n, c, h, w, device=dev).relu_()
+    gy = torch.randn(n, c, h, w, device=dev) * 1e-3
+    amax_of(x), amax_of(gy)
+    it = 3 if c == 720 else 30
+    for _ in range(2):
+        ops.conv3x3_wgrad(x, gy)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it):
+        ops.conv3x3_wgrad(x, gy)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"  C={c:3d} {h}x{w}: {e0.elapsed_time(e1) / it * 1e3:8.1f} us", flush=True)
+    del x, gy
+    torch.cuda.empty_cache()

@@ -5,6 +5,8 @@ label-stage launches) and PMC FETCH/WRITE averages per kernel.
 
     python tools/summarize_profile.py trace <kernel_trace.csv> <label-stage launches per step | steps=N> [step_index]
     python tools/summarize_profile.py pmc <counter_collection.csv>
+    python tools/summarize_profile.py bygrid <kernel_trace.csv>      per (kernel, grid, workgroup): calls, avg / min us --
+                                                                     one row per SHAPE a kernel template was launched on
 """
 import collections
 import csv
@@ -83,8 +85,25 @@ def pmc(path):
         print(f"\"{k}\",{c},{len(v)},{sum(v) / len(v):.1f},{max(v):.1f}")
 
 
+def bygrid(path):
+    """rocprofv3's own --stats table aggregates a kernel template over every shape it ran on; the dispatch rows of the
+    kernel trace carry the grid, which identifies the shape (the head convolution 12 x 720 x 128 x 256 is the only
+    k_conv3x3<3,4,1> launch with 6 144 workgroups)."""
+    rows = list(csv.DictReader(open(path)))
+    agg = collections.defaultdict(list)
+    for r in rows:
+        grid = "x".join(r.get(f"Grid_Size_{a}", r.get(f"Grid_Size{a}", "?")) for a in "XYZ")
+        wg = "x".join(r.get(f"Workgroup_Size_{a}", r.get(f"Workgroup_Size{a}", "?")) for a in "XYZ")
+        agg[(r["Kernel_Name"][:110], grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    print("kernel,grid_threads,workgroup,calls,avg_us,min_us,max_us")
+    for (k, g, w), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        print(f"\"{k}\",{g},{w},{len(v)},{sum(v) / len(v) / 1e3:.2f},{min(v) / 1e3:.2f},{max(v) / 1e3:.2f}")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "trace":
+    if sys.argv[1] == "bygrid":
+        bygrid(sys.argv[2])
+    elif sys.argv[1] == "trace":
         sc = sys.argv[3] if len(sys.argv) > 3 else "3"
         trace(sys.argv[2], sc if sc.startswith("steps=") else int(sc), int(sys.argv[4]) if len(sys.argv) > 4 else 3)
     else:
