@@ -25,6 +25,9 @@
 //     row segments of the NCHW output.
 // The same kernel computes the data gradient: dx = conv3x3(dy, w') with w'[ci, co, ky, kx] = w[co, ci, 2-ky, 2-kx]
 // (k_pack_w3x3 with `transposed`).
+#include <type_traits>
+#include <utility>
+
 #include "dcl_common.h"
 
 namespace {
@@ -94,6 +97,42 @@ __device__ __forceinline__ float pow2_scale(float amax)
 // MODE 2 ("one tap"): a 1x1 convolution -- the same tile, patch staging and epilogue with ONE MFMA group per chunk
 // (the centre pixel of the patch); the weights are packed with one tap per (tile, chunk) (pack_item, taps = 1) and
 // streamed one chunk ahead.
+// ---- compile-time decode of the k-th MFMA of a chunk (order: kx, tile row rr, pass, valid tap row ky, channel tile r)
+struct MfmaAt {
+    int kx, rr, pass, ky, r, first_of_group;
+};
+template <int R, int P>
+constexpr MfmaAt mfma_at(int k)
+{
+    const int NM = 9 * R * P;
+    MfmaAt m{};
+    m.kx = k / NM;
+    int rem = k - m.kx * NM;
+    for (int rr = 0; rr < P + 2; ++rr) {
+        const int klo = rr - (P - 1) > 0 ? rr - (P - 1) : 0, khi = rr < 2 ? rr : 2;     // valid ky: rr - ky in [0, P)
+        const int npk = khi - klo + 1;
+        if (rem < 3 * R * npk) {
+            m.rr = rr;
+            m.pass = rem / (R * npk);
+            const int q = rem - m.pass * R * npk;
+            m.ky = klo + q / R;
+            m.r = q % R;
+            m.first_of_group = rem == 0;
+            return m;
+        }
+        rem -= 3 * R * npk;
+    }
+    return m;
+}
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (K < N) {
+        f(std::integral_constant<int, K>{});
+        static_for<K + 1, N>(f);
+    }
+}
+
 //
 // IL ("interleaved", stride-1 3x3 tiles with two chunks of look-ahead, Cin % 16 == 0): the staging of the NEXT chunks --
 // the global loads of chunk c + 2, the split + LDS write of chunk c + 1, the weight fragments of the next kx step -- is
@@ -350,27 +389,19 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
         if (c < a.nchunk)
             chunk(std::integral_constant<int, 0>{}, c);
     } else if constexpr (IL) {
-    // A chunk's MFMAs form 3 (kx) x (P + 2) (tile row) x 3 (pass) slices, fenced from each other (sched_barrier), so the
-    // staging work dealt out to a slice stays there: the weight fragments of the next kx step go to the three slices of
-    // the step's first tile row, item m's loads (chunk c + 2) and its split + LDS write (chunk c + 1) to slices spread
-    // evenly over the chunk.  (Scheduling groups were tried first -- "1 MFMA, <= V loads, <= A VALU, <= 1 LDS write" 324
-    // times per chunk -- and the scheduler ignored them: the staging still sat in front of each kx step.)
-    constexpr int NS = 9 * (P + 2);                                // slices per chunk
-    auto load_item = [&](int c, int m, float (&g)[NITEM][8]) {
-        const float *xc = xb + (size_t)(16 * c + 8 * (tid + 256 * m >= TP ? 1 : 0)) * plane + goff[m];
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            g[m][e] = xc[e * plane];
-    };
-    auto write_item = [&](unsigned char *buf, int m, const float (&g)[NITEM][8]) {
-        unsigned hh[4], ll[4];
-        split2(g[m][0], g[m][1], gsc[m], hh[0], ll[0]);
-        split2(g[m][2], g[m][3], gsc[m], hh[1], ll[1]);
-        split2(g[m][4], g[m][5], gsc[m], hh[2], ll[2]);
-        split2(g[m][6], g[m][7], gsc[m], hh[3], ll[3]);
-        *(uint4 *)(buf + loff[m]) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-        *(uint4 *)(buf + loff[m] + 32) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
-    };
+    // Every MFMA of a chunk is followed by AT MOST a few instructions of staging work and a scheduling fence, so the
+    // staging is issued in the shadow of the matrix pipe (an MFMA occupies it for 32 cycles and the wave issues in order:
+    // a block of 8 loads behind 6 MFMAs still leaves the pipe idle for most of the block).  Micro-operations, by MFMA index
+    // k of the chunk (NT = 27 R P MFMAs): the 6 R weight-fragment loads of the next kx step at the first MFMAs of a step;
+    // item m's eight global loads one per MFMA from LB(m); its split in four pieces of 4 VALU and its two LDS writes from
+    // WB(m).  Two register sets (loads of chunk c + 2, writes of chunk c + 1), or ONE for the tiles that cannot afford two
+    // (P = 4, and the (2, 2) tile at two workgroups per CU): loads of chunk c + 1 in the first half of the chunk, writes in
+    // the second.  (Scheduling groups -- "1 MFMA, <= V loads, <= A VALU, <= 1 LDS write" x 324 -- were tried first and
+    // ignored by the scheduler; fences per (tile row, pass) slice left blocks of 8 loads: +13-23 % on the 96 ... 512-channel
+    // shapes, little on the head.)
+    constexpr int NT = 27 * R * P, NM = 9 * R * P;
+    constexpr int HALF = NT / 2;
+    unsigned sh_[NITEM][4], sl_[NITEM][4];
     for (int c = 0; c < a.nchunk; ++c) {
         const unsigned char *cur = lds + (c & 1) * BUFB;
         unsigned char *nxt = lds + ((c + 1) & 1) * BUFB;            // (past the last chunk: written, never read)
@@ -383,57 +414,53 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
         };
         __builtin_amdgcn_sched_barrier(0);
         read_b(0, bq[0]);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int s2 = min(3 * c + kx + AD, nsteps - 1);          // step whose weight fragments are fetched in this one
-#pragma unroll
-            for (int rr = 0; rr < P + 2; ++rr) {
-                const int g = kx * (P + 2) + rr;
-                const half8 bh = bq[g & 1][0], bl = bq[g & 1][1];
-#pragma unroll
-                for (int pass = 0; pass < 3; ++pass) {
-                    const int sl = g * 3 + pass;                        // slice index, 0 .. NS - 1
-                    if (pass == 0 && g + 1 < 3 * (P + 2))
-                        read_b(g + 1, bq[(g + 1) & 1]);
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int p = rr - ky;
-                        if (p >= 0 && p < P) {
-#pragma unroll
-                            for (int r = 0; r < R; ++r)
-                                acc[r][p] = DCL_MFMA(Ab[kx][ky][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh, acc[r][p]);
-                        }
-                    }
-                    // ---- this slice's share of the staging
-                    if (rr == 0) {                                      // weights of the next step: tap row `pass`
-                        const int c3 = s2 / 3, kx3 = s2 % 3;
-#pragma unroll
-                        for (int r = 0; r < R; ++r)
-#pragma unroll
-                            for (int part = 0; part < 2; ++part) {
-                                const uint4 v = (DCL_CONV_PROBE & 8) ? make_uint4(pass, c3, r, part)
-                                    : wa[r][(((size_t)c3 * 9 + pass * 3 + kx3) * 2 + part) * 64];
-                                Ab[(kx + AD) % 3][pass][r][part] = __builtin_bit_cast(half8, v);
-                            }
-                    }
-#pragma unroll
-                    for (int m = 0; m < NITEM; ++m) {
-                        if (ONESET) {
-                            if (sl == m * (NS / 2) / NITEM)               // loads of chunk c + 1, item m: first half
-                                load_item(c2, m, gA);
-                            if (sl == NS / 2 + m * (NS / 2) / NITEM)      // its split + write: half a chunk later
-                                write_item(nxt, m, gA);
-                        } else {
-                            if (sl == (2 * m + 1) * NS / (2 * NITEM))     // loads of chunk c + 2, item m
-                                load_item(c2, m, gB);
-                            if (sl == (2 * m) * NS / (2 * NITEM) + 1)     // split + write of chunk c + 1, item m
-                                write_item(nxt, m, gA);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NT>([&](auto KC) {
+            constexpr int k = decltype(KC)::value;
+            constexpr MfmaAt at = mfma_at<R, P>(k);
+            constexpr int g = at.kx * (P + 2) + at.rr;
+            if constexpr (at.first_of_group && g + 1 < 3 * (P + 2))
+                read_b(g + 1, bq[(g + 1) & 1]);
+            acc[at.r][at.rr - at.ky] = DCL_MFMA(Ab[at.kx][at.ky][at.r][at.pass == 2 ? 1 : 0],
+                                                at.pass == 1 ? bq[g & 1][1] : bq[g & 1][0], acc[at.r][at.rr - at.ky]);
+            // ---- micro-operations of this MFMA
+            {   // weight fragments of step kx + AD: fragment f = (tap row, tile, part) at MFMA kx * NM + f
+                constexpr int f = k - at.kx * NM;
+                if constexpr (f < 6 * R) {
+                    const int s2 = min(3 * c + at.kx + AD, nsteps - 1), c3 = s2 / 3, kx3 = s2 % 3;
+                    constexpr int ky = f / (2 * R), r = (f / 2) % R, part = f & 1;
+                    const uint4 v = (DCL_CONV_PROBE & 8) ? make_uint4(ky, c3, r, part)
+                                                         : wa[r][(((size_t)c3 * 9 + ky * 3 + kx3) * 2 + part) * 64];
+                    Ab[(at.kx + AD) % 3][ky][r][part] = __builtin_bit_cast(half8, v);
                 }
             }
-        }
+            static_for<0, NITEM>([&](auto MC) {
+                constexpr int m = decltype(MC)::value;
+                // first MFMA of the item's eight loads / of its four split pieces + two writes: spread over the chunk (one
+                // set: loads in the first half, writes in the second), every micro-operation inside [0, NT)
+                constexpr int lb = ONESET ? m * (HALF - 8) / NITEM : m * (NT - 8) / NITEM + (NT - 8) / (2 * NITEM);
+                constexpr int wb = ONESET ? HALF + m * (NT - HALF - 6) / NITEM : m * (NT - 6) / NITEM;
+                static_assert(lb >= 0 && lb + 8 <= NT && wb >= 0 && wb + 6 <= NT && (!ONESET || lb + 8 <= wb),
+                              "staging micro-operations must fall inside the chunk");
+                if constexpr (k >= lb && k < lb + 8) {                  // one of the item's eight loads
+                    constexpr int e = k - lb;
+                    const float *xc = xb + (size_t)(16 * c2 + 8 * (tid + 256 * m >= TP ? 1 : 0)) * plane + goff[m];
+                    const float v = (DCL_CONV_PROBE & 2) ? 1.0f : xc[e * plane];
+                    if constexpr (ONESET)
+                        gA[m][e] = v;
+                    else
+                        gB[m][e] = v;
+                }
+                if constexpr (k >= wb && k < wb + 4) {                  // a quarter of the split
+                    constexpr int q = k - wb;
+                    split2(gA[m][2 * q], gA[m][2 * q + 1], gsc[m], sh_[m][q], sl_[m][q]);
+                }
+                if constexpr (k == wb + 4)
+                    *(uint4 *)(nxt + loff[m]) = make_uint4(sh_[m][0], sh_[m][1], sh_[m][2], sh_[m][3]);
+                if constexpr (k == wb + 5)
+                    *(uint4 *)(nxt + loff[m] + 32) = make_uint4(sl_[m][0], sl_[m][1], sl_[m][2], sl_[m][3]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
         __syncthreads();
         if (!ONESET) {
 #pragma unroll

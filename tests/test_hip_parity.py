@@ -695,6 +695,41 @@ def test_direct_conv3x3_forward_dgrad_match_fp64(dev, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("interleave", [1, 0])
+def test_direct_conv3x3_every_tile_matches_fp64(dev, interleave):
+    """Every (channel tiles, pixel tiles) instantiation of the stride-1 kernel -- with the staging interleaved among the
+    MFMAs (k_conv3x3_il, the default for Cin % 16 == 0: one and two register sets, micro-operations placed by MFMA index)
+    and in fenced blocks (k_conv3x3) -- on shapes with ragged tiles, one to five K chunks and images smaller than a tile,
+    against float64 (3e-6 of max); forward and, through the transposed fragments, the data gradient."""
+    import torch.nn.functional as F
+    from mscs_amd import _lib
+    from mscs_amd.models import ops
+    from mscs_amd.models.amax import amax_of
+    L = _lib.lib()
+    torch.manual_seed(11)
+    try:
+        L.dcl_conv3x3_set_interleave(interleave)
+        for (n, ci, co, h, w) in [(2, 16, 32, 9, 40), (1, 48, 96, 20, 33), (2, 80, 48, 5, 7), (1, 32, 64, 33, 64)]:
+            x = torch.randn(n, ci, h, w, device=dev).relu_()
+            wt = torch.randn(co, ci, 3, 3, device=dev) * 0.1
+            ref = F.conv2d(x.double(), wt.double(), padding=1)
+            sx, sw = amax_of(x), amax_of(wt)
+            wp = ops.conv3x3_pack(wt, sw)
+            for r in (1, 2, 3):
+                for p in (1, 2, 4):
+                    out = torch.full((n, co, h, w), float("nan"), device=dev)
+                    ops.conv3x3_launch(x, wp, co, sx, sw, out, r, p)
+                    err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+                    assert err < 3e-6, (interleave, n, ci, co, h, w, r, p, err)
+            gy = torch.randn(n, co, h, w, device=dev) * 1e-3
+            gref = F.conv_transpose2d(gy.double(), wt.double(), padding=1)
+            gx = ops.conv3x3_direct(gy, wt, transposed=True)
+            assert ((gx.double() - gref).abs().max() / gref.abs().max()).item() < 3e-6
+    finally:
+        L.dcl_conv3x3_set_interleave(1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [s for s in _DIRECT_SHAPES if s[1] % 16 == 0 and s[2] % 16 == 0 and s[4] % 8 == 0])
 def test_direct_conv3x3_wgrad_matches_fp64(dev, shape):
     """csrc/dcl_wgrad3x3.hip against the float64 weight gradient (3e-6 of max), and bitwise run-to-run
