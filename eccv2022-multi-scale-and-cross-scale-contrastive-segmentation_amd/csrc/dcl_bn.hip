@@ -16,7 +16,10 @@
 namespace {
 
 constexpr int BN_THREADS = 256;
-constexpr int BN_UNROLL = 4;       // 16-byte vectors per thread in the element-wise kernels
+#ifndef DCL_BN_UNROLL
+#define DCL_BN_UNROLL 4
+#endif
+constexpr int BN_UNROLL = DCL_BN_UNROLL;       // 16-byte vectors per thread in the element-wise kernels
 
 __device__ inline void block_reduce2(float &a, float &b, float *sh)
 {
@@ -160,7 +163,9 @@ __device__ __forceinline__ void block_amax(float m, float *dst)
         m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0)
         wmax[threadIdx.x >> 6] = m;
-    __syncthreads();
+    // raw barrier behind an LDS-only wait: __syncthreads() also waits for the wave's outstanding STORES (they count in
+    // vmcnt on this target), i.e. every workgroup would sit on its CU slot until its output has been acknowledged
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int w = 1; w < BN_THREADS / 64; ++w)
@@ -277,25 +282,27 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
         f32x4 v[BN_UNROLL], r[BN_UNROLL];
         size_t off[BN_UNROLL];                                  // element offset of the vector, per u
         int pl[BN_UNROLL], ivv[BN_UNROLL];                      // its plane and vector index inside the plane
+        // Loads are UNCONDITIONAL from clamped (always valid) vector indices and only the stores are predicated: with the
+        // loads inside `if (j < nv)` branches the compiler lost count of the outstanding memory operations and put
+        // s_waitcnt vmcnt(0) in front of EVERY store -- on this target stores count in vmcnt, so each of a thread's four
+        // stores waited for the previous one to be acknowledged.
 #pragma unroll
         for (int u = 0; u < BN_UNROLL; ++u) {
-            const unsigned j = j0 + u * BN_THREADS;
+            const unsigned j = min(j0 + u * BN_THREADS, nv - 1);
             const int n = flat ? (int)(j / (unsigned)hw4) : n0;
             ivv[u] = flat ? (int)(j - (unsigned)n * (unsigned)hw4) : (int)j;
             pl[u] = n * C + c;
             off[u] = (size_t)pl[u] * HW + 4 * (size_t)ivv[u];
-            if (j < nv) {
-                v[u] = *(const f32x4 *)(x + off[u]);
-                if (RES)
-                    r[u] = *(const f32x4 *)(res + off[u]);
-            }
+            v[u] = *(const f32x4 *)(x + off[u]);
+            if (RES)
+                r[u] = *(const f32x4 *)(res + off[u]);
         }
         __syncthreads();
         sc = bc[0];
         sh = bc[1];
 #pragma unroll
         for (int u = 0; u < BN_UNROLL; ++u) {
-            if (j0 + u * BN_THREADS < nv) {
+            {
                 f32x4 w = v[u];
                 w.x = bn_eval(w.x, sc, sh); w.y = bn_eval(w.y, sc, sh); w.z = bn_eval(w.z, sc, sh); w.w = bn_eval(w.w, sc, sh);
                 if (RES) {
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
                 }
                 if (RELU) {
                     w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
-                    if (f.mask_out) {                           // (wave-uniform: HW % 256 == 0)
+                    if (f.mask_out && j0 + u * BN_THREADS < nv) {   // (wave-uniform: HW % 256 == 0)
                         const unsigned long long b0 = __ballot(w.x > 0.f), b1 = __ballot(w.y > 0.f),
                                                  b2 = __ballot(w.z > 0.f), b3 = __ballot(w.w > 0.f);
                         const int ln = threadIdx.x & 63;
@@ -311,10 +318,19 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
                             f.mask_out[relu_mask_word(pl[u], hw4, ivv[u]) + ln] = ln == 0 ? b0 : ln == 1 ? b1 : ln == 2 ? b2 : b3;
                     }
                 }
-                *(f32x4 *)(y + off[u]) = w;
-                am = fmaxf(am, fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
+                v[u] = w;
+                if (j0 + u * BN_THREADS < nv)
+                    am = fmaxf(am, fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
             }
         }
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u)
+            if (j0 + u * BN_THREADS < nv)
+                *(f32x4 *)(y + off[u]) = v[u];
+        // the absmax exchange behind the stores (its barrier waits for LDS only, see block_amax)
+        if (amax)
+            block_amax(am, amax + ((n0 * C + c) & (DCL_AMAX_SLOTS - 1)));
+        return;
     } else {
         __syncthreads();
         sc = bc[0];
@@ -477,11 +493,11 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
         size_t off[BN_UNROLL];
 #pragma unroll
         for (int u = 0; u < BN_UNROLL; ++u) {
-            const unsigned j = j0 + u * BN_THREADS;
+            const unsigned j = min(j0 + u * BN_THREADS, nv - 1);     // unconditional loads from clamped indices (k_bn_apply)
             const int n = flat ? (int)(j / (unsigned)hw4) : n0;
             const int iv = flat ? (int)(j - (unsigned)n * (unsigned)hw4) : (int)j, plane = n * C + c;
             off[u] = (size_t)plane * HW + 4 * (size_t)iv;
-            if (j < nv) {
+            {
                 gv[u] = *(const f32x4 *)(dy + off[u]);
                 xv[u] = *(const f32x4 *)(x + off[u]);
                 if (RELU && mask) {
@@ -498,7 +514,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
         mgx = bc[1];
 #pragma unroll
         for (int u = 0; u < BN_UNROLL; ++u) {
-            if (j0 + u * BN_THREADS < nv) {
+            {
                 f32x4 g = gv[u];
                 const f32x4 xx = xv[u];
                 if (RELU) {
@@ -512,17 +528,27 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                     g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
                     g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
                 }
-                if (dres)
-                    *(f32x4 *)(dres + off[u]) = g;
                 f32x4 o;
                 o.x = k * (g.x - mg - (xx.x - m) * is * mgx);
                 o.y = k * (g.y - mg - (xx.y - m) * is * mgx);
                 o.z = k * (g.z - mg - (xx.z - m) * is * mgx);
                 o.w = k * (g.w - mg - (xx.w - m) * is * mgx);
-                *(f32x4 *)(dx + off[u]) = o;
-                am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+                gv[u] = g;
+                xv[u] = o;
+                if (j0 + u * BN_THREADS < nv)
+                    am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
             }
         }
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u)
+            if (j0 + u * BN_THREADS < nv) {
+                if (dres)
+                    *(f32x4 *)(dres + off[u]) = gv[u];
+                *(f32x4 *)(dx + off[u]) = xv[u];
+            }
+        if (amax)                                   // behind the stores, LDS-only barrier: see k_bn_apply
+            block_amax(am, amax + ((n0 * C + c) & (DCL_AMAX_SLOTS - 1)));
+        return;
     } else {
         __syncthreads();
         mg = bc[0];

@@ -14,6 +14,7 @@ if len(sys.argv) > 1:
     shapes = [shapes[int(sys.argv[1])]]
 for (c, h, w) in shapes:
     bn = FusedBatchNorm2d(c).to(dev).train()
+    bn.emit_amax = os.environ.get('BN_NO_AMAX') is None
     x = torch.randn(12, c, h, w, device=dev, generator=gen).requires_grad_(True)
     r = torch.randn(12, c, h, w, device=dev, generator=gen).requires_grad_(True)
     gy = torch.randn(12, c, h, w, device=dev, generator=gen)
