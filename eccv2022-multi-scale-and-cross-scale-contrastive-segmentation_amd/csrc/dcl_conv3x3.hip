@@ -340,6 +340,31 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
 #pragma unroll
     for (int m = 0; m < NITEM; ++m)
         gsc[m] = gok[m] ? xs : 0.f;
+    // Epilogue addend (residual gradient) / bias: the accumulators START at (addend + bias) * (x scale * w scale) instead of
+    // at zero, so the epilogue is scaling + stores only.  Loading them there -- 16 loads per accumulator tile, then its 16
+    // stores -- put s_waitcnt vmcnt(0) in front of every tile's stores, i.e. behind the previous tile's (stores count in
+    // vmcnt on this target): a dozen store round trips per wave in a row.
+    if (a.addend || a.bias) {
+        const float sc2 = xs * pow2_scale(a.wamax[0]);
+        const int col0 = PH ? 2 * (x0 + li) + px : x0 + li;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int row = PH ? 2 * (y0 + P * wave + p) + py : y0 + P * wave + p;
+                const int cob = (T0 + r) * 32 + 4 * h;
+                const bool ok = row < a.Ho && col0 < a.Wo && cob < a.Cout;
+                const size_t o0 = (((size_t)n * a.Cout + min(cob, a.Cout - 1)) * a.Ho + min(row, a.Ho - 1)) * a.Wo +
+                                  min(col0, a.Wo - 1);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int k = ok ? min((q & 3) + 8 * (q >> 2), a.Cout - 1 - cob) : 0;
+                    const float ad = (a.addend ? a.addend[o0 + (size_t)k * oplane] : 0.f) +
+                                     (a.bias ? a.bias[min(cob, a.Cout - 1) + k] : 0.f);
+                    acc[r][p][q] = ad * sc2;
+                }
+            }
+    }
     write_items(lds, gA);
     // (IL with P = 4: ONE register set -- a chunk's items are loaded during the first half of the previous chunk's slices
     // and split + written during its second half; the two-set scheme spills at (3, 4))
@@ -582,19 +607,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
             if (row < a.Ho && col < a.Wo && cob < a.Cout && !((DCL_CONV_PROBE & 4) && acc[r][p][0] != 12345.f)) {
                 const size_t o0 = (((size_t)n * a.Cout + cob) * a.Ho + row) * a.Wo + col;
                 float *yp = a.y + o0;
-                if (a.addend || a.bias) {
-                    // all 16 addend / bias loads first, from clamped (always valid) channel offsets, then the stores
-                    float ad[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int k = min((q & 3) + 8 * (q >> 2), a.Cout - 1 - cob);
-                        ad[q] = (a.addend ? a.addend[o0 + (size_t)k * oplane] : 0.f) + (a.bias ? a.bias[cob + k] : 0.f);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        if (cob + (q & 3) + 8 * (q >> 2) < a.Cout)
-                            yp[(size_t)((q & 3) + 8 * (q >> 2)) * oplane] = acc[r][p][q] * inv + ad[q];
-                } else if (cob + 28 <= a.Cout) {     // whole channel tile inside Cout
+                if (cob + 28 <= a.Cout) {            // whole channel tile inside Cout
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
                         yp[(size_t)((q & 3) + 8 * (q >> 2)) * oplane] = acc[r][p][q] * inv;
