@@ -141,14 +141,22 @@ __device__ __forceinline__ void static_for(F &&f)
 // matrix work: on every shape time(no MFMAs) + time(no loads, no stores) = time(product), e.g. head 2.2 + 6.5 = 8.8 ms,
 // 96 channels 21 + 45 = 63 us -- at one wave per SIMD the 40-94 vector-memory instructions and ~160 VALU of a chunk's
 // staging are issued while the matrix pipe idles.
-template <int R, int P, int S, int MODE = 0, bool IL = false>
+//
+// WS ("wave split", 1 | 2): 1 = the four waves of a workgroup stack along the rows, every wave owns all R channel tiles;
+// 2 = two waves along the rows x two along the channel tiles (the workgroup covers 2 P rows x 2 R channel tiles, a wave
+// P rows x R tiles).  For the 48 / 64-channel layers -- three or four K chunks, tile (R, P) = (2, 2) -- every wave
+// streaming BOTH channel tiles' weight fragments is 1 KiB from L1 per ~3 MFMAs and wave, 85 B / clk at two workgroups per
+// CU against the L1's 64: the (1, 4) wave of WS = 2 does the same 108 MFMAs per chunk on half the fragments.
+template <int R, int P, int S, int MODE = 0, bool IL = false, int WS = 1>
 __device__ __forceinline__ void conv_body(const ConvArgs &a)
 {
     constexpr bool PH = MODE == 1, T1 = MODE == 2;
+    constexpr int WR = 4 / WS;                    // waves along the rows
+    static_assert(WS == 1 || (WS == 2 && IL), "wave split: interleaved stride-1 tiles only");
     static_assert(!IL || (S == 1 && MODE == 0), "interleaved staging: stride-1 3x3 tiles");
     static_assert(MODE == 0 || S == 1, "phases / one tap: stride-1 tile");
     constexpr int LW = S * (TW - 1) + 3;          // patch width incl. halo: 34 | 65
-    constexpr int ROWS = S * (4 * P - 1) + 3;     // 4P + 2 | 8P + 1
+    constexpr int ROWS = S * (WR * P - 1) + 3;    // 4P + 2 | 8P + 1 (WS = 1)
     constexpr int TP = ROWS * LW;
     constexpr int NITEM = (2 * TP + 255) / 256;
     constexpr int BUFB = TP * PIXB;
@@ -187,8 +195,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     bx /= a.tiles_x;
     const int ty = bx % a.tiles_y;
     const int n = bx / a.tiles_y;
-    const int x0 = tx * TW, y0 = ty * 4 * P;
-    const int T0 = cg * R;
+    const int x0 = tx * TW, y0 = ty * WR * P;
+    const int wrow = wave / WS;                   // this wave's row group (= wave for WS = 1)
+    const int T0 = (cg * WS + wave % WS) * R;
     const size_t plane = (size_t)a.Hs * a.Ws;                // stored input plane
     const size_t oplane = (size_t)a.Ho * a.Wo;
     const float *xb = a.x + (size_t)n * a.Cin * plane;
@@ -295,7 +304,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     // kx (static indices, no copies): one step ahead when a step holds >= 54 MFMAs (R = 3), two steps ahead for
     // the smaller tiles, whose steps are shorter than an L2 round trip.
     constexpr int AD = (R >= 3 || (R == 2 && P == 2)) ? 1 : 2;   // (2, 2) must stay under 256 registers
-    constexpr bool O2 = S == 1 && R == 2 && P == 2 && !T1;              // the tile that runs at two workgroups per CU
+    constexpr bool O2 = S == 1 && ((R == 2 && P == 2) || WS == 2) && !T1;              // the tile that runs at two workgroups per CU
                                                                  // ((3, 1) was tried: its spills cost more than it gains)
     constexpr bool LA2 = !O2;                                    // two chunks of patch look-ahead (one for those)
     constexpr bool BPIPE = LA2 && !PH;                           // B fragments one group ahead (not for (2, 2): registers;
@@ -351,7 +360,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int row = PH ? 2 * (y0 + P * wave + p) + py : y0 + P * wave + p;
+                const int row = PH ? 2 * (y0 + P * wrow + p) + py : y0 + P * wrow + p;
                 const int cob = (T0 + r) * 32 + 4 * h;
                 const bool ok = row < a.Ho && col0 < a.Wo && cob < a.Cout;
                 const size_t o0 = (((size_t)n * a.Cout + min(cob, a.Cout - 1)) * a.Ho + min(row, a.Ho - 1)) * a.Wo +
@@ -373,7 +382,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
         load_items(min(1, a.nchunk - 1), gA);
     __syncthreads();
 
-    const int brow = (S * P * wave) * LW + S * li;      // patch pixel of this lane's output pixel, tap (0, 0)
+    const int brow = (S * P * wrow) * LW + S * li;      // patch pixel of this lane's output pixel, tap (0, 0)
     if constexpr (T1) {
         // one tap: chunk c = P B fragments (patch pixel (p + 1, li + 1)) x R channel tiles x 3 passes; the weight
         // fragments of chunk c + 1 are fetched while chunk c runs (two register sets, loop unrolled by two)
@@ -602,7 +611,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const int row = PH ? 2 * (y0 + P * wave + p) + py : y0 + P * wave + p;
+            const int row = PH ? 2 * (y0 + P * wrow + p) + py : y0 + P * wrow + p;
             const int cob = (T0 + r) * 32 + 4 * h;
             if (row < a.Ho && col < a.Wo && cob < a.Cout && !((DCL_CONV_PROBE & 4) && acc[r][p][0] != 12345.f)) {
                 const size_t o0 = (((size_t)n * a.Cout + cob) * a.Ho + row) * a.Wo + col;
@@ -637,6 +646,13 @@ template <int R, int P>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_il_o2(ConvArgs a)
 {
     conv_body<R, P, 1, 0, true>(a);
+}
+
+// two workgroups per CU, waves split 2 (rows) x 2 (channel tiles): workgroup tile 2 P rows x 2 R channel tiles
+template <int R, int P>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_il_ws2(ConvArgs a)
+{
+    conv_body<R, P, 1, 0, true, 2>(a);
 }
 
 template <int R, int P>
@@ -870,11 +886,12 @@ extern "C" int dcl_conv3x3_pack_multi(const void *jobs, const int32_t *blk2job, 
     return 0;
 }
 
-static int g_conv_interleave = 1;      // staging interleaved with the MFMAs (k_conv3x3_il); 0 = the fenced blocks
+static int g_conv_interleave = 2;      // 2 = staging interleaved with the MFMAs (k_conv3x3_il) + the (2, 2) tile's waves split
+                                       // 2 x 2 (k_conv3x3_il_ws2); 1 = interleaved only; 0 = the fenced blocks
 
 extern "C" int dcl_conv3x3_set_interleave(int on)
 {
-    g_conv_interleave = on ? 1 : 0;
+    g_conv_interleave = on;      // 0 fenced blocks, 1 interleaved, 2 interleaved + wave-split (2, 2) tile
     return 0;
 }
 
@@ -899,7 +916,10 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
         }
     }
     if constexpr (S == 1 && R == 2 && P == 2) {
-        if (g_conv_interleave && (a.Cin & 15) == 0 && a.up == 1)
+        if (g_conv_interleave == 2 && (a.Cin & 15) == 0 && a.up == 1 && !a.phases && !a.onetap) {
+            // (1, 4) waves, 2 x 2 per workgroup: the same 8 x 32 pixels x 64 channels per workgroup, same grid
+            hipLaunchKernelGGL((k_conv3x3_il_ws2<1, 4>), grid, dim3(256), 0, stream, a);
+        } else if (g_conv_interleave && (a.Cin & 15) == 0 && a.up == 1)
             hipLaunchKernelGGL((k_conv3x3_il_o2<R, P>), grid, dim3(256), 0, stream, a);
         else
             hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);

@@ -695,11 +695,11 @@ def test_direct_conv3x3_forward_dgrad_match_fp64(dev, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("interleave", [1, 0])
+@pytest.mark.parametrize("interleave", [1, 0, 2])
 def test_direct_conv3x3_every_tile_matches_fp64(dev, interleave):
     """Every (channel tiles, pixel tiles) instantiation of the stride-1 kernel -- with the staging interleaved among the
     MFMAs (k_conv3x3_il, the default for Cin % 16 == 0: one and two register sets, micro-operations placed by MFMA index)
-    and in fenced blocks (k_conv3x3) -- on shapes with ragged tiles, one to five K chunks and images smaller than a tile,
+    and in fenced blocks (k_conv3x3), and with the (2, 2) tile's waves split 2 x 2 over rows and channel tiles (mode 2) -- on shapes with ragged tiles, one to five K chunks and images smaller than a tile,
     against float64 (3e-6 of max); forward and, through the transposed fragments, the data gradient."""
     import torch.nn.functional as F
     from mscs_amd import _lib
@@ -726,7 +726,7 @@ def test_direct_conv3x3_every_tile_matches_fp64(dev, interleave):
             gx = ops.conv3x3_direct(gy, wt, transposed=True)
             assert ((gx.double() - gref).abs().max() / gref.abs().max()).item() < 3e-6
     finally:
-        L.dcl_conv3x3_set_interleave(1)
+        L.dcl_conv3x3_set_interleave(2)
 
 
 @pytest.mark.gpu

@@ -43,4 +43,4 @@ for (n, ci, co, h, w) in shapes:
           f"{res[0][0] / res[1][0]:.3f}x", flush=True)
     del x, wt, out
     torch.cuda.empty_cache()
-L.dcl_conv3x3_set_interleave(1)
+L.dcl_conv3x3_set_interleave(2)
