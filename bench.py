@@ -455,14 +455,20 @@ def time_train_step(args, dev, rank, world):
             mgr.step_metrics(1, ret, lbl, 0.0)
         return ret
 
-    for _ in range(args.warmup):
-        step()
-    sync(world)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ret = step()
-    sync(world)
-    dt = time.perf_counter() - t0
+    main_ctx = contextlib.nullcontext()
+    if os.environ.get("DCL_BENCH_MAIN_PRIO"):       # experiment: the whole step on a high-priority stream
+        hp = torch.cuda.Stream(device=dev, priority=int(os.environ["DCL_BENCH_MAIN_PRIO"]))
+        hp.wait_stream(torch.cuda.current_stream())
+        main_ctx = torch.cuda.stream(hp)
+    with main_ctx:
+        for _ in range(args.warmup):
+            step()
+        sync(world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ret = step()
+        sync(world)
+        dt = time.perf_counter() - t0
     mgr.flush_logging()
     # a timing of a run whose numbers went bad is not a measurement (a chip multiplying NaNs even clocks higher):
     # the last loss and every parameter must be finite after the timed steps

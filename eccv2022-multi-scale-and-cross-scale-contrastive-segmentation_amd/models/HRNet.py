@@ -87,7 +87,9 @@ def _side_streams(device, n):
     key = (device.type, device.index)
     have = _SIDE_STREAMS.setdefault(key, [])
     while len(have) < n:
-        have.append(torch.cuda.Stream(device=device))
+        # (experiment switch: HIP priority of the branch streams; larger = lower priority, 0 = the default stream's)
+        prio = _dbg.side_stream_priority
+        have.append(torch.cuda.Stream(device=device) if prio is None else torch.cuda.Stream(device=device, priority=prio))
     return have[:n]
 
 
