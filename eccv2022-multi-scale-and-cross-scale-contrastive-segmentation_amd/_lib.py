@@ -57,6 +57,8 @@ SIGNATURES = {
     "dcl_upsample_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_upsample_bilinear_bwd": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_amax_sum2": [_vp, _i, _vp, _i, _vp, _vp],
+    "dcl_tapup_fwd": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "dcl_tapup_bwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_add_n": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dcl_upsample_bilinear_fwd_slice": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "dcl_upsample_bilinear_bwd_slice": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],

@@ -291,6 +291,290 @@ extern "C" int dcl_upsample_bilinear_bwd_slice(const float *dy_wide, int ctot, i
     return upsample_bwd(dy_wide, N * C, h, w, H, W, align_corners, dx, Slice{C, ctot, c0}, stream);
 }
 
+// ---- 3x3 convolution of a bilinearly up-sampled map WITHOUT the up-sampled map ("tap-up") --------------------------------
+// The head of HRNet convolves cat(x0, up(x1), up(x2), up(x3)) with a 3x3 kernel (reference models/HRNet.py:549-553, :596-600).
+// For an up-sampled input the two linear maps commute:
+//     conv3x3(up(x), W)[co, Y, X] = sum_tap (S_tap U)(W_tap x)[co, Y, X],     z[tap] = W_tap x  (a 1x1 convolution at LOW resolution)
+// with S_tap the shift by the tap offset (zero outside the image: the convolution's padding) and U the bilinear interpolation.
+// The 9 x Cout channel products z run on a fraction of the pixels (1/16 and 1/64 for HRNet's two coarsest branches: 80 % of the
+// head's multiply-adds), and what is left at full resolution is this gather: 9 taps x 4 neighbours per source.
+//   forward : y[n, co, Y, X] (+)= sum_src sum_tap interp(z_src[n, tap * Co + co], (Y + ky - 1, X + kx - 1))     k_tapup_fwd
+//   backward: dz[n, tap * Co + co, r, c] = sum_{Y, X} wy(Y + ky - 1 -> r) wx(X + kx - 1 -> c) dy[n, co, Y, X]     k_tapup_bwd
+// Both are separable (vertical pass through LDS at the low-resolution columns, then the horizontal one), gather form,
+// fixed summation order.  Index arithmetic: ATen's, as everywhere in this file.
+namespace {
+
+struct TapSrc {
+    const float *z;        // plane (n, tap * Co + co) at z + n * sn + (tap * Co + co) * sc, [h][w] each
+    long long sn, sc;      // batch / channel stride in floats ([N][9 Co][h][w]: 9 Co h w, h w; [9 Co][N][h][w]: h w, N h w)
+    int h, w;
+    Axis ay, ax;
+    int wr, wc;            // LDS window reserved for this source: rows, columns (+ 1 pad column: wc counts it)
+    int zoff;              // float offset of the window inside the workgroup's LDS
+};
+
+constexpr int TAP_RC = 32;         // output rows per workgroup (forward)
+constexpr int TAP_TW = 256;        // output columns per workgroup = threads
+
+// Forward.  One workgroup = one (n, co) plane x 32 output rows x 256 output columns.  The low-resolution windows of BOTH
+// sources (9 taps each) that the tile's shifted coordinates interpolate from are staged once (a duplicate of the last
+// column pads every window row, so that the right-hand neighbour c0 + 1 always exists: at the border its weight only
+// multiplies the same value); per output row the (row pair, weights) of each shifted row come from an LDS table, the
+// (column pair, weights) of the thread's three shifted columns live in registers; 2 x 9 taps x 4 neighbours per output.
+__global__ __launch_bounds__(TAP_TW) void k_tapup_fwd(TapSrc s0, TapSrc s1, int nsrc, int Co, int H, int W, int tiles_y,
+                                                     int tiles_x, int tabfloats, float *__restrict__ y, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) float tap_lds[];
+    // row table: for source si and shifted row Ys = Y0 - 1 + j (j in [0, RC + 2)): {r0 - ra, r1 - ra, l0, l1} (l = 0 outside)
+    float *rtab = tap_lds;
+    float *Zbase = tap_lds + tabfloats;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int plane = b / tiles_y;          // n * Co + co
+    const int n = plane / Co, co = plane - n * Co;
+    const int Y0 = ty * TAP_RC, X0 = tx * TAP_TW;
+    const int t = threadIdx.x, X = X0 + t;
+    int cix[2][3];
+    float cw0[2][3], cw1[2][3];
+#pragma unroll
+    for (int si = 0; si < 2; ++si) {
+        if (si >= nsrc)
+            break;
+        const TapSrc s = si == 0 ? s0 : s1;
+        int ra, rb, ca, cb, d0, d1;
+        float f0, f1;
+        src_index(s.ay, max(Y0 - 1, 0), s.h, ra, d1, f0, f1);
+        src_index(s.ay, min(Y0 + TAP_RC, H - 1), s.h, d0, rb, f0, f1);
+        src_index(s.ax, max(X0 - 1, 0), s.w, ca, d1, f0, f1);
+        src_index(s.ax, min(X0 + TAP_TW, W - 1), s.w, d0, cb, f0, f1);
+        const int nr = rb - ra + 1, nc = cb - ca + 1;           // <= s.wr, s.wc - 1 (host-side bound)
+        const float *zp = s.z + (size_t)n * s.sn + (size_t)co * s.sc;
+        const size_t tapstride = (size_t)Co * s.sc;
+        float *Zw = Zbase + s.zoff;                             // [9][wr][wc]
+        for (int e = t; e < 9 * nr * (nc + 1); e += TAP_TW) {
+            const int c = e % (nc + 1), r = (e / (nc + 1)) % nr, tap = e / ((nc + 1) * nr);
+            Zw[(tap * s.wr + r) * s.wc + c] = zp[tap * tapstride + (size_t)(ra + r) * s.w + ca + min(c, nc - 1)];
+        }
+        for (int j = t; j < TAP_RC + 2; j += TAP_TW) {
+            const int Ys = Y0 - 1 + j;
+            int r0 = ra, r1 = ra;
+            float l0 = 0.f, l1 = 0.f;
+            if (Ys >= 0 && Ys < H)
+                src_index(s.ay, Ys, s.h, r0, r1, l0, l1);
+            float *e = rtab + (si * (TAP_RC + 2) + j) * 4;
+            e[0] = __int_as_float((r0 - ra) * s.wc);
+            e[1] = __int_as_float((r1 - ra) * s.wc);
+            e[2] = l0;
+            e[3] = l1;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int Xs = X + kx - 1;
+            int c0 = ca, c1 = ca;
+            float l0 = 0.f, l1 = 0.f;
+            if (Xs >= 0 && Xs < W && X < W)
+                src_index(s.ax, Xs, s.w, c0, c1, l0, l1);
+            cix[si][kx] = c0 - ca;
+            cw0[si][kx] = l0;
+            cw1[si][kx] = (c1 == c0) ? 0.f : l1;                // right neighbour = c0 + 1 or (border) weightless
+            if (c1 == c0)
+                cw0[si][kx] = l0 + l1;
+        }
+    }
+    __syncthreads();
+    if (X >= W)
+        return;
+    float *yp = y + ((size_t)plane * H + Y0) * W + X;
+    for (int yy = 0; yy < TAP_RC && Y0 + yy < H; ++yy) {
+        float acc = 0.f;
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+            if (si >= nsrc)
+                break;
+            const TapSrc s = si == 0 ? s0 : s1;
+            const float *Zw = Zbase + s.zoff;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const f32x4 rt = *(const f32x4 *)(rtab + (si * (TAP_RC + 2) + yy + ky) * 4);
+                const int o0 = __float_as_int(rt.x), o1 = __float_as_int(rt.y);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float *zt = Zw + (size_t)(ky * 3 + kx) * s.wr * s.wc + cix[si][kx];
+                    const float a0 = zt[o0], a1 = zt[o0 + 1], b0 = zt[o1], b1 = zt[o1 + 1];
+                    acc += rt.z * (cw0[si][kx] * a0 + cw1[si][kx] * a1) + rt.w * (cw0[si][kx] * b0 + cw1[si][kx] * b1);
+                }
+            }
+        }
+        yp[(size_t)yy * W] = accumulate ? yp[(size_t)yy * W] + acc : acc;
+    }
+}
+
+constexpr int TAP_TRL = 4;         // low-resolution rows per workgroup (backward), at most
+
+// Backward, one source per launch.  One workgroup = one (n, co) plane x trl low-resolution rows.  Vertical pass first, one
+// thread per HIGH-resolution column (coalesced reads of dy straight from memory, no staging): the thread folds the rows of
+// dy whose shifted coordinate touches the tile into 3 (ky) x trl sums with row weights from an LDS table; the sums go to
+// LDS and the horizontal pass gathers each (tap, row, column) of dz from its footprint with column weights from a second
+// table.  (The other order -- lanes along the low-resolution columns read dy rows with a stride of the scale factor --
+// is 4- to 8-way bank conflicted on ten times the volume.)
+__global__ __launch_bounds__(256) void k_tapup_bwd(const float *__restrict__ dy, int Co, int H, int W, int h, int w,
+                                                  Axis ay, Axis ax, int trl, int tiles_r, int gr, int kxn,
+                                                  float *__restrict__ dz, long long sn, long long sc)
+{
+    extern __shared__ __attribute__((aligned(16))) float tap_lds[];
+    float *wt = tap_lds;                                  // [gr][3][TAP_TRL] row weights
+    float *wxt = wt + (size_t)gr * 3 * TAP_TRL;           // [w][kxn] column weights of shifted coordinate xlo[c] + k
+    int *xlo = (int *)(wxt + (size_t)w * kxn);            // [w]
+    float *Vt = (float *)(xlo + w);                       // [3 * TAP_TRL][W]
+    const int tile = blockIdx.x % tiles_r, plane = blockIdx.x / tiles_r;
+    const int n = plane / Co, co = plane - n * Co;
+    const int r_a = tile * trl, r_b = min(r_a + trl, h) - 1;
+    int lo, hi, d0, d1;
+    out_range(ay, r_a, h, H, lo, d1);
+    out_range(ay, r_b, h, H, d0, hi);
+    const int Ya = max(lo - 1, 0), Yb = min(hi + 1, H - 1);       // rows of dy whose shifted coordinate may touch the tile
+    const int nrows = min(Yb - Ya + 1, gr);
+    const int t = threadIdx.x;
+    for (int e = t; e < nrows * 3 * TAP_TRL; e += 256) {
+        const int rr = e % TAP_TRL, ky = (e / TAP_TRL) % 3, j = e / (3 * TAP_TRL);
+        const int Ys = Ya + j + ky - 1;
+        wt[e] = (rr <= r_b - r_a && Ys >= 0 && Ys < H) ? axis_weight(ay, Ys, h, r_a + rr) : 0.f;
+    }
+    for (int c = t; c < w; c += 256) {
+        int xs_lo, xs_hi;
+        out_range(ax, c, w, W, xs_lo, xs_hi);
+        xlo[c] = xs_lo;
+        for (int k = 0; k < kxn; ++k)
+            wxt[c * kxn + k] = (xs_lo + k <= xs_hi) ? axis_weight(ax, xs_lo + k, w, c) : 0.f;
+    }
+    __syncthreads();
+    const float *g = dy + ((size_t)plane * H + Ya) * W;
+    for (int X = t; X < W; X += 256) {
+        float acc[3][TAP_TRL];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int rr = 0; rr < TAP_TRL; ++rr)
+                acc[ky][rr] = 0.f;
+        for (int j = 0; j < nrows; ++j) {
+            const float v = g[(size_t)j * W + X];
+            const float *wj = wt + j * 3 * TAP_TRL;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int rr = 0; rr < TAP_TRL; ++rr)
+                    acc[ky][rr] += wj[ky * TAP_TRL + rr] * v;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int rr = 0; rr < TAP_TRL; ++rr)
+                Vt[(ky * TAP_TRL + rr) * W + X] = acc[ky][rr];
+    }
+    __syncthreads();
+    const int nr = r_b - r_a + 1;
+    float *out = dz + (size_t)n * sn + (size_t)co * sc;
+    const size_t tapstride = (size_t)Co * sc;
+    for (int e = t; e < 9 * nr * w; e += 256) {
+        const int c = e % w, rr = (e / w) % nr, tap = e / (w * nr);
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const float *vrow = Vt + (size_t)(ky * TAP_TRL + rr) * W;
+        const float *wc = wxt + c * kxn;
+        const int x0 = xlo[c] - (kx - 1);                         // dy column of shifted coordinate xlo[c]
+        float a = 0.f;
+        for (int k = 0; k < kxn; ++k) {
+            const int Xd = x0 + k;
+            if (Xd >= 0 && Xd < W)
+                a += wc[k] * vrow[Xd];
+        }
+        out[tap * tapstride + (size_t)(r_a + rr) * w + c] = a;
+    }
+}
+
+// conservative bound of the low-resolution window a run of `n_out` consecutive output coordinates (+ one on either side)
+// interpolates from
+int tap_window(int in_size, int out_size, int n_out)
+{
+    const double ratio = out_size > 1 ? (double)in_size / (double)out_size : 1.0;
+    int wdw = (int)((n_out + 2) * ratio + 4.0);
+    return wdw > in_size ? in_size : (wdw < 2 ? 2 : wdw);
+}
+
+// output coordinates whose interpolation can touch one input index (bound of out_range's span), + margin
+int tap_footprint(int in_size, int out_size)
+{
+    const double inv = in_size > 0 ? (double)out_size / (double)in_size : 1.0;
+    int fp = (int)(2.0 * (inv > 1.0 ? inv : 1.0) + 6.0);
+    return fp > out_size ? out_size : fp;
+}
+
+}  // namespace
+
+extern "C" int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1, int h1, int w1, int N, int Co, int H, int W,
+                             int align_corners, int channel_major, float *y, int accumulate, void *stream)
+{
+    DCL_CHECK_ARG(z0 && y && N > 0 && Co > 0 && H > 0 && W > 0 && h0 > 0 && w0 > 0, "bad arguments");
+    DCL_CHECK_ARG(!z1 || (h1 > 0 && w1 > 0), "bad second source");
+    TapSrc s[2] = {};
+    const float *zs[2] = {z0, z1};
+    const int hs[2] = {h0, h1}, ws[2] = {w0, w1};
+    const int nsrc = z1 ? 2 : 1;
+    const int tabfloats = 2 * (TAP_RC + 2) * 4;
+    int zfloats = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        s[i].z = zs[i];
+        s[i].h = hs[i];
+        s[i].w = ws[i];
+        s[i].sn = channel_major ? (long long)hs[i] * ws[i] : (long long)9 * Co * hs[i] * ws[i];
+        s[i].sc = channel_major ? (long long)N * hs[i] * ws[i] : (long long)hs[i] * ws[i];
+        s[i].ay = make_axis(hs[i], H, align_corners);
+        s[i].ax = make_axis(ws[i], W, align_corners);
+        s[i].wr = tap_window(hs[i], H, TAP_RC);
+        s[i].wc = tap_window(ws[i], W, TAP_TW) + 1;
+        s[i].zoff = zfloats;
+        zfloats += 9 * s[i].wr * s[i].wc;
+    }
+    const size_t lds = (size_t)(tabfloats + zfloats) * sizeof(float);
+    DCL_CHECK_ARG(lds <= 64 * 1024, "source maps too large for the tap-up tile (LDS): convolve the up-sampled map instead");
+    const int tiles_y = (H + TAP_RC - 1) / TAP_RC, tiles_x = (W + TAP_TW - 1) / TAP_TW;
+    const long long blocks = (long long)N * Co * tiles_y * tiles_x;
+    DCL_CHECK_ARG(blocks < (1LL << 31), "too many tiles");
+    hipLaunchKernelGGL(k_tapup_fwd, dim3((unsigned)blocks), dim3(TAP_TW), lds, (hipStream_t)stream, s[0], s[1], nsrc, Co, H, W,
+                       tiles_y, tiles_x, tabfloats, y, accumulate);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners,
+                             int channel_major, float *dz, void *stream)
+{
+    DCL_CHECK_ARG(dy && dz && N > 0 && Co > 0 && H > 0 && W > 0 && h > 0 && w > 0, "bad arguments");
+    const Axis ay = make_axis(h, H, align_corners), ax = make_axis(w, W, align_corners);
+    const int kxn = tap_footprint(w, W);
+    int trl = TAP_TRL;
+    auto rows_for = [&](int tr) {                   // rows of dy a tile of tr low-resolution rows can touch (+ tap shift)
+        int r = tap_footprint(h, H) + (int)((tr - 1) * ((double)H / (double)h > 1.0 ? (double)H / (double)h : 1.0)) + 4;
+        return r > H ? H : r;
+    };
+    auto lds_for = [&](int tr) {
+        return ((size_t)rows_for(tr) * 3 * TAP_TRL + (size_t)w * kxn + (size_t)w + (size_t)3 * TAP_TRL * W) * sizeof(float);
+    };
+    while (trl > 1 && lds_for(trl) > 48 * 1024)
+        trl >>= 1;
+    DCL_CHECK_ARG(lds_for(trl) <= 64 * 1024, "maps too wide for the tap-up backward tile (LDS)");
+    const int gr = rows_for(trl);
+    const int tiles_r = (h + trl - 1) / trl;
+    const long long blocks = (long long)N * Co * tiles_r;
+    DCL_CHECK_ARG(blocks < (1LL << 31), "too many tiles");
+    hipLaunchKernelGGL(k_tapup_bwd, dim3((unsigned)blocks), dim3(256), lds_for(trl), (hipStream_t)stream, dy, Co, H, W, h, w, ay,
+                       ax, trl, tiles_r, gr, kxn, dz, channel_major ? (long long)h * w : (long long)9 * Co * h * w,
+                       channel_major ? (long long)N * h * w : (long long)h * w);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- out = a + b (+ c) (+ d): the gradient of a tensor with several consumers in ONE pass (models/ops.py _FanOut) instead of
 // autograd's chain of two-input adds (k + 1 tensor passes instead of 3 (k - 1))
 namespace {

@@ -28,8 +28,8 @@ import torch.nn.functional as F
 from ..debug import cfg as _dbg
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
-from .ops import (ConvPackGroup, DirectConv2d, GradToken, use_gemm_conv1x1, upsample_bilinear, use_direct_conv3x3,
-                  use_direct_conv1x1, upsample_concat, fan_out)
+from .ops import (ConvPackGroup, DirectConv2d, GradToken, LazyConcat, conv3x3_over_upsampled, use_gemm_conv1x1,
+                  upsample_bilinear, use_direct_conv3x3, use_direct_conv1x1, upsample_concat, fan_out)
 from .amax import record_stream as _amax_record_stream
 from .fused_bn import FusedBatchNorm2d, bn_act, bn_act_group, can_group
 
@@ -509,7 +509,9 @@ class HighResolutionNet(nn.Module):
         y = self.stage3(self._enter_stage(self.transition2, y, self.stage2_cfg['NUM_BRANCHES']))
         y = self.stage4(self._enter_stage(self.transition3, y, self.stage3_cfg['NUM_BRANCHES']))
         assert self.use_as_backbone
-        cat = upsample_concat(list(y), self.align_corners)
+        # (lazy_concat: the head convolution consumes the four maps themselves, ops.conv3x3_over_upsampled)
+        cat = LazyConcat(list(y), self.align_corners) if getattr(self, 'lazy_concat', False) and y[0].is_cuda \
+            else upsample_concat(list(y), self.align_corners)
         if self.return_all_scales:
             return cat, [y[0], y[1], y[2], y[3]]
         return cat
@@ -603,6 +605,11 @@ class HRNet(nn.Module):
         # 'direct' (default): the head's 720 -> 720 convolution on the same direct split-f16 kernels as the backbone
         # (32 ms for its three directions at batch 12); 'library': MIOpen
         self.head_conv = config.get('head_conv', 'direct')
+        # head_split (default on with the direct head convolution): the 3x3 head convolution takes the four branch maps
+        # instead of their up-sampled concatenation and moves the channel products of the two coarsest ones to low
+        # resolution (models/ops.py conv3x3_over_upsampled); False = convolve the materialised 720-channel concatenation
+        self.head_split = bool(config.get('head_split', True)) and self.head_conv == 'direct'
+        self.backbone.lazy_concat = self.head_split and not self.return_backbone_feats and 'projector' not in config
         # 'f16x3': the backbone's 3x3 / stride-1 convolutions (BasicBlock, Bottleneck, transitions: ~80 % of the
         # FLOPs) on the direct split-f16 kernel (csrc/dcl_conv3x3.hip, fp32-equivalent); 'library': MIOpen
         self.branch_conv = config.get('branch_conv', 'f16x3')
@@ -629,6 +636,17 @@ class HRNet(nn.Module):
             self._conv_packs = ConvPackGroup(self)
 
     def _head(self, x):
+        if isinstance(x, LazyConcat):
+            conv = self.cls_head[0]
+            t0 = x.ts[0]
+            if (self.head_split and isinstance(conv, DirectConv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+                    and t0.is_cuda and t0.dtype == torch.float32 and not torch.is_autocast_enabled()
+                    and all(t.is_contiguous() for t in x.ts)):
+                y = conv3x3_over_upsampled(x.ts, x.align_corners, conv.weight, conv.bias)
+                for layer in list(self.cls_head)[1:]:
+                    y = layer(y)
+                return y
+            x = x.materialize()
         return self.cls_head(x)
 
     def forward(self, x):

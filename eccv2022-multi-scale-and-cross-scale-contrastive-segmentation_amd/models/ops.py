@@ -536,6 +536,145 @@ def use_direct_conv1x1(module: torch.nn.Module) -> torch.nn.Module:
     return module
 
 
+# ---- head convolution over a concatenation of up-sampled maps, without the up-sampled maps ---------------------------
+
+class _CoarseTaps(torch.autograd.Function):
+    """addend [N, Co, H, W] = sum over the coarse maps x_b of conv3x3(up(x_b), weight[:, slice_b], padding=1), computed as
+    z_b = W_b x_b (ONE fp32 GEMM per map over all images: [9 Co, C_b] x [C_b, N h w]) at LOW resolution followed by the tap-wise
+    bilinear gather of csrc/dcl_resize.hip (k_tapup_fwd); backward: the gather's adjoint (k_tapup_bwd), then two GEMMs per map
+    (dx_b = W_b^T dz_b, dW_b = dz_b x_b^T).  ``weight`` is the FULL [Co, Cin, 3, 3] parameter, ``c0`` the first input channel
+    of the first coarse map; its gradient comes back full-size (zero outside the coarse slices)."""
+
+    @staticmethod
+    def forward(ctx, align, H, W, c0, weight, *ts):
+        from .. import _lib
+        L = _lib.lib()
+        Co = weight.shape[0]
+        n = ts[0].shape[0]
+        y = torch.empty((n, Co, H, W), dtype=torch.float32, device=weight.device)
+        st = _lib.stream_ptr(y.device)
+        saved, zs, off = [], [], c0
+        for t in ts:
+            cb, h, w = t.shape[1:]
+            xc = t.transpose(0, 1).reshape(cb, n * h * w)                                   # [C_b, N h w] (one copy)
+            wb = weight[:, off:off + cb].permute(2, 3, 0, 1).reshape(9 * Co, cb)           # [(tap, co), ci]
+            zs.append((torch.mm(wb, xc), h, w))
+            saved += [xc, wb]
+            off += cb
+        for i in range(0, len(zs), 2):
+            z0, h0, w0 = zs[i]
+            z1, h1, w1 = zs[i + 1] if i + 1 < len(zs) else (None, 0, 0)
+            _lib.check(L.dcl_tapup_fwd(_lib.ptr(z0), h0, w0, _lib.ptr(z1), h1, w1, n, Co, H, W, 1 if align else 0, 1,
+                                       _lib.ptr(y), 1 if i else 0, st), "dcl_tapup_fwd")
+        ctx.save_for_backward(*saved)
+        ctx.geom = (bool(align), H, W, c0, tuple(weight.shape), [tuple(t.shape) for t in ts])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import _lib
+        L = _lib.lib()
+        align, H, W, c0, wshape, shapes = ctx.geom
+        Co = wshape[0]
+        dy = dy.contiguous()
+        st = _lib.stream_ptr(dy.device)
+        gw = torch.zeros(wshape, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[4] else None
+        grads, off = [], c0
+        for i, (n, cb, h, w) in enumerate(shapes):
+            xc, wb = ctx.saved_tensors[2 * i], ctx.saved_tensors[2 * i + 1]
+            dz = torch.empty((9 * Co, n * h * w), dtype=torch.float32, device=dy.device)
+            _lib.check(L.dcl_tapup_bwd(_lib.ptr(dy), n, Co, H, W, h, w, 1 if align else 0, 1, _lib.ptr(dz), st),
+                       "dcl_tapup_bwd")
+            gx = None
+            if ctx.needs_input_grad[5 + i]:
+                gx = torch.mm(wb.t(), dz).view(cb, n, h, w).transpose(0, 1).contiguous()
+            if gw is not None:
+                gw[:, off:off + cb] = torch.mm(dz, xc.t()).view(3, 3, Co, cb).permute(2, 3, 0, 1)
+            grads.append(gx)
+            off += cb
+        return (None, None, None, None, gw, *grads)
+
+
+class _Conv3x3Addend(torch.autograd.Function):
+    """y = conv2d(x, weight, bias, padding=1) + addend on the direct f16x3 kernels with an explicit weight tensor (a slice of a
+    module's parameter): forward / data gradient through csrc/dcl_conv3x3.hip (the addend and the bias enter as the
+    accumulators' start values), weight gradient through csrc/dcl_wgrad3x3d.hip; the addend's gradient is the output's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, addend):
+        from .amax import amax_of
+        w = weight.contiguous()
+        wamax = amax_of(w)
+        out = torch.empty((x.shape[0], w.shape[0], x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+        conv3x3_launch(x, conv3x3_pack(w, wamax), w.shape[0], amax_of(x), wamax, out, addend=addend, bias=bias)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .amax import amax_of
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wamax = amax_of(w)
+            gx = torch.empty_like(x)
+            conv3x3_launch(gy, conv3x3_pack(w, wamax, True), w.shape[1], amax_of(gy), wamax, gx)
+        if ctx.needs_input_grad[1]:
+            if conv3x3_wgrad_supported(x, w.shape[0]):
+                gw = conv3x3_wgrad(x, gy)
+            else:
+                gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb, (gy if ctx.needs_input_grad[3] else None)
+
+
+class LazyConcat:
+    """``torch.cat([ts[0]] + [interpolate(t, ts[0] size) for t in ts[1:]], 1)`` that has not been formed (reference
+    models/HRNet.py:549-553): the head convolution of this repo consumes the parts (``conv3x3_over_upsampled``); anything
+    else calls ``materialize()``."""
+
+    def __init__(self, ts, align_corners):
+        self.ts, self.align_corners = list(ts), bool(align_corners)
+        self._full = None
+
+    @property
+    def shape(self):
+        t0 = self.ts[0]
+        return torch.Size((t0.shape[0], sum(t.shape[1] for t in self.ts)) + tuple(t0.shape[2:]))
+
+    def materialize(self):
+        if self._full is None:
+            self._full = upsample_concat(self.ts, self.align_corners)
+        return self._full
+
+
+def conv3x3_over_upsampled(ts, align_corners, weight, bias, min_scale=4):
+    """``conv2d(cat([ts[0]] + [up(t) for t in ts[1:]], 1), weight, bias, padding=1)`` (bilinear ``up`` to ts[0]'s size)
+    without up-sampling the maps that are at least ``min_scale`` times coarser than ts[0]:
+
+        conv3x3(up(x), W) = sum_tap (shift_tap . up)(W_tap x)        (the convolution acts on channels, up on pixels)
+
+    so their channel products are 1x1 convolutions at LOW resolution (library fp32 GEMMs producing 9 * Co maps per source)
+    and the rest is the tap-wise bilinear gather of ``_CoarseTaps``; the finer maps are concatenated and convolved directly, with
+    the gathered sum as the convolution's addend.  For HRNet-W48's head (48 + 96 + 192 + 384 channels at scales 1, 2, 4,
+    8) 80 % of the multiply-adds move to 1/16 and 1/64 of the pixels.  Equal to the reference formulation up to fp32
+    round-off (tests/test_hip_parity.py::test_head_conv_over_upsampled_matches_fp64)."""
+    t0 = ts[0]
+    n, _, H, W = t0.shape
+    Co = weight.shape[0]
+    fine = [t for t in ts if t is t0 or t.shape[-1] * min_scale > W]
+    coarse = [t for t in ts if not (t is t0 or t.shape[-1] * min_scale > W)]
+    assert [id(t) for t in fine + coarse] == [id(t) for t in ts], "maps must be ordered fine to coarse"
+    c_fine = sum(t.shape[1] for t in fine)
+    hi = upsample_concat(fine, align_corners) if len(fine) > 1 else t0
+    addend = _CoarseTaps.apply(bool(align_corners), H, W, c_fine, weight, *coarse) if coarse else None
+    return _Conv3x3Addend.apply(hi, weight[:, :c_fine], bias, addend)
+
+
 # ---- 1x1 convolutions as plain batched GEMMs ----------------------------------------------------------------------
 
 class _Conv1x1Gemm(torch.autograd.Function):

@@ -270,6 +270,19 @@ int dcl_upsample_bilinear_fwd_slice(const float *x, int N, int C, int h, int w, 
 int dcl_upsample_bilinear_bwd_slice(const float *dy_wide, int ctot, int c0, int N, int C, int h, int w, int H, int W,
                                     int align_corners, float *dx, void *stream);
 
+/* ---- 3x3 convolution of bilinearly up-sampled maps without the up-sampled maps (head of HRNet: reference
+ * models/HRNet.py:549-553 concat of the up-sampled branches, :596-600 the 3x3 head convolution).  With z[tap] = W_tap x, a 1x1
+ * convolution at LOW resolution with 9 * Co output maps (map tap * Co + co, tap = ky * 3 + kx),
+ *   conv3x3(up(x), W, padding 1)[n, co, Y, X] = sum_tap interp(z[n, tap * Co + co], (Y + ky - 1, X + kx - 1))   (0 outside the image)
+ * dcl_tapup_fwd  y f32 [N, Co, H, W] = (accumulate ? y : 0) + that sum over one or two sources (z1 may be NULL);
+ * dcl_tapup_bwd  dz = its adjoint applied to dy f32 [N, Co, H, W], one source per call.
+ * z / dz layout: channel_major = 0: [N, 9 * Co, h, w]; 1: [9 * Co, N, h, w] (what ONE GEMM over all images produces).
+ * Bilinear index arithmetic as dcl_upsample_bilinear_*; gather form, deterministic. */
+int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1 /* may be NULL */, int h1, int w1, int N, int Co, int H,
+                  int W, int align_corners, int channel_major, float *y, int accumulate, void *stream);
+int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
+                  float *dz, void *stream);
+
 /* out = a + b (+ c) (+ d), n floats: the gradient of a tensor with several consumers in one pass (HRNet exchange
  * modules: every branch output feeds all fuse rows, reference models/HRNet.py:264-287). */
 int dcl_add_n(const float *a, const float *b, const float *c /* or NULL */, const float *d /* or NULL */, int64_t n,

@@ -1264,6 +1264,39 @@ def test_fan_out_sums_consumer_gradients_in_one_kernel(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("chans,H,W,Co,bias", [((16, 32, 48, 64), 32, 64, 48, True), ((16, 16, 32, 32), 24, 40, 32, False),
+                                               ((48, 96, 192, 384), 64, 128, 96, True)])
+def test_head_conv_over_upsampled_matches_fp64(dev, align, chans, H, W, Co, bias):
+    """ops.conv3x3_over_upsampled (the channel products of the coarse maps at LOW resolution + the tap-wise bilinear gather
+    k_tapup_fwd / k_tapup_bwd + a direct convolution of the fine maps) against the reference formulation -- F.conv2d over
+    torch.cat of the F.interpolate'd maps (models/HRNet.py:549-553, :596-600) -- in float64: output and the gradients of
+    every map, the weight and the bias, 3e-6 / 1e-5 of max; both align_corners settings, sizes that are not multiples of
+    the tiles, four pyramid levels (scales 1, 2, 4, 8) and a level count where only one map is coarse."""
+    import torch.nn.functional as F
+    from mscs_amd.models import ops
+    torch.manual_seed(3)
+    n = 2
+    ts = [torch.randn(n, c, max(H >> i, 1), max(W >> i, 1), device=dev).requires_grad_(True) for i, c in enumerate(chans)]
+    wt = (torch.randn(Co, sum(chans), 3, 3, device=dev) * 0.05).requires_grad_(True)
+    b = torch.randn(Co, device=dev).requires_grad_(True) if bias else None
+    gy = torch.randn(n, Co, H, W, device=dev)
+    y = ops.conv3x3_over_upsampled(ts, align, wt, b)
+    y.backward(gy)
+    got = [y.detach()] + [t.grad for t in ts] + [wt.grad] + ([b.grad] if bias else [])
+    ts64 = [t.detach().double().requires_grad_(True) for t in ts]
+    w64 = wt.detach().double().requires_grad_(True)
+    b64 = b.detach().double().requires_grad_(True) if bias else None
+    cat = torch.cat([ts64[0]] + [F.interpolate(t, size=(H, W), mode="bilinear", align_corners=align) for t in ts64[1:]], 1)
+    y64 = F.conv2d(cat, w64, b64, padding=1)
+    y64.backward(gy.double())
+    ref = [y64.detach()] + [t.grad for t in ts64] + [w64.grad] + ([b64.grad] if bias else [])
+    for k, (a, r) in enumerate(zip(got, ref)):
+        err = ((a.double() - r).abs().max() / r.abs().max()).item()
+        assert err < (3e-6 if k == 0 else 1e-5), (k, err)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 2])
 def test_weight_gradient_kernel_variants_match_fp64(dev, variant):
     """The two stride-1 weight-gradient kernels of the library -- MFMA-order loads (0, dcl_wgrad3x3.hip: the fallback) and
