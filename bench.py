@@ -15,10 +15,10 @@ Workloads:
         `--config 4`: UPerNet + Swin-T, ADE20K 512x512, TwoScaleLoss + DCV2_ms (4 scales), AdamW, batch 16 per GPU.
   loss  the contrastive loss alone (forward + backward) on synthetic 256-d projector outputs
 Extra keys of the JSON line:
-  roofline / roofline_other   dominant hand-written kernel (step: the direct 3x3 convolution `k_conv3x3<3,4,1>` on its
-        heaviest launch, the head convolution 720 -> 720; loss: the InfoNCE backward sweep): algorithmic FLOPs over the
-        HIP-event launch time measured live, against the peak of its arithmetic mode; `traffic` from the committed PMC
-        passes (profiles/r02_*_pmc_*.csv); per-shape rows: profiles/r02_conv_per_shape.csv
+  roofline / roofline_other   dominant hand-written kernel (step: the weight-gradient kernel `k_wgrad3x3d<3,1>` on its
+        heaviest launch, the 144 -> 720 full-resolution part of the head convolution; loss: the InfoNCE backward sweep):
+        algorithmic FLOPs over the HIP-event launch time measured live, against the peak of its arithmetic mode; `traffic`
+        only where a PMC pass of that kernel / shape is committed (else null); per-shape rows: profiles/r03_conv_per_shape.csv
   cpu_baseline                oracle/eager_torch.py + the same model code on the host cores: median of 3 after one
         warm-up, ONE image of the model (x batch) and ONE full N = 9804 loss term (x number of terms)
   eager_gpu_step_ms, speedup_vs_eager_gpu_step   the reference-structure eager step on the same GPU in the same run
@@ -159,15 +159,6 @@ def sync(world):
         torch.cuda.synchronize()
 
 
-# HBM-side traffic of the direct convolution kernels at the benchmark's 48-channel shape (12 x 48 x 128 x 256), KiB
-# per launch (FETCH_SIZE, WRITE_SIZE) from the committed PMC passes (profiles/r01_conv_pmc_*.csv)
-# (round 2: profiles/r02_conv_pmc_fetch.csv / _write.csv; the head launch is the per-kernel maximum of its family.  The
-# 48-channel rows of those files average several shapes of the same kernel family, so no per-launch figure is given)
-PMC_CONV48 = None
-PMC_CONV720 = (2585440.6, 1105920.0)      # head convolution 12 x 720 x 128 x 256, k_conv3x3<3,4,1>
-PMC_WGRAD48 = None
-
-
 def _time_launches(launch, iters):
     launch()
     torch.cuda.synchronize()
@@ -181,11 +172,14 @@ def _time_launches(launch, iters):
 
 
 def roofline_conv_kernels(args, dev, iters=20):
-    """Average launch duration of the direct f16x3 convolution kernels, HIP events on the launch stream:
-      * `k_conv3x3<3,4,1>` on the head convolution (batch x 720 x H/4 x W/4, 720 -> 720; the data gradient is the same
-        kernel) -- the top kernel of the step profile, 47 % of the model's FLOPs;
-      * `k_conv3x3_o2<2,2,1>` and the weight-gradient kernel on the backbone's highest-resolution BasicBlock shape
-        (batch x 48 x H/4 x W/4).
+    """Average launch duration of the step's dominant hand-written kernels, HIP events on the launch stream.
+
+    Since round 3 the head convolution runs over the branch maps (ops.conv3x3_over_upsampled): what is left of it at full
+    resolution is a 144 -> 720 convolution.  The kernel family with the largest share of a step is the weight gradient
+    `k_wgrad3x3d<3,1>` (17 % of the kernel time, profiles/r03_step_kernels.csv); its heaviest launch is that head part
+    (batch x 144 -> 720 x H/4 x W/4), which is what `roofline` reports (kernel + its slab reduction).  `roofline_other`:
+    the forward / data-gradient kernel `k_conv3x3_il<3,4>` on the same layer, the 48-channel BasicBlock shape
+    (`k_conv3x3_il_ws2<1,4>` and its weight gradient) and the InfoNCE backward sweep.
     Algorithmic FLOPs = 2 * N * Cout * Cin * 9 * H * W; every one of them costs three f16 MFMA passes
     (hi.hi + hi.lo + lo.hi), hence peak = 2500 / 3 TFLOP/s."""
     from mscs_amd.models import ops
@@ -194,36 +188,37 @@ def roofline_conv_kernels(args, dev, iters=20):
     gen = torch.Generator(device=dev).manual_seed(1)
     peak = MFMA_F16_PEAK_TFLOPS / 3.0
     note = "every algorithmic FLOP is issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): 2.5 PFLOP/s / 3"
-    default_shape = (n, h, w) == (12, 128, 256)
 
-    def conv_entry(c, kernel, pmc, it):
-        x = torch.randn(n, c, h, w, device=dev, generator=gen).relu_()
-        wt = torch.randn(c, c, 3, 3, device=dev, generator=gen) * (2.0 / (9 * c)) ** 0.5
+    def entry(kernel, flops, ms, abytes):
+        return {"bound": "mfma", "kernel": kernel, "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_note": note, "traffic": None,
+                "traffic_source": "not collected for this kernel / shape (profiles/r03_conv_pmc_*.csv hold the per-kernel "
+                                  "FETCH_SIZE / WRITE_SIZE of tools/per_shape_roofline.py)",
+                "algorithmic_bytes": abytes, "launch_ms": round(ms, 4)}
+
+    def conv_and_wgrad(ci, co, it):
+        x = torch.randn(n, ci, h, w, device=dev, generator=gen).relu_()
+        wt = torch.randn(co, ci, 3, 3, device=dev, generator=gen) * (2.0 / (9 * ci)) ** 0.5
+        gy = torch.randn(n, co, h, w, device=dev, generator=gen) * 1e-4
         xa, wa = amax_of(x), amax_of(wt)
+        amax_of(gy)
         wp = ops.conv3x3_pack(wt, wa)
-        out = torch.empty_like(x)
-        flops = 2.0 * n * c * c * 9 * h * w
-        ms = _time_launches(lambda: ops.conv3x3_launch(x, wp, c, xa, wa, out), it)
-        return {"bound": "mfma", "kernel": f"{kernel} (dcl_conv3x3_f16x3): 3x3 conv forward / data gradient, "
-                                            f"{n}x{c}x{h}x{w}",
-                "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_note": note,
-                "traffic": (2 * pmc[0] + pmc[1]) * 1024 if (default_shape and pmc) else None,
-                "traffic_source": "constant from profiles/r02_conv_pmc_fetch.csv, r02_conv_pmc_write.csv (FETCH_SIZE x 2 + "
-                                  "WRITE_SIZE of a separate rocprofv3 --pmc run; not read live)",
-                "algorithmic_bytes": 2 * n * c * h * w * 4, "launch_ms": round(ms, 4)}, x
-    main, _ = conv_entry(720, "k_conv3x3<3,4,1>", PMC_CONV720, 5)
+        out = torch.empty(n, co, h, w, device=dev)
+        flops = 2.0 * n * co * ci * 9 * h * w
+        ms_f = _time_launches(lambda: ops.conv3x3_launch(x, wp, co, xa, wa, out), it)
+        ms_w = _time_launches(lambda: ops.conv3x3_wgrad(x, gy), it)
+        return flops, ms_f, ms_w, (n * (ci + co) * h * w) * 4
+
+    flops, ms_f, ms_w, ab = conv_and_wgrad(144, 720, 8)
+    main = entry(f"k_wgrad3x3d<3,1> + k_wgrad_reduce (dcl_wgrad3x3_f16x3): 3x3 weight gradient, {n}x(144->720)x{h}x{w} "
+                 "(the head convolution's full-resolution part)", flops, ms_w, ab)
+    others = [entry(f"k_conv3x3_il<3,4> (dcl_conv3x3_f16x3): 3x3 conv forward, {n}x(144->720)x{h}x{w}", flops, ms_f, ab)]
     torch.cuda.empty_cache()
-    c48, x = conv_entry(48, "k_conv3x3_o2<2,2,1>", PMC_CONV48, iters)
-    gy = torch.randn(n, 48, h, w, device=dev, generator=gen) * 1e-4
-    flops = 2.0 * n * 48 * 48 * 9 * h * w
-    msw = _time_launches(lambda: ops.conv3x3_wgrad(x, gy), iters)
-    wg = {"bound": "mfma", "kernel": f"k_wgrad3x3d<3,1> + k_wgrad_reduce (dcl_wgrad3x3_f16x3), {n}x48x{h}x{w}",
-          "achieved": round(flops / (msw * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-          "frac": round(flops / (msw * 1e-3) / 1e12 / peak, 4),
-          "traffic": (2 * PMC_WGRAD48[0] + PMC_WGRAD48[1]) * 1024 if (default_shape and PMC_WGRAD48) else None,
-          "algorithmic_bytes": 2 * n * 48 * h * w * 4, "launch_ms": round(msw, 4)}
-    return main, [c48, wg]
+    flops, ms_f, ms_w, ab = conv_and_wgrad(48, 48, iters)
+    others.append(entry(f"k_conv3x3_il_ws2<1,4> (dcl_conv3x3_f16x3): 3x3 conv forward / data gradient, {n}x48x{h}x{w}",
+                        flops, ms_f, ab))
+    others.append(entry(f"k_wgrad3x3d<3,1> + k_wgrad_reduce (dcl_wgrad3x3_f16x3), {n}x48x{h}x{w}", flops, ms_w, ab))
+    return main, others
 
 
 def roofline_bwd_kernel(mod, iters=10):

@@ -43,7 +43,8 @@ def main():
     # (name, Cin, Cout, H, W, stride): BasicBlock convolutions of the four branches, the head, the stride-2 fuse convs
     shapes = [("branch0 basicblock", 48, 48, 128, 256, 1), ("branch1 basicblock", 96, 96, 64, 128, 1),
               ("branch2 basicblock", 192, 192, 32, 64, 1), ("branch3 basicblock", 384, 384, 16, 32, 1),
-              ("cls_head", 720, 720, 128, 256, 1), ("layer1 bottleneck", 64, 64, 128, 256, 1),
+              ("cls_head (materialised concat, head_split off)", 720, 720, 128, 256, 1),
+              ("cls_head fine part (x0 + up(x1))", 144, 720, 128, 256, 1), ("layer1 bottleneck", 64, 64, 128, 256, 1),
               ("fuse 48->96 s2", 48, 96, 128, 256, 2), ("fuse 96->192 s2", 96, 192, 64, 128, 2),
               ("fuse 192->384 s2", 192, 384, 32, 64, 2), ("fuse 48->48 s2", 48, 48, 128, 256, 2),
               ("stem conv2 s2", 64, 64, 256, 512, 2)]
