@@ -281,15 +281,18 @@ def roofline_bwd_kernel(mod, iters=10):
             "peak_note": ("f32 MFMA 157.3 TFLOP/s" if mode == "f32" else
                           "4NMC algorithmic FLOP issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): "
                           "2.5 PFLOP/s / 3 = 833.3 TFLOP/s"),
-            "traffic": traffic, "traffic_source": "constant from " + PMC_SOURCE + " (separate rocprofv3 --pmc run; "
-                                                                   "not read live)",
+            "traffic": traffic,
+            "traffic_source": "constant from " + (PMC_SOURCE_SK if G > 0 else PMC_SOURCE) +
+                              " (separate rocprofv3 --pmc run, not read live; 2 x FETCH_SIZE + WRITE_SIZE = bytes that "
+                              "crossed L2 <-> fabric, Infinity-Cache hits included)",
             "algorithmic_bytes": 3 * N * 256 * 4, "launch_ms": round(ms, 4), "N1": N, "N2": N, "C": 256,
             "nsplit": ns if G == 0 else None, "streamk_workgroups": G}
 
 
 PMC_F16X3 = (104540.5, 128128.0)      # KiB per launch (FETCH_SIZE, WRITE_SIZE), profiles/r02_loss_pmc_*.csv
-PMC_F16X3_SK = None                   # stream-K kernel: filled from profiles/r03_loss_pmc_*.csv once collected
+PMC_F16X3_SK = (283395.9, 42511.9)    # stream-K kernel, KiB per launch: profiles/r03_loss_pmc_fetch.csv / _write.csv
 PMC_SOURCE = "profiles/r02_loss_pmc_fetch.csv, r02_loss_pmc_write.csv"
+PMC_SOURCE_SK = "profiles/r03_loss_pmc_fetch.csv, r03_loss_pmc_write.csv"
 
 
 def cpu_baseline_loss(args, n_terms):
