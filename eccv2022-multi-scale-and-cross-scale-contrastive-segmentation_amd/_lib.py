@@ -59,6 +59,12 @@ SIGNATURES = {
     "dcl_amax_sum2": [_vp, _i, _vp, _i, _vp, _vp],
     "dcl_tapup_fwd": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "dcl_tapup_bwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "dcl_gemm_supported": [_i, _i, _i, _i64, _i, _i64, _i],
+    "dcl_gemm_workspace_floats": [_i, _i, _i, _i],
+    "dcl_gemm_suggest_splitk": [_i, _i, _i, _i],
+    "dcl_gemm_set_tile": [_i],
+    "dcl_gemm_f16x3": [_vp, _i64, _i, _i64, _vp, _i64, _i, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i64, _i64, _i,
+                       _vp, _i, _vp, _vp],
     "dcl_add_n": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "dcl_upsample_bilinear_fwd_slice": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp],
     "dcl_upsample_bilinear_bwd_slice": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
@@ -124,6 +130,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
         l.dcl_last_error.restype = ctypes.c_char_p
+        l.dcl_gemm_workspace_floats.restype = ctypes.c_int64
         l.dcl_last_error.argtypes = []
         from .debug import cfg as _dbg       # A/B switches of the tuning tools: one object, read once
         _dbg.apply_to_library(l)

@@ -1,0 +1,600 @@
+// dcl_gemm.hip -- C[M, N] = A[M, K] . B[N, K]^T (+ bias) on the f16 matrix cores at fp32-equivalent accuracy
+// (split-f16: hi.hi + hi.lo + lo.hi with f32 accumulation), f32 operands straight from HBM, gfx950 only.
+//
+// Replaces the library's fp32 GEMMs behind the token-major Linears of the Swin backbone (reference models/Swin.py:62-76
+// Mlp, :198-230 qkv / proj, :357-362 PatchMerging reduction: forward y = x W^T + b, data gradient dx = dy W, weight
+// gradient dW = dy^T x), the decoder's and HRNet's large 1x1 convolutions (models/HRNet.py:63-100, :236-262; batched
+// over the images) and the head's tap products ("the head without its up-sampled input").
+//
+// Both operands are addressed as (row, k): "k-major" = the contraction index is the contiguous one (x[m][k], W[n][k]),
+// otherwise the ROW index is contiguous (element (r, k) at p[k * ld + r]: dy^T, x^T, W read as its transpose).  All
+// four combinations run through one LDS image, so the matrix loop is the same code:
+//
+//   staging   global f32 -> registers (one k-step of 32 ahead, 8 x 16-byte loads per thread) -> split into hi / lo f16
+//             ONCE per element -> LDS.  k-major rows: a lane loads 4 consecutive k (8 lanes = one 128-byte line of a
+//             row).  Row-major-contiguous operands: a lane loads 4 consecutive rows at 8 consecutive k and transposes
+//             the 8 x 4 block in its registers, so the LDS writes are whole 16-byte fragments either way.
+//   LDS       [k-group of 8][row] 16-byte units (hi) + the same (lo): an MFMA operand fragment (32 rows x 8 k per
+//             half-wave) is one ds_read_b128 per lane from 256 consecutive bytes per 16 lanes -- conflict-free; rows are
+//             rotated within 16-row groups and the k-groups padded by 64 bytes so that both kinds of WRITES are
+//             conflict-free too.  Two stages (double buffer), one workgroup barrier per k-step.
+//   waves     WM x WN waves, each TM x TN accumulator tiles of 32 x 32 (v_mfma_f32_32x32x16_f16); the first half of
+//             the waves splits + stores the next stage BEFORE its matrix work, the second half AFTER it: the two waves
+//             that share a SIMD are in opposite phases, one's vector work runs under the other's MFMAs.
+//   grid      one workgroup per (tile, batch, k-split), XCD-contiguous tile ranges; k-splits write slabs that a second
+//             kernel sums in fixed order (deterministic), used where M x N alone cannot fill 256 CUs (weight gradients).
+//
+// Roofline: MFMA; algorithmic FLOP = 2 M N K, issued as 3 f16 passes -> peak 2500 / 3 = 833 TFLOP/s.
+#include "dcl_common.h"
+#include <type_traits>
+
+// A/B and bound probes (tools/probes/gemm_ab.sh); the product build leaves them at their defaults
+#ifndef DCL_GEMM_PROBE
+#define DCL_GEMM_PROBE 0        // bits: 1 no MFMAs, 2 no split + LDS stores, 4 no global loads (results wrong)
+#endif
+#ifndef DCL_GEMM_PINGPONG
+#define DCL_GEMM_PINGPONG 1     // 0: every wave stages before its matrix work
+#endif
+#ifndef DCL_GEMM_PF
+#define DCL_GEMM_PF 1           // 1: fragment reads issued one MFMA group ahead (fenced); 0: compiler order
+#endif
+#define GEMM_MFMA(A, B, C) ((DCL_GEMM_PROBE & 1) ? (C) : __builtin_amdgcn_mfma_f32_32x32x16_f16((A), (B), (C), 0, 0, 0))
+
+namespace {
+
+constexpr float F16_TARGET_G = 16384.0f;
+
+__device__ __forceinline__ float pow2_scale_g(float amax)
+{
+    return amax == 0.f ? 1.f : exp2f(fminf(fmaxf(floorf(log2f(F16_TARGET_G / amax)), -100.f), 100.f));
+}
+
+// packed f16 pairs of hi = f16(v * s), lo = f16(v * s - hi) for two values (see dcl_conv3x3.hip)
+__device__ __forceinline__ void split2g(float v0, float v1, float s, unsigned &hi, unsigned &lo)
+{
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(v0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(v0), "v"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "v"(s), "v"(hi));
+}
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+struct GemmArgs {
+    const float *A, *B;
+    float *C;                       // result, or the slab workspace when splitk > 1
+    const float *bias;              // [N] or null (ignored when splitk > 1: the slab sum adds it)
+    const float *a_amax, *b_amax;   // a_count / b_count partial maxima each: upper bounds of max|A|, max|B|
+    int a_count, b_count;
+    float *c_amax;                  // optional: atomic max of |C| (as int bits; caller zero-initialises)
+    long lda, ldb, ldc;
+    long sA, sB, sC;                // batch strides in elements
+    int M, N, K;
+    int batch, splitk;
+    int tiles_m, tiles_n;
+    int accumulate;                 // C += (splitk == 1 only)
+};
+
+// LDS image of one operand tile and stage: [hi | lo][k-group of 8 k: 4][slot: BX + 2] 16-byte units.  The two pad units
+// make the k-group stride 8 banks (mod 32, the store banking) so that a 16-lane group of ds_write_b64 -- two rows x four
+// k-groups -- lands on 32 distinct banks.  Slot of row r: k-major operands: r (ds_read_b128 serves the lane groups
+// {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}: 16 distinct 16-byte slots of the 256-byte bank row each).  Row-contiguous
+// operands, whose stores are 8-lane groups writing rows 4 l + i: within a 32-row block, row 4 m + i sits at slot
+// 8 i + (m ^ (i >> 1)) -- the 8 lanes of a store hit 8 distinct slots (mod 8), and a read group's 16 rows stay on 16
+// distinct slots (mod 16) because {0, 3, 5, 6} ^ 1 = {1, 2, 4, 7}.
+template <bool KM>
+__device__ __forceinline__ int slot_of(int r)
+{
+    if constexpr (KM)
+        return r;
+    const int m = (r >> 2) & 7, i = r & 3;
+    return (r & ~31) | (8 * i + (m ^ (i >> 1)));
+}
+
+// One thread's share of an operand tile (BX rows x 32 k = BX units of 32 elements; unit u): where it loads from and
+// where it stores to.  All per-k-step address arithmetic is scalar (a uniform base pointer advances; the lane part is a
+// 32-bit byte offset computed once).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BX, bool KM>
+struct Stager {
+    static constexpr int KG = BX + 2;
+    unsigned voff[KM ? 8 : 1];      // lane byte offsets into the operand (buffer addressing: 32-bit, bounds-checked)
+    unsigned wa, wb;                // LDS byte offsets (from the operand's hi image of stage 0)
+    unsigned step, ldb;             // bytes per k-step (scalar offset advance); row-contiguous: bytes per k row
+
+    __device__ __forceinline__ void init(int u, long ld, int row0, int rows)
+    {
+        if constexpr (KM) {
+            const int k4 = u & 7;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = min(row0 + (u >> 3) + j * (BX / 8), rows - 1);
+                voff[j] = (unsigned)(((long)r * ld + 4 * k4) * 4);
+            }
+            wa = (unsigned)((((k4 >> 1) * KG + (u >> 3)) * 2 + (k4 & 1)) * 8);
+            wb = 0;
+            step = 32 * 4;
+            ldb = 0;
+        } else {
+            const int m4 = u % (BX / 4), kg = u / (BX / 4);
+            const int r = min(row0 + 4 * m4, rows - 4);
+            voff[0] = (unsigned)(((long)(8 * kg) * ld + r) * 4);
+            const int blk = m4 >> 3, m = m4 & 7;
+            wa = (unsigned)((kg * KG + 32 * blk + m) * 16);
+            wb = (unsigned)((kg * KG + 32 * blk + (m ^ 1)) * 16);
+            step = (unsigned)(32 * ld * 4);
+            ldb = (unsigned)(ld * 4);
+        }
+    }
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, unsigned soff, float4 (&v)[8]) const
+    {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            u32x4 w;
+            if constexpr (KM)
+                w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], soff, 0);
+            else
+                w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[0], soff + j * ldb, 0);
+            v[j] = __builtin_bit_cast(float4, w);
+        }
+    }
+    __device__ __forceinline__ void store(char *__restrict__ hi, float s, const float4 (&v)[8]) const
+    {
+        if constexpr (KM) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint2 h, l;
+                split2g(v[j].x, v[j].y, s, h.x, l.x);
+                split2g(v[j].z, v[j].w, s, h.y, l.y);
+                *reinterpret_cast<uint2 *>(hi + wa + j * (BX / 8) * 16) = h;
+                *reinterpret_cast<uint2 *>(hi + wa + j * (BX / 8) * 16 + 4 * KG * 16) = l;
+            }
+        } else {
+            const float *f = reinterpret_cast<const float *>(&v[0]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint4 h, l;
+                split2g(f[0 * 4 + i], f[1 * 4 + i], s, h.x, l.x);
+                split2g(f[2 * 4 + i], f[3 * 4 + i], s, h.y, l.y);
+                split2g(f[4 * 4 + i], f[5 * 4 + i], s, h.z, l.z);
+                split2g(f[6 * 4 + i], f[7 * 4 + i], s, h.w, l.w);
+                char *q = hi + ((i >> 1) ? wb : wa) + 8 * i * 16;
+                *reinterpret_cast<uint4 *>(q) = h;
+                *reinterpret_cast<uint4 *>(q + 4 * KG * 16) = l;
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ void lds_barrier()
+{
+    // LDS traffic only: __syncthreads() would also drain vmcnt, i.e. the global loads of the NEXT k-step
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int TM, int TN, int WM, int WN, bool AKM, bool BKM>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
+{
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+    constexpr int KGA = BM + 2, KGB = BN + 2;
+    constexpr int A_BYTES = 8 * KGA * 16, B_BYTES = 8 * KGB * 16;
+    constexpr int STAGE = A_BYTES + B_BYTES;            // bytes per stage: A hi | A lo | B hi | B lo
+    static_assert(BM + BN <= NT, "one staging unit per thread");
+    static_assert(BM % 64 == 0 && BN % 64 == 0, "staging roles are wave-uniform");
+    extern __shared__ uint4 lds_u4[];
+    char *lds = reinterpret_cast<char *>(lds_u4);
+
+    // ---- which tile: XCD x gets a contiguous range of the (z, tile_m, tile_n) order
+    const int G = gridDim.x;
+    int g = blockIdx.x;
+    {
+        const int x = g & 7, i = g >> 3;
+        g = x * (G >> 3) + min(x, G & 7) + i;
+    }
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int z = g / tiles, t = g - z * tiles;
+    const int tm = t / a.tiles_n, tn = t - tm * a.tiles_n;
+    const int b = z / a.splitk, ks = z - b * a.splitk;
+    const int nk = a.K / 32;
+    const int kbeg = (int)((long)nk * ks / a.splitk), kend = (int)((long)nk * (ks + 1) / a.splitk);
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const bool stA = wave < BM / 64;                    // wave-uniform staging roles
+    const bool stB = !stA && wave < (BM + BN) / 64;
+    const bool early = !DCL_GEMM_PINGPONG || wave < (WM * WN) / 2;            // split + store before (true) or after (false) the MFMAs:
+                                                        // waves w and w + 4 share a SIMD
+    float ma = 0.f, mb = 0.f;
+    for (int i = lane; i < a.a_count; i += 64)
+        ma = fmaxf(ma, a.a_amax[i]);
+    for (int i = lane; i < a.b_count; i += 64)
+        mb = fmaxf(mb, a.b_amax[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ma = fmaxf(ma, __shfl_xor(ma, o, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+    }
+    const float sa = pow2_scale_g(ma), sb = pow2_scale_g(mb);
+
+    // the operand this wave stages, as a bounds-checked buffer (reads past the last element return 0), and the scalar
+    // byte offset of the k-step it loads next
+    Stager<BM, AKM> sA;
+    Stager<BN, BKM> sB;
+    const float *gbase = stA ? a.A + (long)b * a.sA : a.B + (long)b * a.sB;
+    const long gelems = stA ? (AKM ? (long)(a.M - 1) * a.lda + a.K : (long)(a.K - 1) * a.lda + a.M)
+                            : (BKM ? (long)(a.N - 1) * a.ldb + a.K : (long)(a.K - 1) * a.ldb + a.N);
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gbase), 0, (int)(unsigned)(gelems * 4), 0x00020000);
+    unsigned gstep = 0;
+    if (stA) {
+        sA.init(tid, a.lda, row0, a.M);
+        gstep = sA.step;
+    } else if (stB) {
+        sB.init(tid - BM, a.ldb, col0, a.N);
+        gstep = sB.step;
+    }
+    unsigned goff = (unsigned)kbeg * gstep;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.f;
+
+    // fragment addresses: lane (row l & 31, k-group l >> 5 of the substep); tiles, substeps and hi / lo are immediates
+    const unsigned fa = (unsigned)(((lane >> 5) * KGA + slot_of<AKM>(32 * wm * TM + (lane & 31))) * 16);
+    const unsigned fb = (unsigned)(A_BYTES + ((lane >> 5) * KGB + slot_of<BKM>(32 * wn * TN + (lane & 31))) * 16);
+
+    float4 v[8];
+    auto load = [&]() {
+        if (DCL_GEMM_PROBE & 4)
+            return;
+        if (stA)
+            sA.load(rsrc, goff, v);
+        else if (stB)
+            sB.load(rsrc, goff, v);
+        goff += gstep;
+    };
+    auto store = [&](int stage) {
+        if (DCL_GEMM_PROBE & 2)
+            return;
+        char *base = lds + stage * STAGE;
+        if (stA)
+            sA.store(base, sa, v);
+        else if (stB)
+            sB.store(base + A_BYTES, sb, v);
+    };
+
+    if (kbeg < kend) {
+        load();
+        store(0);
+        if (kbeg + 1 < kend)
+            load();
+    }
+    lds_barrier();
+
+    for (int k = kbeg; k < kend; ++k) {
+        const int cur = (k - kbeg) & 1;
+        const bool more = k + 1 < kend;
+        if (early && more) {
+            store(cur ^ 1);
+            if (k + 2 < kend)
+                load();
+        }
+        const char *st = lds + cur * STAGE;
+#if DCL_GEMM_PF
+        // groups: X(s) = {A hi, B lo}, Y(s) = {A lo, B hi} of substep s; each is requested one MFMA group before its
+        // first use (the fences keep the compiler from sinking the reads to their uses)
+        h8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+        auto readX = [&](int s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                ah[s][i] = *reinterpret_cast<const h8 *>(st + fa + (32 * i + 2 * s * KGA) * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bl[s][j] = *reinterpret_cast<const h8 *>(st + fb + (32 * j + 2 * s * KGB + 4 * KGB) * 16);
+        };
+        auto readY = [&](int s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                al[s][i] = *reinterpret_cast<const h8 *>(st + fa + (32 * i + 2 * s * KGA + 4 * KGA) * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bh[s][j] = *reinterpret_cast<const h8 *>(st + fb + (32 * j + 2 * s * KGB) * 16);
+        };
+        auto mm = [&](h8 (&x)[TM], h8 (&y)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = GEMM_MFMA(x[i], y[j], acc[i][j]);
+        };
+        readX(0);
+        readY(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah[0], bl[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        readX(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(al[0], bh[0]);
+        mm(ah[0], bh[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        readY(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah[1], bl[1]);
+        mm(al[1], bh[1]);
+        mm(ah[1], bh[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#else
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const h8 *>(st + fa + (32 * i + 2 * s * KGA) * 16);
+                al[i] = *reinterpret_cast<const h8 *>(st + fa + (32 * i + 2 * s * KGA + 4 * KGA) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const h8 *>(st + fb + (32 * j + 2 * s * KGB) * 16);
+                bl[j] = *reinterpret_cast<const h8 *>(st + fb + (32 * j + 2 * s * KGB + 4 * KGB) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = GEMM_MFMA(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = GEMM_MFMA(al[i], bh[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = GEMM_MFMA(ah[i], bh[j], acc[i][j]);
+        }
+#endif
+        if (!early && more) {
+            store(cur ^ 1);
+            if (k + 2 < kend)
+                load();
+        }
+        lds_barrier();
+    }
+
+    // ---- epilogue: acc register r of tile (i, j) is row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32
+    const float inv = 1.0f / (sa * sb);
+    float *C = a.C + (long)z * a.sC;                    // sC: batch stride, or the slab stride when splitk > 1
+    float mx = 0.f;
+    const bool full = row0 + BM <= a.M && col0 + BN <= a.N;     // uniform: interior tiles store without per-element tests
+    auto epilogue = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + 32 * (wn * TN + j) + (lane & 31);
+            const bool cok = FULL || col < a.N;
+            const float bv = (a.bias && cok) ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = row0 + 32 * (wm * TM + i) + 4 * (lane >> 5);
+                float *p0 = C + (long)rbase * a.ldc + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = 8 * (r >> 2) + (r & 3);
+                    if (FULL || (cok && rbase + dr < a.M)) {
+                        float *p = p0 + (long)dr * a.ldc;
+                        float val = acc[i][j][r] * inv + bv;
+                        if (a.accumulate)
+                            val += *p;
+                        *p = val;
+                        mx = fmaxf(mx, fabsf(val));
+                    }
+                }
+            }
+        }
+    };
+    if (full)
+        epilogue(std::true_type{});
+    else
+        epilogue(std::false_type{});
+    if (a.c_amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0 && mx > __builtin_nontemporal_load(a.c_amax))
+            atomicMax(reinterpret_cast<int *>(a.c_amax), __float_as_int(mx));
+    }
+}
+
+// C[i] = (accumulate ? C[i] : 0) + bias[col] + sum over the slabs in ascending order; 4 x 4 elements per thread
+__global__ __launch_bounds__(256) void k_gemm_slab_sum(const float *__restrict__ ws, int slabs, long slab_stride,
+                                                       const float *__restrict__ bias, float *__restrict__ C, long ldc,
+                                                       int M, int N, int accumulate, float *c_amax)
+{
+    const long total = (long)M * N / 4;
+    float mx = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const long q = ((long)blockIdx.x * 4 + it) * 256 + threadIdx.x;     // quad index over M * N / 4
+        if (q >= total)
+            break;
+        const long e = q * 4;
+        const int row = (int)(e / N), col = (int)(e - (long)row * N);
+        float4 s = *reinterpret_cast<const float4 *>(ws + e);
+        for (int k = 1; k < slabs; ++k) {
+            const float4 p = *reinterpret_cast<const float4 *>(ws + k * slab_stride + e);
+            s.x += p.x, s.y += p.y, s.z += p.z, s.w += p.w;
+        }
+        if (bias)
+            s.x += bias[col], s.y += bias[col + 1], s.z += bias[col + 2], s.w += bias[col + 3];
+        float *p = C + (long)row * ldc + col;
+        if (accumulate)
+            s.x += p[0], s.y += p[1], s.z += p[2], s.w += p[3];
+        *reinterpret_cast<float4 *>(p) = s;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))));
+    }
+    if (c_amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        // one atomic per wave at most, and only while it would still raise the maximum (a plain read first: tens of
+        // thousands of same-address atomics serialise in L2 -- 0.4 ms on a 6400 x 1536 result)
+        if ((threadIdx.x & 63) == 0 && mx > __builtin_nontemporal_load(c_amax))
+            atomicMax(reinterpret_cast<int *>(c_amax), __float_as_int(mx));
+    }
+}
+
+int g_gemm_tile = 0;        // 0 = automatic; 1 = 256 x 256, 2 = 256 x 128, 3 = 128 x 256, 4 = 128 x 128
+
+struct TileCfg { int bm, bn, nt; };
+constexpr TileCfg TILES[4] = {{256, 256, 512}, {256, 128, 512}, {128, 256, 512}, {128, 128, 256}};
+
+int pick_tile(int M, int N, int z)
+{
+    if (g_gemm_tile >= 1 && g_gemm_tile <= 4)
+        return g_gemm_tile - 1;
+    // cost model: rounds of 256 workgroups x work per workgroup (tile area, smaller tiles pay ~10-25 % more per FLOP)
+    const double eff[4] = {1.0, 0.90, 0.90, 0.75};
+    int best = 0;
+    double bc = 1e30;
+    for (int c = 0; c < 4; ++c) {
+        const long wg = (long)((M + TILES[c].bm - 1) / TILES[c].bm) * ((N + TILES[c].bn - 1) / TILES[c].bn) * z;
+        const long rounds = (wg + 255) / 256;
+        // a partial last round costs a full tile time; below one round the time is one tile regardless
+        const double cost = (double)rounds * TILES[c].bm * TILES[c].bn / eff[c];
+        if (cost < bc)
+            bc = cost, best = c;
+    }
+    return best;
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_gemm(const GemmArgs &a, int akm, int bkm, hipStream_t stream)
+{
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr size_t lds_bytes = 2 * (8 * (BM + 2) + 8 * (BN + 2)) * sizeof(uint4);
+    const dim3 grid((unsigned)(a.tiles_m * a.tiles_n * a.batch * a.splitk)), block(64 * WM * WN);
+#define DCL_GEMM_LAUNCH(AK, BK)                                                                                       \
+    do {                                                                                                              \
+        static bool attr_done = false;                                                                                \
+        if (!attr_done) {                                                                                             \
+            (void)hipFuncSetAttribute((const void *)k_gemm<TM, TN, WM, WN, AK, BK>,                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                    \
+            attr_done = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, AK, BK>), grid, block, lds_bytes, stream, a);                      \
+    } while (0)
+    if (akm && bkm)
+        DCL_GEMM_LAUNCH(true, true);
+    else if (akm)
+        DCL_GEMM_LAUNCH(true, false);
+    else if (bkm)
+        DCL_GEMM_LAUNCH(false, true);
+    else
+        DCL_GEMM_LAUNCH(false, false);
+#undef DCL_GEMM_LAUNCH
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dcl_gemm_set_tile(int tile)
+{
+    DCL_CHECK_ARG(tile >= 0 && tile <= 4, "tile must be 0 (automatic) .. 4");
+    g_gemm_tile = tile;
+    return 0;
+}
+
+extern "C" int dcl_gemm_supported(int M, int N, int K, int64_t lda, int a_kmajor, int64_t ldb, int b_kmajor)
+{
+    if (M < 1 || N < 1 || K < 32 || K % 32)
+        return 0;
+    if (lda % 4 || ldb % 4)
+        return 0;
+    if (!a_kmajor && (M % 4 || M < 4))
+        return 0;
+    if (!b_kmajor && (N % 4 || N < 4))
+        return 0;
+    // lane offsets are 32-bit byte offsets from a uniform base
+    const int64_t ea = a_kmajor ? (int64_t)M * lda : (int64_t)32 * lda + M;
+    const int64_t eb = b_kmajor ? (int64_t)N * ldb : (int64_t)32 * ldb + N;
+    if (ea * 4 >= ((int64_t)1 << 32) || eb * 4 >= ((int64_t)1 << 32))
+        return 0;
+    return 1;
+}
+
+extern "C" int64_t dcl_gemm_workspace_floats(int M, int N, int batch, int splitk)
+{
+    return splitk > 1 ? (int64_t)M * N * batch * splitk : 0;
+}
+
+extern "C" int dcl_gemm_suggest_splitk(int M, int N, int K, int batch)
+{
+    // fill 256 CUs: tiles of the largest shape that fits, at least 8 k-steps per split
+    const int c = pick_tile(M, N, batch);
+    const long wg = (long)((M + TILES[c].bm - 1) / TILES[c].bm) * ((N + TILES[c].bn - 1) / TILES[c].bn) * batch;
+    if (wg >= 192)
+        return 1;
+    long s = (256 + wg - 1) / wg;
+    const long maxs = K / 32 / 8;
+    if (s > maxs)
+        s = maxs;
+    return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t strideA, const float *B, int64_t ldb,
+                              int b_kmajor, int64_t strideB, int M, int N, int K, int batch, const float *a_amax,
+                              int a_count, const float *b_amax, int b_count, const float *bias, float *C, int64_t ldc, int64_t strideC,
+                              int accumulate, float *c_amax, int splitk, float *ws, void *stream)
+{
+    DCL_CHECK_ARG(A && B && C && a_amax && b_amax, "null pointer");
+    DCL_CHECK_ARG(batch >= 1 && splitk >= 1 && a_count >= 1 && b_count >= 1, "batch, splitk and the absmax counts must be >= 1");
+    DCL_CHECK_ARG(dcl_gemm_supported(M, N, K, lda, a_kmajor, ldb, b_kmajor),
+                  "unsupported shape (K % 32, leading dimensions % 4, row-contiguous operands need rows % 4)");
+    DCL_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && strideA % 4 == 0 && strideB % 4 == 0,
+                  "operands must be 16-byte aligned");
+    DCL_CHECK_ARG(splitk == 1 || (ws && N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16) == 0),
+                  "split-k needs a workspace and N, ldc multiples of 4");
+    DCL_CHECK_ARG(splitk <= K / 32, "more k-splits than k-steps");
+    GemmArgs a;
+    a.A = A, a.B = B, a.lda = lda, a.ldb = ldb, a.sA = strideA, a.sB = strideB;
+    a.a_amax = a_amax, a.b_amax = b_amax, a.a_count = a_count, a.b_count = b_count;
+    a.M = M, a.N = N, a.K = K, a.batch = batch, a.splitk = splitk;
+    if (splitk > 1) {
+        a.C = ws, a.ldc = N, a.sC = (long)M * N, a.bias = nullptr, a.c_amax = nullptr, a.accumulate = 0;
+    } else {
+        a.C = C, a.ldc = ldc, a.sC = strideC, a.bias = bias, a.c_amax = c_amax, a.accumulate = accumulate;
+    }
+    const int c = pick_tile(M, N, batch * splitk);
+    a.tiles_m = (M + TILES[c].bm - 1) / TILES[c].bm;
+    a.tiles_n = (N + TILES[c].bn - 1) / TILES[c].bn;
+    int rc;
+    switch (c) {
+    case 0: rc = launch_gemm<2, 4, 4, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
+    case 1: rc = launch_gemm<2, 2, 4, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
+    case 2: rc = launch_gemm<2, 2, 2, 4>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
+    default: rc = launch_gemm<2, 2, 2, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
+    }
+    if (rc != 0)
+        return rc;
+    if (splitk > 1) {
+        for (int b = 0; b < batch; ++b) {
+            const long quads = (long)M * N / 4;
+            hipLaunchKernelGGL(k_gemm_slab_sum, dim3((unsigned)((quads + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
+                               ws + (long)b * splitk * M * N, splitk, (long)M * N, bias, C + (long)b * strideC, (long)ldc, M, N,
+                               accumulate, c_amax);
+        }
+        DCL_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float *__restrict__ x, con
             }
         }
     }
-    if (yamax) {                                             // absmax side channel for an f16x3 consumer (dcl_tokgemm.hip)
+    if (yamax) {                                             // absmax side channel for an f16x3 consumer (dcl_gemm.hip)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
             ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));

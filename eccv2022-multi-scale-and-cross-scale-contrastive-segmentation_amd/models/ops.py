@@ -735,71 +735,146 @@ def use_gemm_conv1x1(module: torch.nn.Module) -> torch.nn.Module:
 
 # ---- token-major Linear (Swin: models/Swin.py qkv / proj / fc1 / fc2 / reduction) --------------------------------------
 
-def _token_slabs(m):
-    """Slabs of ~1024 tokens for the weight gradient of a token-major Linear; 0 = leave it to the library."""
-    if m < 32768:
-        return 0
-    for s in (256, 128, 64, 32, 16):
-        if m % s == 0 and m // s >= 1024:
-            return s
-    return 0
+# ---- split-f16 GEMM (csrc/dcl_gemm.hip) ---------------------------------------------------------------------------
+
+def gemm_supported(M, N, K, lda, a_kmajor, ldb, b_kmajor):
+    from .. import _lib
+    return bool(_lib.lib().dcl_gemm_supported(M, N, K, lda, int(a_kmajor), ldb, int(b_kmajor)))
+
+
+def gemm_f16x3(a, a_kmajor, lda, b, b_kmajor, ldb, M, N, K, out, ldc, a_amax, b_amax, bias=None, batch=1,
+               strides=(0, 0, 0), accumulate=False, c_amax=None, splitk=0):
+    """out[b][m][n] (+)= bias[n] + sum_k A[b](m, k) B[b](n, k) on dcl_gemm_f16x3 (fp32-equivalent split-f16 MFMA).
+
+    ``a`` / ``b`` are the tensors whose storage holds the operands (used for their data pointers); X_kmajor says whether
+    element (row, k) sits at X[row * ldx + k] (True) or X[k * ldx + row] (False).  ``a_amax`` / ``b_amax``: 1-D float
+    tensors whose maxima bound max|A| / max|B| (models.amax.amax_of).  splitk = 0: the library's suggestion."""
+    from .. import _lib
+    L = _lib.lib()
+    if splitk == 0:
+        splitk = L.dcl_gemm_suggest_splitk(M, N, K, batch)
+    ws = None
+    if splitk > 1:
+        ws = torch.empty(L.dcl_gemm_workspace_floats(M, N, batch, splitk), dtype=torch.float32, device=out.device)
+    p = _lib.ptr
+    _lib.check(L.dcl_gemm_f16x3(p(a), lda, int(a_kmajor), strides[0], p(b), ldb, int(b_kmajor), strides[1], M, N, K, batch,
+                                p(a_amax), a_amax.numel(), p(b_amax), b_amax.numel(), p(bias), p(out), ldc, strides[2],
+                                int(accumulate), p(c_amax), splitk, p(ws), _stream(out)), "dcl_gemm_f16x3")
+    return out
+
+
+def linear_f16x3(x2, weight, bias=None, tag_out=True):
+    """y [M, N] = x2 [M, K] weight[N, K]^T + bias (the forward of nn.Linear on contiguous rows)."""
+    from . import amax as _am
+    m, k = x2.shape
+    n = weight.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device=x2.device)
+    ca = _am.zeros(1, x2.device) if tag_out else None
+    gemm_f16x3(x2, True, k, weight, True, k, m, n, k, y, n, _am.amax_of(x2), _am.amax_of(weight), bias=bias, c_amax=ca)
+    if tag_out:
+        _am.tag(y, ca)
+    return y
+
+
+def linear_dgrad_f16x3(gy2, weight):
+    """dx [M, K] = gy2 [M, N] weight[N, K]."""
+    from . import amax as _am
+    m, n = gy2.shape
+    k = weight.shape[1]
+    gx = torch.empty((m, k), dtype=torch.float32, device=gy2.device)
+    ca = _am.zeros(1, gy2.device)
+    gemm_f16x3(gy2, True, n, weight, False, k, m, k, n, gx, k, _am.amax_of(gy2), _am.amax_of(weight), c_amax=ca)
+    return _am.tag(gx, ca)
+
+
+def linear_wgrad_f16x3(gy2, x2):
+    """dW [N, K] = gy2 [M, N]^T x2 [M, K] (contraction over the M rows, k-split slabs summed in fixed order)."""
+    from . import amax as _am
+    m, n = gy2.shape
+    k = x2.shape[1]
+    gw = torch.empty((n, k), dtype=torch.float32, device=gy2.device)
+    gemm_f16x3(gy2, False, n, x2, False, k, n, k, m, gw, k, _am.amax_of(gy2), _am.amax_of(x2))
+    return gw
 
 
 class _TokenLinear(torch.autograd.Function):
-    """y = x W^T + b on [tokens, K] rows with a slab-wise weight gradient.
+    """y = x W^T + b on [tokens, K] rows: forward, data gradient and weight gradient on dcl_gemm_f16x3.
 
-    dW = dY^T X reduces over 10^4..10^5 tokens into a tiny [N, K] output, a shape the library's fp32 kernels run at
-    10-40 TFLOP/s (one macro tile per output tile, the whole token axis serial: 450-1030 us where HBM allows 45-110,
-    tools/probes/linear_wgrad_split.py).  Here the token axis is cut into slabs of ~1024 rows, one batched GEMM computes
-    a partial dW per slab and a fixed-order sum adds them: 3-5x faster, deterministic.  Forward and data gradient are the
-    library's fp32 GEMMs.  (An f16x3 token GEMM on the direct convolutions' arithmetic was built in round 2, came out
-    within noise in the step and was retired in round 3: tools/probes/retired/dcl_tokgemm.hip.)"""
+    The library's fp32 GEMMs run these shapes at 60-110 TFLOP/s (forward / data gradient) and 10-40 TFLOP/s (dW = dY^T X
+    reduces over 10^4..10^5 tokens into a tiny [N, K] output: one macro tile per output tile, the whole token axis
+    serial); the split-f16 kernel reaches 190-360 with errors below the library's (tools/gemm_shapes.py), the weight
+    gradient as k-split slabs summed in fixed order (deterministic).  Operand scales come from absmax tags: the GEMM's own
+    epilogue tags its result, LayerNorm tags its output, GELU hands its input's bound through; anything else costs
+    one dcl_absmax pass."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+        n, k = weight.shape
+        x2 = x.reshape(-1, k)
+        ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        ctx.xshape = x.shape
+        y = linear_f16x3(x2, weight, bias)
+        out = y.view(*x.shape[:-1], n)
+        from . import amax as _am
+        t = _am.tag_of(y)
+        if t is not None:
+            _am.tag(out, t)
+        return out
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x2, weight = ctx.saved_tensors
         n, k = weight.shape
         gy2 = gy.reshape(-1, n)
-        x2 = x.reshape(-1, k)
-        m = x2.shape[0]
+        if not gy2.is_contiguous():
+            gy2 = gy2.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = gy2.mm(weight).view(x.shape)
+            gx = linear_dgrad_f16x3(gy2, weight).view(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            s = _token_slabs(m)
-            if s and gy2.is_contiguous() and x2.is_contiguous():
-                gw = torch.bmm(gy2.view(s, m // s, n).transpose(1, 2), x2.view(s, m // s, k)).sum(0)
-            else:
-                gw = gy2.t().mm(x2)
+            gw = linear_wgrad_f16x3(gy2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gy2.sum(0)
         return gx, gw, gb
 
 
+def _token_gemm_ok(x, weight):
+    """Shapes the split-f16 GEMM takes for all three products of a Linear: every extent a multiple of 32 (each is the
+    contraction of one of them), the token rows contiguous."""
+    n, k = weight.shape
+    m = x.numel() // k
+    return m >= 1024 and m % 32 == 0 and k % 32 == 0 and n % 32 == 0 and x.is_contiguous() and weight.is_contiguous() \
+        and m * max(n, k) * 4 < (1 << 32)
+
+
 class TokenLinear(torch.nn.Linear):
-    """nn.Linear (same parameters / state_dict keys) for token-major fp32 CUDA rows in training: slab-wise weight
-    gradient from 32768 rows on; anything else is nn.Linear.forward."""
+    """nn.Linear (same parameters / state_dict keys) for token-major fp32 CUDA rows in training: the three GEMMs on the
+    split-f16 kernel (csrc/dcl_gemm.hip); anything else is nn.Linear.forward.  ``f16x3 = False`` (class switch, the
+    eager comparator of tools / tests) keeps the library's GEMMs."""
+
+    f16x3 = True
 
     def forward(self, x):
-        if (x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and self.weight.requires_grad
-                and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
-            if _token_slabs(x.numel() // x.shape[-1]):
-                return _TokenLinear.apply(x, self.weight, self.bias)
+        if (self.f16x3 and x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32
+                and self.weight.requires_grad and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+                and _token_gemm_ok(x, self.weight)):
+            return _TokenLinear.apply(x, self.weight, self.bias)
         return super().forward(x)
 
 
 # ---- LayerNorm over token-major rows (csrc/dcl_layernorm.hip) -----------------------------------------------------
 
 def tagged_gelu(h):
-    """nn.GELU() (exact erf form).  (Kept under its round-2 name: it used to hand absmax tags through for the retired
-    f16x3 token GEMM.)"""
-    return torch.nn.functional.gelu(h)
+    """nn.GELU() (exact erf form); |gelu(v)| <= |v|, so the absmax tag of h bounds the result too (the operand scale of
+    the following fc2 GEMM without a pass over the 4C-wide activation)."""
+    out = torch.nn.functional.gelu(h)
+    if h.is_cuda:
+        from . import amax as _am
+        t = _am.tag_of(h)
+        if t is not None:
+            _am.tag(out, t)
+    return out
 
 
 def _amax_mod():
@@ -815,6 +890,10 @@ class _LayerNormFn(torch.autograd.Function):
         m = x.numel() // c
         y = torch.empty_like(x)
         stats = torch.empty((2, m), dtype=torch.float32, device=x.device)
+        if ybuf is None:            # absmax tag of y for the Linear behind the norm (the split-f16 GEMM's operand scale)
+            from . import amax as _am
+            ybuf = _am.zeros(_am.SLOTS, x.device)
+            _am.tag(y, ybuf)
         _lib.check(_lib.lib().dcl_layernorm_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, float(eps),
                                                 _lib.ptr(y), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(ybuf),
                                                 _stream(x)), "dcl_layernorm_fwd")

@@ -283,6 +283,32 @@ int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1 /* may be NUL
 int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
                   float *dz, void *stream);
 
+/* ---- split-f16 GEMM, f32 in / out (csrc/dcl_gemm.hip) ------------------------------------------------------------
+ * C[b][m][n] = (accumulate ? C : 0) + bias[n] + sum_k A[b](m, k) * B[b](n, k),  b < batch, at fp32-equivalent accuracy
+ * (hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16, f32 accumulation).  Drop-in for the fp32 library GEMMs behind
+ * nn.Linear on token-major rows (reference models/Swin.py:62-76, :198-230, :357-362: forward x W^T + b, data gradient
+ * dy W, weight gradient dy^T x), the large 1x1 convolutions (models/HRNet.py:63-100, :236-262, models/UPerNet.py) and
+ * the tap products of the HRNet head (dcl_tapup_*).
+ *   operand X in {A, B} is addressed as (row, k): x_kmajor = 1: element at X[row * ldx + k] (the contraction index is
+ *   contiguous); 0: X[k * ldx + row] (the row index is contiguous, rows % 4 == 0).  K % 32 == 0, ldx % 4 == 0, 16-byte
+ *   aligned bases and batch strides (dcl_gemm_supported says whether a shape qualifies; 0 -> use the library).
+ *   a_amax / b_amax: a_count / b_count device floats whose maximum is an upper bound of max|A| / max|B| (dcl_absmax,
+ *   or a producer's partial maxima): the operand scales are powers of two derived from them on the device.  c_amax (optional, zero-initialised by the caller)
+ *   receives max|C| through an integer atomic max -- the tag of the next consumer.
+ *   splitk > 1: the contraction is cut into splitk ranges, each writes a slab to ws (dcl_gemm_workspace_floats floats)
+ *   and a second kernel sums the slabs in ascending order (+ bias, + C): deterministic; for outputs too small to fill
+ *   256 CUs (weight gradients).  dcl_gemm_suggest_splitk returns 1 when the tiles alone fill the chip.
+ *   dcl_gemm_set_tile: 0 automatic, 1..4 = 256x256 / 256x128 / 128x256 / 128x128 workgroup tile (A/B runs). */
+int dcl_gemm_supported(int M, int N, int K, int64_t lda, int a_kmajor, int64_t ldb, int b_kmajor);
+int64_t dcl_gemm_workspace_floats(int M, int N, int batch, int splitk);
+int dcl_gemm_suggest_splitk(int M, int N, int K, int batch);
+int dcl_gemm_set_tile(int tile);
+int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t strideA, const float *B, int64_t ldb, int b_kmajor,
+                   int64_t strideB, int M, int N, int K, int batch, const float *a_amax, int a_count,
+                   const float *b_amax, int b_count,
+                   const float *bias /* [N] or NULL */, float *C, int64_t ldc, int64_t strideC, int accumulate,
+                   float *c_amax /* or NULL */, int splitk, float *ws /* or NULL */, void *stream);
+
 /* out = a + b (+ c) (+ d), n floats: the gradient of a tensor with several consumers in one pass (HRNet exchange
  * modules: every branch output feeds all fuse rows, reference models/HRNet.py:264-287). */
 int dcl_add_n(const float *a, const float *b, const float *c /* or NULL */, const float *d /* or NULL */, int64_t n,

@@ -1346,3 +1346,66 @@ def test_stride2_gradient_formulations_agree(dev):
     finally:
         L.dcl_conv3x3_set_up2_phases(1)
         L.dcl_wgrad3x3_set_stride2(1)
+
+
+# ---- split-f16 GEMM (csrc/dcl_gemm.hip) ---------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_gemm_f16x3_every_layout_matches_fp64(dev, tile):
+    """dcl_gemm_f16x3: all four operand layouts (contraction index contiguous / row index contiguous), ragged M and N,
+    one to many k-steps, batch, bias, accumulate, k-split slabs and the absmax side output, every workgroup tile, against
+    float64 (3e-6 of max: the bound of the direct convolutions; the library's fp32 GEMM is measured beside it)."""
+    from mscs_amd import _lib
+    from mscs_amd.models import ops
+    from mscs_amd.models.amax import amax_of
+    L = _lib.lib()
+    torch.manual_seed(5 + tile)
+    try:
+        L.dcl_gemm_set_tile(tile)
+        for (M, N, K, batch) in [(100, 36, 32, 1), (260, 520, 96, 1), (512, 256, 64, 2), (36, 700, 416, 3), (1028, 132, 160, 1)]:
+            for akm in (True, False):
+                for bkm in (True, False):
+                    A = torch.randn((batch, M, K) if akm else (batch, K, M), device=dev)
+                    B = torch.randn((batch, N, K) if bkm else (batch, K, N), device=dev) * 0.03
+                    bias = torch.randn(N, device=dev)
+                    C0 = torch.randn(batch, M, N, device=dev)
+                    Ad = A.double() if akm else A.double().transpose(1, 2)
+                    Bd = B.double() if bkm else B.double().transpose(1, 2)
+                    ref = Ad @ Bd.transpose(1, 2)
+                    for splitk in (1, 2) if K >= 64 else (1,):
+                        for acc in (False, True):
+                            out = C0.clone() if acc else torch.full((batch, M, N), float("nan"), device=dev)
+                            ca = torch.zeros(1, device=dev)
+                            ops.gemm_f16x3(A, akm, K if akm else M, B, bkm, K if bkm else N, M, N, K, out, N, amax_of(A),
+                                           amax_of(B), bias=bias, batch=batch, strides=(M * K, N * K, M * N),
+                                           accumulate=acc, c_amax=ca, splitk=splitk)
+                            want = ref + bias.double() + (C0.double() if acc else 0)
+                            err = ((out.double() - want).abs().max() / ref.abs().max()).item()
+                            assert err < 3e-6, (tile, M, N, K, batch, akm, bkm, splitk, acc, err)
+                            assert abs(ca.item() - out.abs().max().item()) <= 1e-6 * out.abs().max().item()
+    finally:
+        L.dcl_gemm_set_tile(0)
+
+
+@pytest.mark.gpu
+def test_gemm_f16x3_linear_triplet_at_swin_shapes(dev):
+    """The three GEMMs of a token-major Linear (forward, data gradient, slab-wise weight gradient) at a Swin stage-3 shape:
+    each at least as close to float64 as the library's fp32 GEMM, and bitwise reproducible (fixed-order slab sums)."""
+    from mscs_amd.models import ops
+    torch.manual_seed(17)
+    m, k, n = 6400, 768, 2304
+    x = torch.randn(m, k, device=dev)
+    w = torch.randn(n, k, device=dev) * 0.02
+    b = torch.randn(n, device=dev)
+    gy = torch.randn(m, n, device=dev) * 1e-3
+    for mine, lib, ref in [
+            (lambda: ops.linear_f16x3(x, w, b), lambda: torch.nn.functional.linear(x, w, b), lambda: x.double() @ w.double().t() + b.double()),
+            (lambda: ops.linear_dgrad_f16x3(gy, w), lambda: gy.mm(w), lambda: gy.double() @ w.double()),
+            (lambda: ops.linear_wgrad_f16x3(gy, x), lambda: gy.t().mm(x), lambda: gy.double().t() @ x.double())]:
+        r = ref()
+        a, a2, l = mine(), mine(), lib()
+        e_mine = ((a.double() - r).abs().max() / r.abs().max()).item()
+        e_lib = ((l.double() - r).abs().max() / r.abs().max()).item()
+        assert e_mine < 3e-6 and e_mine <= 2 * e_lib + 1e-7, (e_mine, e_lib)
+        assert torch.equal(a, a2)

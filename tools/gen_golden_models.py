@@ -181,7 +181,25 @@ def module_cases(only):
         c = 720
         return nn.Sequential(nn.Conv2d(c, c, 3, 1, 1), nn.BatchNorm2d(c), nn.Conv2d(c, 19, 1, bias=False)), [(2, c, 32, 64)]
 
-    builders = {"G13_module_stage3": lambda: exchange(3, (48, 96, 192), (64, 128)),
+    def swin_stage():
+        # one Swin-L stage-1 layer (two blocks, the second shifted) + patch merging on 2 x (32 x 32) tokens: the Linears
+        # (2 048 rows), LayerNorms and 7 x 7 window attention with padding (32 -> 35) of the f3 / f4 rows
+        ref_swin = importlib.import_module("models.Swin")
+
+        class Stage(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.layer = ref_swin.BasicLayer(dim=192, depth=2, num_heads=6, window_size=7,
+                                                 downsample=ref_swin.PatchMerging)
+
+            def forward(self, x):
+                o = self.layer(x, 32, 32)
+                return o[0], o[3]
+
+        return Stage(), [(2, 1024, 192)]
+
+    builders = {"G13_module_swin_stage": swin_stage,
+                "G13_module_stage3": lambda: exchange(3, (48, 96, 192), (64, 128)),
                 "G13_module_stage4": lambda: exchange(4, (48, 96, 192, 384), (64, 128)),
                 "G13_module_layer1": layer1, "G13_module_head": head}
     for name, build in builders.items():
@@ -211,7 +229,7 @@ def module_cases(only):
             d[tag + "pgrad_abs_max"] = np.array([g.abs().max().item() for g in grads], dtype=np.float32)
             d[tag + "pgrad_sample"], d[tag + "pgrad_step"] = strided(torch.cat([g.flatten() for g in grads]), 16384)
             stats = torch.cat([b.flatten().float() for k, b in mod.named_buffers()
-                               if k.endswith("running_mean") or k.endswith("running_var")])
+                               if k.endswith("running_mean") or k.endswith("running_var")] + [torch.zeros(1)])
             d[tag + "running_sample"], d[tag + "running_step"] = strided(stats, 4096)
         d["input_shapes"] = np.array(shapes, dtype=np.int32)
         d["n_outputs"] = np.int32(len(outs))
