@@ -30,7 +30,8 @@
 
 // A/B and bound probes (tools/probes/gemm_ab.sh); the product build leaves them at their defaults
 #ifndef DCL_GEMM_PROBE
-#define DCL_GEMM_PROBE 0        // bits: 1 no MFMAs, 2 no split + LDS stores, 4 no global loads (results wrong)
+#define DCL_GEMM_PROBE 0        // bits: 1 no MFMAs, 2 no split + LDS stores, 4 no global loads, 8 no split (raw bits
+                                // stored), 16 split but no LDS stores (results wrong)
 #endif
 #ifndef DCL_GEMM_PINGPONG
 #define DCL_GEMM_PINGPONG 1     // 0: every wave stages before its matrix work
@@ -145,8 +146,17 @@ struct Stager {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 uint2 h, l;
-                split2g(v[j].x, v[j].y, s, h.x, l.x);
-                split2g(v[j].z, v[j].w, s, h.y, l.y);
+                if (DCL_GEMM_PROBE & 8) {
+                    h = uint2{__float_as_uint(v[j].x), __float_as_uint(v[j].y)};
+                    l = uint2{__float_as_uint(v[j].z), __float_as_uint(v[j].w)};
+                } else {
+                    split2g(v[j].x, v[j].y, s, h.x, l.x);
+                    split2g(v[j].z, v[j].w, s, h.y, l.y);
+                }
+                if (DCL_GEMM_PROBE & 16) {
+                    asm volatile("" ::"v"(h.x), "v"(h.y), "v"(l.x), "v"(l.y));
+                    continue;
+                }
                 *reinterpret_cast<uint2 *>(hi + wa + j * (BX / 8) * 16) = h;
                 *reinterpret_cast<uint2 *>(hi + wa + j * (BX / 8) * 16 + 4 * KG * 16) = l;
             }
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
     const int z = g / tiles, t = g - z * tiles;
     const int tm = t / a.tiles_n, tn = t - tm * a.tiles_n;
     const int b = z / a.splitk, ks = z - b * a.splitk;
-    const int nk = a.K / 32;
+    const int nk = (a.K + 31) / 32;     // ragged only with two row-contiguous operands: k rows past K read as 0 (buffer bounds)
     const int kbeg = (int)((long)nk * ks / a.splitk), kend = (int)((long)nk * (ks + 1) / a.splitk);
     const int row0 = tm * BM, col0 = tn * BN;
 
@@ -517,7 +527,9 @@ extern "C" int dcl_gemm_set_tile(int tile)
 
 extern "C" int dcl_gemm_supported(int M, int N, int K, int64_t lda, int a_kmajor, int64_t ldb, int b_kmajor)
 {
-    if (M < 1 || N < 1 || K < 32 || K % 32)
+    if (M < 1 || N < 1 || K < 32)
+        return 0;
+    if (K % 32 && (a_kmajor || b_kmajor))       // a ragged contraction needs k rows that run out of the buffer
         return 0;
     if (lda % 4 || ldb % 4)
         return 0;
@@ -526,8 +538,8 @@ extern "C" int dcl_gemm_supported(int M, int N, int K, int64_t lda, int a_kmajor
     if (!b_kmajor && (N % 4 || N < 4))
         return 0;
     // lane offsets are 32-bit byte offsets from a uniform base
-    const int64_t ea = a_kmajor ? (int64_t)M * lda : (int64_t)32 * lda + M;
-    const int64_t eb = b_kmajor ? (int64_t)N * ldb : (int64_t)32 * ldb + N;
+    const int64_t ea = a_kmajor ? (int64_t)M * lda : (int64_t)(K + 31) * lda + M;
+    const int64_t eb = b_kmajor ? (int64_t)N * ldb : (int64_t)(K + 31) * ldb + N;
     if (ea * 4 >= ((int64_t)1 << 32) || eb * 4 >= ((int64_t)1 << 32))
         return 0;
     return 1;
@@ -560,12 +572,12 @@ extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t
     DCL_CHECK_ARG(A && B && C && a_amax && b_amax, "null pointer");
     DCL_CHECK_ARG(batch >= 1 && splitk >= 1 && a_count >= 1 && b_count >= 1, "batch, splitk and the absmax counts must be >= 1");
     DCL_CHECK_ARG(dcl_gemm_supported(M, N, K, lda, a_kmajor, ldb, b_kmajor),
-                  "unsupported shape (K % 32, leading dimensions % 4, row-contiguous operands need rows % 4)");
+                  "unsupported shape (K % 32 unless both operands are row-contiguous, leading dimensions % 4, row-contiguous operands need rows % 4)");
     DCL_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && strideA % 4 == 0 && strideB % 4 == 0,
                   "operands must be 16-byte aligned");
     DCL_CHECK_ARG(splitk == 1 || (ws && N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16) == 0),
                   "split-k needs a workspace and N, ldc multiples of 4");
-    DCL_CHECK_ARG(splitk <= K / 32, "more k-splits than k-steps");
+    DCL_CHECK_ARG(splitk <= (K + 31) / 32, "more k-splits than k-steps");
     GemmArgs a;
     a.A = A, a.B = B, a.lda = lda, a.ldb = ldb, a.sA = strideA, a.sB = strideB;
     a.a_amax = a_amax, a.b_amax = b_amax, a.a_count = a_count, a.b_count = b_count;

@@ -540,26 +540,40 @@ def use_direct_conv1x1(module: torch.nn.Module) -> torch.nn.Module:
 
 class _CoarseTaps(torch.autograd.Function):
     """addend [N, Co, H, W] = sum over the coarse maps x_b of conv3x3(up(x_b), weight[:, slice_b], padding=1), computed as
-    z_b = W_b x_b (ONE fp32 GEMM per map over all images: [9 Co, C_b] x [C_b, N h w]) at LOW resolution followed by the tap-wise
-    bilinear gather of csrc/dcl_resize.hip (k_tapup_fwd); backward: the gather's adjoint (k_tapup_bwd), then two GEMMs per map
-    (dx_b = W_b^T dz_b, dW_b = dz_b x_b^T).  ``weight`` is the FULL [Co, Cin, 3, 3] parameter, ``c0`` the first input channel
-    of the first coarse map; its gradient comes back full-size (zero outside the coarse slices)."""
+    z_b = W_b x_b (ONE split-f16 GEMM per map over all images: [9 Co, C_b] x [C_b, N h w], dcl_gemm_f16x3) at LOW resolution
+    followed by the tap-wise bilinear gather of csrc/dcl_resize.hip (k_tapup_fwd); backward: the gather's adjoint
+    (k_tapup_bwd), then two GEMMs per map (dx_b = W_b^T dz_b, dW_b = dz_b x_b^T as k-split slabs).  ``weight`` is the FULL
+    [Co, Cin, 3, 3] parameter, ``c0`` the first input channel of the first coarse map; its gradient comes back full-size
+    (zero outside the coarse slices).  ``gemm = False`` (class switch): the library's fp32 GEMMs."""
+
+    gemm = True
 
     @staticmethod
     def forward(ctx, align, H, W, c0, weight, *ts):
         from .. import _lib
+        from . import amax as _am
         L = _lib.lib()
         Co = weight.shape[0]
         n = ts[0].shape[0]
         y = torch.empty((n, Co, H, W), dtype=torch.float32, device=weight.device)
         st = _lib.stream_ptr(y.device)
-        saved, zs, off = [], [], c0
+        use_gemm = _CoarseTaps.gemm and all(t.shape[1] % 32 == 0 and (n * t.shape[2] * t.shape[3]) % 32 == 0 for t in ts)
+        wam = _am.amax_of(weight) if use_gemm else None
+        saved, zs, off, xams = [], [], c0, []
         for t in ts:
             cb, h, w = t.shape[1:]
-            xc = t.transpose(0, 1).reshape(cb, n * h * w)                                   # [C_b, N h w] (one copy)
+            P = n * h * w
+            xam = _am.amax_of(t) if use_gemm else None
+            xc = t.transpose(0, 1).reshape(cb, P)                                           # [C_b, N h w] (one copy)
             wb = weight[:, off:off + cb].permute(2, 3, 0, 1).reshape(9 * Co, cb)           # [(tap, co), ci]
-            zs.append((torch.mm(wb, xc), h, w))
+            if use_gemm:
+                z = torch.empty((9 * Co, P), dtype=torch.float32, device=y.device)
+                gemm_f16x3(wb, True, cb, xc, False, P, 9 * Co, P, cb, z, P, wam, xam, splitk=1)
+            else:
+                z = torch.mm(wb, xc)
+            zs.append((z, h, w))
             saved += [xc, wb]
+            xams.append(xam)
             off += cb
         for i in range(0, len(zs), 2):
             z0, h0, w0 = zs[i]
@@ -568,28 +582,47 @@ class _CoarseTaps(torch.autograd.Function):
                                        _lib.ptr(y), 1 if i else 0, st), "dcl_tapup_fwd")
         ctx.save_for_backward(*saved)
         ctx.geom = (bool(align), H, W, c0, tuple(weight.shape), [tuple(t.shape) for t in ts])
+        ctx.ams = (wam, xams) if use_gemm else None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from .. import _lib
+        from . import amax as _am
         L = _lib.lib()
         align, H, W, c0, wshape, shapes = ctx.geom
         Co = wshape[0]
         dy = dy.contiguous()
         st = _lib.stream_ptr(dy.device)
         gw = torch.zeros(wshape, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[4] else None
+        dyam = _am.amax_of(dy) if ctx.ams is not None else None
         grads, off = [], c0
         for i, (n, cb, h, w) in enumerate(shapes):
             xc, wb = ctx.saved_tensors[2 * i], ctx.saved_tensors[2 * i + 1]
-            dz = torch.empty((9 * Co, n * h * w), dtype=torch.float32, device=dy.device)
+            P = n * h * w
+            dz = torch.empty((9 * Co, P), dtype=torch.float32, device=dy.device)
             _lib.check(L.dcl_tapup_bwd(_lib.ptr(dy), n, Co, H, W, h, w, 1 if align else 0, 1, _lib.ptr(dz), st),
                        "dcl_tapup_bwd")
             gx = None
-            if ctx.needs_input_grad[5 + i]:
-                gx = torch.mm(wb.t(), dz).view(cb, n, h, w).transpose(0, 1).contiguous()
-            if gw is not None:
-                gw[:, off:off + cb] = torch.mm(dz, xc.t()).view(3, 3, Co, cb).permute(2, 3, 0, 1)
+            if ctx.ams is not None:
+                wam, xams = ctx.ams
+                # |dz| <= (weight a low-resolution pixel receives from the up-sampled map) x max|dy|: the bilinear weights of
+                # one source pixel sum to s_y s_x in the interior and to < 2 s per axis at a clamped border
+                dzam = dyam * float(4 * -(-H // h) * -(-W // w))
+                if ctx.needs_input_grad[5 + i]:
+                    gxc = torch.empty((cb, P), dtype=torch.float32, device=dy.device)
+                    # dx_b [C_b, P] = W_b^T dz: both operands row-contiguous (the contraction 9 Co = 6480 may be ragged)
+                    gemm_f16x3(wb, False, cb, dz, False, P, cb, P, 9 * Co, gxc, P, wam, dzam, splitk=1)
+                    gx = gxc.view(cb, n, h, w).transpose(0, 1).contiguous()
+                if gw is not None:
+                    gwb = torch.empty((9 * Co, cb), dtype=torch.float32, device=dy.device)
+                    gemm_f16x3(dz, True, P, xc, True, P, 9 * Co, cb, P, gwb, cb, dzam, xams[i])
+                    gw[:, off:off + cb] = gwb.view(3, 3, Co, cb).permute(2, 3, 0, 1)
+            else:
+                if ctx.needs_input_grad[5 + i]:
+                    gx = torch.mm(wb.t(), dz).view(cb, n, h, w).transpose(0, 1).contiguous()
+                if gw is not None:
+                    gw[:, off:off + cb] = torch.mm(dz, xc.t()).view(3, 3, Co, cb).permute(2, 3, 0, 1)
             grads.append(gx)
             off += cb
         return (None, None, None, None, gw, *grads)

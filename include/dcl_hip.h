@@ -290,7 +290,7 @@ int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, in
  * dy W, weight gradient dy^T x), the large 1x1 convolutions (models/HRNet.py:63-100, :236-262, models/UPerNet.py) and
  * the tap products of the HRNet head (dcl_tapup_*).
  *   operand X in {A, B} is addressed as (row, k): x_kmajor = 1: element at X[row * ldx + k] (the contraction index is
- *   contiguous); 0: X[k * ldx + row] (the row index is contiguous, rows % 4 == 0).  K % 32 == 0, ldx % 4 == 0, 16-byte
+ *   contiguous); 0: X[k * ldx + row] (the row index is contiguous, rows % 4 == 0).  K % 32 == 0 (any K >= 32 when BOTH operands are row-contiguous), ldx % 4 == 0, 16-byte
  *   aligned bases and batch strides (dcl_gemm_supported says whether a shape qualifies; 0 -> use the library).
  *   a_amax / b_amax: a_count / b_count device floats whose maximum is an upper bound of max|A| / max|B| (dcl_absmax,
  *   or a producer's partial maxima): the operand scales are powers of two derived from them on the device.  c_amax (optional, zero-initialised by the caller)

@@ -1266,13 +1266,16 @@ def test_fan_out_sums_consumer_gradients_in_one_kernel(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("align", [True, False])
 @pytest.mark.parametrize("chans,H,W,Co,bias", [((16, 32, 48, 64), 32, 64, 48, True), ((16, 16, 32, 32), 24, 40, 32, False),
-                                               ((48, 96, 192, 384), 64, 128, 96, True)])
+                                               ((48, 96, 192, 384), 64, 128, 96, True),
+                                               ((32, 64, 96, 128), 64, 64, 80, False)])
 def test_head_conv_over_upsampled_matches_fp64(dev, align, chans, H, W, Co, bias):
     """ops.conv3x3_over_upsampled (the channel products of the coarse maps at LOW resolution + the tap-wise bilinear gather
     k_tapup_fwd / k_tapup_bwd + a direct convolution of the fine maps) against the reference formulation -- F.conv2d over
     torch.cat of the F.interpolate'd maps (models/HRNet.py:549-553, :596-600) -- in float64: output and the gradients of
     every map, the weight and the bias, 3e-6 / 1e-5 of max; both align_corners settings, sizes that are not multiples of
-    the tiles, four pyramid levels (scales 1, 2, 4, 8) and a level count where only one map is coarse."""
+    the tiles, four pyramid levels (scales 1, 2, 4, 8) and a level count where only one map is coarse; the last two cases
+    take the split-f16 GEMM for the coarse maps' channel products (channel counts % 32; 9 x 80 = 720 is a ragged
+    contraction), the others the library's."""
     import torch.nn.functional as F
     from mscs_amd.models import ops
     torch.manual_seed(3)

@@ -27,6 +27,15 @@ for name, ci, co, h, w in shapes:
     lf = timeit(lambda: torch.matmul(w2, x.view(n, ci, h * w), out=y.view(n, co, h * w)), 20)
     ld = timeit(lambda: torch.matmul(w2.t(), gy.view(n, co, h * w), out=gx.view(n, ci, h * w)), 20)
     lw = timeit(lambda: torch.bmm(gy.view(n, co, h * w), x.view(n, ci, h * w).transpose(1, 2)).sum(0), 20)
+    hw = h * w
+    gf = gd = float("nan")
+    if ci % 32 == 0 and hw % 4 == 0:
+        gf = timeit(lambda: ops.gemm_f16x3(w2, True, ci, x, False, hw, co, hw, ci, y, hw, wa, xa, batch=n,
+                                           strides=(0, ci * hw, co * hw), splitk=1), 20)
+    if co % 4 == 0 and ci % 4 == 0:
+        gd = timeit(lambda: ops.gemm_f16x3(w2, False, ci, gy, False, hw, ci, hw, co, gx, hw, wa, ga, batch=n,
+                                           strides=(0, co * hw, ci * hw), splitk=1), 20)
     mb = (x.numel() + gy.numel()) * 4 / 1e6
     print(f"{name:16s} {mb:6.0f} MB  f16x3 fwd {tf * 1e3:6.1f} dgrad {td * 1e3:6.1f} wgrad {tw * 1e3:6.1f} us | "
-          f"library fwd {lf * 1e3:6.1f} dgrad {ld * 1e3:6.1f} wgrad {lw * 1e3:6.1f} us", flush=True)
+          f"library fwd {lf * 1e3:6.1f} dgrad {ld * 1e3:6.1f} wgrad {lw * 1e3:6.1f} us | "
+          f"dcl_gemm fwd {gf * 1e3:6.1f} dgrad {gd * 1e3:6.1f} us", flush=True)

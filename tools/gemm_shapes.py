@@ -79,19 +79,26 @@ def main():
             c = 96 << s
             for kind, k, n in (("qkv", c, 3 * c), ("fc2", 4 * c, c)):
                 rows.append((f"swinT s{s + 1} {kind}", m, k, n))
+    head_rows = []
     if args.only in ("", "head"):
-        # head tap products: z [9 * 720, P] = wb [6480, cb] . x [cb, P]  -> as a "linear": rows = P, K = cb, N = 6480
+        # the head's tap products (models/ops.py _CoarseTaps): z = W_b x_b, dx_b = W_b^T dz, dW_b = dz x_b^T
         for cb, p in ((96, 12 * 64 * 128), (192, 12 * 32 * 64), (384, 12 * 16 * 32)):
-            rows.append((f"head taps cb={cb}", p, cb, 6480))
+            head_rows.append((cb, p))
     print("shape,ms_f16x3,tflops_f16x3,frac_of_833,ms_library_f32,speedup,err_f16x3,err_library")
-    for name, m, k, n in rows:
-        for label, mine, lib, flop, ref in linear_rows(name, m, k, n):
+    groups = [linear_rows(name, m, k, n) for name, m, k, n in rows] if not head_rows else []
+    for name, m, k, n in (rows if head_rows else []):
+        groups.append(linear_rows(name, m, k, n))
+    for cb, P in head_rows:
+        groups.append(head_gemms(cb, P))
+    for group in groups:
+        m = n = 0
+        for label, mine, lib, flop, ref in group:
             if args.which and f" {args.which} " not in label.replace("  ", " "):
                 continue
             tm = timeit(mine, args.iters)
             tl = float("nan") if args.no_library else timeit(lib, args.iters)
             e1 = e2 = float("nan")
-            if not args.no_library and (args.check or m * n <= (1 << 26)):
+            if not args.no_library and (args.check or flop <= 4e11):
                 r = ref()
                 sc = r.abs().max()
                 e1 = ((mine().double() - r).abs().max() / sc).item()
@@ -100,6 +107,27 @@ def main():
             tf = flop / tm / 1e9
             print(f"{label},{tm:.4f},{tf:.1f},{tf / 833.3:.3f},{tl:.4f},{tl / tm:.2f},{e1:.2e},{e2:.2e}", flush=True)
         torch.cuda.empty_cache()
+
+
+def head_gemms(cb, P, co9=6480):
+    dev = "cuda"
+    wb = torch.randn(co9, cb, device=dev) * 0.05
+    xc = torch.randn(cb, P, device=dev)
+    dz = torch.randn(co9, P, device=dev) * 1e-3
+    am = {id(t): amax_of(t) for t in (wb, xc, dz)}
+    z, gx, gw = torch.empty(co9, P, device=dev), torch.empty(cb, P, device=dev), torch.empty(co9, cb, device=dev)
+    flop = 2.0 * co9 * cb * P
+    return [
+        (f"head cb={cb} z = W x   [{co9}x{cb}] . [{cb}x{P}]",
+         lambda: ops.gemm_f16x3(wb, True, cb, xc, False, P, co9, P, cb, z, P, am[id(wb)], am[id(xc)], splitk=1),
+         lambda: torch.mm(wb, xc), flop, lambda: wb.double() @ xc.double()),
+        (f"head cb={cb} dx = W^T dz [{cb}x{co9}] . [{co9}x{P}]",
+         lambda: ops.gemm_f16x3(wb, False, cb, dz, False, P, cb, P, co9, gx, P, am[id(wb)], am[id(dz)], splitk=1),
+         lambda: torch.mm(wb.t(), dz), flop, lambda: wb.double().t() @ dz.double()),
+        (f"head cb={cb} dW = dz x^T [{co9}x{P}] . [{P}x{cb}]",
+         lambda: ops.gemm_f16x3(dz, True, P, xc, True, P, co9, cb, P, gw, cb, am[id(dz)], am[id(xc)]),
+         lambda: torch.mm(dz, xc.t()), flop, lambda: dz.double() @ xc.double().t()),
+    ]
 
 
 if __name__ == "__main__":
