@@ -37,7 +37,7 @@
 #define DCL_GEMM_PINGPONG 1     // 0: every wave stages before its matrix work
 #endif
 #ifndef DCL_GEMM_PF
-#define DCL_GEMM_PF 1           // 1: fragment reads issued one MFMA group ahead (fenced); 0: compiler order
+#define DCL_GEMM_PF 0           // 1: fragment reads issued one MFMA group ahead (fenced; measured: no gain); 0: compiler order
 #endif
 #define GEMM_MFMA(A, B, C) ((DCL_GEMM_PROBE & 1) ? (C) : __builtin_amdgcn_mfma_f32_32x32x16_f16((A), (B), (C), 0, 0, 0))
 
@@ -97,50 +97,57 @@ __device__ __forceinline__ int slot_of(int r)
 // 32-bit byte offset computed once).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+struct StageState {
+    unsigned voff[8];               // lane byte offsets into the operand (buffer addressing: 32-bit, bounds-checked)
+    unsigned wa, wb;                // LDS byte offsets (from the operand's hi image of stage 0)
+    unsigned step, ldb;             // bytes per k-step (scalar offset advance); row-contiguous: bytes per k row
+};
+
 template <int BX, bool KM>
 struct Stager {
     static constexpr int KG = BX + 2;
-    unsigned voff[KM ? 8 : 1];      // lane byte offsets into the operand (buffer addressing: 32-bit, bounds-checked)
-    unsigned wa, wb;                // LDS byte offsets (from the operand's hi image of stage 0)
-    unsigned step, ldb;             // bytes per k-step (scalar offset advance); row-contiguous: bytes per k row
 
-    __device__ __forceinline__ void init(int u, long ld, int row0, int rows)
+    static __device__ __forceinline__ void init(StageState &q, int u, long ld, int row0, int rows)
     {
         if constexpr (KM) {
             const int k4 = u & 7;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = min(row0 + (u >> 3) + j * (BX / 8), rows - 1);
-                voff[j] = (unsigned)(((long)r * ld + 4 * k4) * 4);
+                q.voff[j] = (unsigned)(((long)r * ld + 4 * k4) * 4);
             }
-            wa = (unsigned)((((k4 >> 1) * KG + (u >> 3)) * 2 + (k4 & 1)) * 8);
-            wb = 0;
-            step = 32 * 4;
-            ldb = 0;
+            q.wa = (unsigned)((((k4 >> 1) * KG + (u >> 3)) * 2 + (k4 & 1)) * 8);
+            q.wb = 0;
+            q.step = 32 * 4;
+            q.ldb = 0;
         } else {
             const int m4 = u % (BX / 4), kg = u / (BX / 4);
             const int r = min(row0 + 4 * m4, rows - 4);
-            voff[0] = (unsigned)(((long)(8 * kg) * ld + r) * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                q.voff[j] = (unsigned)(((long)(8 * kg) * ld + r) * 4);
             const int blk = m4 >> 3, m = m4 & 7;
-            wa = (unsigned)((kg * KG + 32 * blk + m) * 16);
-            wb = (unsigned)((kg * KG + 32 * blk + (m ^ 1)) * 16);
-            step = (unsigned)(32 * ld * 4);
-            ldb = (unsigned)(ld * 4);
+            q.wa = (unsigned)((kg * KG + 32 * blk + m) * 16);
+            q.wb = (unsigned)((kg * KG + 32 * blk + (m ^ 1)) * 16);
+            q.step = (unsigned)(32 * ld * 4);
+            q.ldb = (unsigned)(ld * 4);
         }
     }
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, unsigned soff, float4 (&v)[8]) const
+    static __device__ __forceinline__ void load(const StageState &q, __amdgpu_buffer_rsrc_t rsrc, unsigned soff,
+                                                float4 (&v)[8])
     {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             u32x4 w;
             if constexpr (KM)
-                w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], soff, 0);
+                w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, q.voff[j], soff, 0);
             else
-                w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[0], soff + j * ldb, 0);
+                w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, q.voff[0], soff + j * q.ldb, 0);
             v[j] = __builtin_bit_cast(float4, w);
         }
     }
-    __device__ __forceinline__ void store(char *__restrict__ hi, float s, const float4 (&v)[8]) const
+    static __device__ __forceinline__ void store(const StageState &q, char *__restrict__ hi, float s,
+                                                 const float4 (&v)[8])
     {
         if constexpr (KM) {
 #pragma unroll
@@ -157,8 +164,8 @@ struct Stager {
                     asm volatile("" ::"v"(h.x), "v"(h.y), "v"(l.x), "v"(l.y));
                     continue;
                 }
-                *reinterpret_cast<uint2 *>(hi + wa + j * (BX / 8) * 16) = h;
-                *reinterpret_cast<uint2 *>(hi + wa + j * (BX / 8) * 16 + 4 * KG * 16) = l;
+                *reinterpret_cast<uint2 *>(hi + q.wa + j * (BX / 8) * 16) = h;
+                *reinterpret_cast<uint2 *>(hi + q.wa + j * (BX / 8) * 16 + 4 * KG * 16) = l;
             }
         } else {
             const float *f = reinterpret_cast<const float *>(&v[0]);
@@ -169,9 +176,9 @@ struct Stager {
                 split2g(f[2 * 4 + i], f[3 * 4 + i], s, h.y, l.y);
                 split2g(f[4 * 4 + i], f[5 * 4 + i], s, h.z, l.z);
                 split2g(f[6 * 4 + i], f[7 * 4 + i], s, h.w, l.w);
-                char *q = hi + ((i >> 1) ? wb : wa) + 8 * i * 16;
-                *reinterpret_cast<uint4 *>(q) = h;
-                *reinterpret_cast<uint4 *>(q + 4 * KG * 16) = l;
+                char *p = hi + ((i >> 1) ? q.wb : q.wa) + 8 * i * 16;
+                *reinterpret_cast<uint4 *>(p) = h;
+                *reinterpret_cast<uint4 *>(p + 4 * KG * 16) = l;
             }
         }
     }
@@ -232,21 +239,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
 
     // the operand this wave stages, as a bounds-checked buffer (reads past the last element return 0), and the scalar
     // byte offset of the k-step it loads next
-    Stager<BM, AKM> sA;
-    Stager<BN, BKM> sB;
     const float *gbase = stA ? a.A + (long)b * a.sA : a.B + (long)b * a.sB;
     const long gelems = stA ? (AKM ? (long)(a.M - 1) * a.lda + a.K : (long)(a.K - 1) * a.lda + a.M)
                             : (BKM ? (long)(a.N - 1) * a.ldb + a.K : (long)(a.K - 1) * a.ldb + a.N);
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gbase), 0, (int)(unsigned)(gelems * 4), 0x00020000);
-    unsigned gstep = 0;
-    if (stA) {
-        sA.init(tid, a.lda, row0, a.M);
-        gstep = sA.step;
-    } else if (stB) {
-        sB.init(tid - BM, a.ldb, col0, a.N);
-        gstep = sB.step;
-    }
+    StageState q;
+    if (stA)
+        Stager<BM, AKM>::init(q, tid, a.lda, row0, a.M);
+    else
+        Stager<BN, BKM>::init(q, stB ? tid - BM : 0, a.ldb, col0, a.N);
+    const unsigned gstep = q.step;
     unsigned goff = (unsigned)kbeg * gstep;
 
     f32x16 acc[TM][TN];
@@ -262,41 +265,42 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
     const unsigned fa = (unsigned)(((lane >> 5) * KGA + slot_of<AKM>(32 * wm * TM + (lane & 31))) * 16);
     const unsigned fb = (unsigned)(A_BYTES + ((lane >> 5) * KGB + slot_of<BKM>(32 * wn * TN + (lane & 31))) * 16);
 
-    float4 v[8];
-    auto load = [&]() {
+    float4 v0[8];               // the k-step in flight: loaded one k-step before its split + LDS store
+    auto load = [&](float4 (&v)[8]) {
         if (DCL_GEMM_PROBE & 4)
             return;
-        if (stA)
-            sA.load(rsrc, goff, v);
-        else if (stB)
-            sB.load(rsrc, goff, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q.voff[j], goff + j * q.ldb, 0));
         goff += gstep;
     };
-    auto store = [&](int stage) {
+    auto store = [&](int stage, const float4 (&v)[8]) {
         if (DCL_GEMM_PROBE & 2)
             return;
         char *base = lds + stage * STAGE;
         if (stA)
-            sA.store(base, sa, v);
+            Stager<BM, AKM>::store(q, base, sa, v);
         else if (stB)
-            sB.store(base + A_BYTES, sb, v);
+            Stager<BN, BKM>::store(q, base + A_BYTES, sb, v);
     };
 
-    if (kbeg < kend) {
-        load();
-        store(0);
-        if (kbeg + 1 < kend)
-            load();
-    }
+    // Loads are issued unconditionally (k-steps past the end read zeros through the buffer bounds, or the next k-split's
+    // rows, and are never stored).  A second register set (loads two k-steps ahead) was built and bought nothing: the
+    // compiler's vmcnt bookkeeping across the rotated loop waits for the NEWEST loads at every store (vmcnt(7..0) where
+    // vmcnt(15..8) would do), and asm loads the compiler cannot see are not safe at 250+ live registers.
+    load(v0);
+    store(0, v0);
+    load(v0);
     lds_barrier();
 
-    for (int k = kbeg; k < kend; ++k) {
+    // one k-step: `va` holds k-step k + 1 (stored into the other stage, then refilled with k-step k + 2)
+    auto kstep = [&](int k, float4 (&va)[8]) {
         const int cur = (k - kbeg) & 1;
         const bool more = k + 1 < kend;
-        if (early && more) {
-            store(cur ^ 1);
-            if (k + 2 < kend)
-                load();
+        if (early) {
+            if (more)
+                store(cur ^ 1, va);
+            load(va);
         }
         const char *st = lds + cur * STAGE;
 #if DCL_GEMM_PF
@@ -373,13 +377,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
                     acc[i][j] = GEMM_MFMA(ah[i], bh[j], acc[i][j]);
         }
 #endif
-        if (!early && more) {
-            store(cur ^ 1);
-            if (k + 2 < kend)
-                load();
+        if (!early) {
+            if (more)
+                store(cur ^ 1, va);
+            load(va);
         }
         lds_barrier();
-    }
+    };
+    for (int k = kbeg; k < kend; ++k)
+        kstep(k, v0);
 
     // ---- epilogue: acc register r of tile (i, j) is row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32
     const float inv = 1.0f / (sa * sb);

@@ -38,6 +38,7 @@ struct WaArgs {
     // backward
     const float *dout;      // [B, H*W, C]
     float *dqkv;            // [B, H*W, 3*C]
+    float *dqkv_amax;       // optional: DCL_AMAX_SLOTS partial maxima of |dqkv| (integer atomic max), or null
     float *dpad;            // [B, npad, 3*C]  gradient of the padded tokens' qkv (= of the projection's bias)
     float *dbias_part;      // [nwaves, 49, 49]  partial bias gradients, wave w holds head w % heads
     int B, H, W, Hp, Wp, shift, heads, C;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(64) void k_winattn_bwd(WaArgs a)
     const int i = lane < NT ? lane : NT - 1;
     const bool act = lane < NT;
     float db[WS][WS];
+    float gmax = 0.f;                                         // max |dq|, |dk|, |dv| this lane wrote
 #pragma unroll
     for (int j = 0; j < NT; ++j)
         db[j / WS][j % WS] = 0.f;
@@ -350,9 +352,12 @@ __global__ __launch_bounds__(64) void k_winattn_bwd(WaArgs a)
             float *dqp = (real_i ? a.dqkv + ((size_t)b * a.H * a.W + row_i) * (3 * a.C)
                                  : a.dpad + ((size_t)b * a.npad + (row_i - a.H * a.W)) * (3 * a.C)) + hd * HD;
 #pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4)
-                *(f32x4 *)(dqp + 4 * s4) = f32x4{dq[4 * s4] * a.scale, dq[4 * s4 + 1] * a.scale, dq[4 * s4 + 2] * a.scale,
-                                                dq[4 * s4 + 3] * a.scale};
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const f32x4 o = f32x4{dq[4 * s4] * a.scale, dq[4 * s4 + 1] * a.scale, dq[4 * s4 + 2] * a.scale,
+                                      dq[4 * s4 + 3] * a.scale};
+                *(f32x4 *)(dqp + 4 * s4) = o;
+                gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -386,8 +391,18 @@ __global__ __launch_bounds__(64) void k_winattn_bwd(WaArgs a)
             for (int s4 = 0; s4 < 8; ++s4) {
                 *(f32x4 *)(dkp + 4 * s4) = f32x4{dk[4 * s4], dk[4 * s4 + 1], dk[4 * s4 + 2], dk[4 * s4 + 3]};
                 *(f32x4 *)(dvp + 4 * s4) = f32x4{dv[4 * s4], dv[4 * s4 + 1], dv[4 * s4 + 2], dv[4 * s4 + 3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    gmax = fmaxf(gmax, fmaxf(fabsf(dk[4 * s4 + e]), fabsf(dv[4 * s4 + e])));
             }
         }
+    }
+    if (a.dqkv_amax) {                                       // absmax side channel for the qkv Linear's backward GEMMs
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+        if (lane == 0)
+            atomicMax((int *)a.dqkv_amax + (blockIdx.x & (DCL_AMAX_SLOTS - 1)), __float_as_int(gmax));
     }
     if (act) {                                               // dbias_part[gw][i][:] = lane i's accumulator
         float *dst = a.dbias_part + ((size_t)gw * NT + lane) * NT;
@@ -448,7 +463,7 @@ extern "C" int dcl_winattn_bwd_waves(int B, int H, int W, int heads)
 
 extern "C" int dcl_winattn_bwd(const float *qkv, const float *qkv_bias, const float *bias, const float *lse,
                                const float *dout, int B, int H, int W, int C, int heads, int shift, float scale,
-                               float *dqkv, float *dpad, float *dbias_part, void *stream)
+                               float *dqkv, float *dpad, float *dbias_part, float *dqkv_amax, void *stream)
 {
     DCL_CHECK_ARG(qkv && qkv_bias && bias && lse && dout && dqkv && dbias_part, "null pointer");
     DCL_CHECK_ARG(dpad || dcl_winattn_npad(H, W) == 0, "dpad is required when H or W is not a multiple of 7");
@@ -458,7 +473,7 @@ extern "C" int dcl_winattn_bwd(const float *qkv, const float *qkv_bias, const fl
     DCL_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)dout) | ((uintptr_t)dqkv) | ((uintptr_t)qkv_bias)) & 15) == 0,
                   "16-byte alignment");
     a.qkv = qkv; a.qkv_bias = qkv_bias; a.bias = bias; a.lse = const_cast<float *>(lse); a.dout = dout;
-    a.dqkv = dqkv; a.dpad = dpad; a.dbias_part = dbias_part;
+    a.dqkv = dqkv; a.dpad = dpad; a.dbias_part = dbias_part; a.dqkv_amax = dqkv_amax;
     a.nwaves = dcl_winattn_bwd_waves(B, H, W, heads);
     hipLaunchKernelGGL(k_winattn_bwd, dim3((unsigned)a.nwaves), dim3(64), 0, (hipStream_t)stream, a);
     DCL_LAUNCH_CHECK();

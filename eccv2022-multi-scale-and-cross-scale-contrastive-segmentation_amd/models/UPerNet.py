@@ -149,6 +149,8 @@ class UPerNet(nn.Module):
             if self.aux_head is not None:
                 use_direct_conv3x3(self.aux_head)
             self._conv_packs = ConvPackGroup(self)
+        from .ops import LinearTagGroup
+        self._linear_tags = LinearTagGroup(self)     # absmax tags of the Swin Linears' weights: one launch per step
         if config.get('hip_decoder', True):
             from .ops import use_gemm_conv1x1
             use_gemm_conv1x1(self.fpn)
@@ -215,6 +217,8 @@ class UPerNet(nn.Module):
         size = x.shape[-2:]
         if self._conv_packs is not None and x.is_cuda:
             self._conv_packs.refresh()
+        if x.is_cuda and self.training:
+            self._linear_tags.refresh()
         feats = self.backbone(x)
         logits, fpn_feats, fused = self.fpn(feats)
         # graph key `lazy_logits` (extension, default off = the reference's return values): the logits of both heads stay

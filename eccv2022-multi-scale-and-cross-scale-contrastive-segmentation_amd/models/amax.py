@@ -35,6 +35,15 @@ def tag(t: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def carry(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst (a view / reshape / contiguous copy of src: same values) inherits src's valid tag; returns dst."""
+    if dst is not src:
+        got = getattr(src, "_dcl_amax", None)
+        if got is not None and got[0] == src._version and got[1].device == dst.device:
+            dst._dcl_amax = (dst._version, got[1])
+    return dst
+
+
 def tag_of(t: torch.Tensor):
     """The valid absmax tag of t, or None (no fallback pass)."""
     got = getattr(t, "_dcl_amax", None)

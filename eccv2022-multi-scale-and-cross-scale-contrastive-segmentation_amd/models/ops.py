@@ -516,6 +516,49 @@ class ConvPackGroup:
         self.key = key
 
 
+class LinearTagGroup:
+    """absmax tags of all TokenLinear weights of a model by ONE launch per optimizer step (dcl_absmax_multi) instead of one
+    small dcl_absmax launch per Linear; ``refresh()`` at the start of the model's forward does nothing while no weight
+    was modified."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.lins = [m for m in module.modules() if isinstance(m, TokenLinear)]
+        self.key = None
+        self.tables = None
+
+    def _build(self, dev):
+        import numpy as np
+        jobs = np.zeros(len(self.lins), dtype=[("x", "<u8"), ("out", "<u8"), ("n", "<i8"), ("fb", "<i4"), ("pad", "<i4")])
+        self.amax = torch.zeros(len(self.lins), dtype=torch.float32, device=dev)
+        b2j = []
+        for i, m in enumerate(self.lins):
+            w = m.weight
+            jobs[i] = (w.data_ptr(), self.amax[i:i + 1].data_ptr(), w.numel(), len(b2j), 0)
+            b2j += [i] * ((w.numel() + 4095) // 4096)
+        self.tables = (torch.from_numpy(jobs.view(np.uint8).reshape(-1).copy()).to(dev),
+                       torch.tensor(b2j, dtype=torch.int32, device=dev), len(b2j))
+        self.ptrs = tuple(m.weight.data_ptr() for m in self.lins)
+
+    def refresh(self):
+        from .. import _lib
+        from . import amax as _am
+        if not self.lins or not self.lins[0].weight.is_cuda or self.lins[0].weight.dtype != torch.float32:
+            return
+        key = tuple(m.weight._version for m in self.lins)
+        ptrs = tuple(m.weight.data_ptr() for m in self.lins)
+        if self.tables is None or ptrs != self.ptrs:
+            self._build(self.lins[0].weight.device)
+            self.key = None
+        if key == self.key:
+            return
+        jobs, b2j, nb = self.tables
+        self.amax.zero_()
+        _lib.check(_lib.lib().dcl_absmax_multi(_lib.ptr(jobs), _lib.ptr(b2j), nb, _stream(self.amax)), "dcl_absmax_multi")
+        for i, m in enumerate(self.lins):
+            _am.tag(m.weight, self.amax[i:i + 1])
+        self.key = key
+
+
 def use_direct_conv3x3(module: torch.nn.Module) -> torch.nn.Module:
     """Switch every plain nn.Conv2d with a 3x3 / stride 1 or 2 / pad 1 geometry to DirectConv2d in place."""
     for m in module.modules():
@@ -842,29 +885,27 @@ class _TokenLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        from . import amax as _am
         n, k = weight.shape
-        x2 = x.reshape(-1, k)
+        x2 = _am.carry(x, x.reshape(-1, k))                 # (a view is a new tensor object: the tag travels along)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
         ctx.xshape = x.shape
         y = linear_f16x3(x2, weight, bias)
-        out = y.view(*x.shape[:-1], n)
-        from . import amax as _am
-        t = _am.tag_of(y)
-        if t is not None:
-            _am.tag(out, t)
-        return out
+        return _am.carry(y, y.view(*x.shape[:-1], n))
 
     @staticmethod
     def backward(ctx, gy):
         x2, weight = ctx.saved_tensors
         n, k = weight.shape
-        gy2 = gy.reshape(-1, n)
+        from . import amax as _am
+        gy2 = _am.carry(gy, gy.reshape(-1, n))
         if not gy2.is_contiguous():
-            gy2 = gy2.contiguous()
+            gy2 = _am.carry(gy2, gy2.contiguous())
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = linear_dgrad_f16x3(gy2, weight).view(ctx.xshape)
+            g = linear_dgrad_f16x3(gy2, weight)
+            gx = _am.carry(g, g.view(ctx.xshape))
         if ctx.needs_input_grad[1]:
             gw = linear_wgrad_f16x3(gy2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -898,15 +939,36 @@ class TokenLinear(torch.nn.Linear):
 
 # ---- LayerNorm over token-major rows (csrc/dcl_layernorm.hip) -----------------------------------------------------
 
-def tagged_gelu(h):
-    """nn.GELU() (exact erf form); |gelu(v)| <= |v|, so the absmax tag of h bounds the result too (the operand scale of
-    the following fc2 GEMM without a pass over the 4C-wide activation)."""
-    out = torch.nn.functional.gelu(h)
-    if h.is_cuda:
+class _TaggedGelu(torch.autograd.Function):
+    """nn.GELU() (exact erf form) that hands absmax BOUNDS through in both directions: |gelu(v)| <= |v| and
+    |gelu'(v)| <= 1.13, so the tag of the input bounds the output and 1.13 x the tag of the incoming gradient bounds the
+    outgoing one -- the fc2 / fc1 GEMMs of a Swin Mlp find their operand scales without a pass over the 4C-wide tensors."""
+
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return torch.nn.functional.gelu(h)
+
+    @staticmethod
+    def backward(ctx, gy):
         from . import amax as _am
-        t = _am.tag_of(h)
+        (h,) = ctx.saved_tensors
+        gx = torch.ops.aten.gelu_backward(gy, h, approximate="none")
+        t = _am.tag_of(gy)
         if t is not None:
-            _am.tag(out, t)
+            _am.tag(gx, t * 1.13)
+        return gx
+
+
+def tagged_gelu(h):
+    """nn.GELU() (exact erf form); on CUDA fp32 the absmax tags travel through it (see _TaggedGelu)."""
+    if not (h.is_cuda and h.dtype == torch.float32):
+        return torch.nn.functional.gelu(h)
+    from . import amax as _am
+    out = _TaggedGelu.apply(h) if (h.requires_grad and torch.is_grad_enabled()) else torch.nn.functional.gelu(h)
+    t = _am.tag_of(h)
+    if t is not None:
+        _am.tag(out, t)
     return out
 
 
@@ -1000,9 +1062,12 @@ class _WindowAttention(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dpad = torch.empty((B, npad, C3), dtype=torch.float32, device=qkv.device) if npad else None
         part = torch.empty((nwaves, 49, 49), dtype=torch.float32, device=qkv.device)
+        from . import amax as _am
+        gam = _am.zeros(_am.SLOTS, qkv.device)      # max|dqkv|: the operand scale of the qkv Linear's backward GEMMs
         _lib.check(L.dcl_winattn_bwd(_lib.ptr(qkv), _lib.ptr(qkv_bias), _lib.ptr(bias), _lib.ptr(lse), _lib.ptr(dout),
                                      B, H, W, C, heads, shift, scale, _lib.ptr(dqkv), _lib.ptr(dpad), _lib.ptr(part),
-                                     _lib.stream_ptr(qkv.device)), "dcl_winattn_bwd")
+                                     _lib.ptr(gam), _lib.stream_ptr(qkv.device)), "dcl_winattn_bwd")
+        _am.tag(dqkv, gam)
         dbias = part.view(nwaves // heads, heads, 49, 49).sum(0) if ctx.needs_input_grad[2] else None
         dqb = None
         if ctx.needs_input_grad[1]:

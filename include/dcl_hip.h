@@ -439,7 +439,8 @@ int dcl_winattn_fwd(const float *qkv, const float *qkv_bias, const float *bias, 
 int dcl_winattn_bwd_waves(int B, int H, int W, int heads);
 int dcl_winattn_bwd(const float *qkv, const float *qkv_bias, const float *bias, const float *lse, const float *dout,
                     int B, int H, int W, int C, int heads, int shift, float scale, float *dqkv, float *dpad,
-                    float *dbias_part, void *stream);
+                    float *dbias_part, float *dqkv_amax /* DCL_AMAX_SLOTS partial maxima of |dqkv| and |dpad| (caller zero-
+                    initialises), or NULL: the operand scale of the qkv projection's backward GEMMs */, void *stream);
 
 /* ---- LayerNorm over the channel axis of token-major rows (the Swin backbone) --------
  * Replaces nn.LayerNorm and its autograd in the Swin port (reference models/Swin.py:251-332 norm1 / norm2, :357-362
