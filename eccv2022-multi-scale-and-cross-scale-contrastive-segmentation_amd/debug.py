@@ -33,6 +33,9 @@ class DebugConfig:
     fanout: bool = field(default_factory=lambda: _flag('DCL_FANOUT'))                           # one-kernel gradient sums
     upsample_tag: bool = field(default_factory=lambda: _flag('DCL_UPSAMPLE_TAG'))               # absmax tags of up-sampled maps
     packed_relu_mask: bool = field(default_factory=lambda: _flag('DCL_BN_MASK'))                # packed sign mask in the BN backward
+    gemm_conv1x1: bool = field(default_factory=lambda: _flag('DCL_GEMM_CONV1X1'))               # wide 1x1 convolutions on dcl_gemm_f16x3
+    gemm_head_taps: bool = field(default_factory=lambda: _flag('DCL_GEMM_HEAD'))                # the head's tap products on it
+    gemm_gemm_tile: Optional[int] = field(default_factory=lambda: _int('DCL_GEMM_TILE'))       # 1..4: force a workgroup tile
     coalesced_sync_bn: bool = field(default_factory=lambda: _flag('DCL_SYNCBN_COALESCE'))       # stacked SyncBN exchanges
     side_stream_priority: Optional[int] = field(default_factory=lambda: _int('DCL_SIDE_PRIO'))  # HIP priority of the branch streams
     # ---- loss
@@ -54,6 +57,7 @@ class DebugConfig:
         for val, fn in ((self.wgrad_variant, l.dcl_wgrad3x3_set_variant), (self.wgrad_stride2, l.dcl_wgrad3x3_set_stride2),
                         (self.up2_phases, l.dcl_conv3x3_set_up2_phases),
                         (self.conv_interleave, l.dcl_conv3x3_set_interleave),
+                        (self.gemm_gemm_tile, l.dcl_gemm_set_tile),
                         (self.upce_bwd_chunk, l.dcl_upsample_ce_set_bwd_chunk),
                         (self.upce_fwd_kib, l.dcl_upsample_ce_set_fwd_lds)):
             if val is not None:

@@ -251,6 +251,31 @@ def conv1x1_direct(x, weight, transposed=False):
     return conv1x1_launch(x, wp, cout, amax_of(x), wamax, out)
 
 
+def _conv1x1_by_gemm(rows, k, x, both_row_contiguous):
+    """A 1x1 convolution direction as a batched dcl_gemm_f16x3 over the images ([rows, k] x [k, H W] per image): pays where
+    the produced channel count fills a 256-row tile (tools/conv1x1_shapes.py: 64 -> 256 forward at 128 x 256, batch 12:
+    109 us against 186 library / 290 tile kernel; 256 -> 64 data gradient 120 against 160 / 290; 192 -> 256 forward 17
+    against 32 / 33; 64 -> 64 loses: 87 against 50)."""
+    hw = x.shape[2] * x.shape[3]
+    return GEMM_CONV1X1 and rows >= 192 and k >= 32 and (both_row_contiguous or k % 32 == 0) and hw % 4 == 0 \
+        and rows % 4 == 0 and max(rows, k) * hw * 4 < (1 << 32)
+
+
+GEMM_CONV1X1 = _dbg.gemm_conv1x1     # (DCL_GEMM_CONV1X1=0: the library / tile-kernel paths, for A/B runs)
+
+
+def conv1x1_gemm(x, weight2, out, xamax, wamax, transposed=False):
+    """out[n] [rows, H W] = W x[n] (forward: rows = Co, W = weight2 [Co, Ci]) or W^T x[n] (``transposed``: the data gradient,
+    rows = Ci) as one batched split-f16 GEMM; x, out NCHW contiguous."""
+    n, k, h, w = x.shape
+    hw = h * w
+    co, ci = weight2.shape
+    rows = ci if transposed else co
+    gemm_f16x3(weight2, not transposed, ci, x, False, hw, rows, hw, k, out, hw, wamax, xamax, batch=n,
+               strides=(0, k * hw, rows * hw), splitk=1)
+    return out
+
+
 def _conv1x1_by_library(x, y):
     """Forward / data gradient of a 1x1 convolution: above 64 MB of input + output the layer is bound by HBM and the
     library's streaming GEMM moves the bytes faster than the tile kernel, whose patch staging is built for the 3x3
@@ -367,7 +392,11 @@ class _Conv3x3Direct(torch.autograd.Function):
         wamax, wp, _ = mod.packed_weights()
         out = torch.empty((x.shape[0], weight.shape[0], (x.shape[2] - 1) // st + 1, (x.shape[3] - 1) // st + 1),
                           dtype=torch.float32, device=x.device)
-        if k1 and _conv1x1_by_library(x, out):
+        if k1 and _conv1x1_by_gemm(weight.shape[0], weight.shape[1], x, False):
+            conv1x1_gemm(x, weight.view(weight.shape[0], -1), out, amax_of(x), wamax)
+            if bias is not None:
+                out += bias.view(1, -1, 1, 1)
+        elif k1 and _conv1x1_by_library(x, out):
             n, ci, h, w = x.shape
             torch.matmul(weight.view(-1, ci), x.view(n, ci, h * w), out=out.view(n, -1, h * w))
             if bias is not None:
@@ -392,7 +421,9 @@ class _Conv3x3Direct(torch.autograd.Function):
             addend = None
             if ctx.token is not None and ctx.token.dres is not None:
                 addend, ctx.token.dres = ctx.token.dres, None        # gradient of the residual branch, fused in
-            if ctx.k1 and _conv1x1_by_library(x, gy) and addend is None:
+            if ctx.k1 and addend is None and _conv1x1_by_gemm(weight.shape[1], weight.shape[0], gy, True):
+                conv1x1_gemm(gy, weight.view(weight.shape[0], -1), gx, amax_of(gy), wamax, transposed=True)
+            elif ctx.k1 and _conv1x1_by_library(x, gy) and addend is None:
                 n, ci, h, w = x.shape
                 torch.matmul(weight.view(-1, ci).t(), gy.view(n, -1, h * w), out=gx.view(n, ci, h * w))
             elif ctx.k1:
@@ -589,7 +620,7 @@ class _CoarseTaps(torch.autograd.Function):
     [Co, Cin, 3, 3] parameter, ``c0`` the first input channel of the first coarse map; its gradient comes back full-size
     (zero outside the coarse slices).  ``gemm = False`` (class switch): the library's fp32 GEMMs."""
 
-    gemm = True
+    gemm = _dbg.gemm_head_taps
 
     @staticmethod
     def forward(ctx, align, H, W, c0, weight, *ts):
@@ -763,7 +794,11 @@ class _Conv1x1Gemm(torch.autograd.Function):
         n, ci, h, w = x.shape
         co = weight.shape[0]
         y = torch.empty((n, co, h, w), dtype=x.dtype, device=x.device)       # returned as a base tensor, not a view:
-        torch.matmul(weight.view(co, ci), x.view(n, ci, h * w), out=y.view(n, co, h * w))   # callers relu_() it
+        if _conv1x1_by_gemm(co, ci, x, False):                                # callers relu_() it
+            from .amax import amax_of
+            conv1x1_gemm(x, weight.view(co, ci), y, amax_of(x), amax_of(weight))
+        else:
+            torch.matmul(weight.view(co, ci), x.view(n, ci, h * w), out=y.view(n, co, h * w))
         if bias is not None:
             y += bias.view(1, co, 1, 1)
         ctx.save_for_backward(x, weight)
@@ -778,11 +813,25 @@ class _Conv1x1Gemm(torch.autograd.Function):
         gy = gy.contiguous()
         g2 = gy.view(n, co, h * w)
         gx = gw = gb = None
+        from .amax import amax_of
+        hw = h * w
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            torch.matmul(weight.view(co, ci).t(), g2, out=gx.view(n, ci, h * w))
+            if _conv1x1_by_gemm(ci, co, gy, True):
+                conv1x1_gemm(gy, weight.view(co, ci), gx, amax_of(gy), amax_of(weight), transposed=True)
+            else:
+                torch.matmul(weight.view(co, ci).t(), g2, out=gx.view(n, ci, h * w))
         if ctx.needs_input_grad[1]:
-            gw = torch.bmm(g2, x.view(n, ci, h * w).transpose(1, 2)).sum(0).view_as(weight)
+            if GEMM_CONV1X1 and hw % 32 == 0 and co >= 64 and ci >= 64 and ci % 4 == 0 and co * hw * 4 < (1 << 32) \
+                    and ci * hw * 4 < (1 << 32):
+                # dW = sum_n gy_n [Co, HW] x_n^T: one batched GEMM (both operands k-major: the pixel axis), k-split slabs
+                # per image, then the fixed-order sum over the images
+                part = torch.empty((n, co, ci), dtype=torch.float32, device=x.device)
+                gemm_f16x3(gy, True, hw, x, True, hw, co, ci, hw, part, ci, amax_of(gy), amax_of(x), batch=n,
+                           strides=(co * hw, ci * hw, co * ci))
+                gw = (part.sum(0) if n > 1 else part[0]).view_as(weight)
+            else:
+                gw = torch.bmm(g2, x.view(n, ci, h * w).transpose(1, 2)).sum(0).view_as(weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum((0, 2))
         return gx, gw, gb

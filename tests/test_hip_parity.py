@@ -1219,6 +1219,34 @@ def test_gemm_conv1x1_matches_library(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cls", ["direct", "gemm"])
+def test_wide_conv1x1_on_split_f16_gemm_matches_fp64(dev, cls):
+    """1x1 convolutions whose produced channel count fills a GEMM tile (>= 192: HRNet layer1 64 -> 256 / 256 -> 64, the
+    projector's 192 -> 256, the UPerNet decoder's C -> 512 laterals) run as one batched dcl_gemm_f16x3 over the images --
+    DirectConv2d: forward / data gradient; GemmConv1x1: all three directions -- against float64 (3e-6 of max), bias included."""
+    from mscs_amd.models import ops
+    torch.manual_seed(23)
+    for (ci, co, bias, h, w) in ((64, 256, False, 12, 24), (256, 64, False, 12, 24), (192, 256, True, 8, 16), (96, 512, True, 16, 32),
+                                 (768, 512, False, 8, 8)):
+        conv = torch.nn.Conv2d(ci, co, 1, bias=bias).to(dev)
+        (ops.use_direct_conv1x1 if cls == "direct" else ops.use_gemm_conv1x1)(conv)
+        x = torch.randn(3, ci, h, w, device=dev).requires_grad_(True)
+        gy = torch.randn(3, co, h, w, device=dev) * 1e-3
+        assert ops._conv1x1_by_gemm(co, ci, x, False) or ops._conv1x1_by_gemm(ci, co, gy, True)
+        conv(x).backward(gy)
+        ref = torch.nn.Conv2d(ci, co, 1, bias=bias).double()
+        ref.load_state_dict({k: v.double().cpu() for k, v in conv.state_dict().items()})
+        x64 = x.detach().double().cpu().requires_grad_(True)
+        ref(x64).backward(gy.double().cpu())
+        pairs = [(conv(x), ref(x64)), (x.grad, x64.grad), (conv.weight.grad, ref.weight.grad)]
+        if bias:
+            pairs.append((conv.bias.grad, ref.bias.grad))
+        for k, (got, want) in enumerate(pairs):
+            err = ((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max()).item()
+            assert err < 3e-6, (cls, ci, co, k, err)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("align", [True, False])
 def test_upsample_concat_matches_cat_of_interpolates(dev, align):
     """upsample_concat (every map written straight into its channel slice, gradient read in place) against
