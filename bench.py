@@ -221,6 +221,37 @@ def roofline_conv_kernels(args, dev, iters=20):
     return main, others
 
 
+def roofline_gemm_kernel(args, dev, iters=10):
+    """configs 4 / 5 (UPerNet + Swin): the kernel family with the largest share of the step is dcl_gemm_f16x3 behind the
+    token-major Linears; `roofline` reports it on the stage-3 Mlp fc1 forward of the configured backbone (the heaviest
+    Linear: tokens x C -> 4 C), timed with HIP events on the launch stream; algorithmic FLOP = 2 M N K, peak 2500 / 3."""
+    from mscs_amd.models import ops
+    from mscs_amd.models.amax import amax_of
+    side = 640 if args.config == 5 else 512
+    c = (192 if args.config == 5 else 96) * 4                   # stage-3 width
+    m = args.batch * (side // 16) ** 2
+    x = torch.randn(m, c, device=dev)
+    w = torch.randn(4 * c, c, device=dev) * 0.05
+    b = torch.zeros(4 * c, device=dev)
+    amax_of(x), amax_of(w)
+    ops.linear_f16x3(x, w, b, tag_out=False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.linear_f16x3(x, w, b, tag_out=False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * m * c * 4 * c
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": f"k_gemm<2,4,4,2> (dcl_gemm_f16x3): Swin stage-3 Mlp.fc1 forward, [{m} x {c}] . [{4 * c} x {c}]^T + bias",
+            "achieved": round(achieved, 2), "peak": round(MFMA_F16X3_BWD_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_F16X3_BWD_PEAK_TFLOPS, 4),
+            "peak_note": "2 M N K algorithmic FLOP issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): 2.5 PFLOP/s / 3",
+            "traffic": None, "algorithmic_bytes": 4 * (m * c + 4 * c * c + m * 4 * c), "launch_ms": round(ms, 4)}
+
+
 def roofline_bwd_kernel(mod, iters=10):
     """Average launch duration of the dominant kernel (InfoNCE backward sweep, intra-scale term 0),
     HIP events on the launch stream; algorithmic FLOPs = 4 * N1 * N2 * C (S = A B^T recompute + H B)."""
@@ -587,8 +618,11 @@ def main():
         out.update(extra)
         if workload == "loss":
             out["contrastive_loss_fwd_bwd_ms"] = round(ms_per_step, 3)
-        if workload == "loss" or args.config != 2:
+        if workload == "loss":
             out["roofline"] = roofline_bwd_kernel(mod)
+        elif args.config != 2:
+            out["roofline"] = roofline_gemm_kernel(args, dev)
+            out["roofline_other"] = [roofline_bwd_kernel(mod)]
         else:
             out["roofline"], others = roofline_conv_kernels(args, dev)
             out["roofline_other"] = others + [roofline_bwd_kernel(mod)]
