@@ -353,9 +353,31 @@ __global__ __launch_bounds__(TAP_TW) void k_tapup_fwd(TapSrc s0, TapSrc s1, int 
         const float *zp = s.z + (size_t)n * s.sn + (size_t)co * s.sc;
         const size_t tapstride = (size_t)Co * s.sc;
         float *Zw = Zbase + s.zoff;                             // [9][wr][wc]
-        for (int e = t; e < 9 * nr * (nc + 1); e += TAP_TW) {
-            const int c = e % (nc + 1), r = (e / (nc + 1)) % nr, tap = e / ((nc + 1) * nr);
-            Zw[(tap * s.wr + r) * s.wc + c] = zp[tap * tapstride + (size_t)(ra + r) * s.w + ca + min(c, nc - 1)];
+        {
+            // flat element loop (many independent loads per thread); quotients by multiplication with the reciprocal, exact
+            // for these ranges (e < 2^15, divisors < 2^9), instead of two integer divisions per element
+            const float inv_c = 1.0f / (float)(nc + 1), inv_r = 1.0f / (float)nr;
+            // eight loads in flight per thread: one load -> store per trip leaves the window staging bound by the
+            // memory latency (~33 trips per thread)
+            const int total = 9 * nr * (nc + 1);
+            for (int e0 = t; e0 < total; e0 += 8 * TAP_TW) {
+                float v[8];
+                int dsti[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u * TAP_TW, total - 1);
+                    const int row = (int)(((float)e + 0.5f) * inv_c);
+                    const int c = e - row * (nc + 1);
+                    const int tap = (int)(((float)row + 0.5f) * inv_r);
+                    const int r = row - tap * nr;
+                    dsti[u] = (tap * s.wr + r) * s.wc + c;
+                    v[u] = zp[tap * tapstride + (size_t)(ra + r) * s.w + ca + min(c, nc - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u * TAP_TW < total)
+                        Zw[dsti[u]] = v[u];
+            }
         }
         for (int j = t; j < TAP_RC + 2; j += TAP_TW) {
             const int Ys = Y0 - 1 + j;
@@ -387,7 +409,32 @@ __global__ __launch_bounds__(TAP_TW) void k_tapup_fwd(TapSrc s0, TapSrc s1, int 
     if (X >= W)
         return;
     float *yp = y + ((size_t)plane * H + Y0) * W + X;
+    // Consecutive output rows interpolate from the SAME pair of source rows (4 of them at scale 4, 8 at scale 8): the
+    // horizontally interpolated values of a (source, ky, kx) are kept in registers and re-read from LDS only when the
+    // row pair of that shifted row changes (a wave-uniform test) -- per output ~14 LDS reads and ~45 FMA instead of 72 / 108.
+    // The row-table entries of the three shifted rows live in registers and rotate: ONE new entry per source and output row
+    // is read from LDS, a row ahead of its use (six dependent LDS reads + scalar tests per row had bound the loop).
+    float ha[2][3][3], hb[2][3][3];
+    f32x4 rt[2][3];
+    int o0[2][3], o1[2][3];
+    bool ch[2][3];
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            rt[si][ky] = *(const f32x4 *)(rtab + (si * (TAP_RC + 2) + ky) * 4);
+            o0[si][ky] = __builtin_amdgcn_readfirstlane(__float_as_int(rt[si][ky].x));
+            o1[si][ky] = __builtin_amdgcn_readfirstlane(__float_as_int(rt[si][ky].y));
+            ch[si][ky] = true;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                ha[si][ky][kx] = hb[si][ky][kx] = 0.f;
+        }
     for (int yy = 0; yy < TAP_RC && Y0 + yy < H; ++yy) {
+        f32x4 nx[2];
+#pragma unroll
+        for (int si = 0; si < 2; ++si)          // entry of shifted row yy + 3 (the table is TAP_RC + 2 long: clamp)
+            nx[si] = *(const f32x4 *)(rtab + (si * (TAP_RC + 2) + min(yy + 3, TAP_RC + 1)) * 4);
         float acc = 0.f;
 #pragma unroll
         for (int si = 0; si < 2; ++si) {
@@ -397,17 +444,39 @@ __global__ __launch_bounds__(TAP_TW) void k_tapup_fwd(TapSrc s0, TapSrc s1, int 
             const float *Zw = Zbase + s.zoff;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const f32x4 rt = *(const f32x4 *)(rtab + (si * (TAP_RC + 2) + yy + ky) * 4);
-                const int o0 = __float_as_int(rt.x), o1 = __float_as_int(rt.y);
+                if (ch[si][ky]) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float *zt = Zw + (size_t)(ky * 3 + kx) * s.wr * s.wc + cix[si][kx];
-                    const float a0 = zt[o0], a1 = zt[o0 + 1], b0 = zt[o1], b1 = zt[o1 + 1];
-                    acc += rt.z * (cw0[si][kx] * a0 + cw1[si][kx] * a1) + rt.w * (cw0[si][kx] * b0 + cw1[si][kx] * b1);
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float *zt = Zw + (size_t)(ky * 3 + kx) * s.wr * s.wc + cix[si][kx];
+                        ha[si][ky][kx] = cw0[si][kx] * zt[o0[si][ky]] + cw1[si][kx] * zt[o0[si][ky] + 1];
+                        hb[si][ky][kx] = cw0[si][kx] * zt[o1[si][ky]] + cw1[si][kx] * zt[o1[si][ky] + 1];
+                    }
                 }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc += rt[si][ky].z * ha[si][ky][kx] + rt[si][ky].w * hb[si][ky][kx];
             }
         }
         yp[(size_t)yy * W] = accumulate ? yp[(size_t)yy * W] + acc : acc;
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {        // rotate: (si, ky) of the next row is the entry one further down
+            const int n0 = __builtin_amdgcn_readfirstlane(__float_as_int(nx[si].x));
+            const int n1 = __builtin_amdgcn_readfirstlane(__float_as_int(nx[si].y));
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int a0 = ky < 2 ? o0[si][ky + 1] : n0, a1 = ky < 2 ? o1[si][ky + 1] : n1;
+                ch[si][ky] = a0 != o0[si][ky] || a1 != o1[si][ky];
+            }
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky) {
+                rt[si][ky] = rt[si][ky + 1];
+                o0[si][ky] = o0[si][ky + 1];
+                o1[si][ky] = o1[si][ky + 1];
+            }
+            rt[si][2] = nx[si];
+            o0[si][2] = n0;
+            o1[si][2] = n1;
+        }
     }
 }
 
