@@ -35,6 +35,8 @@ class DebugConfig:
     packed_relu_mask: bool = field(default_factory=lambda: _flag('DCL_BN_MASK'))                # packed sign mask in the BN backward
     gemm_conv1x1: bool = field(default_factory=lambda: _flag('DCL_GEMM_CONV1X1'))               # wide 1x1 convolutions on dcl_gemm_f16x3
     gemm_head_taps: bool = field(default_factory=lambda: _flag('DCL_GEMM_HEAD'))                # the head's tap products on it
+    head_overlap: int = field(default_factory=lambda: 2 if _int('DCL_HEAD_OVERLAP') is None else _int('DCL_HEAD_OVERLAP'))  # coarse half of the head's
+    # backward on a side stream: 0 off, 1 on, 2 on with the fine part's weight gradient first (A/B: 96.4 / 96.0 / 95.6 ms)
     gemm_gemm_tile: Optional[int] = field(default_factory=lambda: _int('DCL_GEMM_TILE'))       # 1..4: force a workgroup tile
     coalesced_sync_bn: bool = field(default_factory=lambda: _flag('DCL_SYNCBN_COALESCE'))       # stacked SyncBN exchanges
     side_stream_priority: Optional[int] = field(default_factory=lambda: _int('DCL_SIDE_PRIO'))  # HIP priority of the branch streams
