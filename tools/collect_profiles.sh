@@ -8,6 +8,8 @@
 #   <tag>_conv_pmc_{fetch,write}.csv                  same for the direct convolution kernels (per-shape tool)
 #   <tag>_conv_per_shape.csv                          HIP-event time per launch and roofline fraction per shape
 #   <tag>_conv_per_shape_rocprof.csv                  rocprofv3 kernel trace of the same tool, one row per (kernel, grid)
+#   <tag>_gemm_shapes_{swinl,swint,head}.csv          dcl_gemm_f16x3 vs the library's fp32 GEMM per shape (time, TFLOP/s, errors)
+#   <tag>_gemm_pmc_{sq,fetch,write}.csv               counters of the GEMM on the Swin-L stage-3 fc1 shape
 set -e
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -40,4 +42,18 @@ python3 $ROOT/tools/per_shape_roofline.py --out $OUT/${TAG}_conv_per_shape.csv >
 D=$OUT/${TAG}_shape_trace; rm -rf $D
 rocprofv3 --kernel-trace --output-format csv -d $D -- python3 $ROOT/tools/per_shape_roofline.py > $D.log 2>&1
 $S bygrid $(find $D -name '*kernel_trace.csv' | head -1) > $OUT/${TAG}_conv_per_shape_rocprof.csv; rm -rf $D $D.log
+# split-f16 GEMM: per-shape table against the library, counters of the Swin-L stage-3 fc1 shape
+python3 $ROOT/tools/gemm_shapes.py --only swinl > $OUT/${TAG}_gemm_shapes_swinl.csv 2>/dev/null
+python3 $ROOT/tools/gemm_shapes.py --only swint > $OUT/${TAG}_gemm_shapes_swint.csv 2>/dev/null
+python3 $ROOT/tools/gemm_shapes.py --only head > $OUT/${TAG}_gemm_shapes_head.csv 2>/dev/null
+D=$OUT/${TAG}_pmc_tmp; rm -rf $D
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+  --kernel-trace --output-format csv -d $D -- python3 $ROOT/tools/gemm_shapes.py --shape 25600,768,3072 --no-library --iters 3 > $D.log 2>&1
+$S pmc $(find $D -name '*counter_collection.csv' | head -1) | grep -v "at::native" > $OUT/${TAG}_gemm_pmc_sq.csv; rm -rf $D
+for C in FETCH_SIZE WRITE_SIZE; do
+  n=$(echo $C | tr A-Z a-z | sed 's/_size//')
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -- python3 $ROOT/tools/gemm_shapes.py --shape 25600,768,3072 --no-library --iters 3 > $D.log 2>&1
+  $S pmc $(find $D -name '*counter_collection.csv' | head -1) | grep -v "at::native" > $OUT/${TAG}_gemm_pmc_$n.csv; rm -rf $D
+done
+rm -f $OUT/*.log
 ls -la $OUT | grep ${TAG}_

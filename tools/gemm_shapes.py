@@ -82,7 +82,7 @@ def main():
     head_rows = []
     if args.only in ("", "head"):
         # the head's tap products (models/ops.py _CoarseTaps): z = W_b x_b, dx_b = W_b^T dz, dW_b = dz x_b^T
-        for cb, p in ((96, 12 * 64 * 128), (192, 12 * 32 * 64), (384, 12 * 16 * 32)):
+        for cb, p in ((192, 12 * 32 * 64), (384, 12 * 16 * 32)):          # HRNet-W48: the 1/4- and 1/8-resolution branches
             head_rows.append((cb, p))
     print("shape,ms_f16x3,tflops_f16x3,frac_of_833,ms_library_f32,speedup,err_f16x3,err_library")
     groups = [linear_rows(name, m, k, n) for name, m, k, n in rows] if not head_rows else []
