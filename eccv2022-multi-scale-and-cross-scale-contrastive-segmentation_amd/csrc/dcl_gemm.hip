@@ -469,23 +469,25 @@ __global__ __launch_bounds__(256) void k_gemm_slab_sum(const float *__restrict__
     }
 }
 
-int g_gemm_tile = 0;        // 0 = automatic; 1 = 256 x 256, 2 = 256 x 128, 3 = 128 x 256, 4 = 128 x 128
+int g_gemm_tile = 0;        // 0 = automatic; 1 = 256 x 256, 2 = 256 x 128, 3 = 128 x 256, 4 = 128 x 128, 5 = 256 x 192
 
 struct TileCfg { int bm, bn, nt; };
-constexpr TileCfg TILES[4] = {{256, 256, 512}, {256, 128, 512}, {128, 256, 512}, {128, 128, 256}};
+constexpr int NTILES = 5;
+constexpr TileCfg TILES[NTILES] = {{256, 256, 512}, {256, 128, 512}, {128, 256, 512}, {128, 128, 256}, {256, 192, 512}};
 
 int pick_tile(int M, int N, int z)
 {
-    if (g_gemm_tile >= 1 && g_gemm_tile <= 4)
+    if (g_gemm_tile >= 1 && g_gemm_tile <= NTILES)
         return g_gemm_tile - 1;
     // cost model: rounds of 256 workgroups x work per workgroup (tile area, smaller tiles pay ~10-25 % more per FLOP)
-    const double eff[4] = {1.0, 0.90, 0.90, 0.75};
+    const double eff[NTILES] = {1.0, 0.90, 0.90, 0.75, 0.96};
     int best = 0;
     double bc = 1e30;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NTILES; ++c) {
         const long wg = (long)((M + TILES[c].bm - 1) / TILES[c].bm) * ((N + TILES[c].bn - 1) / TILES[c].bn) * z;
         const long rounds = (wg + 255) / 256;
         // a partial last round costs a full tile time; below one round the time is one tile regardless
+        // (padding inside the last tile row / column is paid in full: 576 columns are 3 tiles of 192 or 3 of 256)
         const double cost = (double)rounds * TILES[c].bm * TILES[c].bn / eff[c];
         if (cost < bc)
             bc = cost, best = c;
@@ -526,7 +528,7 @@ int launch_gemm(const GemmArgs &a, int akm, int bkm, hipStream_t stream)
 
 extern "C" int dcl_gemm_set_tile(int tile)
 {
-    DCL_CHECK_ARG(tile >= 0 && tile <= 4, "tile must be 0 (automatic) .. 4");
+    DCL_CHECK_ARG(tile >= 0 && tile <= NTILES, "tile must be 0 (automatic) .. 5");
     g_gemm_tile = tile;
     return 0;
 }
@@ -601,6 +603,7 @@ extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t
     case 0: rc = launch_gemm<2, 4, 4, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
     case 1: rc = launch_gemm<2, 2, 4, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
     case 2: rc = launch_gemm<2, 2, 2, 4>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
+    case 4: rc = launch_gemm<2, 3, 4, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
     default: rc = launch_gemm<2, 2, 2, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
     }
     if (rc != 0)

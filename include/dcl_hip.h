@@ -298,7 +298,7 @@ int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, in
  *   splitk > 1: the contraction is cut into splitk ranges, each writes a slab to ws (dcl_gemm_workspace_floats floats)
  *   and a second kernel sums the slabs in ascending order (+ bias, + C): deterministic; for outputs too small to fill
  *   256 CUs (weight gradients).  dcl_gemm_suggest_splitk returns 1 when the tiles alone fill the chip.
- *   dcl_gemm_set_tile: 0 automatic, 1..4 = 256x256 / 256x128 / 128x256 / 128x128 workgroup tile (A/B runs). */
+ *   dcl_gemm_set_tile: 0 automatic, 1..5 = 256x256 / 256x128 / 128x256 / 128x128 / 256x192 workgroup tile (A/B runs). */
 int dcl_gemm_supported(int M, int N, int K, int64_t lda, int a_kmajor, int64_t ldb, int b_kmajor);
 int64_t dcl_gemm_workspace_floats(int M, int N, int batch, int splitk);
 int dcl_gemm_suggest_splitk(int M, int N, int K, int batch);

@@ -1382,7 +1382,7 @@ def test_stride2_gradient_formulations_agree(dev):
 # ---- split-f16 GEMM (csrc/dcl_gemm.hip) ---------------------------------------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_gemm_f16x3_every_layout_matches_fp64(dev, tile):
     """dcl_gemm_f16x3: all four operand layouts (contraction index contiguous / row index contiguous), ragged M and N,
     one to many k-steps, batch, bias, accumulate, k-split slabs and the absmax side output, every workgroup tile, against
