@@ -64,6 +64,7 @@ class FPN(nn.Module):
         self.fpn_num_ch = config.get('fpn_num_ch', 512)
         self.fpn_num_lvl = min(max(config.get('fpn_num_lvl', len(self.in_scales)), 1), len(self.in_scales))
         self.interpolate_result_up = config.get('interpolate_result_up', True)
+        self.head_split = bool(config.get('head_split', True))
         self.return_features = True
         # 'hip_decoder' (default on): fused BN(+ReLU) kernels, HIP bilinear resize (forward with the lateral add folded
         # in, deterministic gather backward) and 1x1 convolutions as batched GEMMs -- same parameters / state_dict
@@ -98,9 +99,30 @@ class FPN(nn.Module):
         # (UPerNet.py:96-101), and conv_last's input channels are laid out accordingly
         # (upsample_concat: the up-sampled levels are written straight into their channel slice of the fusion
         # convolution's 2048-channel input and the gradient is read out of the slice in place -- no cat copy of 537 MB)
-        fused = upsample_concat([pyramid[0]] + [pyramid[-i + 1] for i in range(2, self.fpn_num_lvl + 1)],
-                                self.align_corners)
-        x = self.conv_last(fused)
+        parts = [pyramid[0]] + [pyramid[-i + 1] for i in range(2, self.fpn_num_lvl + 1)]
+        block = self.conv_last[0]
+        conv = block[0] if isinstance(block, nn.Sequential) else block
+        from .ops import DirectConv2d, LazyConcat, conv3x3_over_upsampled
+        if (self.head_split and isinstance(block, _ConvBNAct) and isinstance(conv, DirectConv2d) and len(parts) > 1
+                and parts[0].is_cuda and parts[0].dtype == torch.float32 and not torch.is_autocast_enabled()
+                and all(t.is_contiguous() for t in parts)):
+            # graph key `head_split` (default on): the fusion convolution over the PARTS -- the channel products of the
+            # levels that are >= 4x coarser run at their own resolution (models/ops.py conv3x3_over_upsampled: 47 % of the
+            # 2048 -> 512 convolution's multiply-adds move to 1/16 and 1/64 of the pixels); the concatenation is only formed
+            # if somebody asks for it (a single-scale projector on 'fused_feats')
+            fused = LazyConcat(parts, self.align_corners)
+            y = conv3x3_over_upsampled(parts, self.align_corners, conv.weight, conv.bias)
+            if isinstance(block[1], FusedBatchNorm2d) and (len(block) == 2 or isinstance(block[2], nn.ReLU)):
+                y = bn_act(block[1], y, relu=len(block) == 3)
+            else:
+                for layer in list(block)[1:]:
+                    y = layer(y)
+            x = y
+            for layer in list(self.conv_last)[1:]:
+                x = layer(x)
+        else:
+            fused = upsample_concat(parts, self.align_corners)
+            x = self.conv_last(fused)
         if self.return_features:
             return x, pyramid, fused
         return x
@@ -241,7 +263,7 @@ class UPerNet(nn.Module):
                 else:
                     proj = self.projector_model(fpn_feats)
             else:
-                proj = self.projector_model(fused)
+                proj = self.projector_model(fused.materialize() if hasattr(fused, 'materialize') else fused)
             if self.return_features:
                 return (interm, logits, proj) if self.get_intermediate else (logits, proj)
         if self.get_intermediate:

@@ -612,6 +612,18 @@ def use_direct_conv1x1(module: torch.nn.Module) -> torch.nn.Module:
 
 # ---- head convolution over a concatenation of up-sampled maps, without the up-sampled maps ---------------------------
 
+def _coarse_offsets(c0, channels):
+    """First input channel of every coarse map (``channels``: their channel counts): ``c0`` is either the first one's (the
+    maps follow each other in the weight) or a tuple with one offset per map."""
+    if isinstance(c0, (tuple, list)):
+        return [int(v) for v in c0]
+    offs, off = [], int(c0)
+    for c in channels:
+        offs.append(off)
+        off += c
+    return offs
+
+
 class _CoarseTaps(torch.autograd.Function):
     """addend [N, Co, H, W] = sum over the coarse maps x_b of conv3x3(up(x_b), weight[:, slice_b], padding=1), computed as
     z_b = W_b x_b (ONE split-f16 GEMM per map over all images: [9 Co, C_b] x [C_b, N h w], dcl_gemm_f16x3) at LOW resolution
@@ -633,8 +645,9 @@ class _CoarseTaps(torch.autograd.Function):
         st = _lib.stream_ptr(y.device)
         use_gemm = _CoarseTaps.gemm and all(t.shape[1] % 32 == 0 and (n * t.shape[2] * t.shape[3]) % 32 == 0 for t in ts)
         wam = _am.amax_of(weight) if use_gemm else None
-        saved, zs, off, xams = [], [], c0, []
-        for t in ts:
+        offs = _coarse_offsets(c0, [t.shape[1] for t in ts])
+        saved, zs, xams = [], [], []
+        for t, off in zip(ts, offs):
             cb, h, w = t.shape[1:]
             P = n * h * w
             xam = _am.amax_of(t) if use_gemm else None
@@ -648,7 +661,6 @@ class _CoarseTaps(torch.autograd.Function):
             zs.append((z, h, w))
             saved += [xc, wb]
             xams.append(xam)
-            off += cb
         for i in range(0, len(zs), 2):
             z0, h0, w0 = zs[i]
             z1, h1, w1 = zs[i + 1] if i + 1 < len(zs) else (None, 0, 0)
@@ -670,8 +682,10 @@ class _CoarseTaps(torch.autograd.Function):
         st = _lib.stream_ptr(dy.device)
         gw = torch.zeros(wshape, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[4] else None
         dyam = _am.amax_of(dy) if ctx.ams is not None else None
-        grads, off = [], c0
+        grads = []
+        offs = _coarse_offsets(c0, [sh[1] for sh in shapes])
         for i, (n, cb, h, w) in enumerate(shapes):
+            off = offs[i]
             xc, wb = ctx.saved_tensors[2 * i], ctx.saved_tensors[2 * i + 1]
             P = n * h * w
             dz = torch.empty((9 * Co, P), dtype=torch.float32, device=dy.device)
@@ -698,7 +712,6 @@ class _CoarseTaps(torch.autograd.Function):
                 if gw is not None:
                     gw[:, off:off + cb] = torch.mm(dz, xc.t()).view(3, 3, Co, cb).permute(2, 3, 0, 1)
             grads.append(gx)
-            off += cb
         return (None, None, None, None, gw, *grads)
 
 
@@ -780,15 +793,18 @@ class _HeadSplit(torch.autograd.Function):
     overlap = _dbg.head_overlap        # 0 off, 1 on, 2 on with the fine part's weight gradient first
 
     @staticmethod
-    def forward(ctx, align, H, W, c_fine, hi, weight, bias, *coarse):
+    def forward(ctx, align, H, W, layout, hi, weight, bias, *coarse):
+        fine_ranges, coarse_offs = layout
         cctx, fctx = _ShimCtx(), _ShimCtx()
-        addend = _CoarseTaps.forward(cctx, align, H, W, c_fine, weight, *coarse)
-        out = _Conv3x3Addend.forward(fctx, hi, weight[:, :c_fine], bias, addend)
+        addend = _CoarseTaps.forward(cctx, align, H, W, tuple(coarse_offs), weight, *coarse)
+        w_f = weight[:, fine_ranges[0][0]:fine_ranges[0][1]] if len(fine_ranges) == 1 else \
+            torch.cat([weight[:, a:b] for a, b in fine_ranges], 1)
+        out = _Conv3x3Addend.forward(fctx, hi, w_f, bias, addend)
         ctx.save_for_backward(*cctx.saved_tensors, *fctx.saved_tensors)
         ctx.nc = len(cctx.saved_tensors)
         ctx.c = (cctx.geom, cctx.ams)
         ctx.f = fctx.has_bias
-        ctx.c_fine, ctx.ncoarse = c_fine, len(coarse)
+        ctx.fine_ranges = tuple(fine_ranges)
         return out
 
     @staticmethod
@@ -821,7 +837,10 @@ class _HeadSplit(torch.autograd.Function):
             rf = _Conv3x3Addend.backward(fctx, gy)
         gw = rc[4]
         if gw is not None and rf[1] is not None:
-            gw[:, :ctx.c_fine] = rf[1]
+            off = 0
+            for a, b in ctx.fine_ranges:
+                gw[:, a:b] = rf[1][:, off:off + b - a]
+                off += b - a
         return (None, None, None, None, rf[0], gw, rf[2], *rc[5:])
 
 
@@ -854,19 +873,24 @@ def conv3x3_over_upsampled(ts, align_corners, weight, bias, min_scale=4):
     so their channel products are 1x1 convolutions at LOW resolution (library fp32 GEMMs producing 9 * Co maps per source)
     and the rest is the tap-wise bilinear gather of ``_CoarseTaps``; the finer maps are concatenated and convolved directly, with
     the gathered sum as the convolution's addend.  For HRNet-W48's head (48 + 96 + 192 + 384 channels at scales 1, 2, 4,
-    8) 80 % of the multiply-adds move to 1/16 and 1/64 of the pixels.  Equal to the reference formulation up to fp32
+    8) 80 % of the multiply-adds move to 1/16 and 1/64 of the pixels; UPerNet's fusion convolution (P2, P5, P4, P3 -- the maps
+    may come in any order, ts[0] is the full-resolution one) 47 %.  Equal to the reference formulation up to fp32
     round-off (tests/test_hip_parity.py::test_head_conv_over_upsampled_matches_fp64)."""
     t0 = ts[0]
     n, _, H, W = t0.shape
-    Co = weight.shape[0]
-    fine = [t for t in ts if t is t0 or t.shape[-1] * min_scale > W]
-    coarse = [t for t in ts if not (t is t0 or t.shape[-1] * min_scale > W)]
-    assert [id(t) for t in fine + coarse] == [id(t) for t in ts], "maps must be ordered fine to coarse"
-    c_fine = sum(t.shape[1] for t in fine)
+    offs, off = [], 0
+    for t in ts:
+        offs.append(off)
+        off += t.shape[1]
+    is_fine = [t is t0 or t.shape[-1] * min_scale > W for t in ts]
+    fine = [t for t, f in zip(ts, is_fine) if f]
+    coarse = [t for t, f in zip(ts, is_fine) if not f]
+    fine_ranges = tuple((o, o + t.shape[1]) for t, o, f in zip(ts, offs, is_fine) if f)
+    coarse_offs = tuple(o for o, f in zip(offs, is_fine) if not f)
     hi = upsample_concat(fine, align_corners) if len(fine) > 1 else t0
     if not coarse:
-        return _Conv3x3Addend.apply(hi, weight[:, :c_fine], bias, None)
-    return _HeadSplit.apply(bool(align_corners), H, W, c_fine, hi, weight, bias, *coarse)
+        return _Conv3x3Addend.apply(hi, weight, bias, None)
+    return _HeadSplit.apply(bool(align_corners), H, W, (fine_ranges, coarse_offs), hi, weight, bias, *coarse)
 
 
 # ---- 1x1 convolutions as plain batched GEMMs ----------------------------------------------------------------------

@@ -1328,6 +1328,40 @@ def test_head_conv_over_upsampled_matches_fp64(dev, align, chans, H, W, Co, bias
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("align", [True, False])
+def test_head_conv_over_upsampled_any_map_order(dev, align):
+    """UPerNet's fusion convolution concatenates [P2, P5, P4, P3] (reference models/UPerNet.py:96-101): the coarse maps sit
+    BETWEEN the fine ones in the weight's input channels.  conv3x3_over_upsampled against float64 for that order (output,
+    every map's gradient, weight gradient), with the overlapped backward (the default) and without."""
+    import torch.nn.functional as F
+    from mscs_amd.models import ops
+    torch.manual_seed(9)
+    n, H, W, Co = 2, 64, 64, 64
+    sizes = [(64, 64), (8, 8), (16, 16), (32, 32)]
+    for overlap in (2, 0):
+        prev = ops._HeadSplit.overlap
+        ops._HeadSplit.overlap = overlap
+        try:
+            ts = [torch.randn(n, 64, h, w, device=dev).requires_grad_(True) for (h, w) in sizes]
+            wt = (torch.randn(Co, 256, 3, 3, device=dev) * 0.05).requires_grad_(True)
+            gy = torch.randn(n, Co, H, W, device=dev)
+            y = ops.conv3x3_over_upsampled(ts, align, wt, None)
+            y.backward(gy)
+            got = [y.detach()] + [t.grad for t in ts] + [wt.grad]
+            ts64 = [t.detach().double().requires_grad_(True) for t in ts]
+            w64 = wt.detach().double().requires_grad_(True)
+            cat = torch.cat([ts64[0]] + [F.interpolate(t, size=(H, W), mode="bilinear", align_corners=align) for t in ts64[1:]], 1)
+            y64 = F.conv2d(cat, w64, None, padding=1)
+            y64.backward(gy.double())
+            ref = [y64.detach()] + [t.grad for t in ts64] + [w64.grad]
+            for k, (a, r) in enumerate(zip(got, ref)):
+                err = ((a.double() - r).abs().max() / r.abs().max()).item()
+                assert err < (3e-6 if k == 0 else 1e-5), (overlap, k, err)
+        finally:
+            ops._HeadSplit.overlap = prev
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", [0, 2])
 def test_weight_gradient_kernel_variants_match_fp64(dev, variant):
     """The two stride-1 weight-gradient kernels of the library -- MFMA-order loads (0, dcl_wgrad3x3.hip: the fallback) and

@@ -220,3 +220,37 @@ def test_fused_layernorm_fallbacks():
     assert torch.equal(ln(xt), F.layer_norm(xt, (96,), ln.weight, ln.bias, ln.eps))
 
 
+
+
+@pytest.mark.gpu
+def test_linear_weight_tags_and_tag_carrying():
+    """LinearTagGroup: one multi-tensor launch tags every TokenLinear weight with its exact absmax and re-tags after an
+    in-place update; amax.carry hands a tag to views (the GEMM wrappers find operand scales without a pass); the tagged GELU
+    bounds its output and, backward, its input gradient."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import amax, ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    net = torch.nn.Sequential(ops.TokenLinear(64, 96), ops.TokenLinear(96, 32, bias=False)).to(dev)
+    grp = ops.LinearTagGroup(net)
+    grp.refresh()
+    for m in net:
+        t = amax.tag_of(m.weight)
+        assert t is not None and abs(t.max().item() - m.weight.abs().max().item()) == 0.0
+    with torch.no_grad():
+        net[0].weight.mul_(3.0)
+    assert amax.tag_of(net[0].weight) is None            # stale after the in-place update
+    grp.refresh()
+    assert abs(amax.tag_of(net[0].weight).max().item() - net[0].weight.abs().max().item()) == 0.0
+    x = torch.randn(4, 512, 64, device=dev)
+    amax.amax_of(x)
+    v = amax.carry(x, x.view(-1, 64))
+    assert amax.tag_of(v) is amax.tag_of(x)
+    h = torch.randn(2048, 96, device=dev, requires_grad=True)
+    amax.amax_of(h)
+    g = ops.tagged_gelu(h)
+    assert amax.tag_of(g) is amax.tag_of(h) and g.abs().max() <= amax.tag_of(g).max()
+    gy = torch.randn_like(g)
+    amax.amax_of(gy)
+    g.backward(gy)
+    assert torch.allclose(h.grad, torch.ops.aten.gelu_backward(gy, h.detach(), approximate="none"))
