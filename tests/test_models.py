@@ -382,3 +382,26 @@ def test_lovasz_softmax_matches_reference():
         loss.backward()
         np.testing.assert_allclose(loss.item(), z[name + "_loss"], rtol=1e-5)
         np.testing.assert_allclose(x.grad.numpy(), z[name + "_grad"], atol=1e-6 * np.abs(z[name + "_grad"]).max() + 1e-9)
+
+
+def test_drop_path_fused_residual_matches_two_step_form():
+    """DropPath.add_to (one addcmul with the per-sample factor) == shortcut + DropPath(x): same mask draw from the same
+    generator state, values and both gradients to round-off; identity in eval mode and at rate 0."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models.Swin import DropPath
+    dp = DropPath(0.3).train()
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(123)
+        s = torch.randn(8, 5, 6, requires_grad=True)
+        x = torch.randn(8, 5, 6, requires_grad=True)
+        torch.manual_seed(7)
+        y = dp.add_to(s, x) if fused else s + dp(x)
+        y.backward(torch.ones_like(y) * 0.5)
+        outs.append((y.detach(), s.grad, x.grad))
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    assert (outs[0][2] == 0).any() and (outs[0][2] != 0).any()          # some samples dropped, some kept
+    dp.eval()
+    s, x = torch.randn(2, 3), torch.randn(2, 3)
+    assert torch.equal(dp.add_to(s, x), s + x) and torch.equal(DropPath(0.0).train().add_to(s, x), s + x)
