@@ -96,7 +96,7 @@ SIGNATURES = {
     "dcl_layernorm_supported": [_i],
     "dcl_layernorm_bwd_parts": [_i64, _i],
     "dcl_layernorm_fwd": [_vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _vp, _vp, _vp],
-    "dcl_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp],
+    "dcl_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_upsample_ce_fwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "dcl_upsample_ce_bwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "dcl_suggest_nsplit": [_i, _i],

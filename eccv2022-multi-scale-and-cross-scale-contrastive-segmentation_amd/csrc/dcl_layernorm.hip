@@ -104,10 +104,12 @@ template <int V, int G>
 __global__ __launch_bounds__(256) void k_ln_bwd(const float *__restrict__ gy, const float *__restrict__ x,
                                                 const float *__restrict__ gamma, const float *__restrict__ mean,
                                                 const float *__restrict__ rstd, long long M, float *__restrict__ gx,
-                                                float *__restrict__ parts)
+                                                float *__restrict__ parts, const float *__restrict__ addend,
+                                                float *__restrict__ gxamax)
 {
     constexpr int C = 4 * V * G, RW = 64 / G;
     __shared__ float red[4][2][C];
+    float gmax = 0.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % G, rl = lane / G;
     f32x4 gm[V], dg[V], db[V];
@@ -150,9 +152,22 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float *__restrict__ gy, co
                 o.y = rs * (a[v].y - c1 - xh[v].y * c2);
                 o.z = rs * (a[v].z - c1 - xh[v].z * c2);
                 o.w = rs * (a[v].w - c1 - xh[v].w * c2);
+                if (addend) {           // the gradient of the residual connection around this norm: one pass instead of
+                                        // autograd's separate add (x feeds the norm AND the shortcut)
+                    const f32x4 r = *(const f32x4 *)(addend + row * C + 4 * (sub + v * G));
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
                 *(f32x4 *)(op + 4 * (sub + v * G)) = o;
+                gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             }
         }
+    }
+    if (gxamax) {                       // absmax of the result: the gradient the previous block's Linears receive
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+        if (lane == 0)
+            atomicMax((int *)gxamax + (blockIdx.x & (DCL_AMAX_SLOTS - 1)), __float_as_int(gmax));
     }
     // columns: over the row groups of the wave, then over the waves
 #pragma unroll
@@ -294,16 +309,17 @@ extern "C" int dcl_layernorm_fwd(const float *x, const float *gamma, const float
 
 extern "C" int dcl_layernorm_bwd(const float *gy, const float *x, const float *gamma, const float *mean,
                                  const float *rstd, long long M, int C, float *gx, float *parts, float *dgamma_dbeta,
-                                 void *stream)
+                                 const float *addend, float *gxamax, void *stream)
 {
     DCL_CHECK_ARG(gy && x && gamma && mean && rstd && gx && parts && dgamma_dbeta, "null pointer");
+    DCL_CHECK_ARG(!addend || (((uintptr_t)addend) & 15) == 0, "16-byte alignment");
     int V = 0, G = 0;
     DCL_CHECK_ARG(M > 0 && ln_plan(C, V, G), "unsupported row length (C = 4 V G, G a power of two in 8..64, V in 1,2,3,4,6,8)");
     DCL_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)gy) | ((uintptr_t)gx) | ((uintptr_t)gamma)) & 15) == 0,
                   "16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
     const unsigned blocks = (unsigned)ln_blocks(M, G);
-    DCL_LN_DISPATCH(k_ln_bwd, gy, x, gamma, mean, rstd, M, gx, parts);
+    DCL_LN_DISPATCH(k_ln_bwd, gy, x, gamma, mean, rstd, M, gx, parts, addend, gxamax);
     DCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ln_parts_sum, dim3((2 * C + 15) / 16), dim3(256), 0, s, parts, (int)blocks, 2 * C,
                        dgamma_dbeta);

@@ -68,7 +68,29 @@ class DropPath(nn.Module):
             return shortcut + x
         keep = 1.0 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
-        return torch.addcmul(shortcut, x, mask / keep)
+        return _ScaledResidual.apply(shortcut, x, mask / keep, 1.0 / keep)
+
+
+class _ScaledResidual(torch.autograd.Function):
+    """shortcut + x * scale (scale [B, 1, ...], no gradient); backward: the incoming gradient goes to the shortcut as it
+    is, scaled to x -- with its absmax tag (|g scale| <= |g| / keep), so that the Linear behind x finds its operand scale
+    without a pass over the gradient."""
+
+    @staticmethod
+    def forward(ctx, shortcut, x, scale, bound):
+        ctx.save_for_backward(scale)
+        ctx.bound = float(bound)
+        return torch.addcmul(shortcut, x, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        gx = g * scale
+        if g.is_cuda:
+            t = tag_of(g)
+            if t is not None:
+                tag(gx, t * ctx.bound)
+        return g, gx, None, None
 
 
 def _residual(shortcut, y, drop_path):
@@ -177,7 +199,8 @@ class SwinTransformerBlock(nn.Module):
             # result back in natural order): no pad, roll, partition, reverse, roll, crop copies (csrc/dcl_winattn.hip).
             from .ops import window_attention
             a = self.attn
-            qkv = a.qkv(self.norm1(x))
+            n1, shortcut = self.norm1.with_shortcut(x) if isinstance(self.norm1, FusedLayerNorm) else (self.norm1(x), x)
+            qkv = a.qkv(n1)
             qb = a.qkv.bias if a.qkv.bias is not None else torch.zeros(3 * C, dtype=x.dtype, device=x.device)
             N = ws * ws
             bias = a.relative_position_bias_table[a.relative_position_index.view(-1)].view(N, N, a.num_heads)
@@ -186,7 +209,8 @@ class SwinTransformerBlock(nn.Module):
             if qbuf is not None:
                 tag(att, qbuf)              # a softmax-weighted mean of v rows (or of the bias row): |att| <= max|qkv|
             x = _residual(shortcut, a.proj_drop(a.proj(att)), self.drop_path)
-            return _residual(x, self.mlp(self.norm2(x)), self.drop_path)
+            n2, x = self.norm2.with_shortcut(x) if isinstance(self.norm2, FusedLayerNorm) else (self.norm2(x), x)
+            return _residual(x, self.mlp(n2), self.drop_path)
         x = self.norm1(x).view(B, H, W, C)
         pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
         if pad_r or pad_b:

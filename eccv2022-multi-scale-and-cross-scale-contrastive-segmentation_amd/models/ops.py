@@ -1137,39 +1137,76 @@ def _amax_mod():
     return amax
 
 
+def _ln_forward(x, weight, bias, eps):
+    from .. import _lib
+    from . import amax as _am
+    c = x.shape[-1]
+    m = x.numel() // c
+    y = torch.empty_like(x)
+    stats = torch.empty((2, m), dtype=torch.float32, device=x.device)
+    ybuf = _am.zeros(_am.SLOTS, x.device)       # absmax tag of y for the Linear behind the norm (the GEMM's operand scale)
+    _am.tag(y, ybuf)
+    _lib.check(_lib.lib().dcl_layernorm_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, float(eps),
+                                            _lib.ptr(y), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(ybuf),
+                                            _stream(x)), "dcl_layernorm_fwd")
+    return y, stats
+
+
+def _ln_backward(gy, x, weight, stats, addend=None):
+    """(gx (+ addend), dgamma, dbeta); gx is tagged with its absmax (emitted by the kernel)."""
+    from .. import _lib
+    from . import amax as _am
+    c = x.shape[-1]
+    m = x.numel() // c
+    gy = gy.contiguous()
+    if addend is not None:
+        addend = addend.contiguous()
+    L = _lib.lib()
+    gx = torch.empty_like(x)
+    parts = torch.empty((L.dcl_layernorm_bwd_parts(m, c), 2, c), dtype=torch.float32, device=x.device)
+    gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    gam = _am.zeros(_am.SLOTS, x.device)
+    _lib.check(L.dcl_layernorm_bwd(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(weight), _lib.ptr(stats[0]),
+                                   _lib.ptr(stats[1]), m, c, _lib.ptr(gx), _lib.ptr(parts), _lib.ptr(gwb),
+                                   _lib.ptr(addend), _lib.ptr(gam), _stream(x)), "dcl_layernorm_bwd")
+    _am.tag(gx, gam)
+    return gx, gwb[0], gwb[1]
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, ybuf=None):
-        from .. import _lib
-        c = x.shape[-1]
-        m = x.numel() // c
-        y = torch.empty_like(x)
-        stats = torch.empty((2, m), dtype=torch.float32, device=x.device)
-        if ybuf is None:            # absmax tag of y for the Linear behind the norm (the split-f16 GEMM's operand scale)
-            from . import amax as _am
-            ybuf = _am.zeros(_am.SLOTS, x.device)
-            _am.tag(y, ybuf)
-        _lib.check(_lib.lib().dcl_layernorm_fwd(_lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), m, c, float(eps),
-                                                _lib.ptr(y), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(ybuf),
-                                                _stream(x)), "dcl_layernorm_fwd")
+    def forward(ctx, x, weight, bias, eps):
+        y, stats = _ln_forward(x, weight, bias, eps)
         ctx.save_for_backward(x, weight, stats)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        from .. import _lib
         x, weight, stats = ctx.saved_tensors
-        c = x.shape[-1]
-        m = x.numel() // c
-        gy = gy.contiguous()
-        L = _lib.lib()
-        gx = torch.empty_like(x)
-        parts = torch.empty((L.dcl_layernorm_bwd_parts(m, c), 2, c), dtype=torch.float32, device=x.device)
-        gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
-        _lib.check(L.dcl_layernorm_bwd(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(weight), _lib.ptr(stats[0]),
-                                       _lib.ptr(stats[1]), m, c, _lib.ptr(gx), _lib.ptr(parts), _lib.ptr(gwb),
-                                       _stream(x)), "dcl_layernorm_bwd")
-        return gx, gwb[0], gwb[1], None, None
+        gx, gw, gb = _ln_backward(gy, x, weight, stats)
+        return gx, gw, gb, None
+
+
+class _LayerNormResidualFn(torch.autograd.Function):
+    """(LayerNorm(x), alias of x): for ``x -> norm -> branch`` with ``x`` also feeding the residual sum behind the branch
+    (both halves of a Swin block, reference models/Swin.py:286-321).  The backward receives the branch's gradient AND the
+    shortcut's and adds them inside the norm's backward kernel -- autograd's own sum of the two would be one more
+    element-wise pass (3 tensor passes) per norm."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        y, stats = _ln_forward(x, weight, bias, eps)
+        ctx.save_for_backward(x, weight, stats)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gres):
+        x, weight, stats = ctx.saved_tensors
+        if gy is None:
+            return gres, None, None, None
+        gx, gw, gb = _ln_backward(gy, x, weight, stats, addend=gres)
+        return gx, gw, gb, None
 
 
 class FusedLayerNorm(torch.nn.LayerNorm):
@@ -1185,6 +1222,17 @@ class FusedLayerNorm(torch.nn.LayerNorm):
             if _lib.lib().dcl_layernorm_supported(x.shape[-1]):
                 return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return super().forward(x)
+
+    def with_shortcut(self, x):
+        """(self(x), x') where x' carries x into the residual sum: on the HIP path the two gradients of x meet inside the
+        norm's backward kernel (see _LayerNormResidualFn); elsewhere x' is x."""
+        if (x.is_cuda and x.dtype == torch.float32 and len(self.normalized_shape) == 1 and self.weight is not None
+                and self.bias is not None and self.weight.dtype == torch.float32 and x.is_contiguous()
+                and not torch.is_autocast_enabled() and x.numel() > 0 and torch.is_grad_enabled() and x.requires_grad):
+            from .. import _lib
+            if _lib.lib().dcl_layernorm_supported(x.shape[-1]):
+                return _LayerNormResidualFn.apply(x, self.weight, self.bias, self.eps)
+        return self(x), x
 
 
 # ---- Swin window attention (csrc/dcl_winattn.hip) -----------------------------------------------------------------

@@ -456,7 +456,11 @@ int dcl_layernorm_bwd_parts(long long M, int C);
 int dcl_layernorm_fwd(const float *x, const float *gamma, const float *beta, long long M, int C, float eps, float *y,
                       float *mean, float *rstd, float *yamax, void *stream);
 int dcl_layernorm_bwd(const float *gy, const float *x, const float *gamma, const float *mean, const float *rstd,
-                      long long M, int C, float *gx, float *parts, float *dgamma_dbeta, void *stream);
+                      long long M, int C, float *gx, float *parts, float *dgamma_dbeta,
+                      const float *addend /* [M, C] added to gx, or NULL: the gradient of the residual connection around the
+                                             norm (x feeds norm AND shortcut; reference models/Swin.py:286-321) */,
+                      float *gxamax /* DCL_AMAX_SLOTS partial maxima of |gx| (caller zero-initialises), or NULL */,
+                      void *stream);
 
 /* ---- fused bilinear up-sampling + class-weighted cross-entropy --------------------
  * loss = CrossEntropyLoss(weight, ignore_index)(F.interpolate(z, (H, W), 'bilinear', align_corners), target) without
