@@ -92,6 +92,7 @@ SIGNATURES = {
     "dcl_winattn_npad": [_i, _i],
     "dcl_winattn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp],
     "dcl_winattn_bwd_waves": [_i, _i, _i, _i],
+    "dcl_winattn_set_mfma": [_i],
     "dcl_winattn_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "dcl_layernorm_supported": [_i],
     "dcl_layernorm_bwd_parts": [_i64, _i],

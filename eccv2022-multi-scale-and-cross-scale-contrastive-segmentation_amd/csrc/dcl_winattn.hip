@@ -433,6 +433,18 @@ extern "C" int dcl_winattn_npad(int H, int W)
     return Hp * Wp - H * W;
 }
 
+int dcl_winattn_fwd_mfma_launch(const float *qkv, const float *qkv_bias, const float *bias, int B, int H, int W, int C,
+                                int heads, int shift, float scale, float *out, float *lse, int nwaves, hipStream_t stream);
+extern "C" int dcl_winattn_bwd_waves(int B, int H, int W, int heads);
+static int g_winattn_mfma = 1;      // bit 0: forward on the matrix cores, bit 1: backward (A/B: dcl_winattn_set_mfma)
+
+extern "C" int dcl_winattn_set_mfma(int mask)
+{
+    DCL_CHECK_ARG(mask >= 0 && mask <= 3, "mask: bit 0 forward, bit 1 backward");
+    g_winattn_mfma = mask;
+    return 0;
+}
+
 extern "C" int dcl_winattn_fwd(const float *qkv, const float *qkv_bias, const float *bias, int B, int H, int W, int C,
                                int heads, int shift, float scale, float *out, float *lse, void *stream)
 {
@@ -442,6 +454,13 @@ extern "C" int dcl_winattn_fwd(const float *qkv, const float *qkv_bias, const fl
                   "bad shape (window 7, head_dim 32: C must be 32 * heads; 0 <= shift < 7)");
     DCL_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)out) | ((uintptr_t)qkv_bias)) & 15) == 0, "16-byte alignment");
     a.qkv = qkv; a.qkv_bias = qkv_bias; a.bias = bias; a.out = out; a.lse = lse;
+    if (g_winattn_mfma & 1) {       // matrix-core kernel (dcl_winattn_mfma.hip); token rows are 32-bit there
+        DCL_CHECK_ARG((long long)B * H * W < (1LL << 31), "too many tokens");
+        dcl_winattn_fwd_mfma_launch(qkv, qkv_bias, bias, B, H, W, C, heads, shift, scale, out, lse,
+                                    dcl_winattn_bwd_waves(B, H, W, heads), (hipStream_t)stream);
+        DCL_LAUNCH_CHECK();
+        return 0;
+    }
     const long long total = (long long)B * a.nW * heads;
     hipLaunchKernelGGL(k_winattn_fwd, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     DCL_LAUNCH_CHECK();

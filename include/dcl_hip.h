@@ -437,6 +437,9 @@ int dcl_winattn_npad(int H, int W);
 int dcl_winattn_fwd(const float *qkv, const float *qkv_bias, const float *bias, int B, int H, int W, int C, int heads,
                     int shift, float scale, float *out, float *lse, void *stream);
 int dcl_winattn_bwd_waves(int B, int H, int W, int heads);
+/* kernel variant: bit 0 = forward on the f16 matrix cores (split-f16, fp32-equivalent; csrc/dcl_winattn_mfma.hip; default on),
+ * bit 1 = backward; 0 = the fp32 vector-ALU kernels (A/B runs, tests) */
+int dcl_winattn_set_mfma(int mask);
 int dcl_winattn_bwd(const float *qkv, const float *qkv_bias, const float *bias, const float *lse, const float *dout,
                     int B, int H, int W, int C, int heads, int shift, float scale, float *dqkv, float *dpad,
                     float *dbias_part, float *dqkv_amax /* DCL_AMAX_SLOTS partial maxima of |dqkv| and |dpad| (caller zero-

@@ -254,3 +254,32 @@ def test_linear_weight_tags_and_tag_carrying():
     amax.amax_of(gy)
     g.backward(gy)
     assert torch.allclose(h.grad, torch.ops.aten.gelu_backward(gy, h.detach(), approximate="none"))
+
+
+@pytest.mark.parametrize("std", [1.0, 3.0])
+def test_window_attention_forward_at_size_against_fp64(std):
+    """Forward of both kernel variants (matrix cores = default, vector ALU) on 8 x 70 x 70 tokens x 6 heads (7.5 M outputs, 4 800
+    window-heads) against float64: a rare-event check -- an MFMA reading a register before the high half of an inline-asm
+    split had landed showed up as 1e-4 errors in one of ~10^5 scores, invisible at the sizes of the tests above."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd import _lib
+    from mscs_amd.models import ops
+    L = _lib.lib()
+    dev = "cuda"
+    B, H, W, heads = 8, 70, 70, 6
+    C = 32 * heads
+    torch.manual_seed(1)
+    qkv = torch.randn(B, H * W, 3 * C, device=dev) * std
+    qb = torch.zeros(3 * C, device=dev)
+    bias = torch.randn(heads, 49, 49, device=dev) * 0.5
+    x = qkv.double().view(B, H // 7, 7, W // 7, 7, 3, heads, 32).permute(5, 0, 1, 3, 6, 2, 4, 7).reshape(3, -1, heads, 49, 32)
+    att = ((x[0] * 32 ** -0.5) @ x[1].transpose(-1, -2) + bias.double()).softmax(-1) @ x[2]
+    ref = att.view(B, H // 7, W // 7, heads, 7, 7, 32).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, H * W, C)
+    try:
+        for mask in (0, 1):
+            L.dcl_winattn_set_mfma(mask)
+            out = ops.window_attention(qkv, qb, bias, H, W, heads, 0, 32 ** -0.5)
+            err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+            assert err < 4e-6, (mask, std, err)
+    finally:
+        L.dcl_winattn_set_mfma(3)
