@@ -436,7 +436,10 @@ extern "C" int dcl_winattn_npad(int H, int W)
 int dcl_winattn_fwd_mfma_launch(const float *qkv, const float *qkv_bias, const float *bias, int B, int H, int W, int C,
                                 int heads, int shift, float scale, float *out, float *lse, int nwaves, hipStream_t stream);
 extern "C" int dcl_winattn_bwd_waves(int B, int H, int W, int heads);
-static int g_winattn_mfma = 1;      // bit 0: forward on the matrix cores, bit 1: backward (A/B: dcl_winattn_set_mfma)
+int dcl_winattn_bwd_mfma_launch(const float *qkv, const float *qkv_bias, const float *bias, const float *lse,
+                                const float *dout, int B, int H, int W, int C, int heads, int shift, float scale, float *dqkv,
+                                float *dpad, float *dbias_part, float *dqkv_amax, int nwaves, hipStream_t stream);
+static int g_winattn_mfma = 3;      // bit 0: forward on the matrix cores, bit 1: backward (A/B: dcl_winattn_set_mfma)
 
 extern "C" int dcl_winattn_set_mfma(int mask)
 {
@@ -494,6 +497,12 @@ extern "C" int dcl_winattn_bwd(const float *qkv, const float *qkv_bias, const fl
     a.qkv = qkv; a.qkv_bias = qkv_bias; a.bias = bias; a.lse = const_cast<float *>(lse); a.dout = dout;
     a.dqkv = dqkv; a.dpad = dpad; a.dbias_part = dbias_part; a.dqkv_amax = dqkv_amax;
     a.nwaves = dcl_winattn_bwd_waves(B, H, W, heads);
+    if ((g_winattn_mfma & 2) && (long long)B * H * W < (1LL << 30)) {     // matrix-core kernel (dcl_winattn_mfma.hip)
+        dcl_winattn_bwd_mfma_launch(qkv, qkv_bias, bias, lse, dout, B, H, W, C, heads, shift, scale, dqkv, dpad, dbias_part,
+                                    dqkv_amax, a.nwaves, (hipStream_t)stream);
+        DCL_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_winattn_bwd, dim3((unsigned)a.nwaves), dim3(64), 0, (hipStream_t)stream, a);
     DCL_LAUNCH_CHECK();
     return 0;
