@@ -156,6 +156,26 @@ __global__ __launch_bounds__(64) void k_winattn_fwd_mfma(WmArgs a)
                 }
             }
         }
+        // (the V^T gather of the second product is issued here: its latency runs under the first product and the softmax)
+        float vv[4][8];
+        float mv = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k0 = 32 * i + 16 * s + 4 * h;                          // keys k0 .. k0 + 3 and k0 + 8 .. k0 + 11
+                const int4 ta = *(const int4 *)(Ts + min(k0, 60)), tb = *(const int4 *)(Ts + min(k0 + 8, 60));
+                const int tk[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int key = k0 + 8 * (t >> 2) + (t & 3);
+                    const bool valid = key < NT;
+                    const float *pv = (valid && tk[t] >= 0) ? a.qkv + (size_t)tk[t] * C3 + 2 * a.C + hd * HD : bv;
+                    const float x = valid ? pv[l32] : 0.f;
+                    vv[2 * i + s][t] = x;
+                    mv = fmaxf(mv, fabsf(x));
+                }
+            }
         const float sq = pow2_scale_w(wave_max(mq)), sk = pow2_scale_w(wave_max(mk));
         h8 qh[2][2], ql[2][2], kh[2][2], kl[2][2];
 #pragma unroll
@@ -248,25 +268,6 @@ __global__ __launch_bounds__(64) void k_winattn_fwd_mfma(WmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 ot[j][r] = 0.f;
-        float vv[4][8];
-        float mv = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int k0 = 32 * i + 16 * s + 4 * h;                          // keys k0 .. k0 + 3 and k0 + 8 .. k0 + 11
-                const int4 ta = *(const int4 *)(Ts + min(k0, 60)), tb = *(const int4 *)(Ts + min(k0 + 8, 60));
-                const int tk[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int key = k0 + 8 * (t >> 2) + (t & 3);
-                    const bool valid = key < NT;
-                    const float *pv = (valid && tk[t] >= 0) ? a.qkv + (size_t)tk[t] * C3 + 2 * a.C + hd * HD : bv;
-                    const float x = valid ? pv[l32] : 0.f;
-                    vv[2 * i + s][t] = x;
-                    mv = fmaxf(mv, fabsf(x));
-                }
-            }
         const float sv = pow2_scale_w(wave_max(mv));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
