@@ -179,6 +179,14 @@ class UPerNet(nn.Module):
             if self.aux_head is not None:
                 use_gemm_conv1x1(self.aux_head)
             if self.projector_model is not None:
+                # the projector heads (conv1x1 -> ReLU -> BN -> conv1x1 on every pyramid level, reference
+                # models/Projector.py:46-51): fused norm kernels (class switch: same parameters / buffers / state_dict keys)
+                # and the 512 -> 512 / 512 -> d convolutions as batched split-f16 GEMMs
+                for m in self.projector_model.modules():
+                    if type(m) is nn.BatchNorm2d:
+                        m.__class__ = FusedBatchNorm2d
+                use_gemm_conv1x1(self.projector_model)
+            if self.projector_model is not None:
                 use_gemm_conv1x1(self.projector_model)
 
     def _get_aux_head(self):
