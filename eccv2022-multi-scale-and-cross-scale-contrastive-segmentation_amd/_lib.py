@@ -54,6 +54,10 @@ SIGNATURES = {
                                _vp, _vp, _vp],
     "dcl_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "dcl_bn_bwd_onepass_supported": [_i, _i, _i, _i],
+    "dcl_bn_onepass_workspace_bytes": [],
+    "dcl_bn_bwd_onepass": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                           _vp],
     "dcl_upsample_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_upsample_bilinear_bwd": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_amax_sum2": [_vp, _i, _vp, _i, _vp, _vp],
@@ -132,6 +136,7 @@ def lib():
             fn.restype = ctypes.c_int
         l.dcl_last_error.restype = ctypes.c_char_p
         l.dcl_gemm_workspace_floats.restype = ctypes.c_int64
+        l.dcl_bn_onepass_workspace_bytes.restype = ctypes.c_int64
         l.dcl_last_error.argtypes = []
         from .debug import cfg as _dbg       # A/B switches of the tuning tools: one object, read once
         _dbg.apply_to_library(l)

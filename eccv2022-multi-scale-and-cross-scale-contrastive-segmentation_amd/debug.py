@@ -33,6 +33,9 @@ class DebugConfig:
     fanout: bool = field(default_factory=lambda: _flag('DCL_FANOUT'))                           # one-kernel gradient sums
     upsample_tag: bool = field(default_factory=lambda: _flag('DCL_UPSAMPLE_TAG'))               # absmax tags of up-sampled maps
     packed_relu_mask: bool = field(default_factory=lambda: _flag('DCL_BN_MASK'))                # packed sign mask in the BN backward
+    bn_onepass: bool = field(default_factory=lambda: _flag('DCL_BN_ONEPASS', False))            # one-kernel BN backward (default stream);
+    # OFF by default: its teams of persistent workgroups wait for members that the branch streams' kernels keep off the CUs
+    # (step 104.4 vs 95.5 ms), and alone it only ties the two-kernel form until its barrier is pipelined
     gemm_conv1x1: bool = field(default_factory=lambda: _flag('DCL_GEMM_CONV1X1'))               # wide 1x1 convolutions on dcl_gemm_f16x3
     gemm_head_taps: bool = field(default_factory=lambda: _flag('DCL_GEMM_HEAD'))                # the head's tap products on it
     head_overlap: int = field(default_factory=lambda: 2 if _int('DCL_HEAD_OVERLAP') is None else _int('DCL_HEAD_OVERLAP'))  # coarse half of the head's

@@ -107,6 +107,25 @@ class _FusedBNFunction(torch.autograd.Function):
         relu = (2 if ctx.packed_mask else 1) if ctx.relu else 0         # 2: `y` is the packed sign mask
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        if (ctx.world == 1 and _onepass_stream(dev) and (relu != 1 or y is None)
+                and L.dcl_bn_bwd_onepass_supported(N, C, HW, relu)):
+            # one kernel that reads dy and x ONCE (csrc/dcl_bn_onepass.hip): persistent workgroups keep their share of a
+            # channel in registers across the statistics exchange.  Only on the device's default stream of a single-rank
+            # run: never more than one such kernel may be in flight (its teams wait for all their members)
+            dx = torch.empty_like(x)
+            want_res = ctx.has_res and (ctx.needs_input_grad[1] or ctx.token is not None)
+            dres = torch.empty_like(x) if want_res else None
+            amax = _amax.zeros(_amax.SLOTS, dev) if ctx.emit_amax else None
+            ws, seq = _onepass_workspace(dev)
+            _lib.check(L.dcl_bn_bwd_onepass(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(invstd),
+                                            _lib.ptr(weight), _lib.ptr(bias), ctx.count, N, C, HW, relu, _lib.ptr(dx),
+                                            _lib.ptr(dres), _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(amax),
+                                            _lib.ptr(ws), seq, st), "dcl_bn_bwd_onepass")
+            if amax is not None:
+                _amax.tag(dx, amax)
+            if ctx.token is not None:
+                ctx.token.dres, dres = dres, None
+            return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None
         _lib.check(L.dcl_bn_bwd_reduce_part(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), N, C, HW, relu,
                                             _lib.ptr(part), st), "dcl_bn_bwd_reduce_part")
@@ -132,6 +151,27 @@ class _FusedBNFunction(torch.autograd.Function):
             # the residual's gradient travels through the token to the convolution that shares the input
             ctx.token.dres, dres = dres, None
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+ONEPASS = _dbg.bn_onepass         # one-kernel backward on the default stream (DCL_BN_ONEPASS=0: the two-kernel form)
+_ONEPASS_WS = {}
+
+
+def _onepass_stream(dev):
+    return ONEPASS and torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev)
+
+
+def _onepass_workspace(dev):
+    """(zero-initialised counter / partial-sum workspace of the device, launch number): see dcl_bn_bwd_onepass."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ent = _ONEPASS_WS.get(key)
+    if ent is None:
+        n = int(_lib.lib().dcl_bn_onepass_workspace_bytes())
+        with torch.cuda.stream(torch.cuda.default_stream(dev)):
+            ent = _ONEPASS_WS[key] = [torch.zeros(n // 4, dtype=torch.int32, device=dev), 0]
+    seq = ent[1]
+    ent[1] += 1
+    return ent[0], seq
 
 
 COLLECTIVES = {"count": 0}        # SyncBatchNorm exchanges issued by this process (tests / tools read it)

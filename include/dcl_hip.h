@@ -283,6 +283,20 @@ int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1 /* may be NUL
 int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
                   float *dz, void *stream);
 
+/* ---- one-kernel batch-norm backward (csrc/dcl_bn_onepass.hip) -------------------------------------------------------
+ * dcl_bn_bwd_reduce_part + dcl_bn_bwd_apply_fused of a single-rank norm in ONE launch that reads dy and x once: 256 persistent
+ * workgroups keep their share of a channel in registers across the per-channel statistics exchange (teams of H W / 1024
+ * workgroups of one XCD, relaxed agent-scope counters).  Shapes: H W % 1024 == 0, H W / 1024 in {1, 2, 4, 8, 16, 32}, N <= 12
+ * (dcl_bn_bwd_onepass_supported); relu: 0 none, 1 the mask is recomputed from x (y = NULL), 2 y is the packed sign mask.
+ * ws: dcl_bn_onepass_workspace_bytes() bytes, zeroed ONCE by the caller; seq = 0, 1, 2, ... the launch number on that
+ * workspace.  The teams wait for all their members: launch it on ONE stream only (never two instances in flight). */
+int dcl_bn_bwd_onepass_supported(int N, int C, int HW, int relu);
+int64_t dcl_bn_onepass_workspace_bytes(void);
+int dcl_bn_bwd_onepass(const float *dy, const float *x, const void *y_or_mask, const float *mean, const float *invstd,
+                       const float *gamma, const float *beta, double count, int N, int C, int HW, int relu, float *dx,
+                       float *dres /* or NULL */, float *dbeta /* or NULL */, float *dgamma /* or NULL */,
+                       float *amax /* DCL_AMAX_SLOTS or NULL */, void *ws, int64_t seq, void *stream);
+
 /* ---- split-f16 GEMM, f32 in / out (csrc/dcl_gemm.hip) ------------------------------------------------------------
  * C[b][m][n] = (accumulate ? C : 0) + bias[n] + sum_k A[b](m, k) * B[b](n, k),  b < batch, at fp32-equivalent accuracy
  * (hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16, f32 accumulation).  Drop-in for the fp32 library GEMMs behind
