@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--scales", type=int, default=None)
     ap.add_argument("--no-cross", action="store_true")
+    ap.add_argument("--labels", choices=["iid", "blocky"], default="iid",
+                    help="iid: uniform per pixel, the worst case that pins N at the 10 000 cap (the headline); blocky: uniform at "
+                         "1/32 resolution, repeated 32 x 32 (SURVEY section 8d: the realistic-layout check)")
     ap.add_argument("--mfma", default=None, choices=["f32", "f16x3"],
                     help="similarity-product arithmetic of the loss kernels (default: the library default)")
     ap.add_argument("--branch-conv", default="f16x3", choices=["f16x3", "library"],
@@ -115,10 +118,20 @@ def loss_config(S, cross, dataset="CITYSCAPES"):
             "max_views_per_class": 2500, "max_features_total": 10000, "label_scaling_mode": "nn"}
 
 
+def synth_labels(args, n, H, W, gen):
+    """int64 [n, H, W]: iid-uniform classes (worst-case load: every class in every image, N at the cap), or "blocky":
+    uniform at 1/32 resolution, each value repeated over a 32 x 32 block (class regions as in real masks)."""
+    K = getattr(args, "classes", 20)
+    if getattr(args, "labels", "iid") == "blocky":
+        small = torch.randint(0, K, (n, (H + 31) // 32, (W + 31) // 32), generator=gen)
+        return small.repeat_interleave(32, 1).repeat_interleave(32, 2)[:, :H, :W].contiguous()
+    return torch.randint(0, K, (n, H, W), generator=gen)
+
+
 def synth_loss_inputs(args, dev, rank):
     gen = torch.Generator().manual_seed(1000 * rank)
     n, H, W = args.batch, args.height, args.width
-    label = torch.randint(0, getattr(args, "classes", 20), (n, H, W), generator=gen).to(dev)   # iid: worst-case load
+    label = synth_labels(args, n, H, W, gen).to(dev)
     feats = [torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).to(dev).requires_grad_(True)
              for s in range(args.scales)]
     return label, feats
@@ -393,15 +406,15 @@ def workload_name(args, workload):
     cross = "" if args.no_cross else " + cross-scale"
     if workload == "loss":
         return (f"DenseContrastiveLossV2_ms fwd+bwd, {args.scales} scales{cross}, n={args.batch} "
-                f"{args.height}x{args.width} iid labels K={args.classes}, C=256, per GPU")
+                f"{args.height}x{args.width} {args.labels} labels K={args.classes}, C=256, per GPU")
     if args.config in (4, 5):
         which = "configs[3] on one GPU (SURVEY App. C 4'): UPerNet + Swin-T" if args.config == 4 else \
             "configs[4] on one GPU: UPerNet + Swin-L"
         return (f"BASELINE {which} + LossWrapper(TwoScaleLoss + "
                 f"0.1*DenseContrastiveLossV2_ms, {args.scales} scales{cross}, fpn projector) train step (fwd+bwd+AdamW), "
-                f"synthetic ADE20K {args.height}x{args.width}, batch {args.batch} per GPU, iid labels")
+                f"synthetic ADE20K {args.height}x{args.width}, batch {args.batch} per GPU, {args.labels} labels")
     return (f"HRNet-W48 + LossWrapper(CE + 0.1*DenseContrastiveLossV2_ms, {args.scales} scales{cross}) train step "
-            f"(fwd+bwd+SGD), synthetic Cityscapes {args.height}x{args.width}, batch {args.batch} per GPU, iid labels")
+            f"(fwd+bwd+SGD), synthetic Cityscapes {args.height}x{args.width}, batch {args.batch} per GPU, {args.labels} labels")
 
 
 def step_config_upernet(args, world):
@@ -463,7 +476,7 @@ def time_train_step(args, dev, rank, world):
     mgr.model.train()
     gen = torch.Generator().manual_seed(1000 * rank)
     img = torch.randn(args.batch, 3, args.height, args.width, generator=gen).to(dev)
-    lbl = torch.randint(0, args.classes, (args.batch, args.height, args.width), generator=gen).to(dev)  # int64
+    lbl = synth_labels(args, args.batch, args.height, args.width, gen).to(dev)  # int64
     if args.channels_last:
         img = img.contiguous(memory_format=torch.channels_last)
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if args.amp else contextlib.nullcontext()
@@ -684,7 +697,7 @@ def eager_gpu_step_ms(args, dev, iters=3, miopen_benchmark=False):
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
     gen = torch.Generator().manual_seed(0)
     img = torch.randn(args.batch, 3, args.height, args.width, generator=gen).to(dev)
-    lbl = torch.randint(0, 20, (args.batch, args.height, args.width), generator=gen).to(dev)
+    lbl = synth_labels(args, args.batch, args.height, args.width, gen).to(dev)
     ce = torch.nn.CrossEntropyLoss(ignore_index=19)
     w = [1.0, 0.7, 0.4, 0.1][:S]
     times = []
@@ -718,7 +731,7 @@ def eager_gpu_loss_ms(args, dev):
     from oracle import eager_torch
     gen = torch.Generator().manual_seed(0)
     n, H, W = args.batch, args.height, args.width
-    label = torch.randint(0, 20, (n, H, W), generator=gen).to(dev)
+    label = synth_labels(args, n, H, W, gen).to(dev)
     feats = [torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).to(dev).requires_grad_(True)
              for s in range(args.scales)]
     w = [1.0, 0.7, 0.4, 0.1][:args.scales]
