@@ -74,6 +74,8 @@ struct GemmArgs {
     int batch, splitk;
     int tiles_m, tiles_n;
     int accumulate;                 // C += (splitk == 1 only)
+    float *rowsum;                  // optional (row-contiguous A only): [z][M] sums over k of A(m, k) -- the bias gradient of a
+                                    // Linear rides on its weight-gradient GEMM (A = dy^T); written by the tile column 0 workgroups
 };
 
 // LDS image of one operand tile and stage: [hi | lo][k-group of 8 k: 4][slot: BX + 2] 16-byte units.  The two pad units
@@ -274,10 +276,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
             v[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, q.voff[j], goff + j * q.ldb, 0));
         goff += gstep;
     };
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};     // row sums of this thread's four A rows over the k rows it staged
     auto store = [&](int stage, const float4 (&v)[8]) {
         if (DCL_GEMM_PROBE & 2)
             return;
         char *base = lds + stage * STAGE;
+        if (!AKM && stA && a.rowsum) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                rs[0] += v[j].x;
+                rs[1] += v[j].y;
+                rs[2] += v[j].z;
+                rs[3] += v[j].w;
+            }
+        }
         if (stA)
             Stager<BM, AKM>::store(q, base, sa, v);
         else if (stB)
@@ -387,6 +399,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
     for (int k = kbeg; k < kend; ++k)
         kstep(k, v0);
 
+    if (!AKM && a.rowsum && tn == 0) {       // (uniform) the four k-groups of a row meet in LDS; the stages are free now
+        float *red = reinterpret_cast<float *>(lds);
+        if (stA) {
+            const int m4 = tid % (BM / 4), kg = tid / (BM / 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                red[kg * BM + 4 * m4 + i] = rs[i];
+        }
+        __syncthreads();
+        if (tid < BM && row0 + tid < a.M)
+            a.rowsum[(long)z * a.M + row0 + tid] = (red[tid] + red[BM + tid]) + (red[2 * BM + tid] + red[3 * BM + tid]);
+    }
     // ---- epilogue: acc register r of tile (i, j) is row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32
     const float inv = 1.0f / (sa * sb);
     float *C = a.C + (long)z * a.sC;                    // sC: batch stride, or the slab stride when splitk > 1
@@ -467,6 +491,18 @@ __global__ __launch_bounds__(256) void k_gemm_slab_sum(const float *__restrict__
         if ((threadIdx.x & 63) == 0 && mx > __builtin_nontemporal_load(c_amax))
             atomicMax(reinterpret_cast<int *>(c_amax), __float_as_int(mx));
     }
+}
+
+// out[m] = sum over the k-split slabs, ascending
+__global__ __launch_bounds__(256) void k_gemm_rowsum_sum(const float *__restrict__ ws, int slabs, int M, float *__restrict__ out)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M)
+        return;
+    float s = ws[m];
+    for (int k = 1; k < slabs; ++k)
+        s += ws[(long)k * M + m];
+    out[m] = s;
 }
 
 int g_gemm_tile = 0;        // 0 = automatic; 1 = 256 x 256, 2 = 256 x 128, 3 = 128 x 256, 4 = 128 x 128, 5 = 256 x 192
@@ -555,7 +591,7 @@ extern "C" int dcl_gemm_supported(int M, int N, int K, int64_t lda, int a_kmajor
 
 extern "C" int64_t dcl_gemm_workspace_floats(int M, int N, int batch, int splitk)
 {
-    return splitk > 1 ? (int64_t)M * N * batch * splitk : 0;
+    return splitk > 1 ? ((int64_t)M * N + M) * batch * splitk : 0;       // slabs + the slabs of the optional row sums
 }
 
 extern "C" int dcl_gemm_suggest_splitk(int M, int N, int K, int batch)
@@ -575,8 +611,9 @@ extern "C" int dcl_gemm_suggest_splitk(int M, int N, int K, int batch)
 extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t strideA, const float *B, int64_t ldb,
                               int b_kmajor, int64_t strideB, int M, int N, int K, int batch, const float *a_amax,
                               int a_count, const float *b_amax, int b_count, const float *bias, float *C, int64_t ldc, int64_t strideC,
-                              int accumulate, float *c_amax, int splitk, float *ws, void *stream)
+                              int accumulate, float *c_amax, int splitk, float *ws, float *a_rowsum, void *stream)
 {
+    DCL_CHECK_ARG(!a_rowsum || (!a_kmajor && batch == 1), "a_rowsum needs a row-contiguous A and batch 1");
     DCL_CHECK_ARG(A && B && C && a_amax && b_amax, "null pointer");
     DCL_CHECK_ARG(batch >= 1 && splitk >= 1 && a_count >= 1 && b_count >= 1, "batch, splitk and the absmax counts must be >= 1");
     DCL_CHECK_ARG(dcl_gemm_supported(M, N, K, lda, a_kmajor, ldb, b_kmajor),
@@ -590,6 +627,7 @@ extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t
     a.A = A, a.B = B, a.lda = lda, a.ldb = ldb, a.sA = strideA, a.sB = strideB;
     a.a_amax = a_amax, a.b_amax = b_amax, a.a_count = a_count, a.b_count = b_count;
     a.M = M, a.N = N, a.K = K, a.batch = batch, a.splitk = splitk;
+    a.rowsum = a_rowsum ? (splitk > 1 ? ws + (long)M * N * batch * splitk : a_rowsum) : nullptr;
     if (splitk > 1) {
         a.C = ws, a.ldc = N, a.sC = (long)M * N, a.bias = nullptr, a.c_amax = nullptr, a.accumulate = 0;
     } else {
@@ -615,6 +653,9 @@ extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t
                                ws + (long)b * splitk * M * N, splitk, (long)M * N, bias, C + (long)b * strideC, (long)ldc, M, N,
                                accumulate, c_amax);
         }
+        if (a_rowsum)
+            hipLaunchKernelGGL(k_gemm_rowsum_sum, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               ws + (long)M * N * batch * splitk, splitk, M, a_rowsum);
         DCL_LAUNCH_CHECK();
     }
     return 0;

@@ -979,7 +979,7 @@ def gemm_supported(M, N, K, lda, a_kmajor, ldb, b_kmajor):
 
 
 def gemm_f16x3(a, a_kmajor, lda, b, b_kmajor, ldb, M, N, K, out, ldc, a_amax, b_amax, bias=None, batch=1,
-               strides=(0, 0, 0), accumulate=False, c_amax=None, splitk=0):
+               strides=(0, 0, 0), accumulate=False, c_amax=None, splitk=0, a_rowsum=None):
     """out[b][m][n] (+)= bias[n] + sum_k A[b](m, k) B[b](n, k) on dcl_gemm_f16x3 (fp32-equivalent split-f16 MFMA).
 
     ``a`` / ``b`` are the tensors whose storage holds the operands (used for their data pointers); X_kmajor says whether
@@ -995,7 +995,7 @@ def gemm_f16x3(a, a_kmajor, lda, b, b_kmajor, ldb, M, N, K, out, ldc, a_amax, b_
     p = _lib.ptr
     _lib.check(L.dcl_gemm_f16x3(p(a), lda, int(a_kmajor), strides[0], p(b), ldb, int(b_kmajor), strides[1], M, N, K, batch,
                                 p(a_amax), a_amax.numel(), p(b_amax), b_amax.numel(), p(bias), p(out), ldc, strides[2],
-                                int(accumulate), p(c_amax), splitk, p(ws), _stream(out)), "dcl_gemm_f16x3")
+                                int(accumulate), p(c_amax), splitk, p(ws), p(a_rowsum), _stream(out)), "dcl_gemm_f16x3")
     return out
 
 
@@ -1023,14 +1023,17 @@ def linear_dgrad_f16x3(gy2, weight):
     return _am.tag(gx, ca)
 
 
-def linear_wgrad_f16x3(gy2, x2):
-    """dW [N, K] = gy2 [M, N]^T x2 [M, K] (contraction over the M rows, k-split slabs summed in fixed order)."""
+def linear_wgrad_f16x3(gy2, x2, want_bias=False):
+    """dW [N, K] = gy2 [M, N]^T x2 [M, K] (contraction over the M rows, k-split slabs summed in fixed order); with
+    ``want_bias`` also db [N] = the column sums of gy2, accumulated by the threads that stage the dy^T operand (no extra
+    pass over gy2): returns (dW, db)."""
     from . import amax as _am
     m, n = gy2.shape
     k = x2.shape[1]
     gw = torch.empty((n, k), dtype=torch.float32, device=gy2.device)
-    gemm_f16x3(gy2, False, n, x2, False, k, n, k, m, gw, k, _am.amax_of(gy2), _am.amax_of(x2))
-    return gw
+    gb = torch.empty((n,), dtype=torch.float32, device=gy2.device) if want_bias else None
+    gemm_f16x3(gy2, False, n, x2, False, k, n, k, m, gw, k, _am.amax_of(gy2), _am.amax_of(x2), a_rowsum=gb)
+    return (gw, gb) if want_bias else gw
 
 
 class _TokenLinear(torch.autograd.Function):
@@ -1066,9 +1069,13 @@ class _TokenLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g = linear_dgrad_f16x3(gy2, weight)
             gx = _am.carry(g, g.view(ctx.xshape))
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = linear_wgrad_f16x3(gy2, x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_gb:
+                gw, gb = linear_wgrad_f16x3(gy2, x2, want_bias=True)
+            else:
+                gw = linear_wgrad_f16x3(gy2, x2)
+        elif want_gb:
             gb = gy2.sum(0)
         return gx, gw, gb
 

@@ -321,7 +321,10 @@ int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t strideA, c
                    int64_t strideB, int M, int N, int K, int batch, const float *a_amax, int a_count,
                    const float *b_amax, int b_count,
                    const float *bias /* [N] or NULL */, float *C, int64_t ldc, int64_t strideC, int accumulate,
-                   float *c_amax /* or NULL */, int splitk, float *ws /* or NULL */, void *stream);
+                   float *c_amax /* or NULL */, int splitk, float *ws /* or NULL */,
+                   float *a_rowsum /* or NULL; [M] = sum_k A(m, k), row-contiguous A and batch 1 only: the bias gradient of a
+                                      Linear (column sums of dy) rides on its weight-gradient GEMM, whose A operand is dy^T */,
+                   void *stream);
 
 /* out = a + b (+ c) (+ d), n floats: the gradient of a tensor with several consumers in one pass (HRNet exchange
  * modules: every branch output feeds all fuse rows, reference models/HRNet.py:264-287). */

@@ -1503,6 +1503,15 @@ def test_gemm_f16x3_every_layout_matches_fp64(dev, tile):
                             err = ((out.double() - want).abs().max() / ref.abs().max()).item()
                             assert err < 3e-6, (tile, M, N, K, batch, akm, bkm, splitk, acc, err)
                             assert abs(ca.item() - out.abs().max().item()) <= 1e-6 * out.abs().max().item()
+                    if not akm and batch == 1 and M % 4 == 0:
+                        # the row sums of a row-contiguous A (the bias gradient riding on a weight-gradient GEMM)
+                        for splitk in (1, 2) if K >= 64 else (1,):
+                            out = torch.empty(1, M, N, device=dev)
+                            rsum = torch.full((M,), float("nan"), device=dev)
+                            ops.gemm_f16x3(A, akm, M, B, bkm, K if bkm else N, M, N, K, out, N, amax_of(A), amax_of(B),
+                                           splitk=splitk, a_rowsum=rsum)
+                            want_rs = A.double().sum(1)[0]
+                            assert ((rsum.double() - want_rs).abs().max() / want_rs.abs().max()).item() < 1e-5, (tile, M, N, K, splitk)
     finally:
         L.dcl_gemm_set_tile(0)
 

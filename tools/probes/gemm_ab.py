@@ -11,7 +11,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
-SIG = [vp, i64, i32, i64, vp, i64, i32, i64, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, i64, i64, i32, vp, i32, vp, vp]
+SIG = [vp, i64, i32, i64, vp, i64, i32, i64, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, i64, i64, i32, vp, i32, vp, vp, vp]
 
 
 def main():
@@ -44,7 +44,7 @@ def main():
             def run(l):
                 sk = l.dcl_gemm_suggest_splitk(M, N, K, 1)
                 rc = l.dcl_gemm_f16x3(A.data_ptr(), lda, akm, 0, B.data_ptr(), ldb, bkm, 0, M, N, K, 1, am[id(A)].data_ptr(), 1,
-                                      am[id(B)].data_ptr(), 1, None, C.data_ptr(), ldc, 0, 0, None, sk, ws.data_ptr(), st)
+                                      am[id(B)].data_ptr(), 1, None, C.data_ptr(), ldc, 0, 0, None, sk, ws.data_ptr(), None, st)
                 assert rc == 0, rc
             times = {nm: [] for nm in names}
             for nm in names:
