@@ -511,23 +511,43 @@ struct TileCfg { int bm, bn, nt; };
 constexpr int NTILES = 5;
 constexpr TileCfg TILES[NTILES] = {{256, 256, 512}, {256, 128, 512}, {128, 256, 512}, {128, 128, 256}, {256, 192, 512}};
 
-int pick_tile(int M, int N, int z)
+// Cost of running (tile c, k-split s) in units of one 256 x 256 x 32 tile step / 65536: rounds of 256 workgroups x the work
+// of one workgroup (tile area x its k-steps + ~1.5 steps of prologue / epilogue; smaller tiles pay 4-25 % more per FLOP),
+// plus the slab traffic of a split (each slab written, read by the sum, the result written: ~0.04 units per float at 5 TB/s).
+// Tile and split are chosen TOGETHER: a weight gradient with 36 tiles of 256 x 256 is better served by 7 splits of those
+// (252 workgroups, operand traffic ~ 1 / BM + 1 / BN) than by 4 splits of 72 smaller tiles (288 = a second, almost empty round).
+double plan_cost(int c, int s, int M, int N, int K, int batch)
 {
-    if (g_gemm_tile >= 1 && g_gemm_tile <= NTILES)
-        return g_gemm_tile - 1;
-    // cost model: rounds of 256 workgroups x work per workgroup (tile area, smaller tiles pay ~10-25 % more per FLOP)
     const double eff[NTILES] = {1.0, 0.90, 0.90, 0.75, 0.96};
-    int best = 0;
-    double bc = 1e30;
+    const long nk = (K + 31) / 32;
+    const long wg = (long)((M + TILES[c].bm - 1) / TILES[c].bm) * ((N + TILES[c].bn - 1) / TILES[c].bn) * batch * s;
+    const long rounds = (wg + 255) / 256;
+    const double steps = (double)((nk + s - 1) / s) + 1.5;
+    double cost = (double)rounds * TILES[c].bm * TILES[c].bn / eff[c] * steps;
+    if (s > 1)
+        cost += (2.0 * s + 1.0) * (double)M * N * batch * 0.04;
+    return cost;
+}
+
+// best tile for a given split (s >= 1), or best (tile, split) when *split == 0 (auto: splits up to K / 256, at most 64)
+int plan_gemm(int M, int N, int K, int batch, int *split)
+{
+    const int forced = (g_gemm_tile >= 1 && g_gemm_tile <= NTILES) ? g_gemm_tile - 1 : -1;
+    const long nk = (K + 31) / 32;
+    const int smax = *split > 0 ? *split : (int)(nk / 8 < 1 ? 1 : (nk / 8 > 64 ? 64 : nk / 8));
+    const int smin = *split > 0 ? *split : 1;
+    int best = 0, bs = smin;
+    double bc = 1e300;
     for (int c = 0; c < NTILES; ++c) {
-        const long wg = (long)((M + TILES[c].bm - 1) / TILES[c].bm) * ((N + TILES[c].bn - 1) / TILES[c].bn) * z;
-        const long rounds = (wg + 255) / 256;
-        // a partial last round costs a full tile time; below one round the time is one tile regardless
-        // (padding inside the last tile row / column is paid in full: 576 columns are 3 tiles of 192 or 3 of 256)
-        const double cost = (double)rounds * TILES[c].bm * TILES[c].bn / eff[c];
-        if (cost < bc)
-            bc = cost, best = c;
+        if (forced >= 0 && c != forced)
+            continue;
+        for (int s = smin; s <= smax; ++s) {
+            const double cost = plan_cost(c, s, M, N, K, batch);
+            if (cost < bc)
+                bc = cost, best = c, bs = s;
+        }
     }
+    *split = bs;
     return best;
 }
 
@@ -596,16 +616,9 @@ extern "C" int64_t dcl_gemm_workspace_floats(int M, int N, int batch, int splitk
 
 extern "C" int dcl_gemm_suggest_splitk(int M, int N, int K, int batch)
 {
-    // fill 256 CUs: tiles of the largest shape that fits, at least 8 k-steps per split
-    const int c = pick_tile(M, N, batch);
-    const long wg = (long)((M + TILES[c].bm - 1) / TILES[c].bm) * ((N + TILES[c].bn - 1) / TILES[c].bn) * batch;
-    if (wg >= 192)
-        return 1;
-    long s = (256 + wg - 1) / wg;
-    const long maxs = K / 32 / 8;
-    if (s > maxs)
-        s = maxs;
-    return (int)(s < 1 ? 1 : s);
+    int s = 0;
+    (void)plan_gemm(M, N, K, batch, &s);
+    return s;
 }
 
 extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t strideA, const float *B, int64_t ldb,
@@ -633,7 +646,8 @@ extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t
     } else {
         a.C = C, a.ldc = ldc, a.sC = strideC, a.bias = bias, a.c_amax = c_amax, a.accumulate = accumulate;
     }
-    const int c = pick_tile(M, N, batch * splitk);
+    int sfix = splitk;
+    const int c = plan_gemm(M, N, K, batch, &sfix);
     a.tiles_m = (M + TILES[c].bm - 1) / TILES[c].bm;
     a.tiles_n = (N + TILES[c].bn - 1) / TILES[c].bn;
     int rc;
