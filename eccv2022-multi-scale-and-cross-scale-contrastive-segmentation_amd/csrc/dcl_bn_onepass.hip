@@ -7,15 +7,17 @@
 //             one float4 per thread and image); 32 / T teams per XCD work on different channels;
 //   phase 1   load dy, x (and the packed ReLU mask) of the channel, partial sums, block reduction, the member's two partial
 //             sums to memory, one relaxed agent-scope atomic add on the channel's counter;
-//   overlap   the NEXT channel's loads are issued into a second register set before the wait;
+//   overlap   three register sets: while channel r waits, channel r + 1 is already reduced and published, r + 2 is loading;
 //   phase 2   wait until the counter shows T arrivals, add the T partials in member order (double: the same fixed-order sum as
 //             part_sums), dx (and the residual gradient) from the registers.
-// HBM traffic: dy + x + dx (+ dres) instead of 2 dy + 2 x + dx: 42 us against 68 us on 12 x 48 x 128 x 256
-// (tools/probes/l2_reread.py is the model this was sized on).
+// HBM traffic: dy + x + dx (+ dres) instead of 2 dy + 2 x + dx (tools/probes/l2_reread.py is the model this was sized on: 42 us
+// against 68 us on 12 x 48 x 128 x 256); measured: -15 % without a residual output, no gain with one, and a LOSS inside the
+// multi-stream training step -- the host side keeps it OFF by default (DCL_BN_ONEPASS=1 turns it on).
 // The team barrier needs all members resident: the grid is 256 workgroups of 256 threads, and the host side only takes this
 // path on the device's default stream of a single-rank run, so that never more than ONE such kernel is in flight (two
 // persistent kernels that each hold part of the CUs would wait for each other forever).  A spin that exceeds ~2^27 polls traps.
-// Counters live in a ring of four regions; every launch zeroes the region two launches ahead.
+// A member publishes its two partial sums as ONE 64-bit store into its slot; slots live in a ring of four regions and every
+// launch resets the region two launches ahead to the all-ones "empty" pattern.
 #include "dcl_common.h"
 
 namespace {
@@ -29,8 +31,7 @@ struct OpArgs {
     const unsigned long long *mask;     // packed ReLU mask (relu == 2) or null
     const float *mean, *invstd, *gamma, *beta;
     float *dx, *dres, *dbeta, *dgamma, *amax;
-    int *ctr, *ctr_clear;
-    float *part;                        // [C][T][2]
+    unsigned long long *slots, *slots_clear;   // [C][T] {sum g, sum g xhat} of every member: this launch's region / the one to clear
     int N, C, HW, T;
     float inv_count;
     int relu;                           // 0 none, 1 mask recomputed from x, 2 packed mask
@@ -43,44 +44,55 @@ struct OpSet {
     unsigned mbits[OP_NMAX];            // relu == 2: the four sign bits of this lane's vector
 };
 
+// LDS-only workgroup barrier: __syncthreads() also drains vmcnt on this target, i.e. the loads of the channels in flight
+__device__ __forceinline__ void op_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(OP_THREADS) void k_bn_bwd_onepass(OpArgs a)
 {
     __shared__ float sh[8];
     __shared__ float bc[2];
     const int tid = threadIdx.x, ln = tid & 63;
-    for (int i = blockIdx.x * OP_THREADS + tid; i < a.C; i += gridDim.x * OP_THREADS)
-        a.ctr_clear[i] = 0;
+    for (int i = blockIdx.x * OP_THREADS + tid; i < a.C * a.T; i += gridDim.x * OP_THREADS)
+        a.slots_clear[i] = ~0ull;
     const int xcd = blockIdx.x & 7, mi = blockIdx.x >> 3;          // 32 workgroups per XCD
     const int T = a.T, tpx = OP_TMAX / T;
     const int tq = mi / T, m = mi - tq * T;
     const int hw4 = a.HW >> 2;
-    const int iv = m * OP_THREADS + tid;                            // this thread's vector inside every plane
     const int N = a.N;
     float am = 0.f;
 
+    // A member owns a CONTIGUOUS N x 1024-float range of the channel's [image][pixel] data (chunk q = m N + j: image q / T,
+    // pixels (q % T) 1024 ...): 48 KB per tensor from one or two planes.  (With a slice of EVERY image per member each
+    // workgroup touched 24 planes 94 MB apart per channel -- 2.5 TB/s; the translation caches did not keep up.)
+    auto chunk = [&](int j, int &n, int &ivv) {
+        const int q = m * N + j;
+        n = q / T;
+        ivv = (q - n * T) * OP_THREADS + tid;                       // vector index inside the plane
+    };
     auto load = [&](OpSet &s, int c) {
 #pragma unroll
-        for (int n = 0; n < OP_NMAX; ++n) {
-            const int nn = min(n, N - 1);                           // unconditional loads from clamped planes
-            const size_t plane = (size_t)nn * a.C + c;
-            const size_t off = plane * a.HW + 4 * (size_t)iv;
-            s.g[n] = *(const f32x4 *)(a.dy + off);
-            s.x[n] = *(const f32x4 *)(a.x + off);
+        for (int j = 0; j < OP_NMAX; ++j) {
+            int n, ivv;
+            chunk(min(j, N - 1), n, ivv);                           // unconditional loads from clamped chunks
+            const size_t plane = (size_t)n * a.C + c;
+            const size_t off = plane * a.HW + 4 * (size_t)ivv;
+            s.g[j] = *(const f32x4 *)(a.dy + off);
+            s.x[j] = *(const f32x4 *)(a.x + off);
             if (a.relu == 2) {
-                const unsigned long long *mw = a.mask + mask_word(plane, hw4, iv);
-                s.mbits[n] = (unsigned)((mw[0] >> ln) & 1) | ((unsigned)((mw[1] >> ln) & 1) << 1) |
+                const unsigned long long *mw = a.mask + mask_word(plane, hw4, ivv);
+                s.mbits[j] = (unsigned)((mw[0] >> ln) & 1) | ((unsigned)((mw[1] >> ln) & 1) << 1) |
                              ((unsigned)((mw[2] >> ln) & 1) << 2) | ((unsigned)((mw[3] >> ln) & 1) << 3);
             }
         }
     };
     // channels of this team: c = xcd + 8 (tq + tpx r)
     auto chan = [&](int r) { return xcd + 8 * (tq + tpx * r); };
-    auto one = [&](OpSet &cur, OpSet &nxt, int r) {
+    // stage B of channel r: mask the gradient, partial sums, publish this member's partials, arrive
+    auto reduce_publish = [&](OpSet &cur, int r) {
         const int c = chan(r);
         const float mu = a.mean[c], is = a.invstd[c];
         const float gm = a.gamma ? a.gamma[c] : 1.f;
         const float asc = is * gm, ash = (a.beta ? a.beta[c] : 0.f) - mu * asc;
-        // ---- phase 1: mask the gradient, partial sums
         float sa = 0.f, sb = 0.f;
 #pragma unroll
         for (int n = 0; n < OP_NMAX; ++n) {
@@ -102,46 +114,61 @@ __global__ __launch_bounds__(OP_THREADS) void k_bn_bwd_onepass(OpArgs a)
         sb *= is;
         sa = wave_sum(sa);
         sb = wave_sum(sb);
+        op_barrier();                                            // the previous user of sh is done
         if (ln == 0) {
             sh[tid >> 6] = sa;
             sh[4 + (tid >> 6)] = sb;
         }
-        __syncthreads();
+        op_barrier();
         if (tid == 0) {
-            const float pa = (sh[0] + sh[1]) + (sh[2] + sh[3]), pb = (sh[4] + sh[5]) + (sh[6] + sh[7]);
-            float *pp = a.part + ((size_t)c * T + m) * 2;
-            __hip_atomic_store(pp, pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pp + 1, pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the partials have reached memory before the arrival
-            __hip_atomic_fetch_add(a.ctr + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ONE 64-bit relaxed store carries both partial sums: a slot is valid as soon as it differs from the all-ones
+            // pattern its region was cleared to (a NaN sum is canonicalised so that it can never look like "empty") -- no
+            // arrival counter, no ordering between stores, hence no s_waitcnt vmcnt(0) in the middle of the pipeline
+            float pa = (sh[0] + sh[1]) + (sh[2] + sh[3]), pb = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+            unsigned ua = __float_as_uint(pa), ub = __float_as_uint(pb);
+            ua = pa != pa ? 0x7fc00000u : ua;
+            ub = pb != pb ? 0x7fc00000u : ub;
+            __hip_atomic_store(a.slots + (size_t)c * T + m, ((unsigned long long)ub << 32) | ua, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
-        // ---- the next channel's loads run under the wait
-        if (chan(r + 1) < a.C)
-            load(nxt, chan(r + 1));
-        if (tid == 0) {
-            unsigned polls = 0;
-            while (__hip_atomic_load(a.ctr + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T) {
-                if (++polls > (1u << 27))
-                    __builtin_trap();
-            }
+    };
+    // stage C of channel r: wait for the team, the T partials in member order (wave 0: one lane per member, a fixed
+    // shuffle tree in double), dx (and the residual's gradient) from the registers
+    auto wait_apply = [&](OpSet &cur, int r) {
+        const int c = chan(r);
+        const float mu = a.mean[c], is = a.invstd[c];
+        const float gm = a.gamma ? a.gamma[c] : 1.f;
+        if (tid < 64) {
             double da = 0.0, db = 0.0;
-            for (int t = 0; t < T; ++t) {
-                da += (double)__hip_atomic_load(a.part + ((size_t)c * T + t) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                db += (double)__hip_atomic_load(a.part + ((size_t)c * T + t) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < T) {
+                unsigned long long v;
+                unsigned polls = 0;
+                while ((v = __hip_atomic_load(a.slots + (size_t)c * T + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) {
+                    if (++polls > (1u << 27))
+                        __builtin_trap();
+                }
+                da = (double)__uint_as_float((unsigned)v);
+                db = (double)__uint_as_float((unsigned)(v >> 32));
             }
-            bc[0] = (float)da;
-            bc[1] = (float)db;
-            if (m == 0) {
-                if (a.dbeta)
-                    a.dbeta[c] = (float)da;
-                if (a.dgamma)
-                    a.dgamma[c] = (float)db;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                da += __shfl_xor(da, o, 64);
+                db += __shfl_xor(db, o, 64);
+            }
+            if (tid == 0) {
+                bc[0] = (float)da;
+                bc[1] = (float)db;
+                if (m == 0) {
+                    if (a.dbeta)
+                        a.dbeta[c] = (float)da;
+                    if (a.dgamma)
+                        a.dgamma[c] = (float)db;
+                }
             }
         }
-        __syncthreads();
+        op_barrier();
         const float mg = bc[0] * a.inv_count, mgx = bc[1] * a.inv_count;
         const float k = is * gm;
-        // ---- phase 2: dx (and the residual's gradient) from the registers
 #pragma unroll
         for (int n = 0; n < OP_NMAX; ++n) {
             if (n < N) {
@@ -151,22 +178,48 @@ __global__ __launch_bounds__(OP_THREADS) void k_bn_bwd_onepass(OpArgs a)
                 o.y = k * (g.y - mg - (xv.y - mu) * is * mgx);
                 o.z = k * (g.z - mg - (xv.z - mu) * is * mgx);
                 o.w = k * (g.w - mg - (xv.w - mu) * is * mgx);
-                const size_t off = ((size_t)n * a.C + c) * a.HW + 4 * (size_t)iv;
+                int nn, ivv;
+                chunk(n, nn, ivv);
+                const size_t off = ((size_t)nn * a.C + c) * a.HW + 4 * (size_t)ivv;
                 if (a.dres)
                     *(f32x4 *)(a.dres + off) = g;
                 *(f32x4 *)(a.dx + off) = o;
                 am = fmaxf(am, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
             }
         }
+        op_barrier();                                            // bc may be rewritten
     };
 
-    OpSet s0, s1;
-    if (chan(0) < a.C)
+    // software pipeline over the team's channels with three register sets: while channel r waits for its team, channel
+    // r + 1 has already been reduced and published and channel r + 2 is being loaded
+    OpSet s0, s1, s2;
+    auto has = [&](int r) { return chan(r) < a.C; };
+    if (has(0)) {
         load(s0, chan(0));
-    for (int r = 0; chan(r) < a.C; r += 2) {
-        one(s0, s1, r);
-        if (chan(r + 1) < a.C)
-            one(s1, s0, r + 1);
+        reduce_publish(s0, 0);
+    }
+    if (has(1))
+        load(s1, chan(1));
+    for (int r = 0; has(r); r += 3) {
+        if (has(r + 1))
+            reduce_publish(s1, r + 1);
+        if (has(r + 2))
+            load(s2, chan(r + 2));
+        wait_apply(s0, r);
+        if (!has(r + 1))
+            break;
+        if (has(r + 2))
+            reduce_publish(s2, r + 2);
+        if (has(r + 3))
+            load(s0, chan(r + 3));
+        wait_apply(s1, r + 1);
+        if (!has(r + 2))
+            break;
+        if (has(r + 3))
+            reduce_publish(s0, r + 3);
+        if (has(r + 4))
+            load(s1, chan(r + 4));
+        wait_apply(s2, r + 2);
     }
     if (a.amax) {
         am = fmaxf(am, 0.f);
@@ -190,10 +243,10 @@ extern "C" int dcl_bn_bwd_onepass_supported(int N, int C, int HW, int relu)
 
 extern "C" int64_t dcl_bn_onepass_workspace_bytes(void)
 {
-    return 4 * (4096 * (int64_t)sizeof(int)) + (int64_t)4096 * OP_TMAX * 2 * sizeof(float);
+    return 4 * (int64_t)4096 * OP_TMAX * sizeof(unsigned long long);       // four regions of [4096][32] slots
 }
 
-// ws: dcl_bn_onepass_workspace_bytes() bytes, zero-initialised ONCE by the caller; seq: launch counter of that workspace
+// ws: dcl_bn_onepass_workspace_bytes() bytes, set to 0xFF bytes ONCE by the caller; seq: launch counter of that workspace
 // (0, 1, 2, ...: selects the counter region).  relu: 0 none, 1 the mask is recomputed from x, 2 `y` is the packed mask.
 extern "C" int dcl_bn_bwd_onepass(const float *dy, const float *x, const void *y_or_mask, const float *mean,
                                   const float *invstd, const float *gamma, const float *beta, double count, int N, int C,
@@ -208,10 +261,10 @@ extern "C" int dcl_bn_bwd_onepass(const float *dy, const float *x, const void *y
     a.dy = dy; a.x = x; a.mask = (const unsigned long long *)(relu == 2 ? y_or_mask : nullptr);
     a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
     a.dx = dx; a.dres = dres; a.dbeta = dbeta; a.dgamma = dgamma; a.amax = amax;
-    int *ctrs = (int *)ws;
-    a.ctr = ctrs + (seq & 3) * 4096;
-    a.ctr_clear = ctrs + ((seq + 2) & 3) * 4096;
-    a.part = (float *)(ctrs + 4 * 4096);
+    unsigned long long *slots = (unsigned long long *)ws;
+    const size_t region = (size_t)4096 * OP_TMAX;
+    a.slots = slots + (seq & 3) * region;
+    a.slots_clear = slots + ((seq + 2) & 3) * region;
     a.N = N; a.C = C; a.HW = HW; a.T = HW / 1024;
     a.inv_count = (float)(1.0 / count);
     a.relu = relu;

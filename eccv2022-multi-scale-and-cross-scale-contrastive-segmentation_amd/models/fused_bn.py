@@ -162,13 +162,13 @@ def _onepass_stream(dev):
 
 
 def _onepass_workspace(dev):
-    """(zero-initialised counter / partial-sum workspace of the device, launch number): see dcl_bn_bwd_onepass."""
+    """(slot workspace of the device -- all bits set = every slot empty --, launch number): see dcl_bn_bwd_onepass."""
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ent = _ONEPASS_WS.get(key)
     if ent is None:
         n = int(_lib.lib().dcl_bn_onepass_workspace_bytes())
         with torch.cuda.stream(torch.cuda.default_stream(dev)):
-            ent = _ONEPASS_WS[key] = [torch.zeros(n // 4, dtype=torch.int32, device=dev), 0]
+            ent = _ONEPASS_WS[key] = [torch.full((n // 4,), -1, dtype=torch.int32, device=dev), 0]
     seq = ent[1]
     ent[1] += 1
     return ent[0], seq

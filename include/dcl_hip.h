@@ -288,7 +288,7 @@ int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, in
  * workgroups keep their share of a channel in registers across the per-channel statistics exchange (teams of H W / 1024
  * workgroups of one XCD, relaxed agent-scope counters).  Shapes: H W % 1024 == 0, H W / 1024 in {1, 2, 4, 8, 16, 32}, N <= 12
  * (dcl_bn_bwd_onepass_supported); relu: 0 none, 1 the mask is recomputed from x (y = NULL), 2 y is the packed sign mask.
- * ws: dcl_bn_onepass_workspace_bytes() bytes, zeroed ONCE by the caller; seq = 0, 1, 2, ... the launch number on that
+ * ws: dcl_bn_onepass_workspace_bytes() bytes, every byte 0xFF ONCE by the caller; seq = 0, 1, 2, ... the launch number on that
  * workspace.  The teams wait for all their members: launch it on ONE stream only (never two instances in flight). */
 int dcl_bn_bwd_onepass_supported(int N, int C, int HW, int relu);
 int64_t dcl_bn_onepass_workspace_bytes(void);

@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--shape", default="", help="m,k,n: one Linear only")
     ap.add_argument("--which", default="", help="fwd|dgrad|wgrad: only that GEMM of each Linear")
     ap.add_argument("--no-library", action="store_true")
+    ap.add_argument("--sweep-tiles", action="store_true", help="time every forced tile (1..5) next to the automatic plan")
     args = ap.parse_args()
     L = _lib.lib()
     L.dcl_gemm_set_tile(args.tile)
@@ -96,6 +97,19 @@ def main():
             if args.which and f" {args.which} " not in label.replace("  ", " "):
                 continue
             tm = timeit(mine, args.iters)
+            if args.sweep_tiles:
+                ts = []
+                for t in range(1, 6):
+                    L.dcl_gemm_set_tile(t)
+                    try:
+                        ts.append(timeit(mine, args.iters))
+                    except RuntimeError:
+                        ts.append(float("nan"))
+                L.dcl_gemm_set_tile(args.tile)
+                best = min(range(5), key=lambda i: ts[i] if ts[i] == ts[i] else 1e9)
+                print(f"{label},auto {tm:.4f},best tile {best + 1} {ts[best]:.4f},ratio {tm / ts[best]:.2f}," +
+                      " ".join(f"{v:.4f}" for v in ts), flush=True)
+                continue
             tl = float("nan") if args.no_library else timeit(lib, args.iters)
             e1 = e2 = float("nan")
             if not args.no_library and (args.check or flop <= 4e11):

@@ -10,7 +10,7 @@ import __graft_entry__  # noqa: F401,E402
 import mscs_amd.models.fused_bn as fb  # noqa: E402
 
 dev = "cuda"
-for shape in ((12, 48, 128, 256), (12, 96, 64, 128), (12, 192, 32, 64), (12, 64, 128, 256), (12, 256, 128, 256)):
+for shape in ((12, 48, 128, 256), (12, 96, 64, 128), (12, 64, 128, 256), (12, 256, 128, 256), (12, 720, 128, 256)):
     for (res, relu) in ((False, True), (True, True)):
         row = []
         for onepass in (False, True):
