@@ -223,8 +223,9 @@ def roofline_conv_kernels(args, dev, iters=20):
         return flops, ms_f, ms_w, (n * (ci + co) * h * w) * 4
 
     flops, ms_f, ms_w, ab = conv_and_wgrad(144, 720, 8)
-    main = entry(f"k_wgrad3x3d<3,1> + k_wgrad_reduce (dcl_wgrad3x3_f16x3): 3x3 weight gradient, {n}x(144->720)x{h}x{w} "
-                 "(the head convolution's full-resolution part)", flops, ms_w, ab)
+    main = entry(f"k_wgrad3x3d<3,1,wave-level splits> + k_wgrad_reduce (dcl_wgrad3x3_f16x3): 3x3 weight gradient, "
+                 f"{n}x(144->720)x{h}x{w} (the head convolution's full-resolution part; 135 tile pairs x 7 pixel splits on "
+                 "1024 waves)", flops, ms_w, ab)
     others = [entry(f"k_conv3x3_il<3,4> (dcl_conv3x3_f16x3): 3x3 conv forward, {n}x(144->720)x{h}x{w}", flops, ms_f, ab)]
     torch.cuda.empty_cache()
     flops, ms_f, ms_w, ab = conv_and_wgrad(48, 48, iters)

@@ -83,6 +83,7 @@ SIGNATURES = {
     "dcl_wgrad3x3_splits": [_i, _i, _i, _i, _i, _i],
     "dcl_wgrad3x3_set_stride2": [_i],
     "dcl_wgrad3x3_set_splits": [_i],
+    "dcl_wgrad3x3_set_wave_mode": [_i],
     "dcl_conv3x3_set_up2_phases": [_i],
     "dcl_conv3x3_set_interleave": [_i],
     "dcl_upsample_ce_set_bwd_chunk": [_i],

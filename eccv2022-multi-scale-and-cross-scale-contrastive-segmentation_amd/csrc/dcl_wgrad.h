@@ -11,8 +11,10 @@ struct WgradArgs {
     int Hd, Wd;                  // stored size of dy (= H, W; or the even samples of a zero-inserted dy: stride 2)
     int strips, nseg, units, S, ncig, npairs, nx;
     int rect_c, rect_i, rect_mode;  // many pairs: pair-grid rectangle that shares an XCD (rect_c * rect_i = 32)
+    int wave_mode;               // 1: S pixel splits per pair dealt out to WAVES (k_wgrad3x3d<.., true>), one slab per split
 };
 
 // dcl_wgrad3x3d.hip: the stride-1 kernel with LDS-DMA operand staging; same grid, slabs and arguments as k_wgrad3x3
 bool dcl_wgrad_dma_supported(int nco, int nci);
 void dcl_wgrad_dma_launch(const WgradArgs &a, int nco, int nci, dim3 grid, hipStream_t s);
+bool dcl_wgrad_dma_wave_mode_supported(int nco, int nci);

@@ -500,7 +500,10 @@ void dcl_wgrad_s2_launch(const float *x, const float *dy, int N, int Cin, int Co
                          hipStream_t s, int *nslab);
 static int g_s2_native = 1;     // stride 2: 1 = output-pixel formulation (dcl_wgrad3x3_s2.hip), 0 = zero-inserted dy
 
-static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nci, int &S, int &units)
+static int g_wave_mode = 2;     // 129 .. 256 tile pairs of the (3, 1) tile: pixel splits dealt out to waves (dcl_wgrad3x3d.hip);
+                                // 2 = a workgroup's waves take the same split of four neighbouring pairs, 1 = four splits of a pair
+
+static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nci, int &S, int &units, bool *wave_mode = nullptr)
 {
     const int cot = Cout / 16, cit = Cin / 16;
     // Tiles per wave, measured on the HRNet-W48 shapes at batch 12 (tools/wgrad_tiles.py, and bench.py with
@@ -531,6 +534,14 @@ static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nc
     S = 4 * nx;
     if ((long long)S > (long long)units * H)
         S = units * H;
+    if (wave_mode) {
+        // one workgroup per pair and CUs left over: the splits go to single waves, S = 128 / (pairs of one XCD) of them
+        const int sw = 128 / ((pairs + 7) / 8);
+        *wave_mode = g_wave_mode && g_force_nx == 0 && pairs > 128 && pairs <= 256 && sw > 4 &&
+                     dcl_wgrad_dma_wave_mode_supported(nco, nci) && (long long)sw <= (long long)units * H;
+        if (*wave_mode)
+            S = sw;
+    }
 }
 
 extern "C" int dcl_wgrad3x3_set_tile(int nco, int nci)
@@ -556,6 +567,12 @@ extern "C" int dcl_wgrad3x3_set_splits(int nx)
     return 0;
 }
 
+extern "C" int dcl_wgrad3x3_set_wave_mode(int on)
+{
+    g_wave_mode = on < 0 ? 0 : on;
+    return 0;
+}
+
 extern "C" int dcl_wgrad3x3_set_stride2(int native)
 {
     g_s2_native = native ? 1 : 0;
@@ -569,7 +586,10 @@ extern "C" int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W, int s
     if (stride == 2 && g_s2_native && dcl_wgrad_s2_supported(H, W))
         return dcl_wgrad_s2_slabs(N, Cin, Cout, H, W, g_tile_nco, g_tile_nci);
     int nco, nci, S, units;
-    wgrad_plan(N, Cin, Cout, H, W, nco, nci, S, units);
+    bool wm = false;
+    wgrad_plan(N, Cin, Cout, H, W, nco, nci, S, units, stride == 1 && use_dma(Cin > Cout ? Cin : Cout, H, W) ? &wm : nullptr);
+    if (wm)
+        return S;                                  // one slab per wave-level split
     return nco * nci <= 4 ? (S + 3) / 4 : S;      // one slab per workgroup (4 splits), or per wave (6-tile variant)
 }
 
@@ -612,7 +632,10 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     a.strips = (W + 31) / 32;
     a.nseg = 1;
     int nco, nci;
-    wgrad_plan(N, Cin, Cout, H, W, nco, nci, a.S, a.units);
+    bool wm = false;
+    wgrad_plan(N, Cin, Cout, H, W, nco, nci, a.S, a.units,
+               stride == 1 && use_dma(Cin > Cout ? Cin : Cout, H, W) ? &wm : nullptr);
+    a.wave_mode = wm ? g_wave_mode : 0;
     a.ncig = (Cin / 16 + nci - 1) / nci;
     a.npairs = (Cout / 16 / nco) * a.ncig;
     a.nx = (a.S + 3) / 4;                                    // workgroups per pair (4 splits each)
@@ -631,7 +654,7 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
         DCL_LAUNCH_CHECK();
         const int total = 9 * Cout * Cin;
         (void)total;
-        launch_wgrad_reduce(part, nco * nci <= 4 ? a.nx : a.S, Cout, Cin, dw, s);
+        launch_wgrad_reduce(part, (nco * nci <= 4 && !wm) ? a.nx : a.S, Cout, Cin, dw, s);
         DCL_LAUNCH_CHECK();
         return 0;
     }

@@ -50,6 +50,7 @@ class DebugConfig:
     # ---- kernel variants set on the library at load (include/dcl_hip.h "tuning hook" entries)
     wgrad_variant: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_VARIANT'))
     wgrad_stride2: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_S2'))
+    wgrad_wave_mode: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_WAVE'))      # 0 = a workgroup per tile pair
     up2_phases: Optional[int] = field(default_factory=lambda: _int('DCL_UP2_PHASES'))
     conv_interleave: Optional[int] = field(default_factory=lambda: _int('DCL_CONV_IL'))
     upce_bwd_chunk: Optional[int] = field(default_factory=lambda: _int('DCL_UPCE_BWD_CHUNK'))
@@ -60,6 +61,7 @@ class DebugConfig:
     def apply_to_library(self, l) -> None:
         """Hand the kernel-variant switches to a freshly loaded libdcl_hip.so."""
         for val, fn in ((self.wgrad_variant, l.dcl_wgrad3x3_set_variant), (self.wgrad_stride2, l.dcl_wgrad3x3_set_stride2),
+                        (self.wgrad_wave_mode, l.dcl_wgrad3x3_set_wave_mode),
                         (self.up2_phases, l.dcl_conv3x3_set_up2_phases),
                         (self.conv_interleave, l.dcl_conv3x3_set_interleave),
                         (self.gemm_gemm_tile, l.dcl_gemm_set_tile),

@@ -392,6 +392,11 @@ int dcl_wgrad3x3_set_variant(int variant);
 int dcl_wgrad3x3_set_stride2(int native);
 /* tuning hook (per-wave kernels): pixel splits per tile pair, 0 = automatic.  Changes dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_splits(int nx);
+/* tuning hook (stride 1, LDS-DMA kernel, (3, 1) tile): 2 (default) / 1 = with 129 .. 256 tile pairs (one workgroup per pair
+ * would leave CUs empty: the head's 144 -> 720 launch has 135) the pixel splits go to single waves, 128 / ceil(pairs / 8) per
+ * pair, each XCD owning a contiguous run of pairs (2: a workgroup's four waves take one split of four pairs, 1: four splits of
+ * one pair); 0 = one workgroup per pair.  Changes dcl_wgrad3x3_splits(). */
+int dcl_wgrad3x3_set_wave_mode(int on);
 int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W /* of x */,
                        const float *xamax, int xcount, const float *gamax, int gcount,
                        int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,

@@ -1441,6 +1441,36 @@ def test_weight_gradient_kernel_variants_match_fp64(dev, variant):
 
 
 @pytest.mark.gpu
+def test_weight_gradient_wave_level_splits_match_fp64_and_workgroup_form(dev):
+    """129 .. 256 tile pairs of the (3, 1) tile (the head's 144 -> 720 launch: 135; 384 -> 384: 192): the pixel splits go to
+    single waves, XCD by XCD (k_wgrad3x3d<3, 1, true>).  Against float64 (3e-6 of max), bitwise reproducible, and equal to
+    the one-workgroup-per-pair form to f16x3 round-off; a tiny image (fewer row steps than splits) keeps the old form."""
+    from mscs_amd import _lib
+    from mscs_amd.models import ops
+    L = _lib.lib()
+    torch.manual_seed(91)
+    try:
+        for (n, ci, co, h, w) in [(2, 144, 720, 12, 40), (1, 384, 384, 9, 32), (3, 144, 720, 5, 72), (1, 144, 720, 1, 8),
+                                  (1, 240, 432, 7, 24)]:
+            x = torch.randn(n, ci, h, w, device=dev).relu_() * 2.0
+            gy = torch.randn(n, co, h, w, device=dev) * 1e-4
+            ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), torch.zeros(co, ci, 3, 3, device=dev).double(),
+                                                     None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            for mode in (1, 2):
+                L.dcl_wgrad3x3_set_wave_mode(mode)
+                slabs = L.dcl_wgrad3x3_splits(n, ci, co, h, w, 1)
+                gw = ops.conv3x3_wgrad(x, gy)
+                assert ((gw.double() - ref).abs().max() / ref.abs().max()).item() < 3e-6, (mode, n, ci, co, h, w)
+                assert torch.equal(gw, ops.conv3x3_wgrad(x, gy))
+            L.dcl_wgrad3x3_set_wave_mode(0)
+            assert (L.dcl_wgrad3x3_splits(n, ci, co, h, w, 1) == 1) == (slabs > 1 or h * w == 8), (slabs, n, ci, co, h, w)
+            old = ops.conv3x3_wgrad(x, gy)
+            assert ((gw - old).abs().max() / ref.abs().max()).item() < 3e-6
+    finally:
+        L.dcl_wgrad3x3_set_wave_mode(2)
+
+
+@pytest.mark.gpu
 def test_stride2_gradient_formulations_agree(dev):
     """Stride-2 data gradient by output parity classes (default) against the stride-1 tile over the zero-inserted gradient
     (dcl_conv3x3_set_up2_phases(0)), and the weight gradient over the output pixels against the zero-inserted dY operand
