@@ -100,7 +100,7 @@ __device__ __forceinline__ float axis_weight(const Axis a, int o, int in_size, i
 }
 
 // candidate output range touching input index i (conservative; weights decide)
-__device__ __forceinline__ void out_range(const Axis a, int i, int in_size, int out_size, int &lo, int &hi)
+__host__ __device__ __forceinline__ void out_range(const Axis a, int i, int in_size, int out_size, int &lo, int &hi)
 {
     // src(o) is non-decreasing in o; input i is touched when src(o) in (i-1, i+1)
     const float inv = a.scale > 0.f ? 1.f / a.scale : 0.f;
@@ -562,6 +562,136 @@ __global__ __launch_bounds__(256) void k_tapup_bwd(const float *__restrict__ dy,
     }
 }
 
+// Backward, second form (the default wherever its column window fits NW4 <= 8 float4s).  Same tiles and summation structure;
+// what changed is the arithmetic per element (the first form spent ~1 000 instructions per thread in its horizontal pass:
+// 9 outputs x kxn terms, each with two compares, two scalar LDS reads -- 4-way bank conflicted at a column stride of the scale
+// factor -- and its address arithmetic; 2.5 ms per launch on 12 x 720 x 128 x 256 against ~0.4 ms of HBM time):
+//   vertical   per low-resolution row rr only the FR = footprint + 2 rows of dy that can reach it are read (not every row of
+//              the tile for every rr): 3 sums (ky) per row, the three row weights of (rr, j) in ONE uniform 16-byte LDS read;
+//   horizontal one item = (column c, ky, rr) produces the three kx taps from ONE window of 4 NW4 values of the vertical sums,
+//              read as aligned float4s (lanes along c: neighbouring lanes read neighbouring float4s), against a per-column
+//              weight row wf[c][m] = weight of shifted coordinate (window start + m - 1) that is built once per workgroup:
+//              out[kx] = sum_m wf[m + kx] V[m] -- no compares (zero-padded V rows, zero weights outside the image).
+template <int NW4>
+__global__ __launch_bounds__(256) void k_tapup_bwd_w(const float *__restrict__ dy, int Co, int H, int W, int h, int w, Axis ay,
+                                                    Axis ax, int trl, int tiles_r, int FR, int WP, float *__restrict__ dz,
+                                                    long long sn, long long sc)
+{
+    constexpr int PADL = 4, TS = (NW4 + 1) | 1;            // weight row of a column: TS float4s (odd: conflict-free b128 reads)
+    extern __shared__ __attribute__((aligned(16))) float tap_lds[];
+    f32x4 *wt = (f32x4 *)tap_lds;                           // [TAP_TRL][FR] {w(ky = 0), w(1), w(2), 0}
+    f32x4 *wf = wt + TAP_TRL * FR;                          // [w][TS]
+    float *Vt = (float *)(wf + (size_t)w * TS);             // [3 * TAP_TRL][WP], column X at PADL + X
+    int *a4s = (int *)(Vt + (size_t)3 * TAP_TRL * WP);      // [w] window start (padded index, multiple of 4)
+    int *ylo = a4s + w;                                     // [TAP_TRL] first dy row of a low-resolution row's footprint
+    const int tile = blockIdx.x % tiles_r, plane = blockIdx.x / tiles_r;
+    const int n = plane / Co, co = plane - n * Co;
+    const int r_a = tile * trl, nr = min(r_a + trl, h) - r_a;
+    const int t = threadIdx.x;
+    for (int e = t; e < TAP_TRL * FR; e += 256) {
+        const int rr = e / FR, j = e - rr * FR;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int lo = 0, hi = 0;
+        if (rr < nr) {
+            out_range(ay, r_a + rr, h, H, lo, hi);
+            const int Y = lo - 1 + j;
+            if (Y >= 0 && Y < H && Y <= hi + 1) {
+                v.x = (Y - 1 >= 0) ? axis_weight(ay, Y - 1, h, r_a + rr) : 0.f;
+                v.y = axis_weight(ay, Y, h, r_a + rr);
+                v.z = (Y + 1 < H) ? axis_weight(ay, Y + 1, h, r_a + rr) : 0.f;
+            }
+        }
+        wt[e] = v;
+        if (j == 0)
+            ylo[rr] = lo - 1;
+    }
+    for (int c = t; c < w; c += 256) {
+        int xs_lo, xs_hi;
+        out_range(ax, c, w, W, xs_lo, xs_hi);
+        a4s[c] = (xs_lo - 1 + PADL) & ~3;
+    }
+    for (int e = t; e < 3 * TAP_TRL * (WP - W); e += 256) {                 // zero pads of the V rows
+        const int row = e / (WP - W), k = e - row * (WP - W);
+        Vt[(size_t)row * WP + (k < PADL ? k : W + k)] = 0.f;
+    }
+    __syncthreads();
+    for (int e = t; e < w * TS * 4; e += 256) {
+        const int c = e / (TS * 4), m = e - c * (TS * 4);
+        const int Xs = a4s[c] - PADL + m - 1;
+        int xs_lo, xs_hi;
+        out_range(ax, c, w, W, xs_lo, xs_hi);
+        ((float *)wf)[e] = (m < 4 * NW4 + 2 && Xs >= xs_lo && Xs <= xs_hi) ? axis_weight(ax, Xs, w, c) : 0.f;
+    }
+    const float *g = dy + (size_t)plane * H * W;
+    for (int X = t; X < W; X += 256) {
+#pragma unroll
+        for (int rr = 0; rr < TAP_TRL; ++rr) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            if (rr < nr) {
+                const int y0 = ylo[rr];
+                const f32x4 *wr = wt + rr * FR;
+                int j = 0;
+                for (; j + 4 <= FR; j += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = g[(size_t)min(max(y0 + j + u, 0), H - 1) * W + X];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const f32x4 q = wr[j + u];
+                        a0 += q.x * v[u];
+                        a1 += q.y * v[u];
+                        a2 += q.z * v[u];
+                    }
+                }
+                for (; j < FR; ++j) {
+                    const float v = g[(size_t)min(max(y0 + j, 0), H - 1) * W + X];
+                    const f32x4 q = wr[j];
+                    a0 += q.x * v;
+                    a1 += q.y * v;
+                    a2 += q.z * v;
+                }
+            }
+            Vt[(size_t)(0 * TAP_TRL + rr) * WP + PADL + X] = a0;
+            Vt[(size_t)(1 * TAP_TRL + rr) * WP + PADL + X] = a1;
+            Vt[(size_t)(2 * TAP_TRL + rr) * WP + PADL + X] = a2;
+        }
+    }
+    __syncthreads();
+    float *out = dz + (size_t)n * sn + (size_t)co * sc;
+    const size_t tapstride = (size_t)Co * sc;
+    for (int e = t; e < 3 * nr * w; e += 256) {
+        const int c = e % w, q = e / w, rr = q % nr, ky = q / nr;
+        const f32x4 *vrow = (const f32x4 *)(Vt + (size_t)(ky * TAP_TRL + rr) * WP + a4s[c]);
+        const f32x4 *wc = wf + (size_t)c * TS;
+        float wv[4 * NW4 + 4];
+#pragma unroll
+        for (int m = 0; m <= NW4; ++m) {
+            const f32x4 q4 = wc[m];
+            wv[4 * m] = q4.x;
+            wv[4 * m + 1] = q4.y;
+            wv[4 * m + 2] = q4.z;
+            wv[4 * m + 3] = q4.w;
+        }
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < NW4; ++m) {
+            const f32x4 v = vrow[m];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                o0 += wv[4 * m + u] * vv[u];
+                o1 += wv[4 * m + u + 1] * vv[u];
+                o2 += wv[4 * m + u + 2] * vv[u];
+            }
+        }
+        float *op = out + (size_t)(3 * ky) * tapstride + (size_t)(r_a + rr) * w + c;
+        op[0] = o0;
+        op[tapstride] = o1;
+        op[2 * tapstride] = o2;
+    }
+}
+
 // conservative bound of the low-resolution window a run of `n_out` consecutive output coordinates (+ one on either side)
 // interpolates from
 int tap_window(int in_size, int out_size, int n_out)
@@ -616,6 +746,8 @@ extern "C" int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1, i
     return 0;
 }
 
+static int g_tapup_bwd_form = 2;        // 2 = k_tapup_bwd_w (windowed horizontal pass), 1 = k_tapup_bwd
+
 extern "C" int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners,
                              int channel_major, float *dz, void *stream)
 {
@@ -637,10 +769,59 @@ extern "C" int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h
     const int tiles_r = (h + trl - 1) / trl;
     const long long blocks = (long long)N * Co * tiles_r;
     DCL_CHECK_ARG(blocks < (1LL << 31), "too many tiles");
+    const long long sn = channel_major ? (long long)h * w : (long long)9 * Co * h * w;
+    const long long sc = channel_major ? (long long)N * h * w : (long long)h * w;
+    // second form: 4 low-resolution rows per tile, a column window of NW4 float4s
+    // exact spans of out_range() over the rows / columns (+ 1: host and device may round a quotient differently);
+    // tap_footprint()'s 2 s + 6 is too small for align_corners on few source pixels (3 -> 24: s = 11.5, not 8)
+    int span_r = 1, span_c = 1;
+    for (int r = 0; r < h; ++r) {
+        int lo, hi;
+        out_range(ay, r, h, H, lo, hi);
+        span_r = hi - lo + 1 > span_r ? hi - lo + 1 : span_r;
+    }
+    for (int c = 0; c < w; ++c) {
+        int lo, hi;
+        out_range(ax, c, w, W, lo, hi);
+        span_c = hi - lo + 1 > span_c ? hi - lo + 1 : span_c;
+    }
+    const int nw4 = (span_c + 1 + 5 + 3) / 4, FR = span_r + 1 + 2, PADL = 4;
+    const int WP = (W + PADL + 4 * nw4 + 4 + 3) & ~3;
+    const int ts = (nw4 + 1) | 1;
+    const size_t lds2 = ((size_t)TAP_TRL * FR * 4 + (size_t)w * ts * 4 + (size_t)3 * TAP_TRL * WP + (size_t)w + TAP_TRL) * sizeof(float);
+    if (g_tapup_bwd_form == 2 && nw4 >= 2 && nw4 <= 8 && lds2 <= 64 * 1024) {
+        const int tiles2 = (h + TAP_TRL - 1) / TAP_TRL;
+        const long long blocks2 = (long long)N * Co * tiles2;
+        DCL_CHECK_ARG(blocks2 < (1LL << 31), "too many tiles");
+#define DCL_TAPUP_CASE(K)                                                                                                   \
+    case K:                                                                                                                 \
+        hipLaunchKernelGGL(k_tapup_bwd_w<K>, dim3((unsigned)blocks2), dim3(256), lds2, (hipStream_t)stream, dy, Co, H, W, h, w, \
+                           ay, ax, TAP_TRL, tiles2, FR, WP, dz, sn, sc);                                                     \
+        break;
+        switch (nw4) {
+            DCL_TAPUP_CASE(2)
+            DCL_TAPUP_CASE(3)
+            DCL_TAPUP_CASE(4)
+            DCL_TAPUP_CASE(5)
+            DCL_TAPUP_CASE(6)
+            DCL_TAPUP_CASE(7)
+            DCL_TAPUP_CASE(8)
+        }
+#undef DCL_TAPUP_CASE
+        DCL_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_tapup_bwd, dim3((unsigned)blocks), dim3(256), lds_for(trl), (hipStream_t)stream, dy, Co, H, W, h, w, ay,
-                       ax, trl, tiles_r, gr, kxn, dz, channel_major ? (long long)h * w : (long long)9 * Co * h * w,
-                       channel_major ? (long long)N * h * w : (long long)h * w);
+                       ax, trl, tiles_r, gr, kxn, dz, sn, sc);
     DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_tapup_set_bwd_form(int form)
+{
+    if (form != 1 && form != 2)
+        return DCL_EINVAL;
+    g_tapup_bwd_form = form;
     return 0;
 }
 

@@ -52,6 +52,7 @@ class DebugConfig:
     wgrad_stride2: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_S2'))
     wgrad_wave_mode: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_WAVE'))      # 0 = a workgroup per tile pair
     up2_phases: Optional[int] = field(default_factory=lambda: _int('DCL_UP2_PHASES'))
+    tapup_bwd_form: Optional[int] = field(default_factory=lambda: _int('DCL_TAPUP_BWD'))         # 1 = first form of the tap-up backward
     conv_interleave: Optional[int] = field(default_factory=lambda: _int('DCL_CONV_IL'))
     upce_bwd_chunk: Optional[int] = field(default_factory=lambda: _int('DCL_UPCE_BWD_CHUNK'))
     upce_fwd_kib: Optional[int] = field(default_factory=lambda: _int('DCL_UPCE_FWD_KIB'))
@@ -63,6 +64,7 @@ class DebugConfig:
         for val, fn in ((self.wgrad_variant, l.dcl_wgrad3x3_set_variant), (self.wgrad_stride2, l.dcl_wgrad3x3_set_stride2),
                         (self.wgrad_wave_mode, l.dcl_wgrad3x3_set_wave_mode),
                         (self.up2_phases, l.dcl_conv3x3_set_up2_phases),
+                        (self.tapup_bwd_form, l.dcl_tapup_set_bwd_form),
                         (self.conv_interleave, l.dcl_conv3x3_set_interleave),
                         (self.gemm_gemm_tile, l.dcl_gemm_set_tile),
                         (self.upce_bwd_chunk, l.dcl_upsample_ce_set_bwd_chunk),

@@ -282,6 +282,9 @@ int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1 /* may be NUL
                   int W, int align_corners, int channel_major, float *y, int accumulate, void *stream);
 int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
                   float *dz, void *stream);
+/* tuning hook: 2 (default) = windowed horizontal pass (k_tapup_bwd_w), 1 = the first form (also the fallback for column
+ * windows beyond 8 float4s). */
+int dcl_tapup_set_bwd_form(int form);
 
 /* ---- one-kernel batch-norm backward (csrc/dcl_bn_onepass.hip) -------------------------------------------------------
  * dcl_bn_bwd_reduce_part + dcl_bn_bwd_apply_fused of a single-rank norm in ONE launch that reads dy and x once: 256 persistent

@@ -56,9 +56,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   $S pmc $(find $D -name '*counter_collection.csv' | head -1) | grep -v "at::native" > $OUT/${TAG}_gemm_pmc_$n.csv; rm -rf $D
 done
 rm -f $OUT/*.log
-# configs 4 / 5: one steady-state step of config 4, rocprofv3's aggregate of config 5
-cd $ROOT && bash tools/profile_config4.sh $TAG > /dev/null 2>&1; cd /tmp
-D=$OUT/${TAG}_c5_trace; rm -rf $D
-rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $ROOT/bench.py --config 5 --steps 3 --warmup 2 --no-cpu-baseline > $D.log 2>&1
-cp $(find $D -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_config5_kernels.csv; rm -rf $D $D.log
+# configs 4 / 5: one steady-state step each (the aggregate of a run also holds MIOpen's solver search of the first step)
+cd $ROOT && bash tools/profile_config4.sh $TAG 4 > /dev/null 2>&1
+cd $ROOT && bash tools/profile_config4.sh $TAG 5 > /dev/null 2>&1; cd /tmp
 ls -la $OUT | grep ${TAG}_
