@@ -352,15 +352,23 @@ def conv3x3_direct(x, weight, transposed=False, stride=1, out_hw=None):
     return conv3x3_launch(x, wp, cout, amax_of(x), wamax, out, stride=stride)
 
 
-def conv3x3_wgrad_supported(x, cout):
-    return x.shape[1] % 16 == 0 and cout % 16 == 0 and x.shape[3] % 8 == 0
+def conv3x3_wgrad_supported(x, cout, stride=1):
+    """channel counts in multiples of 16; widths in multiples of 8 (stride 1: any width -- conv3x3_wgrad pads the rows)"""
+    return x.shape[1] % 16 == 0 and cout % 16 == 0 and (x.shape[3] % 8 == 0 or stride == 1)
 
 
 def conv3x3_wgrad(x, gy, stride=1):
     """dw [Co, Ci, 3, 3] = weight gradient of conv2d(x, w, stride=stride, padding=1) for the output gradient gy,
     on the f16x3 kernel of csrc/dcl_wgrad3x3.hip (x [N, Ci, H, W], gy [N, Co, Ho, Wo], contiguous f32)."""
     from .. import _lib
-    from .amax import amax_of
+    from .amax import amax_of, tag
+    if stride == 1 and x.shape[3] % 8:
+        # the kernel walks the rows in octets: zero columns on the right change nothing (x: the convolution's own padding;
+        # gy: no output there) -- e.g. the 20 x 20 maps of a 640 x 640 input at stride 32
+        pad = 8 - x.shape[3] % 8
+        xa, ga = amax_of(x), amax_of(gy)
+        x, gy = torch.nn.functional.pad(x, (0, pad)), torch.nn.functional.pad(gy, (0, pad))
+        tag(x, xa), tag(gy, ga)
     n, ci, h, w = x.shape
     co = gy.shape[1]
     L = _lib.lib()
@@ -439,7 +447,7 @@ class _Conv3x3Direct(torch.autograd.Function):
                 else:
                     n, ci, h, w = x.shape
                     gw = torch.bmm(gy.view(n, -1, h * w), x.view(n, ci, h * w).transpose(1, 2)).sum(0).view_as(weight)
-            elif conv3x3_wgrad_supported(x, weight.shape[0]):
+            elif conv3x3_wgrad_supported(x, weight.shape[0], ctx.stride):
                 gw = conv3x3_wgrad(x, gy, ctx.stride)
             else:
                 st = ctx.stride

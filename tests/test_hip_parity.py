@@ -1420,7 +1420,7 @@ def test_head_conv_over_upsampled_any_map_order(dev, align):
 def test_weight_gradient_kernel_variants_match_fp64(dev, variant):
     """The two stride-1 weight-gradient kernels of the library -- MFMA-order loads (0, dcl_wgrad3x3.hip: the fallback) and
     LDS-DMA staging (2, dcl_wgrad3x3d.hip, the default) -- against float64 (3e-6 of max) and bitwise reproducible,
-    ragged strips and channel tiles included."""
+    ragged strips and channel tiles included; widths that are not multiples of 8 go in zero-padded (ops.conv3x3_wgrad)."""
     from mscs_amd import _lib
     from mscs_amd.models import ops
     L = _lib.lib()
@@ -1428,7 +1428,7 @@ def test_weight_gradient_kernel_variants_match_fp64(dev, variant):
     try:
         L.dcl_wgrad3x3_set_variant(variant)
         for (n, ci, co, h, w) in [(2, 48, 96, 19, 40), (3, 96, 48, 16, 64), (1, 32, 64, 9, 72), (2, 192, 192, 8, 32),
-                                  (1, 80, 112, 5, 24)]:
+                                  (1, 80, 112, 5, 24), (2, 32, 48, 20, 20), (1, 64, 32, 5, 12)]:    # last two: W % 8 != 0
             x = torch.randn(n, ci, h, w, device=dev).relu_() * 2.0
             gy = torch.randn(n, co, h, w, device=dev) * 1e-4
             ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), torch.zeros(co, ci, 3, 3, device=dev).double(),

@@ -12,6 +12,7 @@ F=$(find $OUT -name '*kernel_trace.csv' | head -1)
 python3 $ROOT/tools/summarize_profile.py trace $F 3 5 > $ROOT/gpurun_out/${TAG}_step_kernels.csv
 cp $(find $OUT -name '*kernel_stats.csv' | head -1) $ROOT/gpurun_out/${TAG}_step_kernel_stats.csv
 python3 $ROOT/tools/queue_busy.py $F 5 > $ROOT/gpurun_out/${TAG}_queue_busy.txt 2>&1 || true
+python3 $ROOT/tools/step_timeline.py $F 5 > $ROOT/gpurun_out/${TAG}_step_timeline.txt 2>&1 || true
 head -40 $ROOT/gpurun_out/${TAG}_step_kernels.csv
 # the raw trace is large: keep only the summaries
 rm -rf $OUT
