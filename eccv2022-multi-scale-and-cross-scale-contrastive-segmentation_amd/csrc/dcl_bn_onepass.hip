@@ -52,7 +52,9 @@ __global__ __launch_bounds__(OP_THREADS) void k_bn_bwd_onepass(OpArgs a)
     __shared__ float sh[8];
     __shared__ float bc[2];
     const int tid = threadIdx.x, ln = tid & 63;
-    for (int i = blockIdx.x * OP_THREADS + tid; i < a.C * a.T; i += gridDim.x * OP_THREADS)
+    // the WHOLE region: the launch that dirtied it may have had more channels x members than this one (a Bottleneck
+    // alternates 64 and 256 channels; clearing only C * T of the current shape left stale "published" slots behind)
+    for (int i = blockIdx.x * OP_THREADS + tid; i < 4096 * OP_TMAX; i += gridDim.x * OP_THREADS)
         a.slots_clear[i] = ~0ull;
     const int xcd = blockIdx.x & 7, mi = blockIdx.x >> 3;          // 32 workgroups per XCD
     const int T = a.T, tpx = OP_TMAX / T;

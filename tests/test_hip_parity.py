@@ -1123,6 +1123,7 @@ def test_fused_bn_one_kernel_backward_matches_fp64_and_two_kernel_form(dev, shap
     N, C, H, W = shape
     assert _lib.lib().dcl_bn_bwd_onepass_supported(N, C, H * W, 2)
     assert torch.cuda.current_stream() == torch.cuda.default_stream()
+    prev_onepass = fb.ONEPASS
     for (res, relu) in ((False, False), (False, True), (True, True)):
         outs = {}
         for mode in ("one", "one_again", "two"):
@@ -1140,7 +1141,7 @@ def test_fused_bn_one_kernel_backward_matches_fp64_and_two_kernel_form(dev, shap
                 y.backward(gy)
                 outs[mode] = [x.grad, bn.weight.grad, bn.bias.grad] + ([r.grad] if res else [])
             finally:
-                fb.ONEPASS = True
+                fb.ONEPASS = prev_onepass
         # float64 reference
         x64 = x.detach().double().requires_grad_(True)
         r64 = r.detach().double().requires_grad_(True) if res else None
@@ -1161,6 +1162,35 @@ def test_fused_bn_one_kernel_backward_matches_fp64_and_two_kernel_form(dev, shap
             assert e1 < 2e-5 and e1 <= 3 * e2 + 1e-6, (shape, res, relu, k, e1, e2)
         for a, b in zip(outs["one"], outs["one_again"]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_fused_bn_one_kernel_backward_alternating_shapes(dev):
+    """Successive one-kernel launches share a ring of four slot regions; a launch clears the region two launches ahead.
+    Layers of different size alternate in a model (a Bottleneck: 64 and 256 channels) -- a region dirtied by the large
+    shape must be clean again when the next large launch reuses it (a clear limited to the CURRENT shape's slots left
+    stale 'published' sums behind: wrong gradients every few launches)."""
+    import mscs_amd.models.fused_bn as fb
+    prev = fb.ONEPASS
+    shapes = [(2, 256, 32, 64), (2, 16, 32, 32), (1, 64, 64, 128), (3, 128, 32, 32)]
+    try:
+        g = torch.Generator(device=dev).manual_seed(21)
+        data = [(torch.randn(sh, device=dev, generator=g), torch.randn(sh, device=dev, generator=g)) for sh in shapes]
+        outs = {}
+        for mode in (True, False):
+            fb.ONEPASS = mode
+            res = []
+            for rep in range(5):
+                for (x0, gy), sh in zip(data, shapes):
+                    bn = fb.FusedBatchNorm2d(sh[1]).to(dev).train()
+                    x = x0.clone().requires_grad_(True)
+                    bn(x, relu=True).backward(gy)
+                    res.append(x.grad)
+            outs[mode] = res
+        for a, b in zip(outs[True], outs[False]):
+            assert ((a - b).abs().max() / b.abs().max()).item() < 2e-5
+    finally:
+        fb.ONEPASS = prev
 
 
 @pytest.mark.gpu
