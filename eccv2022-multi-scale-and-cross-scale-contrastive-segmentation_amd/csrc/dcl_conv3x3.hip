@@ -935,6 +935,13 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
 }
 
 static int g_up2_phases = 1;    // in_up = 2: 1 = one output parity class per workgroup, 0 = zero-inserted input
+static int g_conv_min_wgs = 192;        // automatic tile: fewest workgroups a launch may have before the rows per wave are halved
+
+extern "C" int dcl_conv3x3_set_min_workgroups(int n)
+{
+    g_conv_min_wgs = n > 0 ? n : 192;
+    return 0;
+}
 
 extern "C" int dcl_conv3x3_set_up2_phases(int on)
 {
@@ -1028,7 +1035,7 @@ static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *
             return (long)((a.Wo + TW - 1) / TW) * ((a.Ho + 4 * p - 1) / (4 * p)) * N * ((mtiles + r - 1) / r);
         };
         P = stride == 2 ? 1 : 4;
-        while (P > 1 && wgs(R, P) < 192)
+        while (P > 1 && wgs(R, P) < g_conv_min_wgs)
             P >>= 1;
         if (R == 2 && P == 4 && stride == 1 && !a.phases && a.nchunk <= 4)
             P = 2;              // the (2, 2) tile runs two workgroups per CU (k_conv3x3_o2): 81 vs 100 us at 48 channels;

@@ -54,6 +54,7 @@ class DebugConfig:
     up2_phases: Optional[int] = field(default_factory=lambda: _int('DCL_UP2_PHASES'))
     tapup_bwd_form: Optional[int] = field(default_factory=lambda: _int('DCL_TAPUP_BWD'))         # 1 = first form of the tap-up backward
     conv_interleave: Optional[int] = field(default_factory=lambda: _int('DCL_CONV_IL'))
+    conv_min_workgroups: Optional[int] = field(default_factory=lambda: _int('DCL_CONV_MIN_WGS'))
     upce_bwd_chunk: Optional[int] = field(default_factory=lambda: _int('DCL_UPCE_BWD_CHUNK'))
     upce_fwd_kib: Optional[int] = field(default_factory=lambda: _int('DCL_UPCE_FWD_KIB'))
     wgrad_tile: Optional[Tuple[int, int]] = field(default_factory=lambda: (
@@ -66,6 +67,7 @@ class DebugConfig:
                         (self.up2_phases, l.dcl_conv3x3_set_up2_phases),
                         (self.tapup_bwd_form, l.dcl_tapup_set_bwd_form),
                         (self.conv_interleave, l.dcl_conv3x3_set_interleave),
+                        (self.conv_min_workgroups, l.dcl_conv3x3_set_min_workgroups),
                         (self.gemm_gemm_tile, l.dcl_gemm_set_tile),
                         (self.upce_bwd_chunk, l.dcl_upsample_ce_set_bwd_chunk),
                         (self.upce_fwd_kib, l.dcl_upsample_ce_set_fwd_lds)):
