@@ -202,12 +202,19 @@ def roofline_conv_kernels(args, dev, iters=20):
     peak = MFMA_F16_PEAK_TFLOPS / 3.0
     note = "every algorithmic FLOP is issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): 2.5 PFLOP/s / 3"
 
-    def entry(kernel, flops, ms, abytes):
-        return {"bound": "mfma", "kernel": kernel, "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_note": note, "traffic": None,
-                "traffic_source": "not collected for this kernel / shape (profiles/r03_conv_pmc_*.csv hold the per-kernel "
-                                  "FETCH_SIZE / WRITE_SIZE of tools/per_shape_roofline.py)",
-                "algorithmic_bytes": abytes, "launch_ms": round(ms, 4)}
+    def entry(kernel, flops, ms, abytes, pmc=None):
+        # pmc = (FETCH_SIZE, WRITE_SIZE) KiB per launch of a committed rocprofv3 --pmc pass on exactly this kernel and shape
+        e = {"bound": "mfma", "kernel": kernel, "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
+             "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4), "peak_note": note, "traffic": None,
+             "traffic_source": "not collected for this kernel / shape (profiles/r03_conv_pmc_*.csv hold the per-kernel "
+                               "FETCH_SIZE / WRITE_SIZE of tools/per_shape_roofline.py)",
+             "algorithmic_bytes": abytes, "launch_ms": round(ms, 4)}
+        if pmc:
+            e["traffic"] = (2 * pmc[0] + pmc[1]) * 1024
+            e["traffic_source"] = ("constant from profiles/r03_head_wgrad_pmc.csv (separate rocprofv3 --pmc passes of "
+                                   "tools/probes/head_wgrad_pmc.sh, not read live; 2 x FETCH_SIZE + WRITE_SIZE = bytes that "
+                                   "crossed L2 <-> fabric, Infinity-Cache hits included)")
+        return e
 
     def conv_and_wgrad(ci, co, it):
         x = torch.randn(n, ci, h, w, device=dev, generator=gen).relu_()
@@ -225,8 +232,9 @@ def roofline_conv_kernels(args, dev, iters=20):
     flops, ms_f, ms_w, ab = conv_and_wgrad(144, 720, 8)
     main = entry(f"k_wgrad3x3d<3,1,wave-level splits> + k_wgrad_reduce (dcl_wgrad3x3_f16x3): 3x3 weight gradient, "
                  f"{n}x(144->720)x{h}x{w} (the head convolution's full-resolution part; 135 tile pairs x 7 pixel splits on "
-                 "1024 waves)", flops, ms_w, ab)
-    others = [entry(f"k_conv3x3_il<3,4> (dcl_conv3x3_f16x3): 3x3 conv forward, {n}x(144->720)x{h}x{w}", flops, ms_f, ab)]
+                 "1024 waves)", flops, ms_w, ab, PMC_HEAD_WGRAD if (n, h, w) == (12, 128, 256) else None)
+    others = [entry(f"k_conv3x3_il<3,4> (dcl_conv3x3_f16x3): 3x3 conv forward, {n}x(144->720)x{h}x{w}", flops, ms_f, ab,
+                    PMC_HEAD_FWD if (n, h, w) == (12, 128, 256) else None)]
     torch.cuda.empty_cache()
     flops, ms_f, ms_w, ab = conv_and_wgrad(48, 48, iters)
     others.append(entry(f"k_conv3x3_il_ws2<1,4> (dcl_conv3x3_f16x3): 3x3 conv forward / data gradient, {n}x48x{h}x{w}",
@@ -334,6 +342,8 @@ def roofline_bwd_kernel(mod, iters=10):
             "nsplit": ns if G == 0 else None, "streamk_workgroups": G}
 
 
+PMC_HEAD_WGRAD = (3514955.5 + 19856.5, 26330.0 + 3645.0)   # k_wgrad3x3d<3,1,true> + its slab reduction, 12 x (144 -> 720) x 128 x 256
+PMC_HEAD_FWD = (516063.4, 1228800.0)                        # k_conv3x3_il<3,4> on the same layer (profiles/r03_head_wgrad_pmc.csv)
 PMC_F16X3 = (104540.5, 128128.0)      # KiB per launch (FETCH_SIZE, WRITE_SIZE), profiles/r02_loss_pmc_*.csv
 PMC_F16X3_SK = (283395.9, 42511.9)    # stream-K kernel, KiB per launch: profiles/r03_loss_pmc_fetch.csv / _write.csv
 PMC_SOURCE = "profiles/r02_loss_pmc_fetch.csv, r02_loss_pmc_write.csv"
