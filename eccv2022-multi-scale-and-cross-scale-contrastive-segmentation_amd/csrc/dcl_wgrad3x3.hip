@@ -500,6 +500,7 @@ void dcl_wgrad_s2_launch(const float *x, const float *dy, int N, int Cin, int Co
                          hipStream_t s, int *nslab);
 static int g_s2_native = 1;     // stride 2: 1 = output-pixel formulation (dcl_wgrad3x3_s2.hip), 0 = zero-inserted dy
 
+static int g_strip_group = 1;   // waves of a workgroup on adjacent strips (WgradArgs::grp)
 static int g_wave_mode = 2;     // 129 .. 256 tile pairs of the (3, 1) tile: pixel splits dealt out to waves (dcl_wgrad3x3d.hip);
                                 // 2 = a workgroup's waves take the same split of four neighbouring pairs, 1 = four splits of a pair
 
@@ -573,6 +574,12 @@ extern "C" int dcl_wgrad3x3_set_wave_mode(int on)
     return 0;
 }
 
+extern "C" int dcl_wgrad3x3_set_strip_group(int on)
+{
+    g_strip_group = on ? 1 : 0;
+    return 0;
+}
+
 extern "C" int dcl_wgrad3x3_set_stride2(int native)
 {
     g_s2_native = native ? 1 : 0;
@@ -636,6 +643,10 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     wgrad_plan(N, Cin, Cout, H, W, nco, nci, a.S, a.units,
                stride == 1 && use_dma(Cin > Cout ? Cin : Cout, H, W) ? &wm : nullptr);
     a.wave_mode = wm ? g_wave_mode : 0;
+    // adjacent strips for the waves of a workgroup (dcl_wgrad3x3d.hip): LDS-reduced tiles, unclamped split count, strips in fours / pairs
+    a.grp = 1;
+    if (g_strip_group && !wm && nco * nci <= 4 && a.S == 4 * ((a.S + 3) / 4) && a.S >= 4)
+        a.grp = (a.strips % 4 == 0) ? 4 : ((a.strips % 2 == 0) ? 2 : 1);
     a.ncig = (Cin / 16 + nci - 1) / nci;
     a.npairs = (Cout / 16 / nco) * a.ncig;
     a.nx = (a.S + 3) / 4;                                    // workgroups per pair (4 splits each)

@@ -220,9 +220,16 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
             for (int k = 0; k < 9; ++k)
                 acc[t][u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const long long T = (long long)a.units * a.H;
-    long long t = min(T, T * split / a.S);
-    const long long t1 = min(T, T * (split + 1) / a.S);
+    // Which rows: split `split` of S over the columns (image, strip) x H rows -- or, a.grp = G > 1 (workgroup form only), the G
+    // waves w % G of a workgroup take G ADJACENT strips over the SAME rows (sub-range w / G of the workgroup's share of the
+    // "super-columns" (image, G strips)).  An x row piece with its halo touches three 128-byte lines, two of them the neighbouring
+    // strips' own: with the neighbours in the same CU at the same time they are L1 / L2 hits instead of a second and third fetch
+    // through the fabric (FETCH_SIZE of the 64 -> 64 launch was 2.05x the tensors: 1 + 3 lines per dY + x row against 1 + 1).
+    const int G = WAVE ? 1 : a.grp;
+    const long long T = (long long)(a.units / G) * a.H;
+    const int q = G > 1 ? xsplit * (4 / G) + wave / G : split, Sq = G > 1 ? a.nx * (4 / G) : a.S;
+    long long t = min(T, T * q / Sq);
+    const long long t1 = min(T, T * (q + 1) / Sq);
     if (t >= t1)
         scales();
     while (t < t1) {
@@ -230,8 +237,9 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
         const int r0 = (int)(t - (long long)col * a.H);
         const int r1 = (int)min((long long)a.H, r0 + (t1 - t));
         t += r1 - r0;
-        const int strip = col % a.strips;
-        const int n = col / a.strips;
+        const int sgs = a.strips / G;
+        const int strip = (col % sgs) * G + (G > 1 ? wave % G : 0);
+        const int n = col / sgs;
         const int px0 = strip * 32, px = px0 + 8 * q4;
         const bool oct_ok = px < a.W;
         float sx_c, sx_l, sx_r;                                 // set once the scales are known (below)

@@ -403,6 +403,10 @@ int dcl_wgrad3x3_set_splits(int nx);
  * pair, each XCD owning a contiguous run of pairs (2: a workgroup's four waves take one split of four pairs, 1: four splits of
  * one pair); 0 = one workgroup per pair.  Changes dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_wave_mode(int on);
+/* tuning hook (stride 1, LDS-DMA kernel, workgroup form): 1 (default) = the four waves of a workgroup walk four (two) ADJACENT
+ * 32-pixel strips over the same rows, so that the halo lines of an x row are its neighbours' own lines in the same CU's L1 / L2;
+ * 0 = four row ranges of one strip. */
+int dcl_wgrad3x3_set_strip_group(int on);
 int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W /* of x */,
                        const float *xamax, int xcount, const float *gamax, int gcount,
                        int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,

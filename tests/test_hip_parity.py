@@ -1501,6 +1501,31 @@ def test_weight_gradient_wave_level_splits_match_fp64_and_workgroup_form(dev):
 
 
 @pytest.mark.gpu
+def test_weight_gradient_adjacent_strip_grouping_matches_fp64(dev):
+    """The four waves of a workgroup walk four (W % 128 == 0), two (W % 64 == 0) adjacent 32-pixel strips over the same rows, or
+    four row ranges of one strip (dcl_wgrad3x3_set_strip_group): every form against float64 (3e-6 of max), bitwise
+    reproducible, ragged last strips and fewer rows than splits included."""
+    from mscs_amd import _lib
+    from mscs_amd.models import ops
+    L = _lib.lib()
+    torch.manual_seed(17)
+    try:
+        for (n, ci, co, h, w) in [(2, 48, 48, 24, 256), (3, 64, 64, 7, 128), (2, 96, 96, 9, 64), (1, 48, 96, 5, 192),
+                                  (2, 32, 32, 3, 96), (1, 64, 48, 2, 120), (12, 48, 48, 2, 128)]:
+            x = torch.randn(n, ci, h, w, device=dev).relu_() * 2.0
+            gy = torch.randn(n, co, h, w, device=dev) * 1e-4
+            ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), torch.zeros(co, ci, 3, 3, device=dev).double(),
+                                                     None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            for on in (1, 0):
+                L.dcl_wgrad3x3_set_strip_group(on)
+                gw = ops.conv3x3_wgrad(x, gy)
+                assert ((gw.double() - ref).abs().max() / ref.abs().max()).item() < 3e-6, (on, n, ci, co, h, w)
+                assert torch.equal(gw, ops.conv3x3_wgrad(x, gy))
+    finally:
+        L.dcl_wgrad3x3_set_strip_group(1)
+
+
+@pytest.mark.gpu
 def test_stride2_gradient_formulations_agree(dev):
     """Stride-2 data gradient by output parity classes (default) against the stride-1 tile over the zero-inserted gradient
     (dcl_conv3x3_set_up2_phases(0)), and the weight gradient over the output pixels against the zero-inserted dY operand
