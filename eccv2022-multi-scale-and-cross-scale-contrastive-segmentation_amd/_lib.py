@@ -86,6 +86,7 @@ SIGNATURES = {
     "dcl_wgrad3x3_set_splits": [_i],
     "dcl_wgrad3x3_set_wave_mode": [_i],
     "dcl_wgrad3x3_set_strip_group": [_i],
+    "dcl_wgrad3x3_set_wave_band": [_i],
     "dcl_conv3x3_set_up2_phases": [_i],
     "dcl_conv3x3_set_min_workgroups": [_i],
     "dcl_conv3x3_set_interleave": [_i],

@@ -12,6 +12,7 @@ struct WgradArgs {
     int strips, nseg, units, S, ncig, npairs, nx;
     int rect_c, rect_i, rect_mode;  // many pairs: pair-grid rectangle that shares an XCD (rect_c * rect_i = 32)
     int wave_mode;               // 1: S pixel splits per pair dealt out to WAVES (k_wgrad3x3d<.., true>), one slab per split
+    int band;                    // rows per column of the traversal (H, or a divisor of H: wave form, see k_wgrad3x3d)
     int grp;                     // 1 | 2 | 4: the waves of a workgroup walk `grp` ADJACENT strips over the same rows (k_wgrad3x3d)
 };
 

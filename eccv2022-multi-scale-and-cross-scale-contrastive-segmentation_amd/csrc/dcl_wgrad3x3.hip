@@ -500,6 +500,8 @@ void dcl_wgrad_s2_launch(const float *x, const float *dy, int N, int Cin, int Co
                          hipStream_t s, int *nslab);
 static int g_s2_native = 1;     // stride 2: 1 = output-pixel formulation (dcl_wgrad3x3_s2.hip), 0 = zero-inserted dy
 
+static int g_wave_band = 0;     // wave form: rows per column of the traversal (0 = whole strips: the default -- 32-row bands
+                                // re-use the halo lines in L2 but pay a column prologue every 32 rows: 2.01 vs 1.91 ms on the head)
 static int g_strip_group = 1;   // waves of a workgroup on adjacent strips (WgradArgs::grp)
 static int g_wave_mode = 2;     // 129 .. 256 tile pairs of the (3, 1) tile: pixel splits dealt out to waves (dcl_wgrad3x3d.hip);
                                 // 2 = a workgroup's waves take the same split of four neighbouring pairs, 1 = four splits of a pair
@@ -574,6 +576,12 @@ extern "C" int dcl_wgrad3x3_set_wave_mode(int on)
     return 0;
 }
 
+extern "C" int dcl_wgrad3x3_set_wave_band(int rows)
+{
+    g_wave_band = rows > 0 ? rows : 0;
+    return 0;
+}
+
 extern "C" int dcl_wgrad3x3_set_strip_group(int on)
 {
     g_strip_group = on ? 1 : 0;
@@ -645,6 +653,7 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     a.wave_mode = wm ? g_wave_mode : 0;
     // adjacent strips for the waves of a workgroup (dcl_wgrad3x3d.hip): LDS-reduced tiles, unclamped split count, strips in fours / pairs
     a.grp = 1;
+    a.band = (wm && g_wave_band > 0 && H % g_wave_band == 0 && H > g_wave_band) ? g_wave_band : H;
     if (g_strip_group && !wm && nco * nci <= 4 && a.S == 4 * ((a.S + 3) / 4) && a.S >= 4)
         a.grp = (a.strips % 4 == 0) ? 4 : ((a.strips % 2 == 0) ? 2 : 1);
     a.ncig = (Cin / 16 + nci - 1) / nci;

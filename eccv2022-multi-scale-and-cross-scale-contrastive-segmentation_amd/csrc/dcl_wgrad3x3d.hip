@@ -232,14 +232,20 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
     const long long t1 = min(T, T * (q + 1) / Sq);
     if (t >= t1)
         scales();
+    // a.band < H (wave form): a column is `band` rows of a strip and the strips of an image follow each other band by band, so
+    // that the halo lines of an x row -- the neighbouring strips' own lines -- are touched again `band` row steps later, while
+    // the XCD's L2 still has them, not H row steps later
+    const int RB = a.band, nb = a.H / RB;
     while (t < t1) {
-        const int col = (int)(t / a.H);
-        const int r0 = (int)(t - (long long)col * a.H);
-        const int r1 = (int)min((long long)a.H, r0 + (t1 - t));
-        t += r1 - r0;
+        const int colb = (int)(t / RB);                         // (image, band, strip) or, one band, (image, strip)
+        const int rr0 = (int)(t - (long long)colb * RB);
+        const int len = (int)min((long long)(RB - rr0), t1 - t);
+        t += len;
         const int sgs = a.strips / G;
-        const int strip = (col % sgs) * G + (G > 1 ? wave % G : 0);
-        const int n = col / sgs;
+        const int strip = (colb % sgs) * G + (G > 1 ? wave % G : 0);
+        const int band = (colb / sgs) % nb;
+        const int n = colb / (sgs * nb);
+        const int r0 = band * RB + rr0, r1 = r0 + len;
         const int px0 = strip * 32, px = px0 + 8 * q4;
         const bool oct_ok = px < a.W;
         float sx_c, sx_l, sx_r;                                 // set once the scales are known (below)

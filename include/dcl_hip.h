@@ -407,6 +407,10 @@ int dcl_wgrad3x3_set_wave_mode(int on);
  * 32-pixel strips over the same rows, so that the halo lines of an x row are its neighbours' own lines in the same CU's L1 / L2;
  * 0 = four row ranges of one strip. */
 int dcl_wgrad3x3_set_strip_group(int on);
+/* tuning hook (wave form): rows per column of the traversal (a divisor of H; default 0 = whole strips): with bands the strips of
+ * an image follow each other band by band, so that the halo lines of an x row are still in L2 when the neighbouring strip comes
+ * (measured: no gain, a column prologue every `rows` rows costs more). */
+int dcl_wgrad3x3_set_wave_band(int rows);
 int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W /* of x */,
                        const float *xamax, int xcount, const float *gamax, int gcount,
                        int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,
