@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--materialize-logits", action="store_true",
                     help="HRNet returns the up-sampled logits like the reference instead of the lazy 1/4-resolution form "
                          "(graph key lazy_logits) that the fused up-sampling + cross-entropy kernels consume")
+    ap.add_argument("--materialize-projector", action="store_true",
+                    help="the projection heads return their full [n, d, h, w] maps like the reference instead of the lazy form "
+                         "(graph key lazy_projector) whose last 1x1 convolution the loss evaluates on the sampled pixels only")
     ap.add_argument("--no-metrics", action="store_true",
                     help="leave the per-step metrics tail (confusion matrix, accuracies, mIoU, logging) out of the step")
     a = ap.parse_args()
@@ -437,7 +440,7 @@ def step_config_upernet(args, world):
         "parallel": world > 1, "batch_is_global": False,
         "graph": {"model": "UPerNet", "backbone": "swinL" if args.config == 5 else "swinT", "sync_bn": True, "out_stride": 32, "pretrained": False,
                   "align_corners": False, "aux_head": {"in_index": 3, "dropout_rate": 0.1}, "dropout_rate": 0.1,
-                  "lazy_logits": not args.materialize_logits,
+                  "lazy_logits": not args.materialize_logits, "lazy_projector": not args.materialize_projector,
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "position": "fpn"}},
         "data": {"dataset": "ADE20K", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
                  "synthetic": True, "synthetic_length": args.batch * 2,
@@ -463,6 +466,7 @@ def step_config(args, world):
         "parallel": world > 1, "batch_is_global": False, "channels_last": args.channels_last,
         "graph": {"model": "HRNet", "backbone": "hrnet48", "sync_bn": True, "out_stride": 4, "pretrained": False,
                   "align_corners": True, "branch_conv": args.branch_conv, "lazy_logits": not args.materialize_logits,
+             "lazy_projector": not args.materialize_projector,
                   "conv1x1": getattr(args, "conv1x1", "f16x3"),
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "before_context": True}},
         "data": {"dataset": "CITYSCAPES", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
@@ -535,6 +539,9 @@ def time_train_step(args, dev, rank, world):
              # at 1/4 resolution and up-sampling + cross-entropy / arg-max run in fused kernels.  --materialize-logits
              # gives the reference's return value (a full-resolution logits tensor); worth ~0.8 ms of the step
              "lazy_logits": not args.materialize_logits,
+             # second graph key of this repo (default off in the models): the projection heads' last 1x1 convolution is
+             # evaluated on the pixels the contrastive loss samples instead of as a full map (models/Projector.LazyProjection)
+             "lazy_projector": not args.materialize_projector,
              "model_dtype": "bf16-autocast" if args.amp else "f32",
              "memory_format": "channels_last" if args.channels_last else "contiguous",
              "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}

@@ -61,6 +61,7 @@ class _Scale:
     slot_pair: torch.Tensor = None
     sel: torch.Tensor = None
     pix: torch.Tensor = None             # int32 [T, V]
+    rows: bool = False                   # features arrive as [T * V, C] rows (models.Projector.LazyProjection.rows)
     bank: torch.Tensor = None            # f32 [Npad, 256]
     bank_h: torch.Tensor = None          # f16 [Npad, 512] = (hi | lo) halves of bank * 2^10 (f16x3 mode)
     nrm: torch.Tensor = None             # f32 [Npad]
@@ -393,13 +394,36 @@ def presample(cfg: EngineConfig, label: torch.Tensor, geoms, with_cross: bool, s
     return PreSampled(st, key, list(geoms), _cfg_key(cfg, with_cross), side_stream, ev)
 
 
+_ROW_INDEX = {}
+
+
+def _row_index(n: int, dev) -> torch.Tensor:
+    """int32 [>= n] 0, 1, 2, ...: the 'pixel' table of a feature tensor that already holds one row per bank slot."""
+    key = str(dev)
+    t = _ROW_INDEX.get(key)
+    if t is None or t.numel() < n:
+        t = _ROW_INDEX[key] = torch.arange(max(n, 1 << 16), dtype=torch.int32, device=dev)
+    return t
+
+
+def _kernel_pix(sc: _Scale) -> torch.Tensor:
+    return _row_index(sc.plan.T * sc.plan.V, sc.pix.device) if sc.rows else sc.pix
+
+
 def _bind_features(st: StepState, feats: Sequence[torch.Tensor]):
+    from ..models.Projector import LazyProjection
     for s, (sc, f) in enumerate(zip(st.scales, feats)):
         if f.dtype != torch.float32:
             raise RuntimeError(f"features[{s}] must be float32, got {f.dtype}")
         C = f.shape[1]
         if C > _lib.CP:
             raise RuntimeError(f"embedding width {C} > {_lib.CP} is not supported by the sweep kernels")
+        if isinstance(f, LazyProjection):
+            # one row per (pair, view) slot, row t * V + v: the kernels address it as a one-image map of T * V 'pixels'
+            # with pixel stride C (NHWC) through the identity pixel table
+            sc.C, sc.strides, sc.rows = C, (0, 1, C), True
+            continue
+        sc.rows = False
         strides = _feature_strides(f)
         if strides is None:
             raise RuntimeError(f"features[{s}] has a non-collapsible (h, w) layout; call .contiguous()")
@@ -458,7 +482,7 @@ def build_banks(st: StepState, feats: Sequence[torch.Tensor], f16x3: bool = Fals
         sc.nrm = torch.empty((Npad,), dtype=torch.float32, device=f.device)
         sc.bank_h = torch.empty((Npad, 2 * _lib.CP), dtype=torch.float16, device=f.device) if f16x3 else None
         sn, scs, sp = sc.strides
-        _lib.check(L.dcl_gather_normalize(_lib.ptr(f), sn, scs, sp, sc.C, _lib.ptr(sc.pix),
+        _lib.check(L.dcl_gather_normalize(_lib.ptr(f), sn, scs, sp, sc.C, _lib.ptr(_kernel_pix(sc)),
                                           _lib.ptr(sc.pair_b), _lib.ptr(sc.slot_pair), p.T, p.V,
                                           _lib.ptr(sc.bank), _lib.ptr(sc.nrm), _lib.ptr(sc.bank_h), stream),
                    "dcl_gather_normalize")
@@ -684,7 +708,9 @@ class DenseContrastFunction(torch.autograd.Function):
             rank, pb, pbh, lay = gather.finish()                   # waited for just before the first sweep
             attach_global_segments(st, rank, pb, lay, peer_banks_h=pbh)
         else:
-            st = plan_and_sample(cfg, label, feats, with_cross, staged=holder.get("staged"))
+            st = holder.get("st")               # planned ahead: the features are LazyProjection rows of this plan
+            if st is None:
+                st = plan_and_sample(cfg, label, feats, with_cross, staged=holder.get("staged"))
             build_banks(st, feats, f16x3=f16x3)
             if peers is not None:                   # single-process emulation of other ranks (tests)
                 rank, peer_banks, peer_layouts = peers[:3]
@@ -809,7 +835,7 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
             p = sc.plan
             am = _amax.zeros(_amax.SLOTS, dev)
             _lib.check(L.dcl_normalize_bwd_scatter(arr, len(slabs[s]), _lib.ptr(sc.bank),
-                                                   _lib.ptr(sc.nrm), _lib.ptr(sc.pix),
+                                                   _lib.ptr(sc.nrm), _lib.ptr(_kernel_pix(sc)),
                                                    _lib.ptr(sc.pair_b), _lib.ptr(sc.slot_pair), p.T,
                                                    p.V, sc.C, _lib.ptr(dfeat), sn, scs, sp, _lib.ptr(am), stream),
                        "dcl_normalize_bwd_scatter")
@@ -823,7 +849,19 @@ def dense_contrast_terms(cfg: EngineConfig, label: torch.Tensor, feats: Sequence
     """Returns (term_losses f32 [n_terms] with grad, StepState).  Term order: intra scale 0..S-1,
     then cross (0, S-1), then cross (0, S-2) if S > 2.  ``staged``: result of an earlier
     ``stage_labels`` call on the same label tensor (ignored if stale)."""
+    from ..models.Projector import LazyProjection
     holder = {"staged": staged, "emulated_peers": emulated_peers}
     feats = [f if f.dtype == torch.float32 else f.float() for f in feats]
+    if any(isinstance(f, LazyProjection) for f in feats):
+        if emulated_peers is not None or (cfg.global_negatives and _dist_world() > 1):
+            # the shared negative bank plans behind an all-rank agreement inside the autograd node: take the maps
+            feats = [f.materialize() if isinstance(f, LazyProjection) else f for f in feats]
+        else:
+            # plan first (the sampled pixels depend on the labels only), then evaluate the heads' last layer on exactly
+            # the sampled pixels; the autograd node receives [T * V, C] rows instead of [n, C, h, w] maps
+            with_cross = bool(cfg.cross_scale_contrast) and len(feats) > 1
+            st = plan_and_sample(cfg, label, feats, with_cross, staged=staged)
+            feats = [f.rows(sc.pair_b, sc.pix) if isinstance(f, LazyProjection) else f for f, sc in zip(feats, st.scales)]
+            holder["st"] = st
     out = DenseContrastFunction.apply(cfg, label, holder, *feats)
     return out, holder["state"]

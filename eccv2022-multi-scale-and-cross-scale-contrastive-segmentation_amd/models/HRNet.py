@@ -621,6 +621,9 @@ class HRNet(nn.Module):
         # 1x1 convolutions (bottlenecks, fuse layers, projector, classifier): 'f16x3' (default) = the same direct
         # split-f16 kernels in their one-tap mode, all three directions; 'gemm' = plain batched fp32 library GEMMs (the
         # library's own weight gradient for a 1x1 convolution wraps an NHWC kernel in layout transposes); 'library'
+        if self.projector_model is not None:
+            # extension, default off: the heads' last 1x1 convolution is evaluated by the loss on the sampled pixels only
+            self.projector_model.lazy = bool(config.get('lazy_projector', False))
         if config.get('fused_bn', True) and self.projector_model is not None:
             # the projector's norms as well (class switch: same parameters / buffers / state_dict keys); their outputs
             # and gradients then carry the absmax tags the projector's f16x3 1x1 convolutions need

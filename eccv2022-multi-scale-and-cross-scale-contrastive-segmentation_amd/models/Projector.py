@@ -11,7 +11,48 @@ from torch import nn
 from ..utils import printlog
 
 
+class LazyProjection:
+    """Extension (off = the reference's return value, graph key ``lazy_projector``): the projection head WITHOUT its last
+    1x1 convolution applied.  The dense contrastive loss reads the d-dimensional embedding at the few thousand pixels it
+    samples per scale (reference losses/DenseContrastiveLossV2.py:123) and nowhere else, and a 1x1 convolution acts pixel
+    by pixel: ``rows()`` evaluates it on exactly those pixels -- a [rows, c] x [c, d] product instead of the [n, d, h, w]
+    map (403 MB at scale 0 of the benchmark, written once, zero-filled once and read twice per step).  Same values up to
+    fp32 round-off; everything that wants the map (other losses, evaluation, user code) calls ``materialize()``.
+    Quacks like the map for shape checks: ``shape``, ``dim()``, ``dtype``, ``device``."""
+
+    def __init__(self, hidden: torch.Tensor, conv: nn.Conv2d):
+        assert conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1
+        self.hidden, self.conv = hidden, conv
+        n, _, h, w = hidden.shape
+        self.shape = torch.Size((n, conv.out_channels, h, w))
+        self.dtype, self.device, self.is_cuda = hidden.dtype, hidden.device, hidden.is_cuda
+
+    def dim(self):
+        return 4
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def float(self):
+        return self
+
+    def materialize(self) -> torch.Tensor:
+        return self.conv(self.hidden)
+
+    def rows(self, pair_b: torch.Tensor, pix: torch.Tensor) -> torch.Tensor:
+        """Embeddings [T * V, d] of pixel ``pix[t, v]`` (offset in the h x w plane) of image ``pair_b[t]``, row t * V + v;
+        differentiable with respect to the hidden map and the convolution's parameters."""
+        n, c, h, w = self.hidden.shape
+        T, V = pix.shape
+        b = pair_b.long().view(T, 1).expand(T, V).reshape(-1)
+        hs = self.hidden.reshape(n, c, h * w)[b, :, pix.long().reshape(-1)]
+        wt = self.conv.weight.view(self.conv.out_channels, c)
+        return torch.addmm(self.conv.bias, hs, wt.t()) if self.conv.bias is not None else hs @ wt.t()
+
+
 class Projector(nn.Module):
+    lazy = False         # set by the model from its graph key ``lazy_projector``: training forward returns LazyProjection(s)
+
     def __init__(self, config):
         super().__init__()
         self.d = config['d'] if 'd' in config else 128
@@ -52,13 +93,18 @@ class Projector(nn.Module):
         printlog(f'Projector head {c_in} -> {self.d} ({len(self.mlp)} hidden layer(s), bn={self.use_bn})')
         return nn.Sequential(*layers)
 
+    def _run_head(self, head: nn.Sequential, x: torch.Tensor):
+        if self.lazy and self.training and x.is_cuda and x.dtype == torch.float32:
+            return LazyProjection(head[:-1](x), head[-1])
+        return head(x)
+
     def forward(self, x: Union[list, torch.Tensor]):
         if self.is_ms:
             assert isinstance(x, (list, tuple)), \
                 f'if multiscale projector is used a list is expected as input instead got {type(x)}'
-            return [getattr(self, f'project{i}')(x_i) for i, x_i in enumerate(x)]
+            return [self._run_head(getattr(self, f"project{i}"), x_i) for i, x_i in enumerate(x)]
         if isinstance(x, list):
             if len(x) != 1:
                 raise ValueError(f'x is {type(x)}, of length {len(x)}')
             x = x[0]
-        return self.project(x)
+        return self._run_head(self.project, x)

@@ -162,6 +162,8 @@ class UPerNet(nn.Module):
         self.fpn = FPN(config=self.config, experiment=experiment)
         self._get_aux_head()
         self._get_projector()
+        if self.projector_model is not None:
+            self.projector_model.lazy = bool(self.config.get('lazy_projector', False))     # see models/Projector.LazyProjection
         # the FPN's / aux head's 3x3 convolutions on the direct split-f16 kernels (models/ops.py, fp32-equivalent);
         # same parameters and state_dict.  config['direct_conv'] = False keeps them on the library.
         self._conv_packs = None

@@ -173,6 +173,52 @@ def test_vs_oracle_c256_three_scales(dev, oracle, channels_last):
             assert dfeats[s].grad.is_contiguous(memory_format=torch.channels_last)
 
 
+@pytest.mark.parametrize("prepared", [False, True])
+def test_lazy_projection_equals_materialised_projection(dev, prepared):
+    """models.Projector with ``lazy = True`` hands the loss LazyProjection objects: the heads' last 1x1 convolution is
+    evaluated on the sampled pixels only ([T * V, c] x [c, d] instead of the [n, d, h, w] map).  Same sampling plan (same RNG
+    draws), same loss and the same gradients of the projector's parameters and of the backbone features as the
+    materialised maps (3 scales + cross-scale, 256-d embedding), to fp32 round-off; with and without the plan made ahead by
+    prepare(); evaluation mode returns the maps."""
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    from mscs_amd.models.Projector import LazyProjection, Projector
+    label, xs = _random_case(21, 2, 128, 256, 20, 0, (4, 8, 16), classes=[0, 3, 5, 7, 11, 19])
+    chans = (48, 96, 192)
+    gen = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, c, 128 // s, 256 // s, generator=gen) for c, s in zip(chans, (4, 8, 16))]
+    cfg = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": 3,
+           "weights": [1.0, 0.7, 0.4], "cross_scale_contrast": True, "max_features_total": 3000}
+    torch.manual_seed(3)
+    proj = Projector({"mlp": [[1, -1, 1]], "d": 256, "use_bn": True, "c_in": list(chans)}).to(dev).train()
+    results = {}
+    for lazy in (False, True):
+        proj.lazy = lazy
+        proj.zero_grad(set_to_none=True)
+        mod = DenseContrastiveLossV2_ms(cfg)
+        ins = [x.to(dev).requires_grad_(True) for x in xs]
+        lbl = label.to(dev)
+        for rep in range(2 if prepared else 1):          # prepare() needs the geometry of one earlier forward
+            torch.manual_seed(77)
+            if prepared and rep == 1:
+                assert mod.prepare(lbl)
+            feats = proj(ins)
+            assert all(isinstance(f, LazyProjection) == lazy for f in feats)
+            loss = mod(lbl, feats)
+            if rep == (1 if prepared else 0):
+                loss.backward()
+        results[lazy] = (loss.item(), [i.grad.clone() for i in ins], [p.grad.clone() for p in proj.parameters()],
+                         [sc.pix.clone() for sc in mod.last_state.scales])
+    (l0, gi0, gp0, px0), (l1, gi1, gp1, px1) = results[False], results[True]
+    for a, b in zip(px0, px1):
+        assert torch.equal(a, b)
+    assert abs(l0 - l1) <= 2e-6 * abs(l0)
+    for a, b in zip(gi0 + gp0, gi1 + gp1):
+        assert ((a - b).abs().max() / a.abs().max().clamp_min(1e-30)).item() < 2e-5
+    proj.eval()
+    with torch.no_grad():
+        assert all(torch.is_tensor(f) for f in proj([x.to(dev) for x in xs]))
+
+
 def test_deterministic_bitwise(dev):
     from mscs_amd.losses import DenseContrastiveLossV2_ms
     label, feats = _random_case(9, 2, 128, 256, 20, 64, (4, 8))
