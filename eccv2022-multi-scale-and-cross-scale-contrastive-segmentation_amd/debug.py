@@ -37,6 +37,8 @@ class DebugConfig:
     # OFF by default: its teams of persistent workgroups wait for members that the branch streams' kernels keep off the CUs
     # (step 104.4 vs 95.5 ms), and alone it only ties the two-kernel form until its barrier is pipelined
     gemm_conv1x1: bool = field(default_factory=lambda: _flag('DCL_GEMM_CONV1X1'))               # wide 1x1 convolutions on dcl_gemm_f16x3
+    gemm_conv1x1_addend: bool = field(default_factory=lambda: _flag('DCL_GEMM_CONV1X1_ADDEND', False))  # ... with the residual
+    # gradient as C += -- OFF: 467 us per launch on layer 1's 256-channel gradients against 372 for the tile kernel's fused addend
     gemm_head_taps: bool = field(default_factory=lambda: _flag('DCL_GEMM_HEAD'))                # the head's tap products on it
     head_overlap: int = field(default_factory=lambda: 2 if _int('DCL_HEAD_OVERLAP') is None else _int('DCL_HEAD_OVERLAP'))  # coarse half of the head's
     # backward on a side stream: 0 off, 1 on, 2 on with the fine part's weight gradient first (A/B: 96.4 / 96.0 / 95.6 ms)

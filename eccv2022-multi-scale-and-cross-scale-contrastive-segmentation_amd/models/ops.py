@@ -262,17 +262,21 @@ def _conv1x1_by_gemm(rows, k, x, both_row_contiguous):
 
 
 GEMM_CONV1X1 = _dbg.gemm_conv1x1     # (DCL_GEMM_CONV1X1=0: the library / tile-kernel paths, for A/B runs)
+GEMM_CONV1X1_ADDEND = _dbg.gemm_conv1x1_addend   # residual gradient accumulated by the GEMM (DCL_GEMM_CONV1X1_ADDEND=0: tile kernel)
 
 
-def conv1x1_gemm(x, weight2, out, xamax, wamax, transposed=False):
-    """out[n] [rows, H W] = W x[n] (forward: rows = Co, W = weight2 [Co, Ci]) or W^T x[n] (``transposed``: the data gradient,
-    rows = Ci) as one batched split-f16 GEMM; x, out NCHW contiguous."""
+def conv1x1_gemm(x, weight2, out, xamax, wamax, transposed=False, accumulate=False):
+    """out[n] [rows, H W] (+)= W x[n] (forward: rows = Co, W = weight2 [Co, Ci]) or W^T x[n] (``transposed``: the data
+    gradient, rows = Ci) as one batched split-f16 GEMM; x, out NCHW contiguous.  ``accumulate``: added to what ``out`` holds
+    (the residual branch's gradient), in place -- an absmax tag of ``out`` does not describe the sum and is dropped."""
     n, k, h, w = x.shape
     hw = h * w
     co, ci = weight2.shape
     rows = ci if transposed else co
     gemm_f16x3(weight2, not transposed, ci, x, False, hw, rows, hw, k, out, hw, wamax, xamax, batch=n,
-               strides=(0, k * hw, rows * hw), splitk=1)
+               strides=(0, k * hw, rows * hw), splitk=1, accumulate=accumulate)
+    if accumulate and getattr(out, "_dcl_amax", None) is not None:
+        out._dcl_amax = None
     return out
 
 
@@ -429,8 +433,16 @@ class _Conv3x3Direct(torch.autograd.Function):
             addend = None
             if ctx.token is not None and ctx.token.dres is not None:
                 addend, ctx.token.dres = ctx.token.dres, None        # gradient of the residual branch, fused in
-            if ctx.k1 and addend is None and _conv1x1_by_gemm(weight.shape[1], weight.shape[0], gy, True):
-                conv1x1_gemm(gy, weight.view(weight.shape[0], -1), gx, amax_of(gy), wamax, transposed=True)
+            if ctx.k1 and _conv1x1_by_gemm(weight.shape[1], weight.shape[0], gy, True) and (
+                    addend is None or (GEMM_CONV1X1_ADDEND and addend.shape == x.shape and addend.is_contiguous()
+                                       and addend.dtype == torch.float32)):
+                # with a residual gradient (experiment, off by default): accumulated INTO it by the GEMM's epilogue (C += ...).
+                # Measured on the 256-channel gradients of layer 1's Bottlenecks: 467 us against 372 for the tile kernel's
+                # fused addend -- with K = 64 the launch is all epilogue, and the epilogue now also reads 403 MB
+                if addend is not None:
+                    gx = addend
+                conv1x1_gemm(gy, weight.view(weight.shape[0], -1), gx, amax_of(gy), wamax, transposed=True,
+                             accumulate=addend is not None)
             elif ctx.k1 and _conv1x1_by_library(x, gy) and addend is None:
                 n, ci, h, w = x.shape
                 torch.matmul(weight.view(-1, ci).t(), gy.view(n, -1, h * w), out=gx.view(n, ci, h * w))
