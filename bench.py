@@ -449,7 +449,8 @@ def step_config_upernet(args, world):
                      interm={"name": "CrossEntropyLoss", "args": [], "weight": 0.4},
                      final={"name": "CrossEntropyLoss", "args": [], "weight": 1.0},
                      losses={"TwoScaleLoss": 1.0, "DenseContrastiveLossV2_ms": 0.1}),
-        "train": {"lr_batchwise": True, "learning_rate": 0.00006, "lr_fct": "linear-warmup-polynomial",
+        "train": {"fused_optimizer": os.environ.get("DCL_FUSED_OPT", "1") != "0",
+                  "lr_batchwise": True, "learning_rate": 0.00006, "lr_fct": "linear-warmup-polynomial",
                   "lr_params": {"power": 1.0, "warmup_iters": 1500, "warmup_rate": 1e-6, "min_lr": 0.0},
                   "optim": "AdamW", "epochs": 127, "momentum": 0.9, "betas": [0.9, 0.999], "weight_decay": 0.01,
                   "opt_keys": {"absolute_pos_embed": {"wd_mult": 0.0}, "norm": {"wd_mult": 0.0},
@@ -474,7 +475,8 @@ def step_config(args, world):
                  "transform_values": {"crop_shape": [args.height, args.width]}},
         "loss": dict(loss_config(S, not args.no_cross), name="LossWrapper",
                      losses={"CrossEntropyLoss": 1, "DenseContrastiveLossV2_ms": 0.1}),
-        "train": {"learning_rate": 0.01, "lr_fct": "polynomial", "optim": "SGD", "lr_batchwise": True,
+        "train": {"fused_optimizer": os.environ.get("DCL_FUSED_OPT", "1") != "0",
+                  "learning_rate": 0.01, "lr_fct": "polynomial", "optim": "SGD", "lr_batchwise": True,
                   "epochs": 484, "momentum": 0.9, "weight_decay": 0.0005},
     }
 
