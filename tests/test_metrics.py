@@ -95,3 +95,31 @@ def test_hip_confusion_matrix_at_size_vs_oracle(oracle, shape, K):
     bad[0, 0, :7] = K + 3
     t_get_confusion_matrix(logits.to(dev), bad.to(dev), ds)
     assert int(out_of_range(dev).item()) == before + 7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("total,C,K,tdtype", [(12 * 512 * 1024, 19, 20, torch.int64), (1000003, 19, 20, torch.uint8),
+                                               (16 * 128 * 128 + 2, 150, 151, torch.int32), (5, 19, 19, torch.int64),
+                                               (4096 + 1, 200, 200, torch.int64)])
+def test_hip_confusion_matrix_from_argmax_map(total, C, K, tdtype):
+    """dcl_confusion_matrix_pred (the histogram of (arg-max map, target) that the fused up-sampling + CE path leaves to the
+    metrics tail; 512 workgroups, four pixels per thread and trip): exact counts against numpy for the benchmark size, totals
+    that are not multiples of four, the three target types, the LDS and the global-atomic histogram, out-of-range targets
+    counted and skipped."""
+    from mscs_amd import _lib
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(total % 1000)
+    pred = torch.randint(0, C, (total,), generator=gen).to(torch.uint8)
+    hi = 256 if tdtype == torch.uint8 else K + 5
+    target = torch.randint(0, min(hi, K + 5), (total,), generator=gen).to(tdtype)
+    ref = np.zeros((C, K), dtype=np.int64)
+    tn, pn = target.numpy().astype(np.int64), pred.numpy().astype(np.int64)
+    ok = tn < K
+    np.add.at(ref, (pn[ok], tn[ok]), 1)
+    cm = torch.zeros((C, K), dtype=torch.int32, device=dev)
+    oob = torch.zeros(1, dtype=torch.int32, device=dev)
+    p, t = pred.to(dev), target.to(dev)
+    _lib.check(_lib.lib().dcl_confusion_matrix_pred(_lib.ptr(p), total, _lib.ptr(t), t.element_size(), C, K, _lib.ptr(cm),
+                                                    _lib.ptr(oob), _lib.stream_ptr(dev)), "dcl_confusion_matrix_pred")
+    np.testing.assert_array_equal(cm.cpu().numpy(), ref)
+    assert int(oob.item()) == int((~ok).sum())
