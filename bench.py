@@ -440,7 +440,7 @@ def step_config_upernet(args, world):
         "parallel": world > 1, "batch_is_global": False,
         "graph": {"model": "UPerNet", "backbone": "swinL" if args.config == 5 else "swinT", "sync_bn": True, "out_stride": 32, "pretrained": False,
                   "align_corners": False, "aux_head": {"in_index": 3, "dropout_rate": 0.1}, "dropout_rate": 0.1,
-                  "lazy_logits": not args.materialize_logits, "lazy_projector": not args.materialize_projector,
+                  "lazy_logits": not args.materialize_logits, "lazy_projector": not getattr(args, "materialize_projector", False),
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "position": "fpn"}},
         "data": {"dataset": "ADE20K", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
                  "synthetic": True, "synthetic_length": args.batch * 2,
@@ -467,7 +467,7 @@ def step_config(args, world):
         "parallel": world > 1, "batch_is_global": False, "channels_last": args.channels_last,
         "graph": {"model": "HRNet", "backbone": "hrnet48", "sync_bn": True, "out_stride": 4, "pretrained": False,
                   "align_corners": True, "branch_conv": args.branch_conv, "lazy_logits": not args.materialize_logits,
-             "lazy_projector": not args.materialize_projector,
+             "lazy_projector": not getattr(args, "materialize_projector", False),
                   "conv1x1": getattr(args, "conv1x1", "f16x3"),
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "before_context": True}},
         "data": {"dataset": "CITYSCAPES", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
@@ -543,7 +543,7 @@ def time_train_step(args, dev, rank, world):
              "lazy_logits": not args.materialize_logits,
              # second graph key of this repo (default off in the models): the projection heads' last 1x1 convolution is
              # evaluated on the pixels the contrastive loss samples instead of as a full map (models/Projector.LazyProjection)
-             "lazy_projector": not args.materialize_projector,
+             "lazy_projector": not getattr(args, "materialize_projector", False),
              "model_dtype": "bf16-autocast" if args.amp else "f32",
              "memory_format": "channels_last" if args.channels_last else "contiguous",
              "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
