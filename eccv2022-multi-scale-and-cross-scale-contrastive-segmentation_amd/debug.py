@@ -37,6 +37,8 @@ class DebugConfig:
     # OFF by default: its teams of persistent workgroups wait for members that the branch streams' kernels keep off the CUs
     # (step 104.4 vs 95.5 ms), and alone it only ties the two-kernel form until its barrier is pipelined
     gemm_conv1x1: bool = field(default_factory=lambda: _flag('DCL_GEMM_CONV1X1'))               # wide 1x1 convolutions on dcl_gemm_f16x3
+    lib_conv1x1_addend: bool = field(default_factory=lambda: _flag('DCL_LIB_CONV1X1_ADDEND'))   # big 1x1 data gradients: residual
+    # gradient accumulated by the library GEMM (beta = 1)
     gemm_conv1x1_addend: bool = field(default_factory=lambda: _flag('DCL_GEMM_CONV1X1_ADDEND', False))  # ... with the residual
     # gradient as C += -- OFF: 467 us per launch on layer 1's 256-channel gradients against 372 for the tile kernel's fused addend
     gemm_head_taps: bool = field(default_factory=lambda: _flag('DCL_GEMM_HEAD'))                # the head's tap products on it

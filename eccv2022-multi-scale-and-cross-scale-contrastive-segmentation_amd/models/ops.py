@@ -262,6 +262,7 @@ def _conv1x1_by_gemm(rows, k, x, both_row_contiguous):
 
 
 GEMM_CONV1X1 = _dbg.gemm_conv1x1     # (DCL_GEMM_CONV1X1=0: the library / tile-kernel paths, for A/B runs)
+LIB_CONV1X1_ADDEND = _dbg.lib_conv1x1_addend     # ... by the library's GEMM with beta = 1 (DCL_LIB_CONV1X1_ADDEND=0: tile kernel)
 GEMM_CONV1X1_ADDEND = _dbg.gemm_conv1x1_addend   # residual gradient accumulated by the GEMM (DCL_GEMM_CONV1X1_ADDEND=0: tile kernel)
 
 
@@ -446,6 +447,16 @@ class _Conv3x3Direct(torch.autograd.Function):
             elif ctx.k1 and _conv1x1_by_library(x, gy) and addend is None:
                 n, ci, h, w = x.shape
                 torch.matmul(weight.view(-1, ci).t(), gy.view(n, -1, h * w), out=gx.view(n, ci, h * w))
+            elif ctx.k1 and LIB_CONV1X1_ADDEND and _conv1x1_by_library(x, gy) and weight.shape[1] >= 128 \
+                    and addend.shape == x.shape and addend.is_contiguous() and addend.dtype == torch.float32:
+                # HBM-bound size with a residual gradient: the library's GEMM with beta = 1 accumulates INTO it (layer 1's
+                # 256-channel gradients: read 100 + 403 MB, write 403 MB; the tile kernel's fused addend runs at half the HBM rate)
+                n, ci, h, w = x.shape
+                gx = addend
+                gx.view(n, ci, h * w).baddbmm_(weight.view(-1, ci).t().unsqueeze(0).expand(n, ci, weight.shape[0]),
+                                               gy.view(n, -1, h * w))
+                if getattr(gx, "_dcl_amax", None) is not None:
+                    gx._dcl_amax = None
             elif ctx.k1:
                 # (with a residual gradient to add, the tile kernel's fused epilogue beats library GEMM + add kernel
                 # also above the size where the GEMM alone is faster)
