@@ -167,12 +167,13 @@ __global__ __launch_bounds__(256) void k_metrics_from_cm(const int *__restrict__
 
 // confusion matrix from an arg-max map (uint8, produced by the fused up-sampling + cross-entropy forward): the
 // histogram half of k_confusion only, 1 + target bytes per pixel
+template <int CELLS>                   // LDS histogram cells (2048: two workgroups per CU; LDS_CELLS: one); 0: global atomics
 __global__ __launch_bounds__(256) void k_confusion_pred(const unsigned char *__restrict__ pred, const void *target,
                                                        int tbytes, long long total, int C, int cols, int *cm, int *oob)
 {
-    __shared__ int hist[2048];
+    __shared__ int hist[CELLS > 0 ? CELLS : 1];
     const int cells = C * cols;
-    const bool use_lds = cells <= 2048;
+    const bool use_lds = CELLS > 0;
     if (use_lds) {
         for (int i = threadIdx.x; i < cells; i += 256)
             hist[i] = 0;
@@ -225,12 +226,23 @@ extern "C" int dcl_confusion_matrix_pred(const uint8_t *pred, int64_t total, con
     // addresses: with 2 048 workgroups that flush WAS the kernel (1.0 ms on 12 x 512 x 1024 pixels: ~2 000 same-address atomics
     // queue up per cell) -- two workgroups per CU, four pixels per thread and trip
     long long blocks = (total / 4 + 255) / 256;
-    if (blocks > 512)
-        blocks = 512;
+    const long long cells = (long long)C * cols;
+    const long long cap = cells <= 2048 ? 512 : 256;        // (the 96-KiB histogram: one workgroup per CU)
+    if (blocks > cap)
+        blocks = cap;
     if (blocks < 1)
         blocks = 1;
-    hipLaunchKernelGGL(k_confusion_pred, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, target,
-                       target_bytes, (long long)total, C, cols, cm, oob);
+    // 150 x 151 cells (ADE20K): one global atomic per PIXEL took 1.0 ms on 16 x 640 x 640; the LDS histogram's flush issues its
+    // atomics on consecutive addresses (whole cache lines per wave instruction)
+    if (cells <= 2048)
+        hipLaunchKernelGGL(k_confusion_pred<2048>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, target,
+                           target_bytes, (long long)total, C, cols, cm, oob);
+    else if (cells <= LDS_CELLS)
+        hipLaunchKernelGGL(k_confusion_pred<LDS_CELLS>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, target,
+                           target_bytes, (long long)total, C, cols, cm, oob);
+    else
+        hipLaunchKernelGGL(k_confusion_pred<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, target,
+                           target_bytes, (long long)total, C, cols, cm, oob);
     DCL_LAUNCH_CHECK();
     return 0;
 }
