@@ -219,6 +219,28 @@ def test_lazy_projection_equals_materialised_projection(dev, prepared):
         assert all(torch.is_tensor(f) for f in proj([x.to(dev) for x in xs]))
 
 
+def test_matrix_adaptive_avg_pool_matches_aten(dev):
+    """UPerNet's pyramid pooling as one matrix product (models/UPerNet._MatrixAdaptiveAvgPool2d): forward and input gradient
+    against nn.AdaptiveAvgPool2d in float64 (1e-6 of max), bins that overlap (20 -> 6, 20 -> 3), divide evenly (20 -> 2) and
+    are coarser than the input (5 -> 6); bitwise reproducible (ATen's backward uses float atomics)."""
+    from mscs_amd.models.UPerNet import _MatrixAdaptiveAvgPool2d
+    torch.manual_seed(4)
+    for (h, w, s) in [(20, 20, 1), (20, 20, 2), (20, 20, 3), (20, 20, 6), (16, 16, 6), (7, 9, 3), (5, 5, 6)]:
+        x = torch.randn(3, 24, h, w, device=dev, requires_grad=True)
+        gy = torch.randn(3, 24, s, s, device=dev)
+        y = _MatrixAdaptiveAvgPool2d(s)(x)
+        y.backward(gy)
+        x64 = x.detach().double().requires_grad_(True)
+        y64 = torch.nn.functional.adaptive_avg_pool2d(x64, s)
+        y64.backward(gy.double())
+        assert ((y.double() - y64).abs().max() / y64.abs().max()).item() < 1e-6, (h, w, s)
+        assert ((x.grad.double() - x64.grad).abs().max() / x64.grad.abs().max()).item() < 1e-6, (h, w, s)
+        g1 = x.grad.clone()
+        x.grad = None
+        _MatrixAdaptiveAvgPool2d(s)(x).backward(gy)
+        assert torch.equal(g1, x.grad)
+
+
 def test_deterministic_bitwise(dev):
     from mscs_amd.losses import DenseContrastiveLossV2_ms
     label, feats = _random_case(9, 2, 128, 256, 20, 64, (4, 8))
