@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..utils import printlog
-from .amax import tag, tag_of
+from .amax import carry, tag, tag_of
 from .ops import FusedLayerNorm, TokenLinear, tagged_gelu
 
 _COMMON = dict(window_size=7, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
@@ -409,7 +409,8 @@ class SwinTransformer(nn.Module):
             x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
             if i in self.out_indices:
                 x_out = getattr(self, f'norm{i}')(x_out)
-                outs.append(x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
+                # (same values in another order: the norm's absmax tag travels with the NCHW copy the decoder convolves)
+                outs.append(carry(x_out, x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous()))
         return tuple(outs)
 
     def train(self, mode=True):

@@ -11,9 +11,12 @@ set_verbosity(40)
 class Args:
     batch, height, width, scales, no_cross, channels_last, branch_conv = 12, 512, 1024, 3, False, False, "f16x3"
     materialize_logits, head_conv, conv1x1, config, classes = False, "direct", "f16x3", 2, 20
-C4 = "--config" in sys.argv and sys.argv[sys.argv.index("--config") + 1] == "4"      # UPerNet + Swin-T
+CFG = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "2"
+C4 = CFG in ("4", "5")                                                               # UPerNet + Swin-T | Swin-L
 if C4:
     Args.batch, Args.height, Args.width, Args.scales, Args.config, Args.classes = 16, 512, 512, 4, 4, 151
+    if CFG == "5":
+        Args.height, Args.width, Args.config = 640, 640, 5
 mgr = (OCRNetManager if C4 else HRNetManager)(bench.step_config(Args, 1), autostart=False); mgr.setup(); mgr.model.train()
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(0)
