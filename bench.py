@@ -298,7 +298,7 @@ def roofline_bwd_kernel(mod, iters=10):
     if G > 0:        # what the step runs in f16x3 mode: the stream-K partition (finished tiles, no slabs)
         dout = torch.empty((Npad, 256), device=dev)
         ws = torch.empty((G, 128, 256), device=dev)
-        flags = torch.zeros(G, dtype=torch.int32, device=dev)
+        flags = torch.zeros(G + 1, dtype=torch.int32, device=dev)
 
         def launch():
             _lib.check(L.dcl_infonce_bwd_streamk(p(A.bank), N, A.plan.V, p(A.bank), N, p(t.rng_lo), p(t.rng_hi),

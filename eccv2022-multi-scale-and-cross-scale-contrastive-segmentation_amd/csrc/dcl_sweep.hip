@@ -18,7 +18,9 @@
 // :132-161; and the autograd backward of all of them.
 #include <limits.h>
 
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 #include "dcl_common.h"
 
@@ -66,7 +68,11 @@ struct SweepArgs {
     // stream-K backward (SK): gridDim.x persistent workgroups share the (row block, chunk) sequence
     int N1pad;             // rows of the padded anchor bank
     float *sk_ws;          // [gridDim.x][BM][CP] partial tiles of the workgroups whose range ends inside a row block
-    int *sk_flags;         // [gridDim.x] 0 on entry and on exit; 1 = workgroup g's partial tile is in sk_ws
+    int *sk_flags;         // [gridDim.x + 1]: flags[g] == sk_seq: workgroup g's partial tile of THIS launch is in sk_ws (any other
+                           // value = not yet: stale values of earlier or aborted launches never match); flags[gridDim.x] = error
+                           // word (number of hand-overs that timed out, ever; never reset by the kernel)
+    int sk_seq;            // launch number of this (flags, workspace) pair, never 0 (host: dcl_infonce_bwd_streamk)
+    long long sk_timeout;  // s_memrealtime ticks (100 MHz) an owner waits for one partial tile before it gives up
     int sk_probe;          // timing probe (dcl_infonce_set_streamk(2)): no flag traffic, no waiting -- WRONG results
 };
 
@@ -147,7 +153,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // of one row block, whole row blocks, and the head of another: per piece ("segment") the workgroup loads that row block's A
 // panel and runs the chunk pipeline.  The workgroup that finishes a row block (its segment contains the last chunk)
 // owns the result: it waits for the partial tiles of the workgroups that covered the earlier chunks of the row block --
-// always LOWER workgroup ids, which the dispatcher starts first, so the wait cannot deadlock -- adds them in ascending id
+// always LOWER workgroup ids, which the dispatcher starts first (the wait is bounded all the same, see below) -- adds them in ascending id
 // order (fixed order: bitwise reproducible) and writes the finished 128 x 256 tile.  Every other segment is the last one of
 // its workgroup and leaves one partial tile in sk_ws[g].  Against one slab per (row block, column split) that is
 // <= 255 partial tiles of 128 KiB instead of 13 x 77 (131 MB written, then read again by K6), one or two A-panel
@@ -749,10 +755,23 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                     // waits for its stores, then a barrier, then the flag).  Acquire / release fences at agent scope
                     // would do it too, but on this multi-XCD part they invalidate / write back the WHOLE L2 of the XCD
                     // each time: with the owners spinning on acquire loads the launch took 10 ms instead of 0.3.
+                    // The wait is BOUNDED: deadlock-freedom rests on every contributor (a lower workgroup id) being or becoming
+                    // resident, which other streams' persistent kernels, CU masks or several ranks on one device can break.
+                    // After sk_timeout ticks without the flag the owner counts an error in flags[gridDim.x] (the caller reads that word:
+                    // the launch's gradient is then invalid and it falls back to the column-split form) and goes on.
                     if (tid == 0 && p.sk_probe == 0) {
-                        for (int gp = gf; gp < g; ++gp)
-                            while (__hip_atomic_load(p.sk_flags + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+                        bool late = false;
+                        for (int gp = gf; gp < g && !late; ++gp)
+                            while (__hip_atomic_load(p.sk_flags + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_seq) {
                                 __builtin_amdgcn_s_sleep(8);
+                                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > p.sk_timeout) {
+                                    late = true;
+                                    break;
+                                }
+                            }
+                        if (late)
+                            __hip_atomic_fetch_add(p.sk_flags + gridDim.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     __syncthreads();
                     for (int gp = gf; gp < g; ++gp) {
@@ -766,11 +785,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                             __builtin_amdgcn_sched_barrier(0);       // 16 loads in flight, not 128 (registers)
                         }
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();                             // everyone has read the tiles: their flags go back to 0
-                    if (tid == 0)
-                        for (int gp = gf; gp < g; ++gp)
-                            __hip_atomic_store(p.sk_flags + gp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (no flag reset: the next launch on this pair waits for ITS sequence number)
 #pragma unroll
                     for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
@@ -794,7 +809,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's tile rows have reached memory
                 __syncthreads();
                 if (tid == 0 && p.sk_probe == 0)
-                    __hip_atomic_store(p.sk_flags + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.sk_flags + g, p.sk_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #undef DCL_KOFF
         } else if (F16) {
@@ -1058,13 +1073,49 @@ extern "C" int dcl_infonce_set_streamk(int on)
     return 0;
 }
 
+// number of CUs of the current device (queried once per device): the persistent grid is one workgroup per CU
+static int sk_cu_count()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return 256;
+    if (cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                       ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
+static long long g_sk_timeout_ticks = 200000000LL;      // 2 s of the 100-MHz s_memrealtime clock per hand-over
+
+extern "C" int dcl_infonce_set_streamk_timeout_ms(int ms)
+{
+    g_sk_timeout_ticks = (long long)(ms > 0 ? ms : 2000) * 100000LL;
+    return 0;
+}
+
 // 0 = the column-split form should be used (switch off, or fewer units than workgroups would make empty ranges pointless)
 extern "C" int dcl_infonce_bwd_streamk_workgroups(int N1, int N2)
 {
     if (!g_streamk || N1 <= 0 || N2 <= 0)
         return 0;
     const long long units = (long long)(dcl_round_up(N1, BM) / BM) * ((N2 + CJ - 1) / CJ);
-    return units >= 256 ? 256 : (int)units;          // one persistent workgroup per CU
+    const int cus = sk_cu_count();                    // one persistent workgroup per CU of THIS device
+    return units >= cus ? cus : (int)units;
+}
+
+// launch numbers per (flags, workspace) pair: a flag is valid for the launch whose number it holds, so nothing has to be
+// zero on entry and a launch that was aborted (or timed out) leaves nothing behind that a later launch could mistake
+static int sk_next_seq(const void *flags)
+{
+    static std::mutex mu;
+    static std::unordered_map<const void *, int> seq;
+    std::lock_guard<std::mutex> lock(mu);
+    int &s = seq[flags];
+    s = s >= 0x7ffffff0 ? 1 : s + 1;
+    return s;
 }
 
 extern "C" int dcl_infonce_bwd_streamk(const float *A, int N1, int V1, const float *B, int N2,
@@ -1088,6 +1139,8 @@ extern "C" int dcl_infonce_bwd_streamk(const float *A, int N1, int V1, const flo
     p.N1pad = dcl_round_up(N1, BM);
     p.sk_ws = ws;
     p.sk_flags = flags;
+    p.sk_seq = sk_next_seq(flags);
+    p.sk_timeout = g_sk_timeout_ticks;
     p.sk_probe = g_streamk == 2 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
 #define DCL_SK_LAUNCH(PFV)                                                                                    \

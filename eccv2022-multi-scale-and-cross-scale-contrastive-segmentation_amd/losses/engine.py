@@ -737,17 +737,48 @@ class DenseContrastFunction(torch.autograd.Function):
 _SK_WS = {}
 
 
+class StreamKTimeout(RuntimeError):
+    """A stream-K backward launch gave up waiting for a partial tile (see dcl_infonce_bwd_streamk): its gradient was invalid."""
+
+
 def _streamk_workspace(dev, G: int):
-    """(partial-tile workspace f32 [G, 128, 256], flags int32 [G]) of the stream-K backward for the CURRENT stream of
-    ``dev``.  The flags are zero between launches (the kernel resets what it sets) and the launches of one stream run one
-    after the other, so one persistent pair per (device, stream) serves every term of every step."""
+    """(partial-tile workspace f32 [G, 128, 256], flags int32 [G + 1]) of the stream-K backward for the CURRENT stream of
+    ``dev``.  One persistent pair per (device, stream) serves every term of every step: the launches of one stream run one
+    after the other and a flag is only valid for the launch whose number it carries (nothing has to be reset).  flags[G] is
+    the error word (hand-overs that timed out): a copy of it travels to a pinned host word after every backward pass
+    (``_streamk_note_launches``) and is looked at -- without waiting -- when the workspace is asked for the next time; a
+    non-zero value switches stream-K off for the process (column-split ``dcl_infonce_bwd`` from then on) and raises, because
+    the gradients of that earlier step were wrong."""
     key = (dev.index, _lib.stream_ptr(dev))
     got = _SK_WS.get(key)
-    if got is None or got[1].numel() < G:
-        got = (torch.empty((G, _lib.ROW_TILE, _lib.CP), dtype=torch.float32, device=dev),
-               torch.zeros((G,), dtype=torch.int32, device=dev))
+    if got is not None:
+        ev, host = got[2], got[3]
+        if ev is not None and ev.query() and int(host[0]) != 0:
+            _lib.lib().dcl_infonce_set_streamk(0)
+            _SK_WS.pop(key, None)
+            raise StreamKTimeout(
+                f"stream-K backward: {int(host[0])} hand-over(s) between persistent workgroups timed out in an earlier step "
+                "(a contributor workgroup never became resident: CU mask, another persistent kernel, several ranks on one "
+                "device?).  That step's feature gradients were invalid.  Stream-K is now OFF for this process "
+                "(dcl_infonce_set_streamk(0)): later steps use the column-split backward; set DCL_SWEEP_STREAMK=0 to start that way.")
+    if got is None or got[1].numel() < G + 1:
+        got = [torch.empty((G, _lib.ROW_TILE, _lib.CP), dtype=torch.float32, device=dev),
+               torch.zeros((G + 1,), dtype=torch.int32, device=dev), None,
+               torch.zeros((1,), dtype=torch.int32).pin_memory(), G]
         _SK_WS[key] = got
-    return got
+    return got[0], got[1]
+
+
+def _streamk_note_launches(dev):
+    """After the stream-K launches of a backward pass: asynchronous copy of the error word to the host + an event."""
+    got = _SK_WS.get((dev.index, _lib.stream_ptr(dev)))
+    if got is None:
+        return
+    G = got[4]
+    got[3].copy_(got[1][G:G + 1], non_blocking=True)
+    ev = got[2] or torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    got[2] = ev
 
 
 def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_meta, need):
@@ -759,6 +790,7 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
     dev = st.scales[0].bank.device
     g = grad_terms.detach().to(device=dev, dtype=torch.float32).contiguous()
     slabs: List[List[torch.Tensor]] = [[] for _ in st.scales]
+    used_streamk = False
     for idx, t in enumerate(st.terms):
         A, B = st.scales[t.a], st.scales[t.b]
         N1, N2 = A.plan.N, B.plan.N
@@ -782,6 +814,7 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
                     # f16x3: stream-K partition, ONE finished [N1pad, 256] tile array per launch instead of nsplit slabs
                     dout = torch.empty((N1pad, _lib.CP), dtype=torch.float32, device=dev)
                     ws, flags = _streamk_workspace(dev, G)
+                    used_streamk = True
                     _lib.check(L.dcl_infonce_bwd_streamk(_lib.ptr(A.bank), N1, A.plan.V, _lib.ptr(sg.bank), sg.N,
                                                          _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi), inv_tau,
                                                          1 if sym else 0, 1, 1 if sym else 0, _lib.ptr(stat),
@@ -805,6 +838,7 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
             if G > 0:
                 dout = torch.empty((N2pad, _lib.CP), dtype=torch.float32, device=dev)
                 ws, flags = _streamk_workspace(dev, G)
+                used_streamk = True
                 _lib.check(L.dcl_infonce_bwd_streamk(_lib.ptr(B.bank), N2, B.plan.V, _lib.ptr(A.bank), N1,
                                                      _lib.ptr(t.rev_lo), _lib.ptr(t.rev_hi), inv_tau, 0, 0, 1, None,
                                                      _lib.ptr(stat), _lib.ptr(dout), _lib.ptr(ws), _lib.ptr(flags),
@@ -820,6 +854,8 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
                                          _lib.ptr(A.bank_h if B.bank_h is not None else None), stream),
                        "dcl_infonce_bwd")
             slabs[t.b] += [dpart[i] for i in range(ns)]
+    if used_streamk:
+        _streamk_note_launches(dev)
     grads = []
     for s, sc in enumerate(st.scales):
         if not need[s]:

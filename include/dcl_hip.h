@@ -170,12 +170,19 @@ int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, int N2,
  * N2) persistent workgroups (one per CU; 0 = switched off with dcl_infonce_set_streamk(0), use dcl_infonce_bwd) share the
  * (row block, 32-column chunk) sequence in equal contiguous ranges; the workgroup that reaches the end of a row block
  * adds the partial tiles of the (lower-numbered) workgroups that covered its earlier chunks in ascending order --
- * bitwise reproducible -- and writes the tile.  ws f32 [G, DCL_ROW_TILE, DCL_CP] partial tiles; flags int32 [G], must be
- * ZERO on entry and is zero again when the kernel has finished (one buffer can serve every launch of a stream).
+ * bitwise reproducible -- and writes the tile.  ws f32 [G, DCL_ROW_TILE, DCL_CP] partial tiles; flags int32 [G + 1],
+ * zero-initialised ONCE by the caller (one pair per stream serves every launch of it): flags[g] holds the number of the
+ * launch whose partial tile g is valid (the library numbers the launches of a flags pointer), so nothing is reset between
+ * launches and an aborted launch leaves nothing a later one could mistake.  G = min(units, CUs of the device).  The
+ * owner's wait for a contributor is BOUNDED (dcl_infonce_set_streamk_timeout_ms, default 2000 ms per hand-over): when it
+ * expires -- a contributor never became resident: CU masks, other persistent kernels, several ranks on one device --
+ * flags[G] is incremented and the kernel finishes with an INVALID gradient instead of hanging; the caller must read
+ * flags[G] (it only ever grows) and fall back to dcl_infonce_bwd (dcl_infonce_set_streamk(0)).
  * Replaces the same reference lines as dcl_infonce_bwd (autograd of losses/DenseContrastiveLossV2.py:150-192 and
  * losses/DenseContrastiveLossV2_ms.py:84-161). */
 int dcl_infonce_bwd_streamk_workgroups(int N1, int N2);
 int dcl_infonce_set_streamk(int on);
+int dcl_infonce_set_streamk_timeout_ms(int ms);
 int dcl_infonce_bwd_streamk(const float *A, int N1, int V1, const float *B, int N2,
                             const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau, int intra,
                             int use_row, int use_col, const float *rstat, const float *cstat, float *dout,
