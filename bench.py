@@ -15,12 +15,19 @@ Workloads:
         `--config 4`: UPerNet + Swin-T, ADE20K 512x512, TwoScaleLoss + DCV2_ms (4 scales), AdamW, batch 16 per GPU.
   loss  the contrastive loss alone (forward + backward) on synthetic 256-d projector outputs
 Extra keys of the JSON line:
-  roofline / roofline_other   dominant hand-written kernel (step: the weight-gradient kernel `k_wgrad3x3d<3,1>` on its
-        heaviest launch, the 144 -> 720 full-resolution part of the head convolution; loss: the InfoNCE backward sweep):
-        algorithmic FLOPs over the HIP-event launch time measured live, against the peak of its arithmetic mode; `traffic`
-        only where a PMC pass of that kernel / shape is committed (else null); per-shape rows: profiles/r03_conv_per_shape.csv
-  cpu_baseline                oracle/eager_torch.py + the same model code on the host cores: median of 3 after one
-        warm-up, ONE image of the model (x batch) and ONE full N = 9804 loss term (x number of terms)
+  roofline                    step: the kernel SYMBOL with the largest share of one step (all its launches, every shape), time-
+        weighted: sum of the launches' algorithmic FLOPs / sum of their HIP-event durations, measured live in ONE extra step
+        after the timed region with events on the launch streams (mscs_amd/utils/kernel_timer.py); loss workload: the InfoNCE
+        backward sweep.  `traffic` only where a PMC pass of that kernel is committed (else null)
+  roofline_other              the other matrix-pipe symbols of that step (same accounting), the head's 144 -> 720 weight gradient
+        and forward launches alone, the InfoNCE backward sweep alone
+  roofline_hbm                the streaming kernels of that step against the 8 TB/s HBM peak: K1 label_hist, K2 rank_select, K3
+        gather_normalize, K6 normalize_bwd_scatter and the batch-norm kernels -- algorithmic bytes / event time
+  cpu_baseline                oracle/eager_torch.py + the same model code on the host cores, every part MEASURED on the full
+        workload (no multiplication): the model's forward + backward + SGD over all `batch` images (in micro-batches of 4:
+        host memory) and one evaluation of the whole contrastive loss (every scale and cross-scale term)
+  reference_config_ms_per_step   the same step with this repo's three opt-in keys OFF (lazy_logits, lazy_projector, fused
+        optimizer): what a reference JSON config gives unchanged
   eager_gpu_step_ms, speedup_vs_eager_gpu_step   the reference-structure eager step on the same GPU in the same run
         (stock MIOpen / ATen kernels + the eager-structure loss of oracle/eager_torch.py): BASELINE.json's >= 5x target
   contrastive_loss_fwd_bwd_ms, metrics_in_step, peak_mem_gb
@@ -97,6 +104,12 @@ def parse():
     ap.add_argument("--materialize-projector", action="store_true",
                     help="the projection heads return their full [n, d, h, w] maps like the reference instead of the lazy form "
                          "(graph key lazy_projector) whose last 1x1 convolution the loss evaluates on the sampled pixels only")
+    ap.add_argument("--kernel-table", default=None,
+                    help="write the in-step per-kernel table (the rows behind `roofline*`) to this JSON file")
+    ap.add_argument("--no-reference-config", action="store_true",
+                    help="skip the second timing with lazy_logits / lazy_projector / fused optimizer off")
+    ap.add_argument("--plain-config", action="store_true",
+                    help="time the step with this repo's opt-in graph / train keys off (what a reference JSON config gives)")
     ap.add_argument("--no-metrics", action="store_true",
                     help="leave the per-step metrics tail (confusion matrix, accuracies, mIoU, logging) out of the step")
     a = ap.parse_args()
@@ -246,6 +259,52 @@ def roofline_conv_kernels(args, dev, iters=20):
     return main, others
 
 
+# HBM-side bytes per launch from committed rocprofv3 --pmc passes of the step (tools/pmc_step.sh -> profiles/r04_step_pmc.csv),
+# (FETCH_SIZE KiB, WRITE_SIZE KiB) averaged over the symbol's launches of one step; traffic = (2 * FETCH + WRITE) KiB per the gfx950
+# correction of MI355X_MICROARCH.md.  Keys = kernel symbols of mscs_amd/utils/kernel_timer.py.
+PMC_STEP = {}
+PMC_STEP_SOURCE = "profiles/r04_step_pmc.csv"
+
+
+def roofline_from_rows(rows, args):
+    """`roofline` = the matrix-pipe kernel SYMBOL with the largest share of one step, time-weighted over all its launches
+    (sum of algorithmic FLOPs / sum of in-step HIP-event durations); `roofline_other` = the next symbols; `roofline_hbm` = the
+    streaming kernels (K1 / K2 / K3 / K6 and the batch-norm family) against the HBM peak.  One extra step after the timed
+    region, events on every launch stream (mscs_amd/utils/kernel_timer.py)."""
+    total_ms = sum(r["total_ms"] for r in rows)
+
+    def entry(r):
+        top = sorted(r["shapes"].items(), key=lambda kv: -kv[1][1])[:4]
+        e = {"bound": r["bound"], "kernel": f"{r['kernel']} ({r['entry']}): all {r['calls']} launches of one training step, "
+                                            f"time-weighted",
+             "achieved": round(r["achieved"], 2), "peak": round(r["peak"], 1), "unit": r["unit"], "frac": round(r["frac"], 4),
+             "launches": r["calls"], "launch_ms": round(r["total_ms"] / r["calls"], 4), "step_ms": round(r["total_ms"], 3),
+             "share_of_timed_kernels": round(r["total_ms"] / total_ms, 4),
+             "algorithmic_flops" if r["bound"] == "mfma" else "algorithmic_bytes":
+                 (r["flops"] if r["bound"] == "mfma" else r["bytes"]) / r["calls"],
+             "shapes": [{"shape": k, "launches": v[0], "avg_ms": round(v[1] / v[0], 4),
+                         "frac": round(((v[2] / 1e12 if r["bound"] == "mfma" else v[3] / 1e9) / (v[1] / v[0] * 1e-3)) / r["peak"], 4)}
+                        for k, v in top],
+             "traffic": None, "traffic_source": "no PMC pass committed for this symbol"}
+        if r["bound"] == "mfma":
+            e["peak_note"] = "every algorithmic FLOP is issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): 2.5 PFLOP/s / 3"
+        pmc = PMC_STEP.get(r["kernel"])
+        if pmc and (args.batch, args.height, args.width) == (12, 512, 1024):
+            e["traffic"] = (2 * pmc[0] + pmc[1]) * 1024
+            e["traffic_source"] = (f"constant from {PMC_STEP_SOURCE} (separate rocprofv3 --pmc passes of this step, averaged over the "
+                                   "symbol's launches; 2 x FETCH_SIZE + WRITE_SIZE = bytes that crossed L2 <-> fabric)")
+        return e
+
+    mf = [r for r in rows if r["bound"] == "mfma"]
+    hb = [r for r in rows if r["bound"] == "hbm"]
+    out = {"roofline": entry(mf[0]), "roofline_other": [entry(r) for r in mf[1:6]], "roofline_hbm": [entry(r) for r in hb]}
+    if args.kernel_table:
+        slim = [{k: v for k, v in r.items() if k != "shapes"} | {"shapes": {k: v[:2] for k, v in r["shapes"].items()}} for r in rows]
+        with open(args.kernel_table, "w") as f:
+            json.dump({"workload": workload_name(args, "step"), "timed_kernel_ms": total_ms, "rows": slim}, f, indent=1)
+    return out
+
+
 def roofline_gemm_kernel(args, dev, iters=10):
     """configs 4 / 5 (UPerNet + Swin): the kernel family with the largest share of the step is dcl_gemm_f16x3 behind the
     token-major Linears; `roofline` reports it on the stage-3 Mlp fc1 forward of the configured backbone (the heaviest
@@ -353,42 +412,38 @@ PMC_SOURCE = "profiles/r02_loss_pmc_fetch.csv, r02_loss_pmc_write.csv"
 PMC_SOURCE_SK = "profiles/r03_loss_pmc_fetch.csv, r03_loss_pmc_write.csv"
 
 
-def cpu_baseline_loss(args, n_terms):
-    """oracle/eager_torch.py on the host cores.  Bounded sample: ONE intra-scale term with
-    max_features_total = 2500 (N ~ 2.4k instead of ~9.8k); every term of the workload is an
-    N x N evaluation with N ~ 9.8k, so one loss evaluation costs n_terms * (9804 / N_sample)^2 samples.
-    Returns (scale_factor, sample_seconds, threads, description)."""
+def cpu_baseline_loss(args):
+    """oracle/eager_torch.py (the eager-structure restatement: per-(image, class) Python loop, host randperm, N x N
+    matrices, autograd index-backward) on the host cores: ONE evaluation of the WHOLE loss of the workload -- every
+    scale's sampling + intra-scale term and every cross-scale term, forward and backward -- after a warm-up on one small
+    term.  Nothing is multiplied: the seconds reported are the seconds measured.  Returns (seconds, threads, description)."""
     from oracle import eager_torch
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
     gen = torch.Generator().manual_seed(0)
-    n, H, W = args.batch, args.height, args.width
-    label = torch.randint(0, 20, (n, H, W), generator=gen)
-    s = min(2, args.scales - 1)
-    feat = torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).requires_grad_(True)
+    n, H, W, S = args.batch, args.height, args.width, args.scales
+    label = torch.randint(0, args.classes, (n, H, W), generator=gen)
+    feats = [torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).requires_grad_(True) for s in range(S)]
+    w = [1.0, 0.7, 0.4, 0.1][:S]
     torch.manual_seed(0)
-    times, N = [], 0
-    for it in range(4):                                    # 1 warm-up + 3 measured, same inputs
-        feat.grad = None
-        t0 = time.perf_counter()
-        bank, classes = eager_torch.sample_bank(label, feat, 20, 5, 2500, 10000)
-        l = eager_torch.intra_loss(bank, classes, 0.1)
-        l.backward()
-        if it:
-            times.append(time.perf_counter() - t0)
-        N = bank.shape[0] * bank.shape[2]
-    dt = sorted(times)[1]
-    return float(n_terms), dt, threads, (
-        f"loss: ONE full intra-scale term (stride {4 << s}, N={N}, the workload's own cap) fwd+bwd, eager torch fp32 "
-        f"on {threads} host threads, median of 3 after 1 warm-up = {dt:.2f} s; multiplied by the workload's "
-        f"{n_terms} terms (all N x N with N = {N}; the stride-4 / 8 terms gather from larger maps, so this "
-        f"under-states the CPU time)")
+    warm = feats[-1].detach().clone().requires_grad_(True)          # warm-up: thread pool, allocator (one coarse term)
+    bank, classes = eager_torch.sample_bank(label, warm, args.classes, 5, 2500, 2000)
+    eager_torch.intra_loss(bank, classes, 0.1).backward()
+    t0 = time.perf_counter()
+    total, ms, cs = eager_torch.dcv2_ms(label, feats, args.classes, 0.1, w, cross=not args.no_cross)
+    total.backward()
+    dt = time.perf_counter() - t0
+    return dt, threads, (f"loss: ONE evaluation of the whole DenseContrastiveLossV2_ms ({S} scales + {len(cs)} cross-scale "
+                         f"term(s), batch {n}, {H}x{W}, C=256) fwd+bwd, eager torch fp32 on {threads} host threads after a "
+                         f"warm-up term = {dt:.2f} s measured (not extrapolated)")
 
 
-def cpu_baseline_model(args):
-    """HRNet-W48 + projector + CE forward/backward/SGD for ONE image of the benchmark size on the host
-    cores (stock PyTorch CPU, fp32); per-step model time = batch x this."""
+def cpu_baseline_model(args, micro=4):
+    """HRNet-W48 + projector + CE forward / backward / SGD over ALL `batch` images of the benchmark size on the host cores
+    (stock PyTorch CPU, fp32), in micro-batches of `micro` images with gradient accumulation (host memory: a batch-12
+    activation set of this model is ~50 GB) -- every image is computed, nothing is multiplied -- after a one-image warm-up.
+    Returns (seconds for the whole batch, description)."""
     import mscs_amd  # noqa: F401
     from mscs_amd.models import HRNet
     threads = min(os.cpu_count() or 1, 64)
@@ -398,22 +453,25 @@ def cpu_baseline_model(args):
     model = HRNet(graph, 1)
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
     gen = torch.Generator().manual_seed(0)
-    img = torch.randn(1, 3, args.height, args.width, generator=gen)
-    lbl = torch.randint(0, 20, (1, args.height, args.width), generator=gen)
+    img = torch.randn(args.batch, 3, args.height, args.width, generator=gen)
+    lbl = torch.randint(0, 20, (args.batch, args.height, args.width), generator=gen)
     ce = torch.nn.CrossEntropyLoss(ignore_index=19)
-    times = []
-    for it in range(4):                                    # 1 warm-up + 3 measured
-        t0 = time.perf_counter()
-        out, proj = model(img)
-        loss = ce(out, lbl) + sum(p.mean() for p in proj) * 0.0
-        opt.zero_grad()
+
+    def fwd_bwd(lo, hi):
+        out, proj = model(img[lo:hi])
+        loss = ce(out, lbl[lo:hi]) + sum(p.mean() for p in proj) * 0.0
         loss.backward()
-        opt.step()
-        if it:
-            times.append(time.perf_counter() - t0)
-    dt = sorted(times)[1]
-    return dt, (f"model: HRNet-W48 + projector + CE fwd+bwd+SGD on ONE image {args.height}x{args.width}, torch CPU "
-                f"fp32 on {threads} threads, median of 3 after 1 warm-up = {dt:.2f} s; multiplied by batch {args.batch}")
+
+    fwd_bwd(0, 1)                                            # warm-up (thread pool, oneDNN primitives)
+    opt.zero_grad()
+    t0 = time.perf_counter()
+    for lo in range(0, args.batch, micro):
+        fwd_bwd(lo, min(lo + micro, args.batch))
+    opt.step()
+    dt = time.perf_counter() - t0
+    return dt, (f"model: HRNet-W48 + projector + CE fwd+bwd over all {args.batch} images {args.height}x{args.width} "
+                f"(micro-batches of {micro}, gradient accumulation) + one SGD step, torch CPU fp32 on {threads} threads after "
+                f"a one-image warm-up = {dt:.2f} s measured (not extrapolated)")
 
 
 def workload_name(args, workload):
@@ -431,6 +489,25 @@ def workload_name(args, workload):
             f"(fwd+bwd+SGD), synthetic Cityscapes {args.height}x{args.width}, batch {args.batch} per GPU, {args.labels} labels")
 
 
+def opt_out_keys(args):
+    """The graph block of the timed step holds the REFERENCE's keys only: this package's managers turn the fused consumers
+    (graph.lazy_logits, graph.lazy_projector) on by themselves when the loss is their own LossWrapper (BaseManager.load_model).
+    --materialize-logits / --materialize-projector / --plain-config write the explicit `false` that hands out the reference's
+    tensors instead."""
+    keys = {}
+    if args.materialize_logits or args.plain_config:
+        keys["lazy_logits"] = False
+    if getattr(args, "materialize_projector", False) or args.plain_config:
+        keys["lazy_projector"] = False
+    return keys
+
+
+def fused_opt_key(args):
+    if args.plain_config or os.environ.get("DCL_FUSED_OPT", "1") == "0":
+        return {"fused_optimizer": False}       # torch's default (foreach) parameter update
+    return {}
+
+
 def step_config_upernet(args, world):
     """configs/ADE20K/upnswin_contrastive_ADE20K.json of the reference (graph / loss / train blocks as shipped), on the
     synthetic dataset."""
@@ -440,7 +517,7 @@ def step_config_upernet(args, world):
         "parallel": world > 1, "batch_is_global": False,
         "graph": {"model": "UPerNet", "backbone": "swinL" if args.config == 5 else "swinT", "sync_bn": True, "out_stride": 32, "pretrained": False,
                   "align_corners": False, "aux_head": {"in_index": 3, "dropout_rate": 0.1}, "dropout_rate": 0.1,
-                  "lazy_logits": not args.materialize_logits, "lazy_projector": not getattr(args, "materialize_projector", False),
+                  **opt_out_keys(args),
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "position": "fpn"}},
         "data": {"dataset": "ADE20K", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
                  "synthetic": True, "synthetic_length": args.batch * 2,
@@ -449,7 +526,7 @@ def step_config_upernet(args, world):
                      interm={"name": "CrossEntropyLoss", "args": [], "weight": 0.4},
                      final={"name": "CrossEntropyLoss", "args": [], "weight": 1.0},
                      losses={"TwoScaleLoss": 1.0, "DenseContrastiveLossV2_ms": 0.1}),
-        "train": {"fused_optimizer": os.environ.get("DCL_FUSED_OPT", "1") != "0",
+        "train": {**fused_opt_key(args),
                   "lr_batchwise": True, "learning_rate": 0.00006, "lr_fct": "linear-warmup-polynomial",
                   "lr_params": {"power": 1.0, "warmup_iters": 1500, "warmup_rate": 1e-6, "min_lr": 0.0},
                   "optim": "AdamW", "epochs": 127, "momentum": 0.9, "betas": [0.9, 0.999], "weight_decay": 0.01,
@@ -466,8 +543,7 @@ def step_config(args, world):
         "name": "bench", "mode": "training", "manager": "HRNet", "cuda": True, "seed": 0,
         "parallel": world > 1, "batch_is_global": False, "channels_last": args.channels_last,
         "graph": {"model": "HRNet", "backbone": "hrnet48", "sync_bn": True, "out_stride": 4, "pretrained": False,
-                  "align_corners": True, "branch_conv": args.branch_conv, "lazy_logits": not args.materialize_logits,
-             "lazy_projector": not getattr(args, "materialize_projector", False),
+                  "align_corners": True, "branch_conv": args.branch_conv, **opt_out_keys(args),
                   "conv1x1": getattr(args, "conv1x1", "f16x3"),
                   "ms_projector": {"mlp": [[1, -1, 1]], "scales": S, "d": 256, "use_bn": True, "before_context": True}},
         "data": {"dataset": "CITYSCAPES", "experiment": 1, "batch_size": args.batch, "num_workers": 0,
@@ -475,7 +551,7 @@ def step_config(args, world):
                  "transform_values": {"crop_shape": [args.height, args.width]}},
         "loss": dict(loss_config(S, not args.no_cross), name="LossWrapper",
                      losses={"CrossEntropyLoss": 1, "DenseContrastiveLossV2_ms": 0.1}),
-        "train": {"fused_optimizer": os.environ.get("DCL_FUSED_OPT", "1") != "0",
+        "train": {**fused_opt_key(args),
                   "learning_rate": 0.01, "lr_fct": "polynomial", "optim": "SGD", "lr_batchwise": True,
                   "epochs": 484, "momentum": 0.9, "weight_decay": 0.0005},
     }
@@ -537,16 +613,23 @@ def time_train_step(args, dev, rank, world):
     mod = mgr.loss.loss_classes["DenseContrastiveLossV2_ms"]
     extra = {"contrastive_loss_fwd_bwd_ms": round(loss_only_ms(mod, dev, args), 3),
              "metrics_in_step": not args.no_metrics,
-             # graph key of THIS repo (default off in models/HRNet.py; the reference has no such key): the logits stay
-             # at 1/4 resolution and up-sampling + cross-entropy / arg-max run in fused kernels.  --materialize-logits
-             # gives the reference's return value (a full-resolution logits tensor); worth ~0.8 ms of the step
-             "lazy_logits": not args.materialize_logits,
-             # second graph key of this repo (default off in the models): the projection heads' last 1x1 convolution is
-             # evaluated on the pixels the contrastive loss samples instead of as a full map (models/Projector.LazyProjection)
-             "lazy_projector": not getattr(args, "materialize_projector", False),
+             # what the manager resolved (the timed config itself holds reference keys only unless a --materialize-* /
+             # --plain-config flag wrote an explicit `false`): logits kept at 1/4 resolution for the fused up-sampling +
+             # cross-entropy / arg-max kernels
+             "lazy_logits": bool(mgr.config["graph"].get("lazy_logits", False)),
+             # the projection heads' last 1x1 convolution evaluated on the sampled pixels only (models/Projector.LazyProjection)
+             "lazy_projector": bool(mgr.config["graph"].get("lazy_projector", False)),
+             "fused_optimizer": bool(getattr(mgr.optimiser, "defaults", {}).get("fused", False)),
+             "config_keys_beyond_reference": sorted(set(opt_out_keys(args)) | set(fused_opt_key(args))),
              "model_dtype": "bf16-autocast" if args.amp else "f32",
              "memory_format": "channels_last" if args.channels_last else "contiguous",
              "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    if not getattr(args, "no_kernel_table", False) and world == 1:
+        from mscs_amd.utils.kernel_timer import KernelTimer
+        with KernelTimer() as kt:
+            step()
+            torch.cuda.synchronize()
+        extra["_kernel_rows"] = kt.rows()
     del mgr
     return dt, mod, extra
 
@@ -654,22 +737,34 @@ def main():
         if workload == "loss":
             out["roofline"] = roofline_bwd_kernel(mod)
         elif args.config != 2:
+            rows = extra.pop("_kernel_rows", None)
+            out.pop("_kernel_rows", None)
             out["roofline"] = roofline_gemm_kernel(args, dev)
             out["roofline_other"] = [roofline_bwd_kernel(mod)]
+            if rows:
+                tab = roofline_from_rows(rows, args)
+                out["roofline_other"] += [tab["roofline"]] + tab["roofline_other"][:4]
+                out["roofline_hbm"] = tab["roofline_hbm"]
         else:
-            out["roofline"], others = roofline_conv_kernels(args, dev)
-            out["roofline_other"] = others + [roofline_bwd_kernel(mod)]
+            rows = extra.pop("_kernel_rows", None)
+            head_main, head_others = roofline_conv_kernels(args, dev)
+            if rows:
+                out.update(roofline_from_rows(rows, args))
+                out["roofline_other"] += [head_main] + head_others[:1] + [roofline_bwd_kernel(mod)]
+            else:
+                out["roofline"] = head_main
+                out["roofline_other"] = head_others + [roofline_bwd_kernel(mod)]
+        out.pop("_kernel_rows", None)
         if not args.no_cpu_baseline and world == 1 and args.config == 2:    # host baseline: single-GPU headline run only
-            scale, lsec, cores, lsample = cpu_baseline_loss(args, n_terms)
-            loss_sec = lsec * scale
+            lsec, cores, lsample = cpu_baseline_loss(args)
             if workload == "loss":
-                out["cpu_baseline"] = {"value": round(1.0 / loss_sec, 5), "unit": unit, "cores": cores,
+                out["cpu_baseline"] = {"value": round(1.0 / lsec, 5), "unit": unit, "cores": cores,
                                        "kind": "port", "sample": lsample, "sample_seconds": round(lsec, 2)}
             else:
                 msec, msample = cpu_baseline_model(args)
-                step_sec = msec * args.batch + loss_sec
-                out["cpu_baseline"] = {"value": round(args.batch / step_sec, 5), "unit": unit, "cores": cores,
+                out["cpu_baseline"] = {"value": round(args.batch / (msec + lsec), 5), "unit": unit, "cores": cores,
                                        "kind": "port", "sample": msample + "; " + lsample,
+                                       "model_seconds": round(msec, 2), "loss_seconds": round(lsec, 2),
                                        "sample_seconds": round(msec + lsec, 2)}
         if args.eager_baseline:
             out["eager_gpu_loss_ms"] = round(eager_gpu_loss_ms(args, dev), 2)

@@ -29,6 +29,7 @@ SIGNATURES = {
     "dcl_rank_select": [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "dcl_gather_normalize": [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "dcl_gather_raw": [_vp, _i64, _i64, _i64, _i, _vp, _vp, _i, _i, _vp, _vp],
+    "dcl_scatter_raw": [_vp, _i64, _i64, _i64, _i, _vp, _vp, _i, _i, _vp, _vp],
     "dcl_infonce_fwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_infonce_zsweep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp],
     "dcl_infonce_possweep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -65,6 +66,7 @@ SIGNATURES = {
     "dcl_tapup_fwd": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "dcl_tapup_bwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_tapup_set_bwd_form": [_i],
+    "dcl_tapup_supported": [_i, _i, _i, _i, _i, _i, _i],
     "dcl_gemm_supported": [_i, _i, _i, _i64, _i, _i64, _i],
     "dcl_gemm_workspace_floats": [_i, _i, _i, _i],
     "dcl_gemm_suggest_splitk": [_i, _i, _i, _i],
@@ -112,6 +114,7 @@ SIGNATURES = {
     "dcl_upsample_ce_bwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "dcl_suggest_nsplit": [_i, _i],
     "dcl_version": [],
+    "dcl_trace_kernels": [_i],
 }
 
 
@@ -141,6 +144,8 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
         l.dcl_last_error.restype = ctypes.c_char_p
+        l.dcl_last_kernel.restype = ctypes.c_char_p
+        l.dcl_last_kernel.argtypes = []
         l.dcl_gemm_workspace_floats.restype = ctypes.c_int64
         l.dcl_bn_onepass_workspace_bytes.restype = ctypes.c_int64
         l.dcl_last_error.argtypes = []

@@ -99,6 +99,36 @@ extern "C" int dcl_gather_raw(const float *feat, int64_t stride_n, int64_t strid
     return 0;
 }
 
+// Adjoint of k_gather_raw: dfeat[b_t, c, pix[t, v]] = dX[t, c, v].  The sampled pixels of a scale are unique per image
+// and an (image, class) pair owns its pixels, so every address is written once: plain stores into the zero-filled map,
+// deterministic (autograd's index_put_(accumulate=True) of the [T, C, V] bank in the reference).
+__global__ __launch_bounds__(256) void k_scatter_raw(const float *__restrict__ dX, int64_t sn, int64_t sc, int64_t sp,
+                                                    int C, const int32_t *__restrict__ pix,
+                                                    const int32_t *__restrict__ pair_b, int V, int64_t total,
+                                                    float *__restrict__ dfeat)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total)
+        return;
+    const int v = (int)(e % V);
+    const int64_t tc = e / V;
+    const int c = (int)(tc % C);
+    const int t = (int)(tc / C);
+    dfeat[(int64_t)pair_b[t] * sn + (int64_t)c * sc + (int64_t)pix[(int64_t)t * V + v] * sp] = dX[e];
+}
+
+extern "C" int dcl_scatter_raw(const float *dX, int64_t stride_n, int64_t stride_c, int64_t stride_p, int C,
+                               const int32_t *pix, const int32_t *pair_b, int T, int V, float *dfeat, void *stream)
+{
+    DCL_CHECK_ARG(dX && pix && pair_b && dfeat, "null pointer");
+    DCL_CHECK_ARG(C > 0 && T > 0 && V > 0, "bad sizes");
+    const int64_t total = (int64_t)T * C * V;
+    hipLaunchKernelGGL(k_scatter_raw, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dX,
+                       stride_n, stride_c, stride_p, C, pix, pair_b, V, total, dfeat);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
 #define DCL_MAX_SLABS 64
 struct SlabList {
     const float *p[DCL_MAX_SLABS];

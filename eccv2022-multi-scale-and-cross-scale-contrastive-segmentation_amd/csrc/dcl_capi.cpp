@@ -15,6 +15,30 @@ void dcl_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *dcl_last_error(void) { return g_err; }
+
+// Which kernel symbol did the last convolution / weight-gradient entry point of this thread launch?  (The tile and variant
+// are chosen inside the library; bench.py's in-step kernel timer names its rows with this.)  Off unless switched on.
+static thread_local char g_kernel[160] = "";
+static int g_trace_kernels = 0;
+
+void dcl_note_kernel(const char *fmt, ...)
+{
+    if (!g_trace_kernels)
+        return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int dcl_trace_kernels(int on)
+{
+    g_trace_kernels = on ? 1 : 0;
+    g_kernel[0] = 0;
+    return 0;
+}
+
+extern "C" const char *dcl_last_kernel(void) { return g_kernel; }
 extern "C" int dcl_version(void) { return 1; }
 
 // Column splits for the sweep kernels: row blocks x splits workgroups should fill a whole

@@ -7,6 +7,7 @@
 #include "../../include/dcl_hip.h"
 
 void dcl_set_error(const char *fmt, ...);
+void dcl_note_kernel(const char *fmt, ...);     // dcl_capi.cpp: name of the kernel an entry point chose (dcl_trace_kernels)
 
 #define DCL_CHECK_ARG(cond, msg)                              \
     do {                                                      \

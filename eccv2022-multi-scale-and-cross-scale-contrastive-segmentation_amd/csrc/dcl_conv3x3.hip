@@ -908,10 +908,12 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
     if constexpr (S == 1) {
         if (a.phases) {
             hipLaunchKernelGGL((k_conv3x3_phases<R, P>), grid, dim3(256), 0, stream, a);
+            dcl_note_kernel("k_conv3x3_phases<%d,%d>", R, P);
             return 0;
         }
         if (a.onetap) {
             hipLaunchKernelGGL((k_conv1x1<R, P>), grid, dim3(256), 0, stream, a);
+            dcl_note_kernel("k_conv1x1<%d,%d>", R, P);
             return 0;
         }
     }
@@ -919,17 +921,26 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
         if (g_conv_interleave == 2 && (a.Cin & 15) == 0 && a.up == 1 && !a.phases && !a.onetap) {
             // (1, 4) waves, 2 x 2 per workgroup: the same 8 x 32 pixels x 64 channels per workgroup, same grid
             hipLaunchKernelGGL((k_conv3x3_il_ws2<1, 4>), grid, dim3(256), 0, stream, a);
+            dcl_note_kernel("k_conv3x3_il_ws2<1,4>");
         } else if (g_conv_interleave && (a.Cin & 15) == 0 && a.up == 1)
+        {
             hipLaunchKernelGGL((k_conv3x3_il_o2<R, P>), grid, dim3(256), 0, stream, a);
-        else
+            dcl_note_kernel("k_conv3x3_il_o2<%d,%d>", R, P);
+        } else {
             hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);
+            dcl_note_kernel("k_conv3x3_o2<%d,%d,%d>", R, P, S);
+        }
     } else if constexpr (S == 1) {
-        if (g_conv_interleave && (a.Cin & 15) == 0 && a.up == 1)
+        if (g_conv_interleave && (a.Cin & 15) == 0 && a.up == 1) {
             hipLaunchKernelGGL((k_conv3x3_il<R, P>), grid, dim3(256), 0, stream, a);
-        else
+            dcl_note_kernel("k_conv3x3_il<%d,%d>", R, P);
+        } else {
             hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
+            dcl_note_kernel("k_conv3x3<%d,%d,%d>", R, P, S);
+        }
     } else {
         hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
+        dcl_note_kernel("k_conv3x3<%d,%d,%d>", R, P, S);
     }
     return 0;
 }

@@ -748,10 +748,44 @@ extern "C" int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1, i
 
 static int g_tapup_bwd_form = 2;        // 2 = k_tapup_bwd_w (windowed horizontal pass), 1 = k_tapup_bwd
 
+static int tapup_bwd_impl(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
+                          float *dz, void *stream, bool query);
+
 extern "C" int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners,
                              int channel_major, float *dz, void *stream)
 {
     DCL_CHECK_ARG(dy && dz && N > 0 && Co > 0 && H > 0 && W > 0 && h > 0 && w > 0, "bad arguments");
+    return tapup_bwd_impl(dy, N, Co, H, W, h, w, align_corners, channel_major, dz, stream, false);
+}
+
+static size_t tapup_fwd_lds(const int *hs, const int *ws, int nsrc, int H, int W)
+{
+    size_t zfloats = 0;
+    for (int i = 0; i < nsrc; ++i)
+        zfloats += (size_t)9 * tap_window(hs[i], H, TAP_RC) * (tap_window(ws[i], W, TAP_TW) + 1);
+    return ((size_t)2 * (TAP_RC + 2) * 4 + zfloats) * sizeof(float);
+}
+
+// 1 when dcl_tapup_fwd(z0 [h0, w0], z1 [h1, w1] (h1 = 0: one source)) and dcl_tapup_bwd of each source fit their tiles for an
+// [H, W] output, else 0 -- asked BEFORE the step commits to the split form (models/ops.py conv3x3_over_upsampled falls back to
+// convolving the materialised concatenation), so that an oversized map cannot fail mid-step, possibly only in the backward.
+extern "C" int dcl_tapup_supported(int h0, int w0, int h1, int w1, int H, int W, int align_corners)
+{
+    if (h0 <= 0 || w0 <= 0 || H <= 0 || W <= 0 || h1 < 0 || w1 < 0)
+        return 0;
+    const int hs[2] = {h0, h1}, ws[2] = {w0, w1};
+    const int nsrc = (h1 > 0 && w1 > 0) ? 2 : 1;
+    if (tapup_fwd_lds(hs, ws, nsrc, H, W) > 64 * 1024)
+        return 0;
+    for (int i = 0; i < nsrc; ++i)
+        if (tapup_bwd_impl(nullptr, 1, 1, H, W, hs[i], ws[i], align_corners, 1, nullptr, nullptr, true) != 0)
+            return 0;
+    return 1;
+}
+
+static int tapup_bwd_impl(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
+                          float *dz, void *stream, bool query)
+{
     const Axis ay = make_axis(h, H, align_corners), ax = make_axis(w, W, align_corners);
     const int kxn = tap_footprint(w, W);
     int trl = TAP_TRL;
@@ -764,7 +798,7 @@ extern "C" int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h
     };
     while (trl > 1 && lds_for(trl) > 48 * 1024)
         trl >>= 1;
-    DCL_CHECK_ARG(lds_for(trl) <= 64 * 1024, "maps too wide for the tap-up backward tile (LDS)");
+    const bool form1_fits = lds_for(trl) <= 64 * 1024;      // (required below only if the windowed form is not taken)
     const int gr = rows_for(trl);
     const int tiles_r = (h + trl - 1) / trl;
     const long long blocks = (long long)N * Co * tiles_r;
@@ -790,6 +824,8 @@ extern "C" int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h
     const int ts = (nw4 + 1) | 1;
     const size_t lds2 = ((size_t)TAP_TRL * FR * 4 + (size_t)w * ts * 4 + (size_t)3 * TAP_TRL * WP + (size_t)w + TAP_TRL) * sizeof(float);
     if (g_tapup_bwd_form == 2 && nw4 >= 2 && nw4 <= 8 && lds2 <= 64 * 1024) {
+        if (query)
+            return 0;
         const int tiles2 = (h + TAP_TRL - 1) / TAP_TRL;
         const long long blocks2 = (long long)N * Co * tiles2;
         DCL_CHECK_ARG(blocks2 < (1LL << 31), "too many tiles");
@@ -811,6 +847,9 @@ extern "C" int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h
         DCL_LAUNCH_CHECK();
         return 0;
     }
+    if (query)
+        return form1_fits ? 0 : DCL_EUNSUPPORTED;
+    DCL_CHECK_ARG(form1_fits, "maps too wide for the tap-up backward tile (LDS)");
     hipLaunchKernelGGL(k_tapup_bwd, dim3((unsigned)blocks), dim3(256), lds_for(trl), (hipStream_t)stream, dy, Co, H, W, h, w, ay,
                        ax, trl, tiles_r, gr, kxn, dz, sn, sc);
     DCL_LAUNCH_CHECK();

@@ -692,6 +692,7 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     DCL_WG_CASE(2, 1)
     DCL_WG_CASE(1, 1)
 #undef DCL_WG_CASE
+    dcl_note_kernel("k_wgrad3x3<%d,%d,%s>", nco, nci, stride == 2 ? "true" : "false");
     DCL_LAUNCH_CHECK();
     const int total = 9 * Cout * Cin;
     (void)total;

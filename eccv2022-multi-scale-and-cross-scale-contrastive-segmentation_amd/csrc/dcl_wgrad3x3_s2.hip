@@ -390,4 +390,5 @@ void dcl_wgrad_s2_launch(const float *x, const float *dy, int N, int Cin, int Co
     DCL_S2_CASE(1, 2, true)
     DCL_S2_CASE(1, 1, true)
 #undef DCL_S2_CASE
+    dcl_note_kernel("k_wgrad3x3_s2<%d,%d>", p.nco, p.nci);
 }

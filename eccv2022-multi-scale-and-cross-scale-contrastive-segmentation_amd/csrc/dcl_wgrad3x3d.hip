@@ -845,6 +845,7 @@ void dcl_wgrad_dma_launch(const WgradArgs &a, int nco, int nci, dim3 grid, hipSt
 {
     if (a.wave_mode) {
         hipLaunchKernelGGL((k_wgrad3x3d<3, 1, true>), dim3(256), dim3(256), 0, s, a);
+        dcl_note_kernel("k_wgrad3x3d<3,1,true>");
         return;
     }
 #define DCL_WGD_CASE(o, i)       \
@@ -857,6 +858,7 @@ void dcl_wgrad_dma_launch(const WgradArgs &a, int nco, int nci, dim3 grid, hipSt
     DCL_WGD_CASE(2, 1)
     DCL_WGD_CASE(1, 1)
 #undef DCL_WGD_CASE
+    dcl_note_kernel("k_wgrad3x3d<%d,%d,false>", nco, nci);
 }
 
 extern "C" int dcl_wgrad1x1_splits(int N, int Cin, int Cout, int H, int W)
@@ -897,6 +899,7 @@ extern "C" int dcl_wgrad1x1_f16x3(const float *x, const float *dy, int N, int Ci
     DCL_W1_CASE(3, 4)
 #undef DCL_W1_ROW
 #undef DCL_W1_CASE
+    dcl_note_kernel("k_wgrad1x1d<%d,%d>", p.nco, p.nci);
     DCL_LAUNCH_CHECK();
     const int total = Cout * Cin;
     hipLaunchKernelGGL(k_slab_sum, dim3((total + 31) / 32), dim3(256), 0, s, part, p.nx, total, dw);

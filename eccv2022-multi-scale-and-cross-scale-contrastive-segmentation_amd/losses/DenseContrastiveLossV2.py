@@ -30,13 +30,13 @@ class _RawBank(torch.autograd.Function):
     def backward(ctx, dX):
         sc = ctx.sc
         shape, strides = ctx.meta
-        n, C, h, w = shape
-        d = torch.zeros((n, C, h * w), dtype=torch.float32, device=dX.device)
-        b = sc.pair_b.long()[:, None, None].expand(-1, C, sc.plan.V)
-        c = torch.arange(C, device=dX.device)[None, :, None].expand(sc.plan.T, -1, sc.plan.V)
-        p = sc.pix.long()[:, None, :].expand(-1, C, -1)
-        d.index_put_((b, c, p), dX.float(), accumulate=True)
-        return d.view(n, C, h, w), None
+        d = torch.empty_strided(shape, strides, dtype=torch.float32, device=dX.device).zero_()
+        sn, scs, sp = sc.strides
+        p = sc.plan
+        _lib.check(_lib.lib().dcl_scatter_raw(_lib.ptr(dX.float().contiguous()), sn, scs, sp, sc.C, _lib.ptr(sc.pix),
+                                              _lib.ptr(sc.pair_b), p.T, p.V, _lib.ptr(d), _stream_ptr()),
+                   "dcl_scatter_raw")
+        return d, None
 
 
 class DenseContrastiveLossV2(nn.Module):
@@ -92,6 +92,10 @@ class DenseContrastiveLossV2(nn.Module):
                      f'{self.max_views_per_class}, max_features_total={self.max_features_total})')
 
     def forward(self, label: torch.Tensor, features: torch.Tensor):
+        if self.cross_scale_contrast and hasattr(features, 'materialize'):
+            # (a LazyProjection from a model run with graph key lazy_projector: the 4-tuple below hands out the raw
+            # [T, C, V] bank gathered from the MAP, so the map is formed here)
+            features = features.materialize()
         terms, st = dense_contrast_terms(self.engine_config(weights=(1.0,)), label, [features])
         self.last_state = st
         sc = st.scales[0]

@@ -7,6 +7,7 @@ import torch.nn as nn
 from ..utils import DATASETS_INFO, is_distributed, printlog
 from .DenseContrastiveLossV2 import DenseContrastiveLossV2 as DCV2
 from .engine import PreSampleFailed, dense_contrast_terms, presample
+from .plan import NoQualifyingPair
 
 
 class DenseContrastiveLossV2_ms(nn.Module):
@@ -71,12 +72,16 @@ class DenseContrastiveLossV2_ms(nn.Module):
         try:
             self._staged = presample(self._engine_cfg(), label, geoms, bool(self.cross_scale_contrast),
                                      self._side_stream, ready_event=ready_event)
-        except Exception as e:  # noqa: BLE001 -- surfaces in forward(), see the docstring
-            self._staged = PreSampleFailed(e, label)
+        except NoQualifyingPair as e:          # data-dependent: surfaces in forward(), see the docstring.  Anything else
+            self._staged = PreSampleFailed(e, label)       # (a shape / ctypes / launch error) is a bug and raises HERE
         return True
 
     def discard_prepared(self):
-        """Drop what prepare() staged (the step turned out not to evaluate this loss)."""
+        """Drop what prepare() staged (the step turned out not to evaluate this loss).  A parked planning error is logged
+        before it goes: its randperm draws are spent, i.e. the run has left the reference's RNG sequence at this step."""
+        if isinstance(self._staged, PreSampleFailed):
+            printlog(f'DenseContrastiveLossV2_ms: dropping a planning error parked by prepare() for a step that does not '
+                     f'evaluate this loss: {self._staged.error}')
         self._staged = None
 
     def _engine_cfg(self):

@@ -23,6 +23,8 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from ..utils import printlog
+
 from .. import _lib
 from ..models import amax as _amax
 from .plan import HostPlan, build_host_plan, positive_ranges
@@ -445,6 +447,8 @@ def plan_and_sample(cfg: EngineConfig, label: torch.Tensor, feats: Sequence[torc
     if isinstance(staged, PreSampleFailed):
         if staged.key == _label_key(label):
             raise staged.error                       # planning of THIS step already failed in prepare()
+        printlog(f'dense contrastive loss: a planning error parked by prepare() belongs to another label tensor and is '
+                 f'dropped (its randperm draws are spent): {staged.error}')
         staged = None
     if isinstance(staged, PreSampled):
         pre, staged = staged, None

@@ -35,6 +35,13 @@ class HostPlan:
         return self.T * self.V
 
 
+
+class NoQualifyingPair(RuntimeError):
+    """No (image, class) pair reaches ``min_views_per_class`` at a scale: the one planning error that depends on the DATA
+    of a step (the reference dies in torch.min() of an empty tensor, losses/DenseContrastiveLossV2.py:110).  Its own type so
+    that ``DenseContrastiveLossV2_ms.prepare`` can defer exactly this error to forward() and let every other one surface."""
+
+
 def select_views_per_class(min_views: int, total_cls: int, max_views_per_class: int,
                            max_features_total: int):
     """``_select_views_per_class`` (DenseContrastiveLossV2.py:64-84) -> (V, log_this_step)."""
@@ -86,7 +93,7 @@ def build_host_plan(counts: np.ndarray, min_views_per_class: int, max_views_per_
     T = int(pb.shape[0])
     if T == 0:
         # the reference dies in torch.min() of an empty tensor (:110); say why instead
-        raise RuntimeError(
+        raise NoQualifyingPair(
             "DenseContrastiveLoss: no (image, class) pair has >= min_views_per_class="
             f"{min_views_per_class} pixels at this scale (reference: RuntimeError in torch.min, "
             "losses/DenseContrastiveLossV2.py:110)")

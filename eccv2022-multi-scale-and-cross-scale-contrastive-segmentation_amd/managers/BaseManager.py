@@ -139,6 +139,16 @@ class BaseManager:
     # ------------------------------------------------------------------ construction
     def load_model(self):
         graph = self.config['graph']
+        if self.config.get('mode') == 'training' and self.config.get('loss', {}).get('name') == 'LossWrapper' \
+                and self.config.get('cuda', False):
+            # This manager owns BOTH ends of the model's training outputs -- they go to this package's LossWrapper and
+            # metrics, nowhere else (forward_step) -- so a reference JSON config, which knows neither key, gets the fused
+            # consumers: the logits stay at 1/4 resolution (up-sampling + cross-entropy / arg-max in one kernel, models/ops.py
+            # UpsampledLogits) and the projection heads' last 1x1 convolution is evaluated on the sampled pixels only
+            # (models/Projector.LazyProjection).  Same losses and gradients (tests/test_hip_parity.py); a config that says
+            # `false` -- or code that calls the model classes directly -- gets the reference's tensors.
+            graph.setdefault('lazy_logits', True)
+            graph.setdefault('lazy_projector', True)
         model_class = getattr(_models, graph['model'])
         self.model = model_class(config=graph, experiment=self.experiment)
         self.return_features = getattr(self.model, 'projector_model', None) is not None \

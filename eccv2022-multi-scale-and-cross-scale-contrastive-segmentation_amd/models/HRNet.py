@@ -624,6 +624,8 @@ class HRNet(nn.Module):
         if self.projector_model is not None:
             # extension, default off: the heads' last 1x1 convolution is evaluated by the loss on the sampled pixels only
             self.projector_model.lazy = bool(config.get('lazy_projector', False))
+            # (training on the GPU) embedding maps written pixel-major, handed out with channels-last strides: models/ops.py _Conv1x1ToNHWC
+            self.projector_model.nhwc = bool(config.get('nhwc_projector', True))
         if config.get('fused_bn', True) and self.projector_model is not None:
             # the projector's norms as well (class switch: same parameters / buffers / state_dict keys); their outputs
             # and gradients then carry the absmax tags the projector's f16x3 1x1 convolutions need

@@ -93,9 +93,18 @@ class Projector(nn.Module):
         printlog(f'Projector head {c_in} -> {self.d} ({len(self.mlp)} hidden layer(s), bn={self.use_bn})')
         return nn.Sequential(*layers)
 
+    nhwc = True          # training on the GPU: the embedding maps are written pixel-major (channels-last strides, same shape
+                         # and values as the reference's tensor; models/ops.py _Conv1x1ToNHWC) -- what K3 / K6 gather / scatter
+
     def _run_head(self, head: nn.Sequential, x: torch.Tensor):
         if self.lazy and self.training and x.is_cuda and x.dtype == torch.float32:
             return LazyProjection(head[:-1](x), head[-1])
+        if self.nhwc and self.training and x.is_cuda and torch.is_grad_enabled():
+            from .ops import conv1x1_nhwc_supported, conv1x1_to_nhwc
+            hidden = head[:-1](x)
+            if conv1x1_nhwc_supported(hidden, head[-1]):
+                return conv1x1_to_nhwc(hidden, head[-1])
+            return head[-1](hidden)
         return head(x)
 
     def forward(self, x: Union[list, torch.Tensor]):

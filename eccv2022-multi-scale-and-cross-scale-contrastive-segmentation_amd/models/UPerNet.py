@@ -195,6 +195,8 @@ class UPerNet(nn.Module):
         self._get_projector()
         if self.projector_model is not None:
             self.projector_model.lazy = bool(self.config.get('lazy_projector', False))     # see models/Projector.LazyProjection
+            # (training on the GPU) embedding maps written pixel-major, handed out with channels-last strides: models/ops.py _Conv1x1ToNHWC
+            self.projector_model.nhwc = bool(self.config.get('nhwc_projector', True))
         # the FPN's / aux head's 3x3 convolutions on the direct split-f16 kernels (models/ops.py, fp32-equivalent);
         # same parameters and state_dict.  config['direct_conv'] = False keeps them on the library.
         self._conv_packs = None

@@ -918,6 +918,18 @@ def conv3x3_over_upsampled(ts, align_corners, weight, bias, min_scale=4):
     coarse = [t for t, f in zip(ts, is_fine) if not f]
     fine_ranges = tuple((o, o + t.shape[1]) for t, o, f in zip(ts, offs, is_fine) if f)
     coarse_offs = tuple(o for o, f in zip(offs, is_fine) if not f)
+    if coarse:
+        # the tap gather's tiles are sized by LDS: ask the library BEFORE committing to the split form (it would otherwise
+        # raise mid-step, for some shapes only in the backward) and convolve the materialised concatenation instead
+        from .. import _lib
+        L = _lib.lib()
+        for i in range(0, len(coarse), 2):
+            a = coarse[i]
+            b = coarse[i + 1] if i + 1 < len(coarse) else None
+            if not L.dcl_tapup_supported(a.shape[2], a.shape[3], b.shape[2] if b is not None else 0,
+                                         b.shape[3] if b is not None else 0, H, W, 1 if align_corners else 0):
+                x = LazyConcat(list(ts), align_corners).materialize()
+                return _Conv3x3Addend.apply(x, weight, bias, None)
     hi = upsample_concat(fine, align_corners) if len(fine) > 1 else t0
     if not coarse:
         return _Conv3x3Addend.apply(hi, weight, bias, None)
@@ -977,6 +989,81 @@ class _Conv1x1Gemm(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum((0, 2))
         return gx, gw, gb
+
+
+class _Conv1x1ToNHWC(torch.autograd.Function):
+    """The projection heads' last 1x1 convolution (reference models/Projector.py:56-63) with its output written PIXEL-MAJOR:
+    y[n, pix, :] = W x[n, :, pix] + b as one batched split-f16 GEMM per direction.  The result is handed out as the reference's
+    [n, d, h, w] tensor with channels-last strides (same shape, same values), so that the contrastive loss -- the only reader of
+    the embedding (reference losses/DenseContrastiveLossV2.py:113-124) -- gathers ONE contiguous 1-KiB row per sampled pixel
+    (K3) and scatters one per pixel in the backward (K6) instead of 256 strided 4-byte accesses (K3 FETCH_SIZE on the NCHW map:
+    294 MB per launch for 10 MB of rows, profiles/r03_loss_pmc_fetch.csv).  Backward: the gradient arrives in the same layout
+    (K6 writes the strides it was given); dx and dW are GEMMs over it, no layout copy in either direction."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wamax):
+        from .amax import amax_of
+        n, ci, h, w = x.shape
+        co = weight.shape[0]
+        hw = h * w
+        y = torch.empty((n, h, w, co), dtype=torch.float32, device=x.device)
+        gemm_f16x3(x, False, hw, weight, True, ci, hw, co, ci, y, co, amax_of(x), wamax, bias=bias, batch=n,
+                   strides=(ci * hw, 0, hw * co), splitk=1)
+        ctx.save_for_backward(x, weight, wamax)
+        ctx.has_bias = bias is not None
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .amax import amax_of, carry
+        x, weight, wamax = ctx.saved_tensors
+        n, ci, h, w = x.shape
+        co = weight.shape[0]
+        hw = h * w
+        g = carry(gy, gy.permute(0, 2, 3, 1))
+        if not g.is_contiguous():
+            g = g.contiguous()
+        ga = amax_of(g)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            gemm_f16x3(weight, False, ci, g, True, co, ci, hw, co, gx, hw, wamax, ga, batch=n,
+                       strides=(0, hw * co, ci * hw), splitk=1)
+        if ctx.needs_input_grad[1]:
+            part = torch.empty((n, co, ci), dtype=torch.float32, device=x.device)
+            gemm_f16x3(g, False, co, x, True, hw, co, ci, hw, part, ci, ga, amax_of(x), batch=n,
+                       strides=(hw * co, ci * hw, co * ci))
+            gw = (part.sum(0) if n > 1 else part[0]).view_as(weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.reshape(-1, co).sum(0)
+        return gx, gw, gb, None
+
+
+def conv1x1_nhwc_supported(x, conv):
+    """True when ``conv1x1_to_nhwc`` applies: a plain 1x1 convolution on a contiguous fp32 CUDA map whose three GEMM shapes the
+    split-f16 kernel takes."""
+    if not (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1):
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and conv.weight.dtype == torch.float32 and not torch.is_autocast_enabled()):
+        return False
+    n, ci, h, w = x.shape
+    co, hw = conv.out_channels, h * w
+    if max(ci, co) * hw * 4 >= (1 << 32):
+        return False
+    return (gemm_supported(hw, co, ci, hw, False, ci, True) and gemm_supported(ci, hw, co, ci, False, co, True)
+            and gemm_supported(co, ci, hw, co, False, hw, True))
+
+
+def conv1x1_to_nhwc(x, conv):
+    """conv(x) as an [n, d, h, w] tensor with channels-last strides (see _Conv1x1ToNHWC)."""
+    if isinstance(conv, DirectConv2d):
+        wamax = conv.packed_weights()[0]
+    else:
+        from .amax import amax_of
+        wamax = amax_of(conv.weight.detach())
+    return _Conv1x1ToNHWC.apply(x, conv.weight.view(conv.out_channels, -1), conv.bias, wamax)
 
 
 class GemmConv1x1(torch.nn.Conv2d):

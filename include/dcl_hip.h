@@ -42,6 +42,11 @@ extern "C" {
 
 const char *dcl_last_error(void);
 int dcl_version(void);
+/* Measurement aid (bench.py's in-step kernel timer): with dcl_trace_kernels(1) the convolution / weight-gradient entry
+ * points record the symbol of the kernel they chose (tile and variant are picked inside the library);
+ * dcl_last_kernel() returns the calling thread's last one ("" if none).  No effect on results; off by default. */
+int dcl_trace_kernels(int on);
+const char *dcl_last_kernel(void);
 
 /* ---- K1 ---------------------------------------------------------------------------------
  * Nearest down-sample of the label map to (h, w) = (H / scale, W / scale) and per-image class
@@ -96,6 +101,12 @@ int dcl_gather_normalize(const float *feat, int64_t stride_n, int64_t stride_c, 
 int dcl_gather_raw(const float *feat, int64_t stride_n, int64_t stride_c, int64_t stride_p, int C,
                    const int32_t *pix, const int32_t *pair_b, int T, int V, float *X,
                    void *stream);
+/* Its adjoint: dfeat[b_t, c, pix[t, v]] = dX[t, c, v] into a ZERO-FILLED map with the given element strides (every
+ * address written once: sampled pixels are unique per image within a scale) -- autograd's index backward of
+ * `features[b, :, idx]` (losses/DenseContrastiveLossV2.py:123) for the `sampled_features` a bare DenseContrastiveLossV2
+ * with cross_scale_contrast returns (:58-61). */
+int dcl_scatter_raw(const float *dX, int64_t stride_n, int64_t stride_c, int64_t stride_p, int C,
+                    const int32_t *pix, const int32_t *pair_b, int T, int V, float *dfeat, void *stream);
 
 /* ---- K4 ---------------------------------------------------------------------------------
  * Fused similarity + masked InfoNCE forward; the N1 x N2 matrix is never materialised.
@@ -292,6 +303,9 @@ int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, in
 /* tuning hook: 2 (default) = windowed horizontal pass (k_tapup_bwd_w), 1 = the first form (also the fallback for column
  * windows beyond 8 float4s). */
 int dcl_tapup_set_bwd_form(int form);
+/* 1 when dcl_tapup_fwd on the sources [h0, w0] (+ [h1, w1]; h1 = 0: one source) and dcl_tapup_bwd of each fit their LDS tiles for
+ * an [H, W] output, else 0: asked before a step commits to the split head (no failure mid-step / only in the backward). */
+int dcl_tapup_supported(int h0, int w0, int h1, int w1, int H, int W, int align_corners);
 
 /* ---- one-kernel batch-norm backward (csrc/dcl_bn_onepass.hip) -------------------------------------------------------
  * dcl_bn_bwd_reduce_part + dcl_bn_bwd_apply_fused of a single-rank norm in ONE launch that reads dy and x once: 256 persistent

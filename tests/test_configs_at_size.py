@@ -38,10 +38,10 @@ def dev():
 def _dense_term(Fa, ca, Fb, cb, tau, intra):
     """One InfoNCE term exactly as the reference writes it (masks as float matrices, no max-shift)."""
     S = (Fa @ Fb.T) / tau
-    pos = (ca[:, None] == cb[None, :]).float()
+    pos = (ca[:, None] == cb[None, :]).to(Fa.dtype)
     neg = 1 - pos
     if intra:
-        pos = pos * (1 - torch.eye(Fa.shape[0], device=Fa.device))
+        pos = pos * (1 - torch.eye(Fa.shape[0], device=Fa.device, dtype=Fa.dtype))
     E = torch.exp(S)
     Z = (E * neg).sum(1, keepdim=True)
     logp = S - torch.log(E + Z)
@@ -50,7 +50,7 @@ def _dense_term(Fa, ca, Fb, cb, tau, intra):
     return -((pos * logp).sum(1) / Pn).mean()
 
 
-def _run_case(dev, case, mfma, S, cross, weights):
+def _run_case(dev, case, mfma, S, cross, weights, ref_dtype=torch.float32):
     from mscs_amd.losses import DenseContrastiveLossV2_ms
     dataset, K, n, H, W, expect = CASES[case]
     C = 256
@@ -69,7 +69,7 @@ def _run_case(dev, case, mfma, S, cross, weights):
     assert [(sc.plan.T, sc.plan.V) for sc in st.scales] == expect[:S]
 
     # ---- dense fp32 evaluation from the same pixels, through torch indexing and autograd
-    ref_feats = [f.detach().clone().requires_grad_(True) for f in feats]
+    ref_feats = [f.detach().to(ref_dtype).requires_grad_(True) for f in feats]
     banks, classes = [], []
     for s, sc in enumerate(st.scales):
         stride = strides[s]
@@ -96,7 +96,7 @@ def _run_case(dev, case, mfma, S, cross, weights):
         if scale == 0:                          # a scale no weighted term touches (cross-scale-only weights)
             assert g.abs().max().item() == 0
             continue
-        err = (g - r).abs().max().item()
+        err = (g.to(r.dtype) - r).abs().max().item()
         assert err <= GRAD_ATOL_REL * scale, (case, s, err, scale)
         assert torch.equal(g != 0, r != 0) or ((g != 0) & (r == 0)).sum().item() == 0     # support = sampled pixels
     return mod
@@ -112,6 +112,13 @@ def test_config_at_size_four_scales_with_cross(dev, case, mfma):
 def test_config2_three_scales(dev):
     """BASELINE configs[1] as worded ("3 scales"): the workload bench.py times."""
     _run_case(dev, "cfg2_hrnet_cts_n12", "f16x3", 3, True, [1.0, 0.7, 0.4])
+
+
+def test_config2_three_scales_against_fp64(dev):
+    """The same workload against the dense evaluation in FLOAT64 (N x N = 770 MB per matrix at N = 9 804): a comparator
+    that shares no fp32 GEMM rounding with anything -- the fp32 variants above run the reference formulas through the
+    library's fp32 GEMM.  Same tolerances (they are the kernels' bars, not the comparator's)."""
+    _run_case(dev, "cfg2_hrnet_cts_n12", "f16x3", 3, True, [1.0, 0.7, 0.4], ref_dtype=torch.float64)
 
 
 def test_config5_cross_scale_only_weights(dev):

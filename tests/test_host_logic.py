@@ -26,8 +26,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert len(names) >= 11
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/dcl_hip.h but not exported"
-    # and the ctypes table binds exactly the declared entry points (dcl_last_error bound separately)
-    assert set(_lib.SIGNATURES) | {"dcl_last_error"} == set(names)
+    # and the ctypes table binds exactly the declared entry points (dcl_last_error, dcl_last_kernel: char * results, bound separately)
+    assert set(_lib.SIGNATURES) | {"dcl_last_error", "dcl_last_kernel"} == set(names)
 
 
 def test_suggest_nsplit_is_sane():
@@ -135,3 +135,16 @@ def test_native_rng_equals_torch_randperm_and_keeps_stream(seed):
     torch.set_rng_state(st)
     d = build_host_plan(big, 5, 2500, 10000, native_rng=True)
     np.testing.assert_array_equal(c.sel, d.sel)
+
+
+def test_tapup_support_query_needs_no_gpu():
+    """dcl_tapup_supported: pure host arithmetic (LDS tile sizes of the tap gather, forward and both backward forms) -- the
+    benchmark's head shapes fit, an absurdly wide map does not (the caller then convolves the materialised concatenation)."""
+    from mscs_amd import _lib
+    L = _lib.lib()
+    for ac in (0, 1):
+        assert L.dcl_tapup_supported(32, 64, 16, 32, 128, 256, ac) == 1          # HRNet-W48 head, 512 x 1024 input
+        assert L.dcl_tapup_supported(16, 16, 32, 32, 128, 128, ac) == 1          # UPerNet fusion, 512 x 512
+        assert L.dcl_tapup_supported(20, 20, 0, 0, 160, 160, ac) == 1            # Swin-L at 640 x 640, one source
+        assert L.dcl_tapup_supported(64, 16384, 0, 0, 256, 65536, ac) == 0
+    assert L.dcl_tapup_supported(0, 4, 0, 0, 8, 8, 0) == 0
