@@ -268,15 +268,15 @@ PMC_STEP_SOURCE = "profiles/r04_step_pmc.csv"
 
 def roofline_from_rows(rows, args):
     """`roofline` = the matrix-pipe kernel SYMBOL with the largest share of one step, time-weighted over all its launches
-    (sum of algorithmic FLOPs / sum of in-step HIP-event durations); `roofline_other` = the next symbols; `roofline_hbm` = the
-    streaming kernels (K1 / K2 / K3 / K6 and the batch-norm family) against the HBM peak.  One extra step after the timed
-    region, events on every launch stream (mscs_amd/utils/kernel_timer.py)."""
+    (sum of algorithmic FLOPs / sum of HIP-event durations); `roofline_other` = the next symbols; `roofline_hbm` = the
+    streaming kernels (K1 / K2 / K3 / K6 and the batch-norm family) against the HBM peak.  One extra, SERIALISED step after the
+    timed region (every launch on one stream, so an event pair holds one kernel: mscs_amd/utils/kernel_timer.py)."""
     total_ms = sum(r["total_ms"] for r in rows)
 
     def entry(r):
         top = sorted(r["shapes"].items(), key=lambda kv: -kv[1][1])[:4]
-        e = {"bound": r["bound"], "kernel": f"{r['kernel']} ({r['entry']}): all {r['calls']} launches of one training step, "
-                                            f"time-weighted",
+        e = {"bound": r["bound"], "kernel": f"{r['kernel']} ({r['entry']}): all {r['calls']} launches of one training step "
+                                            f"(serialised replay), time-weighted",
              "achieved": round(r["achieved"], 2), "peak": round(r["peak"], 1), "unit": r["unit"], "frac": round(r["frac"], 4),
              "launches": r["calls"], "launch_ms": round(r["total_ms"] / r["calls"], 4), "step_ms": round(r["total_ms"], 3),
              "share_of_timed_kernels": round(r["total_ms"] / total_ms, 4),
@@ -625,10 +625,25 @@ def time_train_step(args, dev, rank, world):
              "memory_format": "channels_last" if args.channels_last else "contiguous",
              "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     if not getattr(args, "no_kernel_table", False) and world == 1:
+        # ONE more step, serialised: every launch on the main stream (no branch streams, no side stream in the head's backward),
+        # so that the two HIP events around a launch bracket that kernel and nothing else -- with one stream per branch an event
+        # pair also counts the time the launch waits for CUs held by the other streams' kernels (measured: 165 us per weight-
+        # gradient launch against 87 us in rocprofv3's trace of the same step).  Same kernels, shapes, tiles and data as the timed
+        # steps; the per-kernel durations of the timed (multi-stream) schedule are in profiles/r04_step_kernels.csv.
         from mscs_amd.utils.kernel_timer import KernelTimer
-        with KernelTimer() as kt:
-            step()
+        import importlib
+        _hr = importlib.import_module("mscs_amd.models.HRNet")     # (the module: the package re-exports the class under this name)
+        from mscs_amd.debug import cfg as _dbg
+        keep = (_hr._BRANCH_STREAMS, _dbg.head_overlap)
+        _hr._BRANCH_STREAMS, _dbg.head_overlap = False, 0
+        try:
+            step()                                   # (allocator / stream state settles)
             torch.cuda.synchronize()
+            with KernelTimer() as kt:
+                step()
+                torch.cuda.synchronize()
+        finally:
+            _hr._BRANCH_STREAMS, _dbg.head_overlap = keep
         extra["_kernel_rows"] = kt.rows()
     del mgr
     return dt, mod, extra
