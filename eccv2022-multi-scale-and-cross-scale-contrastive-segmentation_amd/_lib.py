@@ -51,6 +51,11 @@ SIGNATURES = {
     "dcl_bn_stats_part": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "dcl_bn_apply_fused": [_vp, _vp, _vp, ctypes.c_double, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                            _vp, _vp, _vp],
+    "dcl_bn_apply_parts": [_vp, _vp, _vp, _i, ctypes.c_double, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                           _vp, _vp, _vp],
+    "dcl_bn_compact_parts": [_vp, _i, _i, _vp, _vp],
+    "dcl_conv3x3_bnstats_tiles": [_i, _i, _i, _i, _i],
+    "dcl_conv3x3_bnstats_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_bwd_reduce_part": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "dcl_bn_bwd_apply_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp,
                                _vp, _vp, _vp],

@@ -74,6 +74,13 @@ struct ConvArgs {
     int tiles_x, tiles_y, nchunk, groups;
     int phases;                     // 1: data gradient of a stride-2 convolution, one output parity class per workgroup
     int onetap;                     // 1: 1x1 convolution (weights packed with one tap)
+    // batch-norm statistics of the OUTPUT in the epilogue (ST instantiations; dcl_conv3x3_bnstats_f16x3): per pixel tile and
+    // channel the sums of (y - pivot) and (y - pivot)^2 over the tile's valid pixels, part[(c * ntile + tile) * 2 + {0, 1}] --
+    // the layout dcl_bn_apply_parts combines in its prologue (k_bn_stats' partial sums with one "slice" per pixel tile)
+    float *stat_part;
+    const float *stat_pivot;        // [Cout] shift of the sums (the norm layer's running mean)
+    float *stat_pivot_out;          // [Cout] copy of the pivot actually used (the running mean is updated by the apply kernel)
+    int stat_ntile;                 // pixel tiles of the launch = tiles_x * tiles_y * N
 };
 
 constexpr float F16_TARGET = 16384.0f;      // operands are scaled so that their absmax lands in (2^13, 2^14]
@@ -147,9 +154,18 @@ __device__ __forceinline__ void static_for(F &&f)
 // P rows x R tiles).  For the 48 / 64-channel layers -- three or four K chunks, tile (R, P) = (2, 2) -- every wave
 // streaming BOTH channel tiles' weight fragments is 1 KiB from L1 per ~3 MFMAs and wave, 85 B / clk at two workgroups per
 // CU against the L1's 64: the (1, 4) wave of WS = 2 does the same 108 MFMAs per chunk on half the fragments.
-template <int R, int P, int S, int MODE = 0, bool IL = false, int WS = 1>
+// ST ("statistics"): the epilogue also reduces the tile's outputs to per-channel sums for the batch norm that follows the
+// convolution (reference models/HRNet.py:77-93: conv -> bn), so that the norm needs no statistics pass over y
+// (k_bn_stats: 309 launches and 3.7 ms of a W48 step).  The accumulator layout has the 32 pixels of a tile row across the
+// lanes and 16 channels in the registers, so after the in-lane sums over the wave's P rows the 16 per-channel values of a
+// lane half are reduced ACROSS its 32 lanes by a transposing butterfly: at each of the first four steps a lane keeps half
+// of its values and adds the partner lane's copy of exactly those (16 -> 8 -> 4 -> 2 -> 1 values: 15 + 1 shuffles per
+// quantity instead of 16 x 5), leaving channel slot li / 2 in lane li; the workgroup's waves that share channels are
+// combined through LDS in wave order.  Fixed order everywhere: bitwise reproducible.
+template <int R, int P, int S, int MODE = 0, bool IL = false, int WS = 1, bool ST = false>
 __device__ __forceinline__ void conv_body(const ConvArgs &a)
 {
+    static_assert(!ST || (S == 1 && MODE == 0), "epilogue statistics: stride-1 3x3 tiles");
     constexpr bool PH = MODE == 1, T1 = MODE == 2;
     constexpr int WR = 4 / WS;                    // waves along the rows
     static_assert(WS == 1 || (WS == 2 && IL), "wave split: interleaved stride-1 tiles only");
@@ -628,6 +644,77 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
                 }
             }
         }
+    if constexpr (ST) {
+        // red[wave][r][slot = 16 h + li / 2][2]
+        float *red = (float *)lds;
+        __syncthreads();                                    // every wave has left the patch buffers
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int cob = (T0 + r) * 32 + 4 * h;
+            float s1[16], s2[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ch = cob + (q & 3) + 8 * (q >> 2);
+                const bool chok = ch < a.Cout;
+                const float pv = a.stat_pivot[chok ? ch : a.Cout - 1];
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int row = y0 + P * wrow + p;
+                    const float v = (chok && row < a.Ho && col < a.Wo) ? acc[r][p][q] * inv - pv : 0.f;
+                    t1 += v;
+                    t2 += v * v;
+                }
+                s1[q] = t1;
+                s2[q] = t2;
+            }
+            // transposing butterfly over the 32 lanes of this half: step with lane bit b (16, 8, 4, 2) pairs value k with
+            // value k + n / 2 -- the lane keeps the one its bit selects and adds the partner's copy of it
+#pragma unroll
+            for (int n = 16, b = 16; n > 1; n >>= 1, b >>= 1) {
+                const bool up = (li & b) != 0;
+#pragma unroll
+                for (int k = 0; k < n / 2; ++k) {
+                    const float keep1 = up ? s1[k + n / 2] : s1[k], send1 = up ? s1[k] : s1[k + n / 2];
+                    const float keep2 = up ? s2[k + n / 2] : s2[k], send2 = up ? s2[k] : s2[k + n / 2];
+                    s1[k] = keep1 + __shfl_xor(send1, b, 64);
+                    s2[k] = keep2 + __shfl_xor(send2, b, 64);
+                }
+            }
+            s1[0] += __shfl_xor(s1[0], 1, 64);
+            s2[0] += __shfl_xor(s2[0], 1, 64);
+            // lane li now holds register slot q = li >> 1 of its half: bit 4 of li chose q bit 3, ..., bit 1 chose q bit 0
+            if (!(li & 1)) {
+                float *o = red + ((wave * R + r) * 32 + 16 * h + (li >> 1)) * 2;
+                o[0] = s1[0];
+                o[1] = s2[0];
+            }
+        }
+        __syncthreads();
+        // one thread per (channel group of this workgroup, tile r, slot): the waves that share the channels, in wave order
+        constexpr int NG = WS;                              // channel groups per workgroup (WS = 2: waves w % 2)
+        if (tid < NG * R * 32) {
+            const int g = tid / (R * 32), rs = tid - g * (R * 32), r = rs >> 5, slot = rs & 31;
+            const int hh = slot >> 4, q = slot & 15;
+            const int ch = ((cg * WS + g) * R + r) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+            if (ch < a.Cout) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < WR; ++wv) {
+                    const int w2 = wv * WS + g;              // wave = wrow * WS + (wave % WS)
+                    const float *o = red + ((w2 * R + r) * 32 + slot) * 2;
+                    t1 += o[0];
+                    t2 += o[1];
+                }
+                const int tile = (n * a.tiles_y + ty) * a.tiles_x + tx;
+                float *o = a.stat_part + ((size_t)ch * a.stat_ntile + tile) * 2;
+                o[0] = t1;
+                o[1] = t2;
+                if (tile == 0 && a.stat_pivot_out)
+                    a.stat_pivot_out[ch] = a.stat_pivot[ch];
+            }
+        }
+    }
 }
 
 template <int R, int P, int S>
@@ -653,6 +740,19 @@ template <int R, int P>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_il_ws2(ConvArgs a)
 {
     conv_body<R, P, 1, 0, true, 2>(a);
+}
+
+// the same two kernels with the batch-norm statistics of the output in the epilogue (conv_body, ST)
+template <int R, int P>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_il_st(ConvArgs a)
+{
+    conv_body<R, P, 1, 0, true, 1, true>(a);
+}
+
+template <int R, int P>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_il_ws2_st(ConvArgs a)
+{
+    conv_body<R, P, 1, 0, true, 2, true>(a);
 }
 
 template <int R, int P>
@@ -905,6 +1005,26 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
     const int mtiles = (a.Cout + 31) / 32;
     a.groups = (mtiles + R - 1) / R;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.groups * (a.phases ? 4 : 1)));
+    if (a.stat_part) {
+        // epilogue statistics: the interleaved stride-1 tiles of the BasicBlock shapes ((3, P) and the wave-split (2, 2) tile)
+        a.stat_ntile = a.tiles_x * a.tiles_y * a.N;
+        const bool plain = S == 1 && !a.phases && !a.onetap && (a.Cin & 15) == 0 && a.up == 1;
+        if constexpr (S == 1 && R == 3) {
+            if (plain && g_conv_interleave) {
+                hipLaunchKernelGGL((k_conv3x3_il_st<R, P>), grid, dim3(256), 0, stream, a);
+                dcl_note_kernel("k_conv3x3_il_st<%d,%d>", R, P);
+                return 0;
+            }
+        }
+        if constexpr (S == 1 && R == 2 && P == 2) {
+            if (plain && g_conv_interleave == 2) {
+                hipLaunchKernelGGL((k_conv3x3_il_ws2_st<1, 4>), grid, dim3(256), 0, stream, a);
+                dcl_note_kernel("k_conv3x3_il_ws2_st<1,4>");
+                return 0;
+            }
+        }
+        return DCL_EUNSUPPORTED;
+    }
     if constexpr (S == 1) {
         if (a.phases) {
             hipLaunchKernelGGL((k_conv3x3_phases<R, P>), grid, dim3(256), 0, stream, a);
@@ -960,9 +1080,42 @@ extern "C" int dcl_conv3x3_set_up2_phases(int on)
     return 0;
 }
 
+struct ConvStats {
+    const float *pivot;
+    float *part, *pivot_out;
+};
 static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout, const float *xamax,
                       int xcount, const float *wamax, const float *addend, const float *bias, float *y, int stride,
-                      int in_up, int Hout, int Wout, int tile_r, int tile_p, int onetap, void *stream);
+                      int in_up, int Hout, int Wout, int tile_r, int tile_p, int onetap, void *stream,
+                      const ConvStats *stats = nullptr);
+static void auto_tile(int N, int Cout, int Ho, int Wo, int nchunk, int stride, int phases, int onetap, int tile_r, int tile_p,
+                      int &R, int &P);
+static bool stats_tile(int R, int P, int Cin) { return (Cin & 15) == 0 && ((R == 3 && g_conv_interleave) || (R == 2 && P == 2 && g_conv_interleave == 2)); }
+
+// Pixel tiles (= partial sums per channel) of dcl_conv3x3_bnstats_f16x3 on this shape, 0 = no kernel with epilogue
+// statistics for it (the caller runs dcl_conv3x3_f16x3 and the norm's own statistics pass).
+extern "C" int dcl_conv3x3_bnstats_tiles(int N, int Cin, int Cout, int H, int W)
+{
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
+        return 0;
+    int R, P;
+    auto_tile(N, Cout, H, W, (Cin + 15) / 16, 1, 0, 0, 0, 0, R, P);
+    if (!stats_tile(R, P, Cin))
+        return 0;
+    const int WRP = (R == 2 && P == 2) ? 8 : 4 * P;          // rows per workgroup (the (2, 2) tile runs as 2 x 2 waves of (1, 4))
+    return ((W + TW - 1) / TW) * ((H + WRP - 1) / WRP) * N;
+}
+
+extern "C" int dcl_conv3x3_bnstats_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
+                                         const float *xamax, int xcount, const float *wamax, const float *addend,
+                                         const float *bias, float *y, const float *pivot, float *part, float *pivot_out,
+                                         void *stream)
+{
+    DCL_CHECK_ARG(pivot && part && pivot_out, "null statistics pointer");
+    DCL_CHECK_ARG(dcl_conv3x3_bnstats_tiles(N, Cin, Cout, H, W) > 0, "no epilogue-statistics kernel for this shape");
+    const ConvStats st{pivot, part, pivot_out};
+    return conv_f16x3(x, N, Cin, H, W, wp, Cout, xamax, xcount, wamax, addend, bias, y, 1, 1, H, W, 0, 0, 0, stream, &st);
+}
 
 extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
                                  const float *xamax, int xcount, const float *wamax, const float *addend,
@@ -981,9 +1134,44 @@ extern "C" int dcl_conv1x1_f16x3(const float *x, int N, int Cin, int H, int W, c
                       stream);
 }
 
+static void auto_tile(int N, int Cout, int Ho, int Wo, int nchunk, int stride, int phases, int onetap, int tile_r, int tile_p,
+                      int &R, int &P)
+{
+    const int mtiles = (Cout + 31) / 32;
+    R = tile_r, P = tile_p;
+    if (stride == 2)
+        P = 1;
+    if (R <= 0 || P <= 0 || (stride == 2 && tile_r <= 0)) {
+        // measured on the four BasicBlock shapes of HRNet-W48 at batch 12 (tools/bench_conv3x3.py --tiles):
+        // channel tiles per wave in threes when that leaves no padded tile, else pairs; the most rows per wave
+        // that still give ~one workgroup per CU; tiny images fall back to single-tile waves to get enough
+        // workgroups.
+        R = (mtiles % 3 == 0 || mtiles >= 20) ? 3 : (mtiles == 1 ? 1 : 2);     // >= 20 tiles: one padded tile is < 5 %
+        if (mtiles == 5 && stride == 1 && !onetap)
+            R = 3;      // five tiles pad to six either way, and the (3, P) wave runs 324 P / 4 MFMAs per staged chunk against 216:
+                        // the head's 720 -> 144 data gradient (45 chunks), (2, 4) tile 4.17 ms = 0.21 of the roofline
+        auto wgs = [&](int r, int p) {
+            if (phases)
+                return (long)(((Wo + 1) / 2 + TW - 1) / TW) * (((Ho + 1) / 2 + 4 * p - 1) / (4 * p)) * N *
+                       ((mtiles + r - 1) / r) * 4;
+            return (long)((Wo + TW - 1) / TW) * ((Ho + 4 * p - 1) / (4 * p)) * N * ((mtiles + r - 1) / r);
+        };
+        P = stride == 2 ? 1 : 4;
+        while (P > 1 && wgs(R, P) < g_conv_min_wgs)
+            P >>= 1;
+        if (R == 2 && P == 4 && stride == 1 && !phases && nchunk <= 4)
+            P = 2;              // the (2, 2) tile runs two workgroups per CU (k_conv3x3_o2): 81 vs 100 us at 48 channels;
+                                // a short K loop is mostly prologue / epilogue, which two co-resident workgroups
+                                // hide.  With a long one (the 512-channel decoder convolutions of UPerNet) the (2, 4)
+                                // tile's reuse of the weight fragments wins: 415 vs 386 TFLOP/s
+        if (P == 1 && wgs(R, P) < 128)
+            R = 1;
+    }
+}
+
 static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout, const float *xamax,
                       int xcount, const float *wamax, const float *addend, const float *bias, float *y, int stride,
-                      int in_up, int Hout, int Wout, int tile_r, int tile_p, int onetap, void *stream)
+                      int in_up, int Hout, int Wout, int tile_r, int tile_p, int onetap, void *stream, const ConvStats *stats)
 {
     DCL_CHECK_ARG(x && wp && xamax && wamax && y, "null pointer");
     DCL_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && xcount > 0, "bad shape");
@@ -1029,39 +1217,21 @@ static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *
     a.Wo = a.phases ? Wout : (stride == 2 ? (a.W - 1) / 2 + 1 : a.W);
     DCL_CHECK_ARG((Hout <= 0 || Hout == a.Ho) && (Wout <= 0 || Wout == a.Wo), "Hout / Wout do not match the geometry");
     a.nchunk = (Cin + 15) / 16;
-    const int mtiles = (Cout + 31) / 32;
-    int R = tile_r, P = tile_p;
-    if (stride == 2)
-        P = 1;
-    if (R <= 0 || P <= 0 || (stride == 2 && tile_r <= 0)) {
-        // measured on the four BasicBlock shapes of HRNet-W48 at batch 12 (tools/bench_conv3x3.py --tiles):
-        // channel tiles per wave in threes when that leaves no padded tile, else pairs; the most rows per wave
-        // that still give ~one workgroup per CU; tiny images fall back to single-tile waves to get enough
-        // workgroups.
-        R = (mtiles % 3 == 0 || mtiles >= 20) ? 3 : (mtiles == 1 ? 1 : 2);     // >= 20 tiles: one padded tile is < 5 %
-        auto wgs = [&](int r, int p) {
-            if (a.phases)
-                return (long)(((a.Wo + 1) / 2 + TW - 1) / TW) * (((a.Ho + 1) / 2 + 4 * p - 1) / (4 * p)) * N *
-                       ((mtiles + r - 1) / r) * 4;
-            return (long)((a.Wo + TW - 1) / TW) * ((a.Ho + 4 * p - 1) / (4 * p)) * N * ((mtiles + r - 1) / r);
-        };
-        P = stride == 2 ? 1 : 4;
-        while (P > 1 && wgs(R, P) < g_conv_min_wgs)
-            P >>= 1;
-        if (R == 2 && P == 4 && stride == 1 && !a.phases && a.nchunk <= 4)
-            P = 2;              // the (2, 2) tile runs two workgroups per CU (k_conv3x3_o2): 81 vs 100 us at 48 channels;
-                                // a short K loop is mostly prologue / epilogue, which two co-resident workgroups
-                                // hide.  With a long one (the 512-channel decoder convolutions of UPerNet) the (2, 4)
-                                // tile's reuse of the weight fragments wins: 415 vs 386 TFLOP/s
-        if (P == 1 && wgs(R, P) < 128)
-            R = 1;
-    }
+    int R, P;
+    auto_tile(N, Cout, a.Ho, a.Wo, a.nchunk, stride, a.phases, onetap, tile_r, tile_p, R, P);
+    a.stat_part = stats ? stats->part : nullptr;
+    a.stat_pivot = stats ? stats->pivot : nullptr;
+    a.stat_pivot_out = stats ? stats->pivot_out : nullptr;
+    a.stat_ntile = 0;
     hipStream_t s = (hipStream_t)stream;
-#define DCL_CONV_CASE(r, p, st)                \
-    if (R == r && P == p && stride == st) {    \
-        launch_conv<r, p, st>(a, s);           \
-        DCL_LAUNCH_CHECK();                    \
-        return 0;                              \
+#define DCL_CONV_CASE(r, p, st)                                                                              \
+    if (R == r && P == p && stride == st) {                                                                  \
+        if (launch_conv<r, p, st>(a, s) != 0) {                                                              \
+            dcl_set_error("dcl_conv3x3: no epilogue-statistics kernel for tile (%d, %d), stride %d", r, p, st); \
+            return DCL_EUNSUPPORTED;                                                                         \
+        }                                                                                                    \
+        DCL_LAUNCH_CHECK();                                                                                  \
+        return 0;                                                                                            \
     }
     DCL_CONV_CASE(1, 1, 1)
     DCL_CONV_CASE(1, 2, 1)

@@ -32,6 +32,7 @@ class DebugConfig:
     fuse_order: bool = field(default_factory=lambda: _flag('DCL_FUSE_ORDER'))                   # stride-2 chains last
     fanout: bool = field(default_factory=lambda: _flag('DCL_FANOUT'))                           # one-kernel gradient sums
     upsample_tag: bool = field(default_factory=lambda: _flag('DCL_UPSAMPLE_TAG'))               # absmax tags of up-sampled maps
+    conv_bn_stats: bool = field(default_factory=lambda: _flag('DCL_CONV_BN_STATS'))              # BN statistics in the conv epilogue
     packed_relu_mask: bool = field(default_factory=lambda: _flag('DCL_BN_MASK'))                # packed sign mask in the BN backward
     bn_onepass: bool = field(default_factory=lambda: _flag('DCL_BN_ONEPASS', False))            # one-kernel BN backward (default stream);
     # OFF by default: its teams of persistent workgroups wait for members that the branch streams' kernels keep off the CUs

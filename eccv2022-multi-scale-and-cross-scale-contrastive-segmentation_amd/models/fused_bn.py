@@ -53,39 +53,53 @@ def _check_equal_batch(n, device):
 class _FusedBNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, sync, amax,
-                token=None):
+                token=None, pre=None):
         ctx.token = token
         L = _lib.lib()
         N, C, H, W = x.shape
         HW = H * W
         dev = x.device
-        ns = L.dcl_bn_num_slices(N, C)
         st = _stream()
         world = _world() if sync else 1
         count = float(N * HW * world)
-        # one workspace: [part C*ns*2 | mean C | invstd C | pivot C]; the per-slice partial sums are combined in the
-        # prologue of the apply kernel (no combine / finalize launches); SyncBatchNorm = all-reduce of `part` in
-        # between.  The sums are shifted by the running mean (identical on every rank) against cancellation.
-        ws = torch.empty((C * ns * 2 + 3 * C,), dtype=torch.float32, device=dev)
-        part, mean, invstd = ws[:C * ns * 2], ws[C * ns * 2:C * ns * 2 + C], ws[C * ns * 2 + C:C * ns * 2 + 2 * C]
-        pivot = ws[C * ns * 2 + 2 * C:]
-        _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(running_mean), _lib.ptr(pivot),
-                                       st), "dcl_bn_stats_part")
-        if world > 1:
-            import torch.distributed as dist
-            _check_equal_batch(N, dev)
-            _all_reduce(part)
+        if pre is not None:
+            # partial sums from the epilogue of the convolution that produced x (models/ops.py conv3x3_launch_bnstats): one
+            # per pixel tile of that launch, same shift (the running mean) -- no statistics pass over x
+            part, ns, pivot = pre
+            ws = torch.empty((2 * C,), dtype=torch.float32, device=dev)
+            mean, invstd = ws[:C], ws[C:]
+            if world > 1:
+                # SyncBatchNorm: 2 floats per channel cross the ranks (fixed-order sums of the tiles)
+                _check_equal_batch(N, dev)
+                one = torch.empty((C * 2,), dtype=torch.float32, device=dev)
+                _lib.check(L.dcl_bn_compact_parts(_lib.ptr(part), C, ns, _lib.ptr(one), st), "dcl_bn_compact_parts")
+                _all_reduce(one)
+                part, ns = one, 1
+        else:
+            ns = L.dcl_bn_num_slices(N, C)
+            # one workspace: [part C*ns*2 | mean C | invstd C | pivot C]; the per-slice partial sums are combined in the
+            # prologue of the apply kernel (no combine / finalize launches); SyncBatchNorm = all-reduce of `part` in
+            # between.  The sums are shifted by the running mean (identical on every rank) against cancellation.
+            ws = torch.empty((C * ns * 2 + 3 * C,), dtype=torch.float32, device=dev)
+            part, mean, invstd = ws[:C * ns * 2], ws[C * ns * 2:C * ns * 2 + C], ws[C * ns * 2 + C:C * ns * 2 + 2 * C]
+            pivot = ws[C * ns * 2 + 2 * C:]
+            _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(running_mean), _lib.ptr(pivot),
+                                           st), "dcl_bn_stats_part")
+            if world > 1:
+                import torch.distributed as dist
+                _check_equal_batch(N, dev)
+                _all_reduce(part)
         y = torch.empty_like(x)
         # The backward needs y only for the ReLU mask.  Without a residual it recomputes y > 0 from x (one tensor less
         # to read, twice); with one, the apply kernel packs the sign bits (1/32 of y) and the backward reads those.
         need_y = relu and res is not None
         mask = torch.empty(N * C * HW // 64, dtype=torch.int64, device=dev) if need_y and HW % 256 == 0 and _PACKED_RELU_MASK else None
-        _lib.check(L.dcl_bn_apply_fused(_lib.ptr(x), _lib.ptr(res), _lib.ptr(part), count, eps, momentum,
+        _lib.check(L.dcl_bn_apply_parts(_lib.ptr(x), _lib.ptr(res), _lib.ptr(part), ns, count, eps, momentum,
                                         _lib.ptr(weight), _lib.ptr(bias), N, C, HW, 1 if relu else 0, _lib.ptr(y),
                                         _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(running_mean),
                                         _lib.ptr(running_var), _lib.ptr(nbt), _lib.ptr(amax), _lib.ptr(pivot),
                                         _lib.ptr(mask), st),
-                   "dcl_bn_apply_fused")
+                   "dcl_bn_apply_parts")
         ctx.save_for_backward(x, (mask if mask is not None else y) if need_y else None, weight, bias, mean, invstd)
         ctx.packed_mask = mask is not None
         ctx.relu, ctx.world, ctx.count = relu, world, count
@@ -125,7 +139,7 @@ class _FusedBNFunction(torch.autograd.Function):
                 _amax.tag(dx, amax)
             if ctx.token is not None:
                 ctx.token.dres, dres = dres, None
-            return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+            return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
         _lib.check(L.dcl_bn_bwd_reduce_part(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), N, C, HW, relu,
                                             _lib.ptr(part), st), "dcl_bn_bwd_reduce_part")
@@ -150,7 +164,7 @@ class _FusedBNFunction(torch.autograd.Function):
         if ctx.token is not None:
             # the residual's gradient travels through the token to the convolution that shares the input
             ctx.token.dres, dres = dres, None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 ONEPASS = _dbg.bn_onepass         # one-kernel backward on the default stream (DCL_BN_ONEPASS=0: the two-kernel form)
@@ -379,14 +393,27 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 and (residual is None or (residual.shape == x.shape and residual.is_contiguous()
                                           and residual.dtype == torch.float32)))
 
+    def takes_conv_stats(self, x):
+        """True when this norm, applied to the output of a convolution of ``x``'s kind, can take its partial sums from that
+        convolution's epilogue: the fused training path, and not the stacked SyncBatchNorm schedule of several ranks (whose
+        members run dcl_bn_stats_part into one exchange buffer, _FusedBNGroupFunction)."""
+        return (self.training and self.affine and self.track_running_stats and self.momentum is not None
+                and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and not (FORCE_GROUP or (self.sync and _world() > 1 and _dbg.coalesced_sync_bn)))
+
     def forward(self, x, residual=None, relu=False, grad_token=None):
         if self._fusable(x, residual):
             # partial max|y| side output (64 slots) for the f16x3 convolutions that consume y (models/amax.py)
             amax = _amax.zeros(_amax.SLOTS, x.device) if self.emit_amax else None
+            pre = getattr(x, '_dcl_bnstats', None)
+            if pre is not None:
+                # (version of x when the convolution wrote it, part, tiles, pivot copy, the running mean the sums are shifted by)
+                ok = pre[0] == x._version and pre[4] == self.running_mean.data_ptr() and pre[1].device == x.device
+                pre = pre[1:4] if ok else None
             y = _FusedBNFunction.apply(x, residual, self.weight, self.bias, self.running_mean,
                                        self.running_var, self.num_batches_tracked, float(self.eps),
                                        float(self.momentum), bool(relu), bool(self.sync), amax,
-                                       grad_token if residual is not None else None)
+                                       grad_token if residual is not None else None, pre)
             return _amax.tag(y, amax) if amax is not None else y
         if self.sync and self.training and _world() > 1:
             # convert_sync_batchnorm only flips the flag of a FusedBatchNorm2d: nn.BatchNorm2d.forward below would

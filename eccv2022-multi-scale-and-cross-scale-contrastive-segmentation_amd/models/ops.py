@@ -326,6 +326,31 @@ def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0, addend=No
     return out
 
 
+def conv3x3_bnstats_tiles(x, cout):
+    """Pixel tiles of the epilogue-statistics form of the 3x3 / stride-1 convolution on x (0 = not available for the shape)."""
+    from .. import _lib
+    n, c, h, w = x.shape
+    return int(_lib.lib().dcl_conv3x3_bnstats_tiles(n, c, cout, h, w))
+
+
+def conv3x3_launch_bnstats(x, wp, cout, xamax, wamax, out, pivot, ntile, addend=None, bias=None):
+    """conv3x3_launch (stride 1) whose epilogue also leaves the batch-norm partial sums of ``out``: returns (part f32
+    [cout * ntile * 2], pivot_out f32 [cout]) for ``dcl_bn_apply_parts(ns=ntile)`` -- the norm behind the convolution then
+    runs without its statistics pass (csrc/dcl_conv3x3.hip conv_body ST; reference models/HRNet.py:77-93 conv -> bn)."""
+    from .. import _lib
+    n, c, h, w = x.shape
+    ws = torch.empty((cout * ntile * 2 + cout,), dtype=torch.float32, device=x.device)
+    part, pivot_out = ws[:cout * ntile * 2], ws[cout * ntile * 2:]
+    _lib.check(_lib.lib().dcl_conv3x3_bnstats_f16x3(_lib.ptr(x), n, c, h, w, _lib.ptr(wp), cout, _lib.ptr(xamax),
+                                                    xamax.numel(), _lib.ptr(wamax), _lib.ptr(addend), _lib.ptr(bias),
+                                                    _lib.ptr(out), _lib.ptr(pivot), _lib.ptr(part), _lib.ptr(pivot_out),
+                                                    _stream(x)), "dcl_conv3x3_bnstats_f16x3")
+    return part, pivot_out
+
+
+CONV_BN_STATS = _dbg.conv_bn_stats       # batch-norm statistics in the producing convolution's epilogue (DCL_CONV_BN_STATS=0: off)
+
+
 class GradToken:
     """Carries the gradient of a residual connection from the norm layer that produces it (``bn(y, residual=x,
     grad_token=tok)`` stores it here instead of handing it to autograd) to the convolution that also consumes x
@@ -396,7 +421,7 @@ class _Conv3x3Direct(torch.autograd.Function):
     of 16: ATen / MIOpen)."""
 
     @staticmethod
-    def forward(ctx, x, weight, mod, token=None, bias=None):
+    def forward(ctx, x, weight, mod, token=None, bias=None, stats_for=None):
         from .amax import amax_of
         ctx.token = token
         ctx.has_bias = bias is not None
@@ -417,7 +442,15 @@ class _Conv3x3Direct(torch.autograd.Function):
         elif k1:
             conv1x1_launch(x, wp, weight.shape[0], amax_of(x), wamax, out, bias=bias)
         else:
-            conv3x3_launch(x, wp, weight.shape[0], amax_of(x), wamax, out, stride=st, bias=bias)
+            ntile = conv3x3_bnstats_tiles(x, weight.shape[0]) if (stats_for is not None and st == 1) else 0
+            if ntile > 0:
+                # the norm layer behind this convolution gets its partial sums from the epilogue (handed over by the module:
+                # DirectConv2d.forward tags the output)
+                part, pivot = conv3x3_launch_bnstats(x, wp, weight.shape[0], amax_of(x), wamax, out,
+                                                     stats_for.running_mean, ntile, bias=bias)
+                mod._bnstats = (part, ntile, pivot, stats_for.running_mean.data_ptr())
+            else:
+                conv3x3_launch(x, wp, weight.shape[0], amax_of(x), wamax, out, stride=st, bias=bias)
         ctx.save_for_backward(x, weight)
         ctx.mod = mod
         return out
@@ -477,7 +510,7 @@ class _Conv3x3Direct(torch.autograd.Function):
                 gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [st, st], [1, 1], [1, 1], False,
                                                          [0, 0], 1, [False, True, False])[1]
         gb = gy.sum((0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
-        return gx, gw, None, None, gb
+        return gx, gw, None, None, gb, None
 
 
 class DirectConv2d(torch.nn.Conv2d):
@@ -505,9 +538,18 @@ class DirectConv2d(torch.nn.Conv2d):
             self._packed = cache
         return cache[1], cache[2], cache[3]
 
-    def forward(self, x, grad_token=None):
+    def forward(self, x, grad_token=None, stats_for=None):
+        """``stats_for``: the FusedBatchNorm2d that consumes the result next (training, one rank): the convolution's epilogue
+        then leaves the norm's partial sums and the output carries them (``_dcl_bnstats``) -- no statistics pass over y."""
         if self.eligible(x):
-            return _Conv3x3Direct.apply(x, self.weight, self, grad_token, self.bias)
+            if stats_for is not None and not (CONV_BN_STATS and stats_for.takes_conv_stats(x)):
+                stats_for = None
+            self._bnstats = None
+            out = _Conv3x3Direct.apply(x, self.weight, self, grad_token, self.bias, stats_for)
+            got, self._bnstats = self._bnstats, None
+            if got is not None:
+                out._dcl_bnstats = (out._version,) + got
+            return out
         return super().forward(x)
 
     def fuses_residual_grad(self, x):
@@ -1007,7 +1049,10 @@ class _Conv1x1ToNHWC(torch.autograd.Function):
         co = weight.shape[0]
         hw = h * w
         y = torch.empty((n, h, w, co), dtype=torch.float32, device=x.device)
-        gemm_f16x3(x, False, hw, weight, True, ci, hw, co, ci, y, co, amax_of(x), wamax, bias=bias, batch=n,
+        # both operands with the contraction index (the input channels) OUTERMOST: a ragged K (48 channels = 1.5 k-steps) is
+        # only legal for row-contiguous operands, so the (tiny) weight goes in transposed, [ci, co]
+        wt = weight.t().contiguous()
+        gemm_f16x3(x, False, hw, wt, False, co, hw, co, ci, y, co, amax_of(x), wamax, bias=bias, batch=n,
                    strides=(ci * hw, 0, hw * co), splitk=1)
         ctx.save_for_backward(x, weight, wamax)
         ctx.has_bias = bias is not None
@@ -1052,7 +1097,7 @@ def conv1x1_nhwc_supported(x, conv):
     co, hw = conv.out_channels, h * w
     if max(ci, co) * hw * 4 >= (1 << 32):
         return False
-    return (gemm_supported(hw, co, ci, hw, False, ci, True) and gemm_supported(ci, hw, co, ci, False, co, True)
+    return (gemm_supported(hw, co, ci, hw, False, co, False) and gemm_supported(ci, hw, co, ci, False, co, True)
             and gemm_supported(co, ci, hw, co, False, hw, True))
 
 

@@ -37,6 +37,12 @@ def _conv3x3(a):
     return flops, byts, f"{n}x({ci}->{co})x{h}x{w}" + (" s2" if stride == 2 else "") + (" s2-dgrad" if in_up == 2 else "")
 
 
+def _conv3x3_bnstats(a):
+    # (x, N, Cin, H, W, wp, Cout, xamax, xcount, wamax, addend, bias, y, pivot, part, pivot_out, stream): stride 1
+    n, ci, h, w, co = a[1], a[2], a[3], a[4], a[6]
+    return 2.0 * n * co * ci * 9 * h * w, 4.0 * n * (ci + co) * h * w, f"{n}x({ci}->{co})x{h}x{w} +bn-stats"
+
+
 def _conv1x1(a):
     n, ci, h, w, co = a[1], a[2], a[3], a[4], a[6]
     return 2.0 * n * co * ci * h * w, 4.0 * n * (ci + co) * h * w + (4.0 * n * co * h * w if a[10] else 0.0), \
@@ -75,6 +81,11 @@ def _bn_stats(a):           # (x, N, C, HW, ...): one read of x
 
 def _bn_apply(a):           # (x, res, part, count, eps, momentum, gamma, beta, N, C, HW, relu, y, ...): read x (+ res), write y
     n, c, hw = a[8], a[9], a[10]
+    return 0.0, 4.0 * n * c * hw * (3 if a[1] else 2), f"{n}x{c}x{hw}"
+
+
+def _bn_apply_parts(a):     # (x, res, part, ns, count, eps, momentum, gamma, beta, N, C, HW, relu, y, ...)
+    n, c, hw = a[9], a[10], a[11]
     return 0.0, 4.0 * n * c * hw * (3 if a[1] else 2), f"{n}x{c}x{hw}"
 
 
@@ -123,6 +134,7 @@ def _upsample_bwd(a):       # (dy, planes, h, w, H, W, ...)
 # entry point -> (work model, bound, fixed kernel symbol or None = ask dcl_last_kernel)
 MODELS = {
     "dcl_conv3x3_f16x3": (_conv3x3, "mfma", None),
+    "dcl_conv3x3_bnstats_f16x3": (_conv3x3_bnstats, "mfma", None),
     "dcl_conv1x1_f16x3": (_conv1x1, "mfma", None),
     "dcl_wgrad3x3_f16x3": (_wgrad3x3, "mfma", None),
     "dcl_wgrad1x1_f16x3": (_wgrad1x1, "mfma", None),
@@ -132,6 +144,7 @@ MODELS = {
     "dcl_infonce_bwd": (_sweep(4.0), "mfma", "k_sweep<MODE_BWD>"),
     "dcl_bn_stats_part": (_bn_stats, "hbm", "k_bn_stats"),
     "dcl_bn_apply_fused": (_bn_apply, "hbm", "k_bn_apply"),
+    "dcl_bn_apply_parts": (_bn_apply_parts, "hbm", "k_bn_apply"),
     "dcl_bn_bwd_reduce_part": (_bn_bwd_reduce, "hbm", "k_bn_bwd_reduce"),
     "dcl_bn_bwd_apply_fused": (_bn_bwd_apply, "hbm", "k_bn_bwd_apply"),
     "dcl_gather_normalize": (_gather, "hbm", "k_gather_normalize"),
@@ -171,6 +184,8 @@ class KernelTimer:
             flops, byts, shape = model(a)
             if name == "dcl_bn_apply_fused":
                 sym = f"k_bn_apply<{'true' if a[11] else 'false'},{'true' if a[1] else 'false'}>"
+            elif name == "dcl_bn_apply_parts":
+                sym = f"k_bn_apply<{'true' if a[12] else 'false'},{'true' if a[1] else 'false'}>"
             elif name in ("dcl_bn_bwd_reduce_part", "dcl_bn_bwd_apply_fused"):
                 sym = f"{fixed}<{'true' if a[10 if name == 'dcl_bn_bwd_reduce_part' else 13] else 'false'}>"
             calls.append((name, sym, flops, byts, shape, e0, e1))

@@ -263,6 +263,16 @@ int dcl_bn_apply_fused(const float *x, const float *res, const float *part, doub
                        void *stream);
 /* relu = 2 in the two backward calls: `y` is the packed mask dcl_bn_apply_fused wrote (1/32 of y's size), not y
  * itself -- what the backward of a norm + residual + ReLU needs from y is only y > 0. */
+/* dcl_bn_apply_fused with an explicit number `ns` of partial sums per channel, part f32 [C][ns][2], from any producer: the
+ * epilogue of the convolution in front of the norm (dcl_conv3x3_bnstats_f16x3, ns = dcl_conv3x3_bnstats_tiles(...): the
+ * statistics pass over the convolution's output disappears; reference models/HRNet.py:77-93 conv -> bn) or
+ * dcl_bn_compact_parts (ns = 1).  ns > 64: the workgroup's threads share the prologue's sum (fixed order). */
+int dcl_bn_apply_parts(const float *x, const float *res, const float *part, int ns, double count, float eps, float momentum,
+                       const float *gamma, const float *beta, int N, int C, int HW, int relu, float *y, float *mean,
+                       float *invstd, float *running_mean, float *running_var, int64_t *batches_tracked,
+                       float *amax, const float *pivot, void *relu_mask, void *stream);
+/* out f32 [C][2] = fixed-order (double) sums of part f32 [C][ns][2]: SyncBatchNorm exchanges 2 floats per channel */
+int dcl_bn_compact_parts(const float *part, int C, int ns, float *out, void *stream);
 int dcl_bn_bwd_reduce_part(const float *dy, const float *x, const float *y, const float *mean, const float *invstd,
                            const float *gamma, const float *beta, int N, int C, int HW, int relu, float *part,
                            void *stream);
@@ -392,6 +402,18 @@ int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored inp
                                    the data gradient of a stride-2 convolution (stride must be 1) */,
                       int Hout, int Wout /* output size (checked; required for in_up = 2, may be 0 otherwise) */,
                       int tile_r, int tile_p, void *stream);
+/* The same convolution (stride 1, automatic tile) with the batch-norm statistics of its OUTPUT reduced in the epilogue: per
+ * pixel tile t and output channel c, part[(c * ntile + t) * 2 + {0, 1}] = sum over the tile's pixels of (y - pivot[c]),
+ * (y - pivot[c])^2 -- the partial sums dcl_bn_apply_parts(ns = ntile) combines, so the norm that follows the convolution
+ * (reference models/HRNet.py:77-93) needs no statistics pass over y.  ntile = dcl_conv3x3_bnstats_tiles(N, Cin, Cout, H, W);
+ * 0 = no such kernel for the shape (Cin % 16 != 0, or a tile other than the BasicBlock tiles): use dcl_conv3x3_f16x3 +
+ * dcl_bn_stats_part.  pivot f32 [Cout]: the norm's running mean; pivot_out f32 [Cout] receives a copy (the apply kernel
+ * updates the running mean).  Fixed summation order: bitwise reproducible. */
+int dcl_conv3x3_bnstats_tiles(int N, int Cin, int Cout, int H, int W);
+int dcl_conv3x3_bnstats_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
+                              const float *xamax, int xcount, const float *wamax, const float *addend,
+                              const float *bias, float *y, const float *pivot, float *part, float *pivot_out,
+                              void *stream);
 
 /* tuning hook: in_up = 2 (data gradient of a stride-2 convolution) -- 1 (default): every workgroup computes one parity
  * class of the output pixels with the 1, 2 or 4 taps that class sees; 0: stride-1 tile over the zero-inserted input */
