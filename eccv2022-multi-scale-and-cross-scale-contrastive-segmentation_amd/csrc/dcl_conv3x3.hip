@@ -240,7 +240,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
             sx = gx >> 1;
             ok = ok && sy < a.Hs && sx < a.Ws;
         }
-        loff[m] = pix * PIXB + oct * 16;
+        // stride 2: the columns of a patch row are stored de-interleaved, [33 even | 32 odd] -- tap kx of output column li
+        // reads patch column 2 li + kx, i.e. consecutive lanes read consecutive records of ONE parity plane (80-byte stride:
+        // conflict-free, like stride 1) instead of every second record (160-byte stride: 2-way bank conflicts)
+        const int cs = S == 2 ? ((c & 1) ? (LW + 1) / 2 + (c >> 1) : (c >> 1)) : c;
+        loff[m] = (r * LW + cs) * PIXB + oct * 16;
         goff[m] = ok ? sy * a.Ws + sx : 0;
         gok[m] = ok;
     }
@@ -594,7 +598,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
                 for (int p = 0; p < P; ++p)
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
-                        const unsigned char *bp = cur + (brow + (S * p + ky) * LW + kx) * PIXB + h * 16;
+                        const int cslot = kx == 1 ? (LW + 1) / 2 + li : li + (kx >> 1);      // de-interleaved columns, see loff
+                        const unsigned char *bp = cur + ((S * P * wrow + S * p + ky) * LW + cslot) * PIXB + h * 16;
                         const half8 bh = *(const half8 *)bp;
                         const half8 bl = *(const half8 *)(bp + 32);
 #pragma unroll

@@ -32,7 +32,12 @@ class DebugConfig:
     fuse_order: bool = field(default_factory=lambda: _flag('DCL_FUSE_ORDER'))                   # stride-2 chains last
     fanout: bool = field(default_factory=lambda: _flag('DCL_FANOUT'))                           # one-kernel gradient sums
     upsample_tag: bool = field(default_factory=lambda: _flag('DCL_UPSAMPLE_TAG'))               # absmax tags of up-sampled maps
-    conv_bn_stats: bool = field(default_factory=lambda: _flag('DCL_CONV_BN_STATS'))              # BN statistics in the conv epilogue
+    conv_bn_stats: bool = field(default_factory=lambda: _flag('DCL_CONV_BN_STATS', False))       # BN statistics in the conv epilogue:
+    # OFF by default.  Built and parity-tested (csrc/dcl_conv3x3.hip ST, tests/test_dropin_paths.py); it removes 208 k_bn_stats
+    # launches and 2.3 ms of their kernel time from a W48 step and costs ~0.7 ms in the convolution epilogues and the apply
+    # kernels' wider prologue -- and the step gets SLOWER, 91.1-91.3 against 90.5-90.7 ms (alternating runs on one box,
+    # gpurun_out/r4c): the statistics pass is an HBM-bound kernel that overlaps the other branches' matrix kernels, the epilogue
+    # work sits inside the matrix kernels that bound the step
     packed_relu_mask: bool = field(default_factory=lambda: _flag('DCL_BN_MASK'))                # packed sign mask in the BN backward
     bn_onepass: bool = field(default_factory=lambda: _flag('DCL_BN_ONEPASS', False))            # one-kernel BN backward (default stream);
     # OFF by default: its teams of persistent workgroups wait for members that the branch streams' kernels keep off the CUs
@@ -42,6 +47,8 @@ class DebugConfig:
     # gradient accumulated by the library GEMM (beta = 1)
     gemm_conv1x1_addend: bool = field(default_factory=lambda: _flag('DCL_GEMM_CONV1X1_ADDEND', False))  # ... with the residual
     # gradient as C += -- OFF: 467 us per launch on layer 1's 256-channel gradients against 372 for the tile kernel's fused addend
+    head_dx_splitk: int = field(default_factory=lambda: 1 if _int('DCL_HEAD_DX_SPLITK') is None else _int('DCL_HEAD_DX_SPLITK'))  # k-splits of the
+    # head's coarse data-gradient GEMM [C_b x 6480] . [6480 x P] (0 = the library's plan)
     gemm_head_taps: bool = field(default_factory=lambda: _flag('DCL_GEMM_HEAD'))                # the head's tap products on it
     head_overlap: int = field(default_factory=lambda: 2 if _int('DCL_HEAD_OVERLAP') is None else _int('DCL_HEAD_OVERLAP'))  # coarse half of the head's
     # backward on a side stream: 0 off, 1 on, 2 on with the fine part's weight gradient first (A/B: 96.4 / 96.0 / 95.6 ms)

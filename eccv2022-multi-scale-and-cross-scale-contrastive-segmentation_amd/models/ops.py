@@ -773,7 +773,7 @@ class _CoarseTaps(torch.autograd.Function):
                 if ctx.needs_input_grad[5 + i]:
                     gxc = torch.empty((cb, P), dtype=torch.float32, device=dy.device)
                     # dx_b [C_b, P] = W_b^T dz: both operands row-contiguous (the contraction 9 Co = 6480 may be ragged)
-                    gemm_f16x3(wb, False, cb, dz, False, P, cb, P, 9 * Co, gxc, P, wam, dzam, splitk=1)
+                    gemm_f16x3(wb, False, cb, dz, False, P, cb, P, 9 * Co, gxc, P, wam, dzam, splitk=_dbg.head_dx_splitk)
                     gx = gxc.view(cb, n, h, w).transpose(0, 1).contiguous()
                 if gw is not None:
                     gwb = torch.empty((9 * Co, cb), dtype=torch.float32, device=dy.device)

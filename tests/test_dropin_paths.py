@@ -281,8 +281,10 @@ def test_head_split_falls_back_when_the_tap_gather_does_not_fit(dev, monkeypatch
         assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item()
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 48, 24, 64), (3, 96, 96, 19, 40), (2, 64, 80, 16, 32), (12, 192, 192, 32, 64),
-                                   (2, 384, 384, 16, 32), (1, 48, 48, 7, 33)],
+# (n, Cin, Cout, H, W): shapes whose automatic tile is one of the BasicBlock tiles (the epilogue-statistics kernels): the four
+# branch shapes at a reduced batch, ragged rows / columns (H, W not multiples of the tile) and a ragged last channel tile
+@pytest.mark.parametrize("shape", [(4, 48, 48, 128, 256), (6, 96, 96, 61, 100), (12, 192, 192, 32, 64), (12, 384, 384, 16, 32),
+                                   (12, 96, 80, 64, 120), (3, 48, 48, 99, 250)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_conv_epilogue_batchnorm_statistics(dev, shape):
     """dcl_conv3x3_bnstats_f16x3: the per-tile partial sums of (y - pivot), (y - pivot)^2 the convolution's epilogue leaves
@@ -319,7 +321,7 @@ def test_conv_epilogue_batchnorm_statistics(dev, shape):
     assert ((got[:, 1] - s2).abs() <= 2e-6 * s2 + 1e-12).all(), ((got[:, 1] - s2).abs() / s2).max().item()
 
 
-@pytest.mark.parametrize("ch,hw", [(48, (32, 64)), (96, (19, 40)), (192, (16, 32))])
+@pytest.mark.parametrize("ch,hw", [(48, (128, 256)), (96, (61, 104)), (192, (32, 64))])
 def test_basic_block_with_epilogue_statistics_equals_the_two_pass_norm(dev, ch, hw):
     """BasicBlock (conv -> bn -> relu -> conv -> bn -> + identity -> relu, reference models/HRNet.py:77-93) in training mode
     with the norms' statistics taken from the convolutions' epilogues against the same block with the norms' own
@@ -331,8 +333,9 @@ def test_basic_block_with_epilogue_statistics_equals_the_two_pass_norm(dev, ch, 
     from mscs_amd.models.fused_bn import FusedBatchNorm2d
     from mscs_amd.utils.kernel_timer import KernelTimer
     gen = torch.Generator().manual_seed(0)
-    x0 = torch.randn(4, ch, *hw, generator=gen).to(dev)
-    up = torch.randn(4, ch, *hw, generator=gen).to(dev)
+    nb = 4 if ch == 48 else 12
+    x0 = torch.randn(nb, ch, *hw, generator=gen).to(dev)
+    up = torch.randn(nb, ch, *hw, generator=gen).to(dev)
     res = {}
     for on in (False, True):
         torch.manual_seed(0)
