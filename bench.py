@@ -355,7 +355,7 @@ def roofline_bwd_kernel(mod, iters=10):
     ns = int(L.dcl_suggest_nsplit(N, N))
     G = int(L.dcl_infonce_bwd_streamk_workgroups(N, N)) if A.bank_h is not None else 0
     if G > 0:        # what the step runs in f16x3 mode: the stream-K partition (finished tiles, no slabs)
-        dout = torch.empty((Npad, 256), device=dev)
+        dout = torch.empty((int(L.dcl_infonce_bwd_streamk_slabs(N, N)), Npad, 256), device=dev)
         ws = torch.empty((G, 128, 256), device=dev)
         flags = torch.zeros(G + 1, dtype=torch.int32, device=dev)
 

@@ -37,6 +37,8 @@ SIGNATURES = {
     "dcl_infonce_prep_stats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
     "dcl_infonce_bwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "dcl_infonce_bwd_streamk_workgroups": [_i, _i],
+    "dcl_infonce_bwd_streamk_slabs": [_i, _i],
+    "dcl_infonce_set_streamk_slices": [_i],
     "dcl_infonce_set_streamk": [_i],
     "dcl_infonce_set_streamk_timeout_ms": [_i],
     "dcl_infonce_bwd_streamk": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -71,6 +71,7 @@ struct SweepArgs {
     int *sk_flags;         // [gridDim.x + 1]: flags[g] == sk_seq: workgroup g's partial tile of THIS launch is in sk_ws (any other
                            // value = not yet: stale values of earlier or aborted launches never match); flags[gridDim.x] = error
                            // word (number of hand-overs that timed out, ever; never reset by the kernel)
+    int sk_nslice;         // 1 | 4 | 8 column slices (see k_sweep, SK): slice s writes its own finished slab dpart[s][N1pad][CP]
     int sk_seq;            // launch number of this (flags, workspace) pair, never 0 (host: dcl_infonce_bwd_streamk)
     long long sk_timeout;  // s_memrealtime ticks (100 MHz) an owner waits for one partial tile before it gives up
     int sk_probe;          // timing probe (dcl_infonce_set_streamk(2)): no flag traffic, no waiting -- WRONG results
@@ -183,12 +184,33 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
     // in SGPRs; the other instantiations keep the code they were tuned with)
     const int wave = SK ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     // stream-K: this workgroup's range [su, su1) of the unit sequence (unit = (row block, chunk), row block major)
-    const int sk_nchunk = (p.N2 + CJ - 1) / CJ;
+    // SK, column slices (p.sk_nslice = 4 | 8): the chunk axis is cut into slices and every slice is swept by the workgroups of
+    // ONE XCD (8 slices) or one pair of XCDs (4) -- workgroup ids go round-robin over the 8 XCDs, so "XCD of workgroup g" is
+    // g & 7 -- as a stream-K problem of its own (local workgroup index sk_j of sk_G, slice-local chunk count sk_nchunk, global
+    // chunks [sk_cs0, sk_cs0 + sk_nchunk)).  A slice of the (hi | lo) bank is N2 / nslice KiB: 2.5 MB at N2 = 9 804 and 4 slices,
+    // resident in the 4-MiB L2 of the XCDs that sweep it, so the bank is fetched through the fabric once per XCD instead of once
+    // per workgroup (FETCH_SIZE 283 MB per launch for a 10-MB bank with one slice, profiles/r03_loss_pmc_fetch.csv).  Each slice
+    // leaves its own finished [N1pad, CP] slab; K6 adds the slabs in slice order (fixed order: bitwise reproducible).
+    int sk_slice = 0, sk_j = blockIdx.x, sk_G = gridDim.x, sk_cs0 = 0;
+    int sk_nchunk = (p.N2 + CJ - 1) / CJ;
+    if (SK && p.sk_nslice > 1) {
+        const int g = blockIdx.x, nct = sk_nchunk;
+        if (p.sk_nslice == 8) {
+            sk_slice = g & 7;
+            sk_j = g >> 3;
+        } else {
+            sk_slice = (g & 7) >> 1;
+            sk_j = (g >> 3) * 2 + (g & 1);
+        }
+        sk_G = gridDim.x / p.sk_nslice;
+        sk_cs0 = nct * sk_slice / p.sk_nslice;
+        sk_nchunk = nct * (sk_slice + 1) / p.sk_nslice - sk_cs0;
+    }
     long long su = 0, su1 = 0;
     if (SK) {
         const long long U = (long long)(p.N1pad / BM) * sk_nchunk;
-        su = U * blockIdx.x / gridDim.x;
-        su1 = U * (blockIdx.x + 1) / gridDim.x;
+        su = U * sk_j / sk_G;
+        su1 = U * (sk_j + 1) / sk_G;
         if (su >= su1)
             return;
     }
@@ -286,8 +308,8 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             c0 = c1 = 0;
         }
     } else if (SK) {
-        c0 = (int)max(0LL, su - (long long)rb * sk_nchunk);
-        c1 = (int)(su1 - (long long)rb * sk_nchunk);
+        c0 = sk_cs0 + (int)max(0LL, su - (long long)rb * sk_nchunk);          // (global chunk indices)
+        c1 = sk_cs0 + (int)(su1 - (long long)rb * sk_nchunk);
     } else {
         const int nchunk = (p.N2 + CJ - 1) / CJ;
         c0 = (int)((long long)split * nchunk / p.nsplit);
@@ -730,20 +752,24 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
         if (SK) {
             // natural channel order (column li of MFMA ct <-> channel 32 ct + li), unscaled by 1 / (G * 2^10)
             const int g = blockIdx.x;
+            // global workgroup id of local index jj of this slice (inverse of the decode at the top)
+            auto sk_gid = [&](int jj) {
+                return p.sk_nslice == 8 ? jj * 8 + sk_slice : (p.sk_nslice == 4 ? (jj >> 1) * 8 + sk_slice * 2 + (jj & 1) : jj);
+            };
             // element (r, ct) of this lane sits at toff + KOFF(r, ct) of a 128 x 256 tile, KOFF a compile-time constant.
             // toff is laundered through an empty asm: as a loop invariant of the segment loop the compiler would hoist all
             // 128 (64-bit) store addresses out of it and spill them (1 KiB of scratch per lane)
             unsigned toff = (unsigned)((wave * 32 + 4 * h) * CP + li);
             asm volatile("" : "+v"(toff));
 #define DCL_KOFF(r, ct) ((unsigned)(jrow((r), 0) * CP + 32 * (ct)))
-            if (c1 == sk_nchunk) {
-                // owner of row block rb: the earlier chunks (if any) were covered by workgroups gf .. g - 1, each of
-                // which leaves exactly one partial tile (its last segment) in sk_ws
-                float *out = p.dpart + (size_t)rb * BM * CP;
-                if (c0 > 0) {
+            if (c1 == sk_cs0 + sk_nchunk) {
+                // owner of row block rb (of this slice): the earlier chunks (if any) were covered by the slice's workgroups
+                // gf .. sk_j - 1 (local indices), each of which leaves exactly one partial tile (its last segment) in sk_ws
+                float *out = p.dpart + ((size_t)sk_slice * p.N1pad + (size_t)rb * BM) * CP;
+                if (c0 > sk_cs0) {
                     const long long U = (long long)(p.N1pad / BM) * sk_nchunk, ub = (long long)rb * sk_nchunk;
-                    int gf = g - 1;                              // first contributor: the workgroup holding unit (rb, 0)
-                    while (gf > 0 && U * gf / gridDim.x > ub)
+                    int gf = sk_j - 1;                           // first contributor: the workgroup holding unit (rb, 0)
+                    while (gf > 0 && U * gf / sk_G > ub)
                         --gf;
 #pragma unroll
                     for (int ct = 0; ct < 8; ++ct)
@@ -762,8 +788,8 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                     if (tid == 0 && p.sk_probe == 0) {
                         const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
                         bool late = false;
-                        for (int gp = gf; gp < g && !late; ++gp)
-                            while (__hip_atomic_load(p.sk_flags + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_seq) {
+                        for (int gp = gf; gp < sk_j && !late; ++gp)
+                            while (__hip_atomic_load(p.sk_flags + sk_gid(gp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_seq) {
                                 __builtin_amdgcn_s_sleep(8);
                                 if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > p.sk_timeout) {
                                     late = true;
@@ -774,8 +800,8 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                             __hip_atomic_fetch_add(p.sk_flags + gridDim.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     __syncthreads();
-                    for (int gp = gf; gp < g; ++gp) {
-                        const float *pt = p.sk_ws + (size_t)gp * BM * CP;
+                    for (int gp = gf; gp < sk_j; ++gp) {
+                        const float *pt = p.sk_ws + (size_t)sk_gid(gp) * BM * CP;
 #pragma unroll
                         for (int ct = 0; ct < 8; ++ct) {
 #pragma unroll
@@ -1088,6 +1114,30 @@ static int sk_cu_count()
     return cus[dev];
 }
 
+static int g_sk_slices = 4;        // column slices of the stream-K backward (1 | 4 | 8), see k_sweep; used when the grid is a
+                                   // whole number of XCD rounds and every slice keeps >= 16 chunks
+
+extern "C" int dcl_infonce_set_streamk_slices(int n)
+{
+    if (n != 1 && n != 4 && n != 8)
+        return DCL_EINVAL;
+    g_sk_slices = n;
+    return 0;
+}
+
+static int sk_slices_for(int G, int N2)
+{
+    const int nchunk = (N2 + CJ - 1) / CJ;
+    return (g_sk_slices > 1 && G % (8 * g_sk_slices) == 0 && nchunk >= 16 * g_sk_slices) ? g_sk_slices : 1;
+}
+
+// slabs dcl_infonce_bwd_streamk writes for these sizes (dout f32 [slabs][N1pad][DCL_CP], to be summed in order): 0 = stream-K off
+extern "C" int dcl_infonce_bwd_streamk_slabs(int N1, int N2)
+{
+    const int G = dcl_infonce_bwd_streamk_workgroups(N1, N2);
+    return G > 0 ? sk_slices_for(G, N2) : 0;
+}
+
 static long long g_sk_timeout_ticks = 200000000LL;      // 2 s of the 100-MHz s_memrealtime clock per hand-over
 
 extern "C" int dcl_infonce_set_streamk_timeout_ms(int ms)
@@ -1139,6 +1189,7 @@ extern "C" int dcl_infonce_bwd_streamk(const float *A, int N1, int V1, const flo
     p.N1pad = dcl_round_up(N1, BM);
     p.sk_ws = ws;
     p.sk_flags = flags;
+    p.sk_nslice = sk_slices_for(G, N2);
     p.sk_seq = sk_next_seq(flags);
     p.sk_timeout = g_sk_timeout_ticks;
     p.sk_probe = g_streamk == 2 ? 1 : 0;

@@ -58,6 +58,7 @@ class DebugConfig:
     # ---- loss
     mfma_mode: Optional[str] = field(default_factory=lambda: os.environ.get('DCL_MFMA'))        # 'f32' | 'f16x3' override
     sweep_streamk: Optional[int] = field(default_factory=lambda: _int('DCL_SWEEP_STREAMK'))     # 0 = column-split slabs
+    sweep_slices: Optional[int] = field(default_factory=lambda: _int('DCL_SWEEP_SLICES'))       # 1 | 4 | 8 column slices of stream-K
     lib_path: Optional[str] = field(default_factory=lambda: os.environ.get('DCL_LIB_PATH'))     # probe builds of the library
     # ---- kernel variants set on the library at load (include/dcl_hip.h "tuning hook" entries)
     wgrad_variant: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_VARIANT'))
@@ -89,6 +90,8 @@ class DebugConfig:
                 fn(int(val))
         if self.wgrad_tile:
             l.dcl_wgrad3x3_set_tile(*self.wgrad_tile)
+        if self.sweep_slices is not None:
+            l.dcl_infonce_set_streamk_slices(int(self.sweep_slices))
         if self.sweep_streamk is not None and hasattr(l, 'dcl_infonce_set_streamk'):
             l.dcl_infonce_set_streamk(int(self.sweep_streamk))
 

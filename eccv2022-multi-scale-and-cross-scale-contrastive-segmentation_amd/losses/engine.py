@@ -816,7 +816,8 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
                 G = int(L.dcl_infonce_bwd_streamk_workgroups(N1, sg.N)) if sg.bank_h is not None else 0
                 if G > 0:
                     # f16x3: stream-K partition, ONE finished [N1pad, 256] tile array per launch instead of nsplit slabs
-                    dout = torch.empty((N1pad, _lib.CP), dtype=torch.float32, device=dev)
+                    nsl = int(L.dcl_infonce_bwd_streamk_slabs(N1, sg.N))           # one finished slab per column slice
+                    dout = torch.empty((nsl, N1pad, _lib.CP), dtype=torch.float32, device=dev)
                     ws, flags = _streamk_workspace(dev, G)
                     used_streamk = True
                     _lib.check(L.dcl_infonce_bwd_streamk(_lib.ptr(A.bank), N1, A.plan.V, _lib.ptr(sg.bank), sg.N,
@@ -825,7 +826,7 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
                                                          _lib.ptr(stat) if sym else None, _lib.ptr(dout), _lib.ptr(ws),
                                                          _lib.ptr(flags), _lib.ptr(A.bank_h), _lib.ptr(sg.bank_h), stream),
                                "dcl_infonce_bwd_streamk")
-                    slabs[t.a].append(dout)
+                    slabs[t.a] += [dout[i] for i in range(nsl)]
                     continue
                 dpart = torch.empty((sg.nsplit, N1pad, _lib.CP), dtype=torch.float32, device=dev)
                 _lib.check(L.dcl_infonce_bwd(_lib.ptr(A.bank), N1, A.plan.V, _lib.ptr(sg.bank), sg.N,
@@ -840,7 +841,8 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
             # G^T F1 restricted to this rank's rows of bank b (they are columns of the own segment)
             G = int(L.dcl_infonce_bwd_streamk_workgroups(N2, N1)) if (B.bank_h is not None and A.bank_h is not None) else 0
             if G > 0:
-                dout = torch.empty((N2pad, _lib.CP), dtype=torch.float32, device=dev)
+                nsl = int(L.dcl_infonce_bwd_streamk_slabs(N2, N1))
+                dout = torch.empty((nsl, N2pad, _lib.CP), dtype=torch.float32, device=dev)
                 ws, flags = _streamk_workspace(dev, G)
                 used_streamk = True
                 _lib.check(L.dcl_infonce_bwd_streamk(_lib.ptr(B.bank), N2, B.plan.V, _lib.ptr(A.bank), N1,
@@ -848,7 +850,7 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
                                                      _lib.ptr(stat), _lib.ptr(dout), _lib.ptr(ws), _lib.ptr(flags),
                                                      _lib.ptr(B.bank_h), _lib.ptr(A.bank_h), stream),
                            "dcl_infonce_bwd_streamk")
-                slabs[t.b].append(dout)
+                slabs[t.b] += [dout[i] for i in range(nsl)]
                 continue
             ns = int(L.dcl_suggest_nsplit(N2, N1))
             dpart = torch.empty((ns, N2pad, _lib.CP), dtype=torch.float32, device=dev)

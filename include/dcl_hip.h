@@ -192,6 +192,14 @@ int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, int N2,
  * Replaces the same reference lines as dcl_infonce_bwd (autograd of losses/DenseContrastiveLossV2.py:150-192 and
  * losses/DenseContrastiveLossV2_ms.py:84-161). */
 int dcl_infonce_bwd_streamk_workgroups(int N1, int N2);
+/* Column slices (round 4): the chunk axis of the contrast bank is cut into 4 (default; 1 | 4 | 8:
+ * dcl_infonce_set_streamk_slices) slices, each swept -- as a stream-K problem of its own -- by the workgroups of one pair of
+ * XCDs (one XCD for 8), so that a slice of the (hi | lo) bank stays in those XCDs' L2 instead of every workgroup streaming the
+ * whole bank through the fabric.  Every slice leaves its own finished slab: dout is f32 [slabs][N1pad][DCL_CP] with slabs =
+ * dcl_infonce_bwd_streamk_slabs(N1, N2) (1 when the grid is not a whole number of XCD rounds or the bank is short), to be
+ * summed in slab order (dcl_normalize_bwd_scatter does). */
+int dcl_infonce_bwd_streamk_slabs(int N1, int N2);
+int dcl_infonce_set_streamk_slices(int n);
 int dcl_infonce_set_streamk(int on);
 int dcl_infonce_set_streamk_timeout_ms(int ms);
 int dcl_infonce_bwd_streamk(const float *A, int N1, int V1, const float *B, int N2,

@@ -300,6 +300,8 @@ def test_streamk_backward_equals_column_split_backward(dev, n, H, W, cap):
             want = dpart.sum(0)
             G = int(L.dcl_infonce_bwd_streamk_workgroups(n1, n2))
             assert 0 < G <= 256
+            nsl = int(L.dcl_infonce_bwd_streamk_slabs(n1, n2))       # column slices (4 at the benchmark size, 1 on short banks)
+            assert nsl in (1, 4, 8)
             ws = torch.full((G, 128, 256), float("nan"), device=dev)
             flags = torch.zeros(G + 1, dtype=torch.int32, device=dev)
             outs = []
@@ -307,11 +309,12 @@ def test_streamk_backward_equals_column_split_backward(dev, n, H, W, cap):
                 if k == 1:                 # what an aborted launch leaves behind: every "tile present" mark of the last launch
                     flags[:G] = flags[:G].max()
                     ws.fill_(float("nan"))
-                dout = torch.full((n1pad, 256), float("nan"), device=dev)
+                dout = torch.full((nsl, n1pad, 256), float("nan"), device=dev)
                 _lib.check(L.dcl_infonce_bwd_streamk(p(X.bank), n1, X.plan.V, p(Y.bank), n2, p(lo), p(hi), 1.0 / t.tau,
                                                      intra, use_row, use_col, p(rstat), p(cstat), p(dout), p(ws), p(flags),
                                                      p(X.bank_h), p(Y.bank_h), stream), "bwd_streamk")
-                outs.append(dout)
+                outs.append(dout.sum(0) if nsl > 1 else dout[0])
+                assert torch.isfinite(dout[:, :n1]).all()
                 assert int(flags[G].item()) == 0
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
             scale = want[:n1].abs().max().item()
