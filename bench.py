@@ -104,6 +104,9 @@ def parse():
     ap.add_argument("--materialize-projector", action="store_true",
                     help="the projection heads return their full [n, d, h, w] maps like the reference instead of the lazy form "
                          "(graph key lazy_projector) whose last 1x1 convolution the loss evaluates on the sampled pixels only")
+    ap.add_argument("--feature-layout", choices=["nchw", "nhwc"], default="nchw",
+                    help="loss workload: memory layout of the synthetic embedding maps (nhwc = channels-last strides, what "
+                         "this package's projector hands out in training; nchw = a plain contiguous map)")
     ap.add_argument("--kernel-table", default=None,
                     help="write the in-step per-kernel table (the rows behind `roofline*`) to this JSON file")
     ap.add_argument("--no-reference-config", action="store_true",
@@ -148,8 +151,9 @@ def synth_loss_inputs(args, dev, rank):
     gen = torch.Generator().manual_seed(1000 * rank)
     n, H, W = args.batch, args.height, args.width
     label = synth_labels(args, n, H, W, gen).to(dev)
-    feats = [torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).to(dev).requires_grad_(True)
-             for s in range(args.scales)]
+    fmt = torch.channels_last if getattr(args, "feature_layout", "nchw") == "nhwc" else torch.contiguous_format
+    feats = [torch.randn(n, 256, H // (4 << s), W // (4 << s), generator=gen).to(dev).contiguous(memory_format=fmt)
+             .requires_grad_(True) for s in range(args.scales)]
     return label, feats
 
 

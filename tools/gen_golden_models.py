@@ -198,7 +198,23 @@ def module_cases(only):
 
         return Stage(), [(2, 1024, 192)]
 
-    builders = {"G13_module_swin_stage": swin_stage,
+    def upernet_fpn():
+        # the UPerNet decoder on Swin-T-shaped maps (reference models/UPerNet.py:16-107): pyramid pooling, lateral 1x1s,
+        # top-down up-sampling + add, the four 3x3 convolutions and the 4 x 256 -> 256 fusion convolution over
+        # [P2, up(P5), up(P4), up(P3)], Dropout 0 -- outputs (logits, P2..P5, fusion input)
+        ref_up = importlib.import_module("models.UPerNet")
+        cfg = {"dataset": "ADE20K", "dropout_rate": 0.0, "align_corners": False, "input_channels": [96, 192, 384, 768],
+               "input_scales": [4, 8, 16, 32], "ppm_num_ch": 128, "fpn_num_ch": 256}
+        return ref_up.FPN(cfg, 1), [(2, 96, 64, 64), (2, 192, 32, 32), (2, 384, 16, 16), (2, 768, 8, 8)]
+
+    def fuse_chain():
+        # an exchange module with ONE block per branch: dominated by its fuse rows -- the stride-2 3x3 chains
+        # (conv s2 -> bn -> relu -> conv s2 -> bn), the 1x1 + bn + up-sampling terms and the summed ReLU (HRNet.py:236-287)
+        mod = ref_hrnet.HighResolutionModule(3, ref_hrnet.BasicBlock, [1] * 3, [48, 96, 192], [48, 96, 192], 'SUM', True)
+        return mod, [(4, 48, 64, 128), (4, 96, 32, 64), (4, 192, 16, 32)]
+
+    builders = {"G13_module_upernet_fpn": upernet_fpn, "G13_module_fuse_chain": fuse_chain,
+                "G13_module_swin_stage": swin_stage,
                 "G13_module_stage3": lambda: exchange(3, (48, 96, 192), (64, 128)),
                 "G13_module_stage4": lambda: exchange(4, (48, 96, 192, 384), (64, 128)),
                 "G13_module_layer1": layer1, "G13_module_head": head}
