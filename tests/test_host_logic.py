@@ -135,6 +135,17 @@ def test_native_rng_equals_torch_randperm_and_keeps_stream(seed):
     torch.set_rng_state(st)
     d = build_host_plan(big, 5, 2500, 10000, native_rng=True)
     np.testing.assert_array_equal(c.sel, d.sel)
+    # many views per pair (V = 300: the sparse-permutation path with a large table, lists on both sides of its 1024 threshold)
+    torch.set_rng_state(st)
+    wide = rs.randint(600, 3000, size=(2, 9)).astype(np.int64)
+    wide[1, 2], wide[0, 5] = 1024, 1025
+    e = build_host_plan(wide, 5, 300, 10000, native_rng=False)
+    after_e = torch.rand(3)
+    torch.set_rng_state(st)
+    f = build_host_plan(wide, 5, 300, 10000, native_rng=True)
+    assert e.V == f.V == 300
+    np.testing.assert_array_equal(e.sel, f.sel)
+    assert torch.equal(after_e, torch.rand(3))
 
 
 def test_tapup_support_query_needs_no_gpu():
