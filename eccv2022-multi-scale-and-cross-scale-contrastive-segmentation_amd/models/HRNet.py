@@ -31,7 +31,7 @@ from .Projector import Projector
 from .ops import (ConvPackGroup, DirectConv2d, GradToken, LazyConcat, conv3x3_over_upsampled, use_gemm_conv1x1,
                   upsample_bilinear, use_direct_conv3x3, use_direct_conv1x1, upsample_concat, fan_out)
 from .amax import record_stream as _amax_record_stream
-from .fused_bn import FusedBatchNorm2d, bn_act, bn_act_group, can_group
+from .fused_bn import FusedBatchNorm2d, bn_act, bn_act_group, can_group, can_group_static
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
 
@@ -236,7 +236,20 @@ class HighResolutionModule(nn.Module):
                    for c in chains for blk in c):
             return False
         first = [c[0] for c in chains]
-        return can_group([b.bn1 for b in first], x)
+        bns = [b.bn1 for b in first]
+        # the schedule (and with it the number and order of the SyncBatchNorm collectives) is decided from the model structure
+        # and the process group alone; a tensor the fused norm cannot take is an ERROR on this rank, not a silent switch to
+        # the other schedule (the peers would wait in a collective this rank never issues)
+        if not can_group_static(bns):
+            return False
+        if not can_group(bns, x):
+            raise RuntimeError("HighResolutionModule: stacked SyncBatchNorm schedule selected (several ranks, fused norms) but a "
+                               "branch input is not a contiguous float32 CUDA tensor: " +
+                               ", ".join(f"{tuple(t.shape)}/{t.dtype}/contig={t.is_contiguous()}" for t in x))
+        if _BRANCH_STREAM_MAP:
+            raise RuntimeError("DCL_BRANCH_STREAM_MAP is a single-rank tuning switch: the stacked SyncBatchNorm schedule runs one "
+                               "stream per branch")
+        return True
 
     def _run_branches_grouped(self, x):
         """Depth-major schedule of the branches for SyncBatchNorm on several ranks: at every block depth the branches'

@@ -369,6 +369,17 @@ def bn_act_group(bns, xs, residuals=None, relu=True, tokens=None, streams=None):
     return out
 
 
+def can_group_static(bns):
+    """The part of ``can_group`` that depends on the MODEL and the process group only (identical on every rank): the decision
+    which collective schedule a module takes must not depend on per-rank tensor properties -- ranks that disagree would
+    issue different all-reduce sequences and hang."""
+    if len(bns) < 2 or not _dbg.coalesced_sync_bn:
+        return False
+    if not all(isinstance(bn, FusedBatchNorm2d) and bn.training for bn in bns):
+        return False
+    return FORCE_GROUP or (_world() >= 2 and all(bn.sync for bn in bns))
+
+
 def can_group(bns, xs, residuals=None):
     """True when ``bn_act_group`` applies: several fused norms in SyncBatchNorm mode on more than one rank."""
     if len(bns) < 2 or not _dbg.coalesced_sync_bn:
