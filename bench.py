@@ -26,8 +26,8 @@ Extra keys of the JSON line:
   cpu_baseline                oracle/eager_torch.py + the same model code on the host cores, every part MEASURED on the full
         workload (no multiplication): the model's forward + backward + SGD over all `batch` images (in micro-batches of 4:
         host memory) and one evaluation of the whole contrastive loss (every scale and cross-scale term)
-  reference_config_ms_per_step   the same step with this repo's three opt-in keys OFF (lazy_logits, lazy_projector, fused
-        optimizer): what a reference JSON config gives unchanged
+  plain_config_ms_per_step    the same step with explicit `false` for graph.lazy_logits / lazy_projector and train.fused_optimizer
+        (the headline config holds the reference's keys only; this package's managers choose the fused consumers themselves)
   eager_gpu_step_ms, speedup_vs_eager_gpu_step   the reference-structure eager step on the same GPU in the same run
         (stock MIOpen / ATen kernels + the eager-structure loss of oracle/eager_torch.py): BASELINE.json's >= 5x target
   contrastive_loss_fwd_bwd_ms, metrics_in_step, peak_mem_gb
@@ -266,8 +266,31 @@ def roofline_conv_kernels(args, dev, iters=20):
 # HBM-side bytes per launch from committed rocprofv3 --pmc passes of the step (tools/pmc_step.sh -> profiles/r04_step_pmc.csv),
 # (FETCH_SIZE KiB, WRITE_SIZE KiB) averaged over the symbol's launches of one step; traffic = (2 * FETCH + WRITE) KiB per the gfx950
 # correction of MI355X_MICROARCH.md.  Keys = kernel symbols of mscs_amd/utils/kernel_timer.py.
-PMC_STEP = {}
-PMC_STEP_SOURCE = "profiles/r04_step_pmc.csv"
+PMC_STEP = {
+    "k_wgrad3x3d<3,1,false>": (91616.2, 6737.9),        # (incl. nothing of k_wgrad_reduce_t: 6 KiB fetched per launch)
+    "k_wgrad3x3d<3,1,true>": (415612.4, 25963.1),
+    "k_conv3x3_il_ws2<1,4>": (47565.9, 77383.1),
+    "k_conv3x3_il<3,4>": (45488.3, 67639.9),
+    "k_conv3x3_il<3,2>": (17154.8, 18432.0),
+    "k_conv3x3_il<3,1>": (26919.5, 9216.0),
+    "k_wgrad3x3_s2<3,1>": (62251.2, 6607.0),
+    "k_bn_bwd_apply<true>": (46719.8, 70047.6),
+    "k_bn_bwd_reduce<true>": (46580.7, 13.1),
+    "k_bn_apply<true,true>": (49312.2, 50775.8),
+    "k_bn_apply<true,false>": (21835.1, 43432.8),
+    "k_bn_stats": (22807.4, 17.3),
+    "k_bn_bwd_apply<false>": (42640.9, 46317.2),
+    "k_bn_bwd_reduce<false>": (42496.5, 13.9),
+    "k_bn_apply<false,false>": (26532.9, 52791.1),
+    "k_upsample_fwd": (36652.3, 59328.0),
+    "k_upsample_bwd_rows": (58417.0, 9540.0),
+    "k_normalize_bwd_scatter": (51017.5, 48305.6),
+    "k_label_hist": (3599.6, 294.0),
+    "k_rank_select": (645.7, 44.5),
+    "k_sweep<MODE_Z>": (97282.3, 500.5),
+    "k_sweep<MODE_BWD,stream-K>": (60758.7, 71687.9),
+}
+PMC_STEP_SOURCE = "profiles/r04_step_pmc_fetch.csv, r04_step_pmc_write.csv"
 
 
 def roofline_from_rows(rows, args):
@@ -411,9 +434,10 @@ def roofline_bwd_kernel(mod, iters=10):
 PMC_HEAD_WGRAD = (3514955.5 + 19856.5, 26330.0 + 3645.0)   # k_wgrad3x3d<3,1,true> + its slab reduction, 12 x (144 -> 720) x 128 x 256
 PMC_HEAD_FWD = (516063.4, 1228800.0)                        # k_conv3x3_il<3,4> on the same layer (profiles/r03_head_wgrad_pmc.csv)
 PMC_F16X3 = (104540.5, 128128.0)      # KiB per launch (FETCH_SIZE, WRITE_SIZE), profiles/r02_loss_pmc_*.csv
-PMC_F16X3_SK = (283395.9, 42511.9)    # stream-K kernel, KiB per launch: profiles/r03_loss_pmc_fetch.csv / _write.csv
+PMC_F16X3_SK = (60279.9, 71687.9)     # stream-K kernel with 4 column slices, KiB per launch: profiles/r04_loss_pmc_fetch.csv / _write.csv
+                                      # (one slice, round 3's partition, same run: 281075.0 / 42504.0 -- r04_loss_pmc_*_1slice.csv)
 PMC_SOURCE = "profiles/r02_loss_pmc_fetch.csv, r02_loss_pmc_write.csv"
-PMC_SOURCE_SK = "profiles/r03_loss_pmc_fetch.csv, r03_loss_pmc_write.csv"
+PMC_SOURCE_SK = "profiles/r04_loss_pmc_fetch.csv, r04_loss_pmc_write.csv"
 
 
 def cpu_baseline_loss(args):
@@ -785,6 +809,18 @@ def main():
                                        "kind": "port", "sample": msample + "; " + lsample,
                                        "model_seconds": round(msec, 2), "loss_seconds": round(lsec, 2),
                                        "sample_seconds": round(msec + lsec, 2)}
+        if workload == "step" and world == 1 and not args.no_reference_config and not args.plain_config:
+            # the same step with this package's opt-in behaviour switched OFF by explicit `false` keys: full-resolution logits,
+            # the projector's [n, d, h, w] maps (pixel-major strides), torch's foreach optimizer -- what a user gets who calls the
+            # model classes directly / writes the keys; the timed headline config holds reference keys only
+            import copy
+            a2 = copy.copy(args)
+            a2.plain_config, a2.no_kernel_table, a2.kernel_table = True, True, None
+            torch.cuda.empty_cache()
+            dt2, _, ex2 = time_train_step(a2, dev, rank, world)
+            out["plain_config_ms_per_step"] = round(dt2 / args.steps * 1e3, 3)
+            out["plain_config_keys"] = ex2["config_keys_beyond_reference"]
+            torch.cuda.empty_cache()
         if args.eager_baseline:
             out["eager_gpu_loss_ms"] = round(eager_gpu_loss_ms(args, dev), 2)
         if workload == "step" and world == 1 and not args.no_eager_step and args.config == 2:
