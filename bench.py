@@ -595,6 +595,13 @@ def time_train_step(args, dev, rank, world):
     mgr = (OCRNetManager if args.config in (4, 5) else HRNetManager)(step_config(args, world), autostart=False)
     mgr.setup()
     mgr.model.train()
+    if os.environ.get("DCL_EXP_FREEZE"):        # diagnostic (results are NOT a benchmark): drop the weight gradients of one branch
+        pat = os.environ["DCL_EXP_FREEZE"]      # e.g. "branches.0." -> which queue bounds the step?
+        nfz = 0
+        for n_, p_ in mgr.model.named_parameters():
+            if pat in n_ and n_.endswith("weight") and p_.dim() == 4:
+                p_.requires_grad_(False); nfz += 1
+        print(f"[diagnostic] froze {nfz} convolution weights matching {pat!r}", file=sys.stderr)
     gen = torch.Generator().manual_seed(1000 * rank)
     img = torch.randn(args.batch, 3, args.height, args.width, generator=gen).to(dev)
     lbl = synth_labels(args, args.batch, args.height, args.width, gen).to(dev)  # int64

@@ -49,6 +49,7 @@ class DebugConfig:
     # gradient as C += -- OFF: 467 us per launch on layer 1's 256-channel gradients against 372 for the tile kernel's fused addend
     head_dx_splitk: int = field(default_factory=lambda: 1 if _int('DCL_HEAD_DX_SPLITK') is None else _int('DCL_HEAD_DX_SPLITK'))  # k-splits of the
     # head's coarse data-gradient GEMM [C_b x 6480] . [6480 x P] (0 = the library's plan)
+    head_taps_image_major: bool = field(default_factory=lambda: _flag('DCL_HEAD_TAPS_IMAGE_MAJOR'))   # tap products [N][9 Co][h w], batched GEMMs
     gemm_head_taps: bool = field(default_factory=lambda: _flag('DCL_GEMM_HEAD'))                # the head's tap products on it
     head_overlap: int = field(default_factory=lambda: 2 if _int('DCL_HEAD_OVERLAP') is None else _int('DCL_HEAD_OVERLAP'))  # coarse half of the head's
     # backward on a side stream: 0 off, 1 on, 2 on with the fine part's weight gradient first (A/B: 96.4 / 96.0 / 95.6 ms)

@@ -699,13 +699,21 @@ def _coarse_offsets(c0, channels):
 
 class _CoarseTaps(torch.autograd.Function):
     """addend [N, Co, H, W] = sum over the coarse maps x_b of conv3x3(up(x_b), weight[:, slice_b], padding=1), computed as
-    z_b = W_b x_b (ONE split-f16 GEMM per map over all images: [9 Co, C_b] x [C_b, N h w], dcl_gemm_f16x3) at LOW resolution
-    followed by the tap-wise bilinear gather of csrc/dcl_resize.hip (k_tapup_fwd); backward: the gather's adjoint
-    (k_tapup_bwd), then two GEMMs per map (dx_b = W_b^T dz_b, dW_b = dz_b x_b^T as k-split slabs).  ``weight`` is the FULL
-    [Co, Cin, 3, 3] parameter, ``c0`` the first input channel of the first coarse map; its gradient comes back full-size
-    (zero outside the coarse slices).  ``gemm = False`` (class switch): the library's fp32 GEMMs."""
+    z_b = W_b x_b (split-f16 GEMMs [9 Co, C_b] x [C_b, h w] at LOW resolution, dcl_gemm_f16x3) followed by the tap-wise
+    bilinear gather of csrc/dcl_resize.hip (k_tapup_fwd); backward: the gather's adjoint (k_tapup_bwd), then two GEMMs per map
+    (dx_b = W_b^T dz_b, dW_b = dz_b x_b^T).  ``weight`` is the FULL [Co, Cin, 3, 3] parameter, ``c0`` the first input channel
+    of the first coarse map; its gradient comes back full-size (zero outside the coarse slices).  ``gemm = False`` (class
+    switch): the library's fp32 GEMMs.
+
+    Layout of the tap products (round 4, ``image_major``, default): z / dz are [N][9 Co][h w] and every GEMM is BATCHED over
+    the images -- x_b and dx_b are used / produced as the NCHW tensors they are (no [C_b, N h w] transpose copies), and a
+    256-row operand tile of dz spans 256 x 8 KiB instead of 256 x 96 KiB.  With the channel-major layout of round 3 ([9 Co][N h
+    w]: ONE GEMM over all images) the two backward GEMMs of the 1/16-resolution map streamed their 637-MB operand at 0.66 TB/s
+    -- 0.94 + 0.85 ms for 61 GFLOP each, 0.08 of the f16x3 roofline, against 0.3 for the same kernel on compact operands
+    (profiles/r04_kernel_table_*.json: k_gemm rows)."""
 
     gemm = _dbg.gemm_head_taps
+    image_major = _dbg.head_taps_image_major
 
     @staticmethod
     def forward(ctx, align, H, W, c0, weight, *ts):
@@ -717,31 +725,42 @@ class _CoarseTaps(torch.autograd.Function):
         y = torch.empty((n, Co, H, W), dtype=torch.float32, device=weight.device)
         st = _lib.stream_ptr(y.device)
         use_gemm = _CoarseTaps.gemm and all(t.shape[1] % 32 == 0 and (n * t.shape[2] * t.shape[3]) % 32 == 0 for t in ts)
+        img = bool(_CoarseTaps.image_major and use_gemm and all((t.shape[2] * t.shape[3]) % 32 == 0 and t.is_contiguous()
+                                                                for t in ts))
         wam = _am.amax_of(weight) if use_gemm else None
         offs = _coarse_offsets(c0, [t.shape[1] for t in ts])
         saved, zs, xams = [], [], []
         for t, off in zip(ts, offs):
             cb, h, w = t.shape[1:]
-            P = n * h * w
+            hw = h * w
+            P = n * hw
             xam = _am.amax_of(t) if use_gemm else None
-            xc = t.transpose(0, 1).reshape(cb, P)                                           # [C_b, N h w] (one copy)
             wb = weight[:, off:off + cb].permute(2, 3, 0, 1).reshape(9 * Co, cb)           # [(tap, co), ci]
-            if use_gemm:
-                z = torch.empty((9 * Co, P), dtype=torch.float32, device=y.device)
-                gemm_f16x3(wb, True, cb, xc, False, P, 9 * Co, P, cb, z, P, wam, xam, splitk=1)
+            if img:
+                # z[n] [9 Co, h w] = W_b x[n]: A = wb (k-major), B = x[n] [C_b, h w] (row-contiguous), one launch for all images
+                xc = t
+                z = torch.empty((n, 9 * Co, hw), dtype=torch.float32, device=y.device)
+                gemm_f16x3(wb, True, cb, t, False, hw, 9 * Co, hw, cb, z, hw, wam, xam, batch=n,
+                           strides=(0, cb * hw, 9 * Co * hw), splitk=1)
             else:
-                z = torch.mm(wb, xc)
+                xc = t.transpose(0, 1).reshape(cb, P)                                       # [C_b, N h w] (one copy)
+                if use_gemm:
+                    z = torch.empty((9 * Co, P), dtype=torch.float32, device=y.device)
+                    gemm_f16x3(wb, True, cb, xc, False, P, 9 * Co, P, cb, z, P, wam, xam, splitk=1)
+                else:
+                    z = torch.mm(wb, xc)
             zs.append((z, h, w))
             saved += [xc, wb]
             xams.append(xam)
         for i in range(0, len(zs), 2):
             z0, h0, w0 = zs[i]
             z1, h1, w1 = zs[i + 1] if i + 1 < len(zs) else (None, 0, 0)
-            _lib.check(L.dcl_tapup_fwd(_lib.ptr(z0), h0, w0, _lib.ptr(z1), h1, w1, n, Co, H, W, 1 if align else 0, 1,
-                                       _lib.ptr(y), 1 if i else 0, st), "dcl_tapup_fwd")
+            _lib.check(L.dcl_tapup_fwd(_lib.ptr(z0), h0, w0, _lib.ptr(z1), h1, w1, n, Co, H, W, 1 if align else 0,
+                                       0 if img else 1, _lib.ptr(y), 1 if i else 0, st), "dcl_tapup_fwd")
         ctx.save_for_backward(*saved)
         ctx.geom = (bool(align), H, W, c0, tuple(weight.shape), [tuple(t.shape) for t in ts])
         ctx.ams = (wam, xams) if use_gemm else None
+        ctx.img = img
         return y
 
     @staticmethod
@@ -751,6 +770,7 @@ class _CoarseTaps(torch.autograd.Function):
         L = _lib.lib()
         align, H, W, c0, wshape, shapes = ctx.geom
         Co = wshape[0]
+        img = ctx.img
         dy = dy.contiguous()
         st = _lib.stream_ptr(dy.device)
         gw = torch.zeros(wshape, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[4] else None
@@ -760,9 +780,10 @@ class _CoarseTaps(torch.autograd.Function):
         for i, (n, cb, h, w) in enumerate(shapes):
             off = offs[i]
             xc, wb = ctx.saved_tensors[2 * i], ctx.saved_tensors[2 * i + 1]
-            P = n * h * w
-            dz = torch.empty((9 * Co, P), dtype=torch.float32, device=dy.device)
-            _lib.check(L.dcl_tapup_bwd(_lib.ptr(dy), n, Co, H, W, h, w, 1 if align else 0, 1, _lib.ptr(dz), st),
+            hw = h * w
+            P = n * hw
+            dz = torch.empty((n, 9 * Co, hw) if img else (9 * Co, P), dtype=torch.float32, device=dy.device)
+            _lib.check(L.dcl_tapup_bwd(_lib.ptr(dy), n, Co, H, W, h, w, 1 if align else 0, 0 if img else 1, _lib.ptr(dz), st),
                        "dcl_tapup_bwd")
             gx = None
             if ctx.ams is not None:
@@ -770,15 +791,30 @@ class _CoarseTaps(torch.autograd.Function):
                 # |dz| <= (weight a low-resolution pixel receives from the up-sampled map) x max|dy|: the bilinear weights of
                 # one source pixel sum to s_y s_x in the interior and to < 2 s per axis at a clamped border
                 dzam = dyam * float(4 * -(-H // h) * -(-W // w))
-                if ctx.needs_input_grad[5 + i]:
-                    gxc = torch.empty((cb, P), dtype=torch.float32, device=dy.device)
-                    # dx_b [C_b, P] = W_b^T dz: both operands row-contiguous (the contraction 9 Co = 6480 may be ragged)
-                    gemm_f16x3(wb, False, cb, dz, False, P, cb, P, 9 * Co, gxc, P, wam, dzam, splitk=_dbg.head_dx_splitk)
-                    gx = gxc.view(cb, n, h, w).transpose(0, 1).contiguous()
-                if gw is not None:
-                    gwb = torch.empty((9 * Co, cb), dtype=torch.float32, device=dy.device)
-                    gemm_f16x3(dz, True, P, xc, True, P, 9 * Co, cb, P, gwb, cb, dzam, xams[i])
-                    gw[:, off:off + cb] = gwb.view(3, 3, Co, cb).permute(2, 3, 0, 1)
+                if img:
+                    if ctx.needs_input_grad[5 + i]:
+                        # dx[n] [C_b, h w] = W_b^T dz[n]: both operands row-contiguous (the contraction 9 Co may be ragged); the
+                        # result IS the NCHW gradient
+                        gx = torch.empty((n, cb, h, w), dtype=torch.float32, device=dy.device)
+                        gemm_f16x3(wb, False, cb, dz, False, hw, cb, hw, 9 * Co, gx, hw, wam, dzam, batch=n,
+                                   strides=(0, 9 * Co * hw, cb * hw), splitk=1)
+                    if gw is not None:
+                        # dW_b = sum_n dz[n] [9 Co, h w] x[n]^T: both k-major (the pixels), one slab per image, fixed-order sum
+                        part = torch.empty((n, 9 * Co, cb), dtype=torch.float32, device=dy.device)
+                        gemm_f16x3(dz, True, hw, xc, True, hw, 9 * Co, cb, hw, part, cb, dzam, xams[i], batch=n,
+                                   strides=(9 * Co * hw, cb * hw, 9 * Co * cb), splitk=1)
+                        gwb = part.sum(0) if n > 1 else part[0]
+                        gw[:, off:off + cb] = gwb.view(3, 3, Co, cb).permute(2, 3, 0, 1)
+                else:
+                    if ctx.needs_input_grad[5 + i]:
+                        gxc = torch.empty((cb, P), dtype=torch.float32, device=dy.device)
+                        # dx_b [C_b, P] = W_b^T dz: both operands row-contiguous (the contraction 9 Co = 6480 may be ragged)
+                        gemm_f16x3(wb, False, cb, dz, False, P, cb, P, 9 * Co, gxc, P, wam, dzam, splitk=_dbg.head_dx_splitk)
+                        gx = gxc.view(cb, n, h, w).transpose(0, 1).contiguous()
+                    if gw is not None:
+                        gwb = torch.empty((9 * Co, cb), dtype=torch.float32, device=dy.device)
+                        gemm_f16x3(dz, True, P, xc, True, P, 9 * Co, cb, P, gwb, cb, dzam, xams[i])
+                        gw[:, off:off + cb] = gwb.view(3, 3, Co, cb).permute(2, 3, 0, 1)
             else:
                 if ctx.needs_input_grad[5 + i]:
                     gx = torch.mm(wb.t(), dz).view(cb, n, h, w).transpose(0, 1).contiguous()
