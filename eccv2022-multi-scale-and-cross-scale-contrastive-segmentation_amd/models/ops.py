@@ -911,7 +911,7 @@ class _HeadSplit(torch.autograd.Function):
         out = _Conv3x3Addend.forward(fctx, hi, w_f, bias, addend)
         ctx.save_for_backward(*cctx.saved_tensors, *fctx.saved_tensors)
         ctx.nc = len(cctx.saved_tensors)
-        ctx.c = (cctx.geom, cctx.ams)
+        ctx.c = (cctx.geom, cctx.ams, cctx.img)
         ctx.f = fctx.has_bias
         ctx.fine_ranges = tuple(fine_ranges)
         return out
@@ -921,7 +921,7 @@ class _HeadSplit(torch.autograd.Function):
         need = ctx.needs_input_grad
         cctx = _ShimCtx((False,) * 4 + (need[5],) + tuple(need[7:]))
         cctx.saved_tensors = ctx.saved_tensors[:ctx.nc]
-        cctx.geom, cctx.ams = ctx.c
+        cctx.geom, cctx.ams, cctx.img = ctx.c
         fctx = _ShimCtx((need[4], need[5], need[6], False))
         fctx.saved_tensors = ctx.saved_tensors[ctx.nc:]
         fctx.has_bias = ctx.f
