@@ -669,8 +669,9 @@ def time_train_step(args, dev, rank, world):
         import importlib
         _hr = importlib.import_module("mscs_amd.models.HRNet")     # (the module: the package re-exports the class under this name)
         from mscs_amd.debug import cfg as _dbg
-        keep = (_hr._BRANCH_STREAMS, _dbg.head_overlap)
-        _hr._BRANCH_STREAMS, _dbg.head_overlap = False, 0
+        from mscs_amd.models import ops as _ops
+        keep = (_hr._BRANCH_STREAMS, _dbg.head_overlap, _ops._HeadSplit.overlap)
+        _hr._BRANCH_STREAMS, _dbg.head_overlap, _ops._HeadSplit.overlap = False, 0, 0
         try:
             step()                                   # (allocator / stream state settles)
             torch.cuda.synchronize()
@@ -678,7 +679,7 @@ def time_train_step(args, dev, rank, world):
                 step()
                 torch.cuda.synchronize()
         finally:
-            _hr._BRANCH_STREAMS, _dbg.head_overlap = keep
+            _hr._BRANCH_STREAMS, _dbg.head_overlap, _ops._HeadSplit.overlap = keep
         extra["_kernel_rows"] = kt.rows()
     del mgr
     return dt, mod, extra

@@ -94,6 +94,7 @@ SIGNATURES = {
     "dcl_wgrad3x3_splits": [_i, _i, _i, _i, _i, _i],
     "dcl_wgrad3x3_set_stride2": [_i],
     "dcl_wgrad3x3_set_splits": [_i],
+    "dcl_wgrad3x3_set_workgroup_target": [_i],
     "dcl_wgrad3x3_set_wave_mode": [_i],
     "dcl_wgrad3x3_set_strip_group": [_i],
     "dcl_wgrad3x3_set_wave_band": [_i],

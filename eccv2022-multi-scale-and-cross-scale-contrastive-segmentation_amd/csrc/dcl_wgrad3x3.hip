@@ -483,6 +483,9 @@ static void launch_wgrad_reduce(const float *part, int S, int Cout, int Cin, flo
 
 static int g_tile_nco = 0, g_tile_nci = 0;      // tuning override (dcl_wgrad3x3_set_tile), 0 = automatic
 static int g_force_nx = 0;                      // tuning override: pixel splits per tile pair (0 = automatic)
+static int g_wg_target = 256;                   // workgroups a launch aims at (pixel splits = target / tile pairs): one per CU;
+                                                // tuning hook dcl_wgrad3x3_set_workgroup_target for in-step A/B runs, where the
+                                                // launch shares the chip with the other branches' kernels
 static int g_variant = -1;     // 0 = MFMA-order operand loads (this file), -1 / 2 = LDS-DMA staging (dcl_wgrad3x3d.hip)
 
 // (A third variant -- workgroups handing the dY rows of a co group to each other through LDS, optional stream-K partition
@@ -528,7 +531,7 @@ static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nc
     units = N * ((W + 31) / 32);            // columns: (image, 32-pixel strip), H input rows each
     // One workgroup (4 waves = 4 splits of one pair) per CU is all that fits (a wave owns most of its SIMD's
     // registers): at most 256 workgroups, or the stragglers run as a second round and double the kernel time.
-    int nx = 256 / pairs;
+    int nx = g_wg_target / pairs;
     if (g_force_nx > 0)
         nx = g_force_nx;
     if (nx < 1)
@@ -561,6 +564,12 @@ extern "C" int dcl_wgrad3x3_set_variant(int variant)
     if (variant < -1 || variant > 2 || variant == 1)     // 1 was the retired kernel
         return DCL_EINVAL;
     g_variant = variant;
+    return 0;
+}
+
+extern "C" int dcl_wgrad3x3_set_workgroup_target(int n)
+{
+    g_wg_target = n >= 32 ? n : 256;
     return 0;
 }
 

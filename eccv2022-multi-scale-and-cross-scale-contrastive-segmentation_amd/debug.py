@@ -64,6 +64,7 @@ class DebugConfig:
     # ---- kernel variants set on the library at load (include/dcl_hip.h "tuning hook" entries)
     wgrad_variant: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_VARIANT'))
     wgrad_stride2: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_S2'))
+    wgrad_wg_target: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_TARGET'))    # workgroups a weight-gradient launch aims at
     wgrad_wave_mode: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_WAVE'))      # 0 = a workgroup per tile pair
     wgrad_strip_group: Optional[int] = field(default_factory=lambda: _int('DCL_WGRAD_GROUP'))   # 0 = four row ranges of one strip
     up2_phases: Optional[int] = field(default_factory=lambda: _int('DCL_UP2_PHASES'))
@@ -79,6 +80,7 @@ class DebugConfig:
         """Hand the kernel-variant switches to a freshly loaded libdcl_hip.so."""
         for val, fn in ((self.wgrad_variant, l.dcl_wgrad3x3_set_variant), (self.wgrad_stride2, l.dcl_wgrad3x3_set_stride2),
                         (self.wgrad_wave_mode, l.dcl_wgrad3x3_set_wave_mode),
+                        (self.wgrad_wg_target, l.dcl_wgrad3x3_set_workgroup_target),
                         (self.wgrad_strip_group, l.dcl_wgrad3x3_set_strip_group),
                         (self.up2_phases, l.dcl_conv3x3_set_up2_phases),
                         (self.tapup_bwd_form, l.dcl_tapup_set_bwd_form),

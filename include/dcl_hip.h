@@ -449,6 +449,8 @@ int dcl_wgrad3x3_set_variant(int variant);
 int dcl_wgrad3x3_set_stride2(int native);
 /* tuning hook (per-wave kernels): pixel splits per tile pair, 0 = automatic.  Changes dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_splits(int nx);
+/* tuning hook (per-wave kernels): workgroups a launch aims at, pixel splits = target / tile pairs (default 256 = one per CU). */
+int dcl_wgrad3x3_set_workgroup_target(int n);
 /* tuning hook (stride 1, LDS-DMA kernel, (3, 1) tile): 2 (default) / 1 = with 129 .. 256 tile pairs (one workgroup per pair
  * would leave CUs empty: the head's 144 -> 720 launch has 135) the pixel splits go to single waves, 128 / ceil(pairs / 8) per
  * pair, each XCD owning a contiguous run of pairs (2: a workgroup's four waves take one split of four pairs, 1: four splits of
