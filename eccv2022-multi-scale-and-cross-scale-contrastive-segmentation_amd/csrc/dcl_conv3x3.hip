@@ -780,6 +780,254 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_o2(ConvArgs a)
     conv_body<R, P, S>(a);
 }
 
+
+// ---- "PM": data gradient of a stride-2 convolution, ALL FOUR output parity classes of a tile in one workgroup ----------------
+// dx = conv3x3(dy zero-inserted at the odd coordinates, w').  Output pixel (2 i + py, 2 j + px) sees the taps whose input
+// coordinate is even: patch row offset dr = 1 (stored row i) with weight row 1 for py = 0 and weight row 0 for py = 1, dr = 2
+// (stored row i + 1) with weight row 2 for py = 1; the same along x.  k_conv3x3_phases gives each class its own workgroup --
+// four workgroups stage (load, split, write to LDS) the same patch for 1, 2, 2 and 4 of the 9 taps: 0.09-0.13 of the roofline,
+// bound by the staging.  Here one workgroup stages the patch ONCE and runs all 9 taps against it, each tap into the accumulator
+// of its class (4 R P accumulator tiles per wave): the matrix work per staged patch of a stride-1 tile.  A B fragment
+// (tile row p + dr, column offset dc) feeds the (2 if dr = 1 else 1) x (2 if dc = 1 else 1) taps that read it.  Epilogue: the
+// two px classes of a lane are neighbouring pixels -> one 8-byte store (the per-class kernel scatters 4-byte stores).
+template <int R, int P>
+__device__ __forceinline__ void conv_pm_body(const ConvArgs &a)
+{
+    constexpr int WR = 4;
+    constexpr int LW = TW + 2;
+    constexpr int ROWS = WR * P + 2;
+    constexpr int TP = ROWS * LW;
+    constexpr int NITEM = (2 * TP + 255) / 256;
+    constexpr int BUFB = TP * PIXB;
+    static_assert(4 * R * P <= 12, "PM: at most 12 accumulator tiles per wave (16 spill: 256 accumulator registers + staging)");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, li = lane & 31;
+    int bx, cg;
+    {
+        const int ngrp = a.groups;
+        const int ntile = a.tiles_x * a.tiles_y * a.N, n8 = ntile & ~7, main_blocks = n8 * ngrp;
+        if ((int)blockIdx.x < main_blocks) {
+            const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+            cg = rest % ngrp;
+            bx = xcd * (n8 >> 3) + rest / ngrp;
+        } else {
+            const int rest = blockIdx.x - main_blocks;
+            cg = rest % ngrp;
+            bx = n8 + rest / ngrp;
+        }
+    }
+    const int tx = bx % a.tiles_x;
+    bx /= a.tiles_x;
+    const int ty = bx % a.tiles_y;
+    const int n = bx / a.tiles_y;
+    const int x0 = tx * TW, y0 = ty * WR * P;               // stored-gradient coordinates of the tile
+    const int T0 = cg * R;
+    const size_t plane = (size_t)a.Hs * a.Ws, oplane = (size_t)a.Ho * a.Wo;
+    const float *xb = a.x + (size_t)n * a.Cin * plane;
+    int goff[NITEM], loff[NITEM];
+    float gsc[NITEM];
+    bool gok[NITEM];
+#pragma unroll
+    for (int m = 0; m < NITEM; ++m) {
+        const int it = min(tid + 256 * m, 2 * TP - 1);
+        const int oct = it >= TP ? 1 : 0;
+        const int pix = it - oct * TP;
+        const int r = pix / LW, c = pix - r * LW;
+        const int gy = y0 + r - 1, gx = x0 + c - 1;
+        const bool ok = gy >= 0 && gy < a.Hs && gx >= 0 && gx < a.Ws;
+        loff[m] = pix * PIXB + oct * 16;
+        goff[m] = ok ? gy * a.Ws + gx : 0;
+        gok[m] = ok;
+    }
+    const bool ragged = (a.Cin & 15) != 0;
+    float gA[NITEM][8];
+    auto load_items = [&](int c, float (&g)[NITEM][8]) {
+        if (!ragged || c + 1 < a.nchunk) {
+#pragma unroll
+            for (int m = 0; m < NITEM; ++m) {
+                const float *xc = xb + (size_t)(16 * c + 8 * (tid + 256 * m >= TP ? 1 : 0)) * plane + goff[m];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    g[m][e] = xc[e * plane];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < NITEM; ++m) {
+                const int ch0 = 16 * c + 8 * (tid + 256 * m >= TP ? 1 : 0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    g[m][e] = xb[(size_t)min(ch0 + e, a.Cin - 1) * plane + goff[m]];
+            }
+        }
+    };
+    auto write_items = [&](unsigned char *buf, const float (&g)[NITEM][8]) {
+#pragma unroll
+        for (int m = 0; m < NITEM; ++m) {
+            unsigned hh[4], ll[4];
+            split2(g[m][0], g[m][1], gsc[m], hh[0], ll[0]);
+            split2(g[m][2], g[m][3], gsc[m], hh[1], ll[1]);
+            split2(g[m][4], g[m][5], gsc[m], hh[2], ll[2]);
+            split2(g[m][6], g[m][7], gsc[m], hh[3], ll[3]);
+            *(uint4 *)(buf + loff[m]) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+            *(uint4 *)(buf + loff[m] + 32) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+        }
+    };
+    const int mtiles = (a.Cout + 31) / 32;
+    const uint4 *wa[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        wa[r] = a.wp + (size_t)min(T0 + r, mtiles - 1) * a.nchunk * 9 * 2 * 64 + lane;
+
+    f32x16 acc[4][R][P];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    acc[k][r][p][q] = 0.f;
+
+    load_items(0, gA);
+    float xs;
+    {
+        float m = 0.f;
+        for (int i = tid; i < a.xcount; i += 256)
+            m = fmaxf(m, a.xamax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            m = fmaxf(m, __shfl_xor(m, o, 64));
+        float *wm = (float *)lds;
+        if (lane == 0)
+            wm[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        __syncthreads();
+        xs = pow2_scale(m);
+    }
+#pragma unroll
+    for (int m = 0; m < NITEM; ++m)
+        gsc[m] = gok[m] ? xs : 0.f;
+    const int col0 = 2 * (x0 + li);
+    if (a.addend || a.bias) {
+        const float sc2 = xs * pow2_scale(a.wamax[0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int row = 2 * (y0 + P * wave + p) + (k >> 1), col = col0 + (k & 1);
+                    const int cob = (T0 + r) * 32 + 4 * h;
+                    const bool ok = row < a.Ho && col < a.Wo && cob < a.Cout;
+                    const size_t o0 = (((size_t)n * a.Cout + min(cob, a.Cout - 1)) * a.Ho + min(row, a.Ho - 1)) * a.Wo +
+                                      min(col, a.Wo - 1);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int kk = ok ? min((q & 3) + 8 * (q >> 2), a.Cout - 1 - cob) : 0;
+                        const float ad = (a.addend ? a.addend[o0 + (size_t)kk * oplane] : 0.f) +
+                                         (a.bias ? a.bias[min(cob, a.Cout - 1) + kk] : 0.f);
+                        acc[k][r][p][q] = ok ? ad * sc2 : 0.f;
+                    }
+                }
+    }
+    write_items(lds, gA);
+    __syncthreads();
+
+    for (int c = 0; c < a.nchunk; ++c) {
+        const unsigned char *cur = lds + (c & 1) * BUFB;
+        const bool more = c + 1 < a.nchunk;
+        __builtin_amdgcn_sched_barrier(0);
+        load_items(min(c + 1, a.nchunk - 1), gA);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dr = 1; dr <= 2; ++dr)
+#pragma unroll
+            for (int dc = 1; dc <= 2; ++dc) {
+                // the taps that read patch offset (dr, dc): (weight row, class row) x (weight column, class column)
+                constexpr int WK[3] = {1, 0, 2};        // [0]: dr/dc = 1, class 0;  [1]: dr/dc = 1, class 1;  [2]: dr/dc = 2, class 1
+                const int nyv = dr == 1 ? 2 : 1, nxv = dc == 1 ? 2 : 1;
+                half8 A[2][2][R][2];
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix)
+                        if (iy < nyv && ix < nxv) {
+                            const int wky = dr == 1 ? WK[iy] : 2, wkx = dc == 1 ? WK[ix] : 2;
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+#pragma unroll
+                                for (int part = 0; part < 2; ++part)
+                                    A[iy][ix][r][part] = __builtin_bit_cast(
+                                        half8, wa[r][(((size_t)c * 9 + wky * 3 + wkx) * 2 + part) * 64]);
+                        }
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const unsigned char *bp = cur + ((P * wave + p + dr) * LW + li + dc) * PIXB + h * 16;
+                    const half8 bh = *(const half8 *)bp, bl = *(const half8 *)(bp + 32);
+#pragma unroll
+                    for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+                        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                            for (int ix = 0; ix < 2; ++ix)
+                                if (iy < nyv && ix < nxv) {
+                                    const int cy = dr == 1 ? iy : 1, cx = dc == 1 ? ix : 1;       // class of this tap
+#pragma unroll
+                                    for (int r = 0; r < R; ++r)
+                                        acc[cy * 2 + cx][r][p] = DCL_MFMA(A[iy][ix][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh,
+                                                                          acc[cy * 2 + cx][r][p]);
+                                }
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more)
+            write_items(lds + ((c + 1) & 1) * BUFB, gA);
+        __syncthreads();
+    }
+
+    const float inv = 1.0f / (xs * pow2_scale(a.wamax[0]));
+    const bool pair_ok = (a.Wo & 1) == 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy) {
+                const int row = 2 * (y0 + P * wave + p) + cy;
+                const int cob = (T0 + r) * 32 + 4 * h;
+                if (row < a.Ho && col0 < a.Wo && cob < a.Cout) {
+                    float *yp = a.y + (((size_t)n * a.Cout + cob) * a.Ho + row) * a.Wo + col0;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int k = (q & 3) + 8 * (q >> 2);
+                        if (cob + k < a.Cout) {
+                            const float v0 = acc[cy * 2][r][p][q] * inv, v1 = acc[cy * 2 + 1][r][p][q] * inv;
+                            float *o = yp + (size_t)k * oplane;
+                            if (pair_ok) {                      // (col0 even, Wo even: 8-byte aligned, col0 + 1 < Wo)
+                                float2 v;
+                                v.x = v0;
+                                v.y = v1;
+                                *(float2 *)o = v;
+                            } else {
+                                o[0] = v0;
+                                if (col0 + 1 < a.Wo)
+                                    o[1] = v1;
+                            }
+                        }
+                    }
+                }
+            }
+}
+
+template <int R, int P>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_pm(ConvArgs a)
+{
+    conv_pm_body<R, P>(a);
+}
+
 // weights -> fragment order.  transposed = 0: value(m, k, ky, kx) = w[m][k][ky][kx], w is [M][K][3][3];
 // transposed = 1 (data gradient): value(m, k, ky, kx) = w[k][m][2 - ky][2 - kx], w is [K][M][3][3].
 // One thread per (fragment pair, lane): fragment (T, c, t) lane (hh, i) holds value(32 T + i, 16 c + 8 hh + e, t).
@@ -1009,7 +1257,16 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
     a.tiles_y = ((a.phases ? (a.Ho + 1) / 2 : a.Ho) + 4 * P - 1) / (4 * P);
     const int mtiles = (a.Cout + 31) / 32;
     a.groups = (mtiles + R - 1) / R;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.groups * (a.phases ? 4 : 1)));
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.groups * (a.phases == 1 ? 4 : 1)));
+    if constexpr (S == 1 && 4 * R * P <= 12) {
+        if (a.phases == 2) {                    // all four parity classes of a tile in one workgroup (conv_pm_body)
+            hipLaunchKernelGGL((k_conv3x3_pm<R, P>), grid, dim3(256), 0, stream, a);
+            dcl_note_kernel("k_conv3x3_pm<%d,%d>", R, P);
+            return 0;
+        }
+    }
+    if (a.phases == 2)
+        return DCL_EUNSUPPORTED;
     if (a.stat_part) {
         // epilogue statistics: the interleaved stride-1 tiles of the BasicBlock shapes ((3, P) and the wave-split (2, 2) tile)
         a.stat_ntile = a.tiles_x * a.tiles_y * a.N;
@@ -1031,7 +1288,7 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
         return DCL_EUNSUPPORTED;
     }
     if constexpr (S == 1) {
-        if (a.phases) {
+        if (a.phases == 1) {
             hipLaunchKernelGGL((k_conv3x3_phases<R, P>), grid, dim3(256), 0, stream, a);
             dcl_note_kernel("k_conv3x3_phases<%d,%d>", R, P);
             return 0;
@@ -1070,7 +1327,8 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
     return 0;
 }
 
-static int g_up2_phases = 1;    // in_up = 2: 1 = one output parity class per workgroup, 0 = zero-inserted input
+static int g_up2_phases = 2;    // in_up = 2: 2 = all four output parity classes of a tile in one workgroup (k_conv3x3_pm), 1 = one class
+                                // per workgroup (k_conv3x3_phases), 0 = zero-inserted input
 static int g_conv_min_wgs = 192;        // automatic tile: fewest workgroups a launch may have before the rows per wave are halved
 
 extern "C" int dcl_conv3x3_set_min_workgroups(int n)
@@ -1081,7 +1339,7 @@ extern "C" int dcl_conv3x3_set_min_workgroups(int n)
 
 extern "C" int dcl_conv3x3_set_up2_phases(int on)
 {
-    g_up2_phases = on ? 1 : 0;
+    g_up2_phases = on < 0 ? 0 : (on > 2 ? 2 : on);       // 0 zero-inserted input, 1 one class per workgroup, 2 all four classes per workgroup
     return 0;
 }
 
@@ -1143,6 +1401,20 @@ static void auto_tile(int N, int Cout, int Ho, int Wo, int nchunk, int stride, i
                       int &R, int &P)
 {
     const int mtiles = (Cout + 31) / 32;
+    if (phases == 2) {
+        // merged parity classes: 4 R P accumulator tiles per wave, at most 12 (16 spill) -- (3, 1), (2, 1), (1, 2 | 1); tiles run
+        // over the STORED gradient, ceil(Ho / 2) x ceil(Wo / 2)
+        R = mtiles % 3 == 0 ? 3 : (mtiles == 1 ? 1 : 2);
+        P = R == 1 ? 2 : 1;
+        auto wgs = [&](int p) {
+            return (long)(((Wo + 1) / 2 + TW - 1) / TW) * (((Ho + 1) / 2 + 4 * p - 1) / (4 * p)) * N * ((mtiles + R - 1) / R);
+        };
+        while (P > 1 && wgs(P) < g_conv_min_wgs)
+            P >>= 1;
+        if (tile_r > 0 && tile_p > 0 && 4 * tile_r * tile_p <= 12)
+            R = tile_r, P = tile_p;
+        return;
+    }
     R = tile_r, P = tile_p;
     if (stride == 2)
         P = 1;
@@ -1205,7 +1477,7 @@ static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *
         DCL_CHECK_ARG(Hout > 0 && Wout > 0 && (Hout - 1) / 2 + 1 == H && (Wout - 1) / 2 + 1 == W,
                       "in_up = 2: H, W must be ceil(Hout / 2), ceil(Wout / 2)");
         a.up = 1;
-        a.phases = 1;
+        a.phases = g_up2_phases == 2 ? 2 : 1;
         a.H = H;
         a.W = W;
     } else if (in_up == 2) {

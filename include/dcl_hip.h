@@ -423,8 +423,9 @@ int dcl_conv3x3_bnstats_f16x3(const float *x, int N, int Cin, int H, int W, cons
                               const float *bias, float *y, const float *pivot, float *part, float *pivot_out,
                               void *stream);
 
-/* tuning hook: in_up = 2 (data gradient of a stride-2 convolution) -- 1 (default): every workgroup computes one parity
- * class of the output pixels with the 1, 2 or 4 taps that class sees; 0: stride-1 tile over the zero-inserted input */
+/* tuning hook: in_up = 2 (data gradient of a stride-2 convolution) -- 2 (default, round 4): one workgroup stages a patch of the
+ * stored gradient once and computes all four parity classes of its output tile (9 taps per staged patch, k_conv3x3_pm); 1: every
+ * workgroup computes one parity class with the 1, 2 or 4 taps that class sees; 0: stride-1 tile over the zero-inserted input */
 int dcl_conv3x3_set_up2_phases(int on);
 /* tuning hook (automatic tile choice): the rows per wave are halved while a launch would have fewer workgroups than this
  * (default 192: one round on 256 CUs). */
