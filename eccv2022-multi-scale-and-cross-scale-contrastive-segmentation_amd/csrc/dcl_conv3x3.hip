@@ -936,53 +936,61 @@ __device__ __forceinline__ void conv_pm_body(const ConvArgs &a)
     write_items(lds, gA);
     __syncthreads();
 
+    // Weight fragments of tap group g = (dr, dc) -- 4, 2, 2, 1 taps -- travel one group ahead of their MFMAs in two register
+    // sets (group g in set g & 1; group 0 of chunk c + 1 is fetched under the last group of chunk c): fetched right in front of
+    // their use, every group started with an exposed L2 round trip (first version: 0.078-0.096 of the roofline)
+    constexpr int WK[3] = {1, 0, 2};        // [0]: offset 1, class 0;  [1]: offset 1, class 1;  [2]: offset 2, class 1
+    half8 Aq[2][4][R][2];
+    auto load_group = [&](auto SET, auto G, int cc) {
+        constexpr int set = decltype(SET)::value, g = decltype(G)::value, dr = 1 + g / 2, dc = 1 + g % 2;
+        constexpr int nyv = dr == 1 ? 2 : 1, nxv = dc == 1 ? 2 : 1;
+#pragma unroll
+        for (int iy = 0; iy < nyv; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < nxv; ++ix) {
+                const int wky = dr == 1 ? WK[iy] : 2, wkx = dc == 1 ? WK[ix] : 2;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int part = 0; part < 2; ++part)
+                        Aq[set][iy * 2 + ix][r][part] = __builtin_bit_cast(
+                            half8, wa[r][(((size_t)cc * 9 + wky * 3 + wkx) * 2 + part) * 64]);
+            }
+    };
+    load_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
     for (int c = 0; c < a.nchunk; ++c) {
         const unsigned char *cur = lds + (c & 1) * BUFB;
         const bool more = c + 1 < a.nchunk;
         __builtin_amdgcn_sched_barrier(0);
         load_items(min(c + 1, a.nchunk - 1), gA);
         __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 4>([&](auto GC) {
+            constexpr int g = decltype(GC)::value, dr = 1 + g / 2, dc = 1 + g % 2;
+            constexpr int nyv = dr == 1 ? 2 : 1, nxv = dc == 1 ? 2 : 1;
+            if constexpr (g < 3)
+                load_group(std::integral_constant<int, (g + 1) & 1>{}, std::integral_constant<int, g + 1>{}, c);
+            else
+                load_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, min(c + 1, a.nchunk - 1));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dr = 1; dr <= 2; ++dr)
+            for (int p = 0; p < P; ++p) {
+                const unsigned char *bp = cur + ((P * wave + p + dr) * LW + li + dc) * PIXB + h * 16;
+                const half8 bh = *(const half8 *)bp, bl = *(const half8 *)(bp + 32);
 #pragma unroll
-            for (int dc = 1; dc <= 2; ++dc) {
-                // the taps that read patch offset (dr, dc): (weight row, class row) x (weight column, class column)
-                constexpr int WK[3] = {1, 0, 2};        // [0]: dr/dc = 1, class 0;  [1]: dr/dc = 1, class 1;  [2]: dr/dc = 2, class 1
-                const int nyv = dr == 1 ? 2 : 1, nxv = dc == 1 ? 2 : 1;
-                half8 A[2][2][R][2];
+                for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
-                for (int iy = 0; iy < 2; ++iy)
+                    for (int iy = 0; iy < nyv; ++iy)
 #pragma unroll
-                    for (int ix = 0; ix < 2; ++ix)
-                        if (iy < nyv && ix < nxv) {
-                            const int wky = dr == 1 ? WK[iy] : 2, wkx = dc == 1 ? WK[ix] : 2;
+                        for (int ix = 0; ix < nxv; ++ix) {
+                            const int cy = dr == 1 ? iy : 1, cx = dc == 1 ? ix : 1;       // class of this tap
 #pragma unroll
                             for (int r = 0; r < R; ++r)
-#pragma unroll
-                                for (int part = 0; part < 2; ++part)
-                                    A[iy][ix][r][part] = __builtin_bit_cast(
-                                        half8, wa[r][(((size_t)c * 9 + wky * 3 + wkx) * 2 + part) * 64]);
+                                acc[cy * 2 + cx][r][p] = DCL_MFMA(Aq[g & 1][iy * 2 + ix][r][pass == 2 ? 1 : 0],
+                                                                  pass == 1 ? bl : bh, acc[cy * 2 + cx][r][p]);
                         }
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const unsigned char *bp = cur + ((P * wave + p + dr) * LW + li + dc) * PIXB + h * 16;
-                    const half8 bh = *(const half8 *)bp, bl = *(const half8 *)(bp + 32);
-#pragma unroll
-                    for (int pass = 0; pass < 3; ++pass)
-#pragma unroll
-                        for (int iy = 0; iy < 2; ++iy)
-#pragma unroll
-                            for (int ix = 0; ix < 2; ++ix)
-                                if (iy < nyv && ix < nxv) {
-                                    const int cy = dr == 1 ? iy : 1, cx = dc == 1 ? ix : 1;       // class of this tap
-#pragma unroll
-                                    for (int r = 0; r < R; ++r)
-                                        acc[cy * 2 + cx][r][p] = DCL_MFMA(A[iy][ix][r][pass == 2 ? 1 : 0], pass == 1 ? bl : bh,
-                                                                          acc[cy * 2 + cx][r][p]);
-                                }
-                }
             }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
         if (more)
             write_items(lds + ((c + 1) & 1) * BUFB, gA);
         __syncthreads();
@@ -1477,7 +1485,17 @@ static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *
         DCL_CHECK_ARG(Hout > 0 && Wout > 0 && (Hout - 1) / 2 + 1 == H && (Wout - 1) / 2 + 1 == W,
                       "in_up = 2: H, W must be ceil(Hout / 2), ceil(Wout / 2)");
         a.up = 1;
-        a.phases = g_up2_phases == 2 ? 2 : 1;
+        a.phases = 1;
+        if (g_up2_phases == 2) {
+            // all four classes per workgroup where that still fills the chip (a quarter of the per-class grid): measured on the
+            // HRNet-W48 shapes at batch 12 (gpurun_out/r4i), the merged form wins on the 64 x 128 and larger gradients and on
+            // short contractions, and loses on the 16 x 32 / 32 x 64 maps with 12-24 chunks (96-192 workgroups)
+            int Rm, Pm;
+            auto_tile(N, Cout, Hout, Wout, (Cin + 15) / 16, 1, 2, onetap, tile_r, tile_p, Rm, Pm);
+            const long wg = (long)((W + TW - 1) / TW) * ((H + 4 * Pm - 1) / (4 * Pm)) * N * (((Cout + 31) / 32 + Rm - 1) / Rm);
+            if (wg >= 2 * g_conv_min_wgs || ((Cin + 15) / 16 <= 4 && wg >= g_conv_min_wgs))
+                a.phases = 2;
+        }
         a.H = H;
         a.W = W;
     } else if (in_up == 2) {
