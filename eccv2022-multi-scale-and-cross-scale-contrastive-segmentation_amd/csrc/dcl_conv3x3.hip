@@ -1486,14 +1486,15 @@ static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *
                       "in_up = 2: H, W must be ceil(Hout / 2), ceil(Wout / 2)");
         a.up = 1;
         a.phases = 1;
-        if (g_up2_phases == 2) {
-            // all four classes per workgroup where that still fills the chip (a quarter of the per-class grid): measured on the
-            // HRNet-W48 shapes at batch 12 (gpurun_out/r4i), the merged form wins on the 64 x 128 and larger gradients and on
-            // short contractions, and loses on the 16 x 32 / 32 x 64 maps with 12-24 chunks (96-192 workgroups)
+        if (g_up2_phases >= 2) {
+            // all four classes per workgroup where that still gives a round of workgroups (a quarter of the per-class grid):
+            // on the HRNet-W48 shapes at batch 12 (gpurun_out/r4j, r4k) the merged form wins from 192 workgroups up -- 98 -> 71 us
+            // (96 -> 48 at 64 x 128), 58 -> 44 (192 -> 48 at 32 x 64), 72 -> 58 (192 -> 96) -- and loses on the 16 x 32 maps (48-96
+            // workgroups of 24-chunk K loops), which keep the per-class kernel
             int Rm, Pm;
             auto_tile(N, Cout, Hout, Wout, (Cin + 15) / 16, 1, 2, onetap, tile_r, tile_p, Rm, Pm);
             const long wg = (long)((W + TW - 1) / TW) * ((H + 4 * Pm - 1) / (4 * Pm)) * N * (((Cout + 31) / 32 + Rm - 1) / Rm);
-            if (wg >= 2 * g_conv_min_wgs || ((Cin + 15) / 16 <= 4 && wg >= g_conv_min_wgs))
+            if (wg >= g_conv_min_wgs)
                 a.phases = 2;
         }
         a.H = H;
