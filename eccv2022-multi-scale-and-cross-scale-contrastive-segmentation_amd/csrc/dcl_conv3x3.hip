@@ -169,7 +169,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
     constexpr bool PH = MODE == 1, T1 = MODE == 2;
     constexpr int WR = 4 / WS;                    // waves along the rows
     static_assert(WS == 1 || (WS == 2 && IL), "wave split: interleaved stride-1 tiles only");
-    static_assert(!IL || (S == 1 && MODE == 0), "interleaved staging: stride-1 3x3 tiles");
+    static_assert(!IL || (MODE == 0 && (S == 1 || P == 1)), "interleaved staging: stride-1 3x3 tiles, stride 2 with one row per wave");
     static_assert(MODE == 0 || S == 1, "phases / one tap: stride-1 tile");
     constexpr int LW = S * (TW - 1) + 3;          // patch width incl. halo: 34 | 65
     constexpr int ROWS = S * (WR * P - 1) + 3;    // 4P + 2 | 8P + 1 (WS = 1)
@@ -462,7 +462,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a)
         const int c2 = min(c + (ONESET ? 1 : 2), a.nchunk - 1);
         half8 bq[2][2];
         auto read_b = [&](int g, half8 (&dst)[2]) {
-            const unsigned char *bp = cur + (brow + (g % (P + 2)) * LW + g / (P + 2)) * PIXB + h * 16;
+            // stride 2 (P = 1: fragment group g = (kx, ky)): patch row 2 wrow + ky, de-interleaved column slot of 2 li + kx
+            const int rr = g % (P + 2), kx = g / (P + 2);
+            const unsigned char *bp = S == 2
+                ? cur + ((2 * P * wrow + rr) * LW + (kx == 1 ? (LW + 1) / 2 + li : li + (kx >> 1))) * PIXB + h * 16
+                : cur + (brow + rr * LW + kx) * PIXB + h * 16;
             dst[0] = *(const half8 *)bp;
             dst[1] = *(const half8 *)(bp + 32);
         };
@@ -745,6 +749,13 @@ template <int R, int P>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_il_ws2(ConvArgs a)
 {
     conv_body<R, P, 1, 0, true, 2>(a);
+}
+
+// stride 2 with the interleaved staging (one output row per wave: a B fragment group is one (kx, ky) tap)
+template <int R>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_il_s2(ConvArgs a)
+{
+    conv_body<R, 1, 2, 0, true>(a);
 }
 
 // the same two kernels with the batch-norm statistics of the output in the epilogue (conv_body, ST)
@@ -1250,9 +1261,12 @@ extern "C" int dcl_conv3x3_pack_multi(const void *jobs, const int32_t *blk2job, 
 static int g_conv_interleave = 2;      // 2 = staging interleaved with the MFMAs (k_conv3x3_il) + the (2, 2) tile's waves split
                                        // 2 x 2 (k_conv3x3_il_ws2); 1 = interleaved only; 0 = the fenced blocks
 
+static int g_conv_s2_interleave = 1;   // stride-2 forward tiles on the interleaved staging as well (bit 2 of the hook's argument clears it)
+
 extern "C" int dcl_conv3x3_set_interleave(int on)
 {
-    g_conv_interleave = on;      // 0 fenced blocks, 1 interleaved, 2 interleaved + wave-split (2, 2) tile
+    g_conv_interleave = on & 3;  // 0 fenced blocks, 1 interleaved, 2 interleaved + wave-split (2, 2) tile
+    g_conv_s2_interleave = (on & 4) ? 0 : 1;        // + 4: stride-2 tiles keep the fenced blocks (A/B runs)
     return 0;
 }
 
@@ -1329,6 +1343,13 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
             dcl_note_kernel("k_conv3x3<%d,%d,%d>", R, P, S);
         }
     } else {
+        if constexpr (S == 2 && P == 1) {
+            if (g_conv_interleave && g_conv_s2_interleave && (a.Cin & 15) == 0 && a.up == 1) {
+                hipLaunchKernelGGL((k_conv3x3_il_s2<R>), grid, dim3(256), 0, stream, a);
+                dcl_note_kernel("k_conv3x3_il_s2<%d>", R);
+                return 0;
+            }
+        }
         hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
         dcl_note_kernel("k_conv3x3<%d,%d,%d>", R, P, S);
     }
