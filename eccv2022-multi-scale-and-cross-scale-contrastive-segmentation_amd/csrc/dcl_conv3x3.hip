@@ -1358,11 +1358,14 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
 
 static int g_up2_phases = 2;    // in_up = 2: 2 = all four output parity classes of a tile in one workgroup (k_conv3x3_pm), 1 = one class
                                 // per workgroup (k_conv3x3_phases), 0 = zero-inserted input
-static int g_conv_min_wgs = 192;        // automatic tile: fewest workgroups a launch may have before the rows per wave are halved
+static int g_conv_min_wgs = 96;         // automatic tile: fewest workgroups a launch may have before the rows per wave are halved.
+// 192 (one round of 256 CUs three quarters full) until round 4; 96 since: the 192 / 384-channel branch convolutions then run as 96
+// workgroups with twice the rows per wave -- 22-33 % less CU-time per launch at 55 % more latency -- and leave the rest of the chip to
+// the other branches' kernels: step 90.7 -> 89.7 ms over three alternating pairs (profiles/r04_ab_conv_min_wgs.json)
 
 extern "C" int dcl_conv3x3_set_min_workgroups(int n)
 {
-    g_conv_min_wgs = n > 0 ? n : 192;
+    g_conv_min_wgs = n > 0 ? n : 96;
     return 0;
 }
 

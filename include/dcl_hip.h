@@ -428,7 +428,7 @@ int dcl_conv3x3_bnstats_f16x3(const float *x, int N, int Cin, int H, int W, cons
  * workgroup computes one parity class with the 1, 2 or 4 taps that class sees; 0: stride-1 tile over the zero-inserted input */
 int dcl_conv3x3_set_up2_phases(int on);
 /* tuning hook (automatic tile choice): the rows per wave are halved while a launch would have fewer workgroups than this
- * (default 192: one round on 256 CUs). */
+ * (default 96 since round 4; 192 = one round on 256 CUs three quarters full). */
 int dcl_conv3x3_set_min_workgroups(int n);
 /* tuning hook: 2 (default) = stride-1 3x3 tiles stage the next chunks interleaved with the MFMAs (k_conv3x3_il) and the
  * (2, 2) tile splits its waves 2 (rows) x 2 (channel tiles) (k_conv3x3_il_ws2); 1 = interleaved, no wave split; 0 = staging
