@@ -1363,6 +1363,88 @@ static int g_conv_min_wgs = 96;         // automatic tile: fewest workgroups a l
 // workgroups with twice the rows per wave -- 22-33 % less CU-time per launch at 55 % more latency -- and leave the rest of the chip to
 // the other branches' kernels: step 90.7 -> 89.7 ms over three alternating pairs (profiles/r04_ab_conv_min_wgs.json)
 
+// ---- stem: 3x3 / stride 2 / pad 1 convolution with <= 4 input channels (reference models/HRNet.py:404-405: conv1 = 3 -> 64 on the
+// image), plain fp32 FMAs.  The tile kernels pad the contraction to a 16-channel chunk -- 5x the multiply-adds for 3 channels, each of
+// them three MFMA passes -- and spend 0.46 ms on a layer whose traffic (75 MB in, 403 MB out at batch 12 x 512 x 1024) is worth 0.1 ms.
+// One thread per output pixel, all output channels (<= 64 per pass) in its registers; the 17 x 65 x Cin input patch of an 8 x 32
+// output tile and the weights ([ci][ky][kx][co]: a tap's channels are one broadcast 16-byte LDS read per four) are staged in LDS.
+namespace {
+constexpr int SC_TH = 8, SC_TW = 32, SC_PH = 2 * SC_TH + 1, SC_PW = 2 * SC_TW + 1, SC_CO = 64;
+
+__global__ __launch_bounds__(256) void k_conv3x3_s2_smallcin(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ y, int N, int Cin,
+                                                            int Cout, int H, int W, int Ho, int Wo, int tiles_x, int tiles_y)
+{
+    __shared__ float patch[4][SC_PH][SC_PW + 1];
+    __shared__ __attribute__((aligned(16))) float wl[4 * 9 * SC_CO];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y;
+    b /= tiles_y;
+    const int ngrp = (Cout + SC_CO - 1) / SC_CO;
+    const int cgp = b % ngrp, n = b / ngrp;
+    const int oy0 = ty * SC_TH, ox0 = tx * SC_TW, co0 = cgp * SC_CO;
+    for (int i = tid; i < Cin * SC_PH * SC_PW; i += 256) {
+        const int ci = i / (SC_PH * SC_PW), r = (i / SC_PW) % SC_PH, c = i % SC_PW;
+        const int gy = 2 * oy0 + r - 1, gx = 2 * ox0 + c - 1;
+        patch[ci][r][c] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[(((size_t)n * Cin + ci) * H + gy) * W + gx] : 0.f;
+    }
+    for (int i = tid; i < Cin * 9 * SC_CO; i += 256) {
+        const int co = i % SC_CO, t = i / SC_CO;            // t = ci * 9 + tap
+        const int ci = t / 9, tap = t - 9 * ci;
+        wl[i] = co0 + co < Cout ? w[((size_t)(co0 + co) * Cin + ci) * 9 + tap] : 0.f;
+    }
+    __syncthreads();
+    const int ly = tid >> 5, lx = tid & 31;
+    float acc[SC_CO];
+#pragma unroll
+    for (int k = 0; k < SC_CO; ++k)
+        acc[k] = 0.f;
+    for (int ci = 0; ci < Cin; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float v = patch[ci][2 * ly + ky][2 * lx + kx];
+                const f32x4 *wp = (const f32x4 *)(wl + (ci * 9 + ky * 3 + kx) * SC_CO);
+#pragma unroll
+                for (int k4 = 0; k4 < SC_CO / 4; ++k4) {
+                    const f32x4 wv = wp[k4];
+                    acc[4 * k4 + 0] = fmaf(wv.x, v, acc[4 * k4 + 0]);
+                    acc[4 * k4 + 1] = fmaf(wv.y, v, acc[4 * k4 + 1]);
+                    acc[4 * k4 + 2] = fmaf(wv.z, v, acc[4 * k4 + 2]);
+                    acc[4 * k4 + 3] = fmaf(wv.w, v, acc[4 * k4 + 3]);
+                }
+            }
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    if (oy < Ho && ox < Wo) {
+        float *yp = y + (((size_t)n * Cout + co0) * Ho + oy) * Wo + ox;
+#pragma unroll
+        for (int k = 0; k < SC_CO; ++k)
+            if (co0 + k < Cout)
+                yp[(size_t)k * Ho * Wo] = acc[k] + (bias ? bias[co0 + k] : 0.f);
+    }
+}
+}  // namespace
+
+extern "C" int dcl_conv3x3_s2_smallcin(const float *x, int N, int Cin, int H, int W, const float *w, int Cout, const float *bias,
+                                       float *y, void *stream)
+{
+    DCL_CHECK_ARG(x && w && y && N > 0 && H > 0 && W > 0 && Cout > 0, "bad arguments");
+    DCL_CHECK_ARG(Cin >= 1 && Cin <= 4, "this kernel takes 1 .. 4 input channels");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int tiles_x = (Wo + SC_TW - 1) / SC_TW, tiles_y = (Ho + SC_TH - 1) / SC_TH, ngrp = (Cout + SC_CO - 1) / SC_CO;
+    const long long blocks = (long long)tiles_x * tiles_y * ngrp * N;
+    DCL_CHECK_ARG(blocks < (1LL << 31), "too many tiles");
+    hipLaunchKernelGGL(k_conv3x3_s2_smallcin, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, N, Cin,
+                       Cout, H, W, Ho, Wo, tiles_x, tiles_y);
+    dcl_note_kernel("k_conv3x3_s2_smallcin");
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dcl_conv3x3_set_min_workgroups(int n)
 {
     g_conv_min_wgs = n > 0 ? n : 96;

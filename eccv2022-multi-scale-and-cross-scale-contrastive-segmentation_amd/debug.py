@@ -38,6 +38,7 @@ class DebugConfig:
     # kernels' wider prologue -- and the step gets SLOWER, 91.1-91.3 against 90.5-90.7 ms (alternating runs on one box,
     # gpurun_out/r4c): the statistics pass is an HBM-bound kernel that overlaps the other branches' matrix kernels, the epilogue
     # work sits inside the matrix kernels that bound the step
+    small_cin_stem: bool = field(default_factory=lambda: _flag('DCL_SMALL_CIN_STEM'))            # fp32 kernel for the 3-channel stem conv
     packed_relu_mask: bool = field(default_factory=lambda: _flag('DCL_BN_MASK'))                # packed sign mask in the BN backward
     bn_onepass: bool = field(default_factory=lambda: _flag('DCL_BN_ONEPASS', False))            # one-kernel BN backward (default stream);
     # OFF by default: its teams of persistent workgroups wait for members that the branch streams' kernels keep off the CUs

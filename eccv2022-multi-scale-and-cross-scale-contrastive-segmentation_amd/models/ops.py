@@ -348,6 +348,7 @@ def conv3x3_launch_bnstats(x, wp, cout, xamax, wamax, out, pivot, ntile, addend=
     return part, pivot_out
 
 
+SMALL_CIN_STEM = _dbg.small_cin_stem     # the stem's 3 -> 64 stride-2 convolution on its own fp32 kernel (DCL_SMALL_CIN_STEM=0: tile kernel)
 CONV_BN_STATS = _dbg.conv_bn_stats       # batch-norm statistics in the producing convolution's epilogue (DCL_CONV_BN_STATS=0: off)
 
 
@@ -441,6 +442,13 @@ class _Conv3x3Direct(torch.autograd.Function):
                 out += bias.view(1, -1, 1, 1)
         elif k1:
             conv1x1_launch(x, wp, weight.shape[0], amax_of(x), wamax, out, bias=bias)
+        elif st == 2 and weight.shape[1] <= 4 and SMALL_CIN_STEM:
+            # the stem's convolution on the image: 3 input channels, fp32 FMAs (csrc/dcl_conv3x3.hip k_conv3x3_s2_smallcin)
+            from .. import _lib
+            n, ci, h, w = x.shape
+            _lib.check(_lib.lib().dcl_conv3x3_s2_smallcin(_lib.ptr(x), n, ci, h, w, _lib.ptr(weight.contiguous()),
+                                                          weight.shape[0], _lib.ptr(bias), _lib.ptr(out), _stream(x)),
+                       "dcl_conv3x3_s2_smallcin")
         else:
             ntile = conv3x3_bnstats_tiles(x, weight.shape[0]) if (stats_for is not None and st == 1) else 0
             if ntile > 0:

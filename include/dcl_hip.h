@@ -417,6 +417,11 @@ int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored inp
  * 0 = no such kernel for the shape (Cin % 16 != 0, or a tile other than the BasicBlock tiles): use dcl_conv3x3_f16x3 +
  * dcl_bn_stats_part.  pivot f32 [Cout]: the norm's running mean; pivot_out f32 [Cout] receives a copy (the apply kernel
  * updates the running mean).  Fixed summation order: bitwise reproducible. */
+/* 3x3 / stride 2 / pad 1 convolution with 1 .. 4 input channels on plain fp32 FMAs (the stem's conv1 on the image, reference
+ * models/HRNet.py:404-405): x [N, Cin, H, W], w [Cout, Cin, 3, 3] (unpacked), bias [Cout] or NULL, y [N, Cout, (H - 1) / 2 + 1,
+ * (W - 1) / 2 + 1].  The tile kernels would pad the contraction to 16 channels. */
+int dcl_conv3x3_s2_smallcin(const float *x, int N, int Cin, int H, int W, const float *w, int Cout, const float *bias,
+                            float *y, void *stream);
 int dcl_conv3x3_bnstats_tiles(int N, int Cin, int Cout, int H, int W);
 int dcl_conv3x3_bnstats_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
                               const float *xamax, int xcount, const float *wamax, const float *addend,

@@ -363,3 +363,43 @@ def test_basic_block_with_epilogue_statistics_equals_the_two_pass_norm(dev, ch, 
                   [blk.bn1.running_mean, blk.bn1.running_var, blk.bn2.running_mean, blk.bn2.running_var]
     for a, b in zip(res[False], res[True]):
         assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64, 128), (1, 3, 64, 33, 47), (2, 1, 16, 17, 40), (1, 4, 70, 20, 64), (12, 3, 64, 512, 1024)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_stem_small_cin_stride2_convolution_against_fp64(dev, shape):
+    """dcl_conv3x3_s2_smallcin (the stem's conv1 on the image, reference models/HRNet.py:404-405: 3 -> 64, stride 2): plain fp32
+    FMAs against float64, ragged sizes, 1 .. 4 input channels, more than 64 output channels, with and without bias: 2e-6 of
+    max; and that DirectConv2d takes this kernel for such a layer (forward), with the library's weight gradient behind it."""
+    from mscs_amd import _lib
+    from mscs_amd.models import ops
+    n, ci, co, h, w = shape
+    gen = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(n, ci, h, w, device=dev, generator=gen)
+    wt = torch.randn(co, ci, 3, 3, device=dev, generator=gen) * 0.2
+    bias = torch.randn(co, device=dev, generator=gen)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    for b in (None, bias):
+        y = torch.full((n, co, ho, wo), float("nan"), device=dev)
+        _lib.check(_lib.lib().dcl_conv3x3_s2_smallcin(_lib.ptr(x), n, ci, h, w, _lib.ptr(wt), co, _lib.ptr(b), _lib.ptr(y),
+                                                      _lib.stream_ptr(dev)), "smallcin")
+        worst, top = 0.0, 0.0
+        for i in range(n):
+            ref = F.conv2d(x[i:i + 1].double(), wt.double(), None if b is None else b.double(), 2, 1)
+            worst = max(worst, (y[i:i + 1].double() - ref).abs().max().item())
+            top = max(top, ref.abs().max().item())
+        assert worst <= 2e-6 * top, (worst, top)
+    if n <= 2:
+        conv = torch.nn.Conv2d(ci, co, 3, 2, 1, bias=True).to(dev)
+        ops.use_direct_conv3x3(conv)
+        conv.weight.data.copy_(wt)
+        conv.bias.data.copy_(bias)
+        from mscs_amd.utils.kernel_timer import KernelTimer
+        with KernelTimer(["dcl_conv3x3_s2_smallcin", "dcl_conv3x3_f16x3"]) as kt:
+            out = conv(x)
+            out.square().mean().backward()
+            torch.cuda.synchronize()
+        assert [c[0] for c in kt.calls] == ["dcl_conv3x3_s2_smallcin"]
+        w64 = wt.double().requires_grad_(True)
+        F.conv2d(x.double(), w64, bias.double(), 2, 1).square().mean().backward()
+        assert (conv.weight.grad.double() - w64.grad).abs().max().item() <= 2e-5 * w64.grad.abs().max().item()
