@@ -810,7 +810,7 @@ __device__ __forceinline__ void conv_pm_body(const ConvArgs &a)
     constexpr int TP = ROWS * LW;
     constexpr int NITEM = (2 * TP + 255) / 256;
     constexpr int BUFB = TP * PIXB;
-    static_assert(4 * R * P <= 12, "PM: at most 12 accumulator tiles per wave (16 spill: 256 accumulator registers + staging)");
+    static_assert(4 * R * P <= 12, "PM: at most 12 accumulator tiles per wave (16 spill: 256 accumulator registers + staging + fragments)");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, li = lane & 31;
@@ -951,7 +951,7 @@ __device__ __forceinline__ void conv_pm_body(const ConvArgs &a)
     // sets (group g in set g & 1; group 0 of chunk c + 1 is fetched under the last group of chunk c): fetched right in front of
     // their use, every group started with an exposed L2 round trip (first version: 0.078-0.096 of the roofline)
     constexpr int WK[3] = {1, 0, 2};        // [0]: offset 1, class 0;  [1]: offset 1, class 1;  [2]: offset 2, class 1
-    half8 Aq[2][4][R][2];
+    half8 Aq0[4][R][2], Aq1[2][R][2];          // set 0: groups 0 (4 taps) and 2 (2 taps); set 1: groups 1 (2 taps) and 3 (1 tap)
     auto load_group = [&](auto SET, auto G, int cc) {
         constexpr int set = decltype(SET)::value, g = decltype(G)::value, dr = 1 + g / 2, dc = 1 + g % 2;
         constexpr int nyv = dr == 1 ? 2 : 1, nxv = dc == 1 ? 2 : 1;
@@ -963,9 +963,13 @@ __device__ __forceinline__ void conv_pm_body(const ConvArgs &a)
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int part = 0; part < 2; ++part)
-                        Aq[set][iy * 2 + ix][r][part] = __builtin_bit_cast(
-                            half8, wa[r][(((size_t)cc * 9 + wky * 3 + wkx) * 2 + part) * 64]);
+                    for (int part = 0; part < 2; ++part) {
+                        const half8 v = __builtin_bit_cast(half8, wa[r][(((size_t)cc * 9 + wky * 3 + wkx) * 2 + part) * 64]);
+                        if constexpr (set == 0)
+                            Aq0[iy * nxv + ix][r][part] = v;
+                        else
+                            Aq1[iy * nxv + ix][r][part] = v;
+                    }
             }
     };
     load_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
@@ -996,8 +1000,9 @@ __device__ __forceinline__ void conv_pm_body(const ConvArgs &a)
                             const int cy = dr == 1 ? iy : 1, cx = dc == 1 ? ix : 1;       // class of this tap
 #pragma unroll
                             for (int r = 0; r < R; ++r)
-                                acc[cy * 2 + cx][r][p] = DCL_MFMA(Aq[g & 1][iy * 2 + ix][r][pass == 2 ? 1 : 0],
-                                                                  pass == 1 ? bl : bh, acc[cy * 2 + cx][r][p]);
+                                acc[cy * 2 + cx][r][p] = DCL_MFMA(
+                                    (g & 1) ? Aq1[iy * nxv + ix][r][pass == 2 ? 1 : 0] : Aq0[iy * nxv + ix][r][pass == 2 ? 1 : 0],
+                                    pass == 1 ? bl : bh, acc[cy * 2 + cx][r][p]);
                         }
             }
             __builtin_amdgcn_sched_barrier(0);
