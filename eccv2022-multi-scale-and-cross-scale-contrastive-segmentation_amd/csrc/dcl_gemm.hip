@@ -76,7 +76,59 @@ struct GemmArgs {
     int accumulate;                 // C += (splitk == 1 only)
     float *rowsum;                  // optional (row-contiguous A only): [z][M] sums over k of A(m, k) -- the bias gradient of a
                                     // Linear rides on its weight-gradient GEMM (A = dy^T); written by the tile column 0 workgroups
+    // fused epilogues (template parameter EP; splitk == 1 only).  aux / C2 are addressed like C (ldc, batch stride sC).
+    //   EP_GELU_FWD  C = v (the pre-activation, kept for the backward), C2 = gelu(v)          (Mlp.fc1 + act, Swin.py:62-76)
+    //   EP_GELU_BWD  C = v * gelu'(aux)                                                        (data gradient of fc2 -> fc1's dy)
+    //   EP_RESIDUAL  C = aux + rowscale[row / rows_per_scale] * v  (rowscale NULL: 1)          (shortcut + drop_path(branch), :318-321)
+    float *C2;
+    const float *aux;
+    const float *rowscale;
+    int rows_per_scale;
 };
+
+enum { EP_NONE = 0, EP_GELU_FWD = 1, EP_GELU_BWD = 2, EP_RESIDUAL = 3 };
+
+// nn.GELU() (approximate = 'none') and its derivative -- ATen's formulas (aten/src/ATen/native/cuda/ActivationGeluKernel.cu:
+// 0.5 x (1 + erf(x / sqrt 2)); cdf + x pdf) -- for TWO values at a time on the packed f32 instructions (v_pk_fma_f32: one issue
+// slot per pair).  The epilogue of a tile is exposed time (one workgroup per CU: nothing else runs under it), and with the math
+// library's erff it cost 46 vector instructions per value.  erf: N. Juffa's single-precision form, two polynomials joined at
+// |a| = 0.927734375, < 1 ulp (checked against float64 over [-6, 6]: 0.99 ulp); both are evaluated for the pair, branch-free.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 sp2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 erf2(f32x2 a)
+{
+    const f32x2 t = {fabsf(a.x), fabsf(a.y)};
+    const f32x2 s = a * a;
+    f32x2 r = pk_fma(sp2(-1.72853470e-5f), t, sp2(3.83197126e-4f));
+    const f32x2 u = pk_fma(sp2(-3.88396438e-3f), t, sp2(2.42546219e-2f));
+    r = pk_fma(r, s, u);
+    r = pk_fma(r, t, sp2(-1.06777877e-1f));
+    r = pk_fma(r, t, sp2(-6.34846687e-1f));
+    r = pk_fma(r, t, sp2(-1.28717512e-1f));
+    r = pk_fma(r, t, -t);
+    f32x2 q = pk_fma(sp2(-5.96761703e-4f), s, sp2(4.99119423e-3f));
+    q = pk_fma(q, s, sp2(-2.67681349e-2f));
+    q = pk_fma(q, s, sp2(1.12819925e-1f));
+    q = pk_fma(q, s, sp2(-3.76125336e-1f));
+    q = pk_fma(q, s, sp2(1.28379166e-1f));
+    q = pk_fma(q, a, a);
+    const float bx = copysignf(1.0f - __expf(r.x), a.x), by = copysignf(1.0f - __expf(r.y), a.y);
+    return f32x2{t.x > 0.927734375f ? bx : q.x, t.y > 0.927734375f ? by : q.y};
+}
+__device__ __forceinline__ f32x2 gelu2(f32x2 x)
+{
+    const f32x2 e = erf2(x * sp2(0.70710678118654752440f));
+    return pk_fma(sp2(0.5f) * x, e, sp2(0.5f) * x);
+}
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x)
+{
+    const f32x2 e = erf2(x * sp2(0.70710678118654752440f));
+    const f32x2 cdf = pk_fma(sp2(0.5f), e, sp2(0.5f));
+    const f32x2 h = sp2(-0.5f) * x * x;
+    const f32x2 pdf = f32x2{__expf(h.x), __expf(h.y)} * sp2(0.39894228040143267794f);
+    return pk_fma(x, pdf, cdf);
+}
 
 // LDS image of one operand tile and stage: [hi | lo][k-group of 8 k: 4][slot: BX + 2] 16-byte units.  The two pad units
 // make the k-group stride 8 banks (mod 32, the store banking) so that a 16-lane group of ds_write_b64 -- two rows x four
@@ -192,7 +244,7 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int TM, int TN, int WM, int WN, bool AKM, bool BKM>
+template <int TM, int TN, int WM, int WN, bool AKM, bool BKM, int EP = EP_NONE>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
@@ -427,16 +479,81 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
             for (int i = 0; i < TM; ++i) {
                 const int rbase = row0 + 32 * (wm * TM + i) + 4 * (lane >> 5);
                 float *p0 = C + (long)rbase * a.ldc + col;
+                if constexpr (EP == EP_NONE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = 8 * (r >> 2) + (r & 3);
-                    if (FULL || (cok && rbase + dr < a.M)) {
-                        float *p = p0 + (long)dr * a.ldc;
-                        float val = acc[i][j][r] * inv + bv;
-                        if (a.accumulate)
-                            val += *p;
-                        *p = val;
-                        mx = fmaxf(mx, fabsf(val));
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = 8 * (r >> 2) + (r & 3);
+                        if (FULL || (cok && rbase + dr < a.M)) {
+                            float *p = p0 + (long)dr * a.ldc;
+                            float val = acc[i][j][r] * inv + bv;
+                            if (a.accumulate)
+                                val += *p;
+                            *p = val;
+                            mx = fmaxf(mx, fabsf(val));
+                        }
+                    }
+                } else {
+                    // 32-bit element offsets from the uniform bases of C / C2 / aux (the entry point checks M * ldc < 2^30): one
+                    // address register per element instead of a 64-bit pointer per array -- with those the 256 x 256 tile spilled
+                    const unsigned ldc32 = (unsigned)a.ldc;
+                    const unsigned o0 = (unsigned)rbase * ldc32 + (unsigned)col;
+                    const float *__restrict__ auxz = a.aux + (long)z * a.sC;
+                    float *__restrict__ c2z = a.C2 + (long)z * a.sC;
+                    // the second operand of the epilogue (h / the shortcut) is requested for the whole 32 x 32 tile before the
+                    // first value is used: 16 independent loads in flight per lane
+                    float xin[16];
+                    if constexpr (EP == EP_GELU_BWD || EP == EP_RESIDUAL) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dr = 8 * (r >> 2) + (r & 3);
+                            xin[r] = (FULL || (cok && rbase + dr < a.M)) ? auxz[o0 + (unsigned)dr * ldc32] : 0.f;
+                        }
+                    }
+                    // per-sample factor of the rows of this tile: ONE division per tile -- rows_per_scale >= 32 (checked by the entry
+                    // point) and dr <= 27, so row (rbase + dr) lies in sample q0 or q0 + 1
+                    int q0 = 0, rem0 = 0;
+                    if constexpr (EP == EP_RESIDUAL) {
+                        if (a.rowscale) {
+                            q0 = rbase / a.rows_per_scale;
+                            rem0 = rbase - q0 * a.rows_per_scale;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int dr = 8 * (r >> 2) + (r & 3);                  // rows dr, dr + 1
+                        const bool ok0 = FULL || (cok && rbase + dr < a.M), ok1 = FULL || (cok && rbase + dr + 1 < a.M);
+                        const unsigned o = o0 + (unsigned)dr * ldc32;
+                        f32x2 val = pk_fma(f32x2{acc[i][j][r], acc[i][j][r + 1]}, sp2(inv), sp2(bv));
+                        if constexpr (EP == EP_GELU_FWD) {
+                            const f32x2 gv = gelu2(val);
+                            if (ok0) {
+                                C[o] = val.x;
+                                c2z[o] = gv.x;
+                            }
+                            if (ok1) {
+                                C[o + ldc32] = val.y;
+                                c2z[o + ldc32] = gv.y;
+                            }
+                        } else {
+                            if constexpr (EP == EP_GELU_BWD) {
+                                val = val * gelu_grad2(f32x2{xin[r], xin[r + 1]});
+                            } else {
+                                f32x2 sc = sp2(1.f);
+                                if (a.rowscale) {
+                                    sc.x = a.rowscale[q0 + (rem0 + dr >= a.rows_per_scale ? 1 : 0)];
+                                    sc.y = a.rowscale[q0 + (rem0 + dr + 1 >= a.rows_per_scale ? 1 : 0)];
+                                }
+                                val = pk_fma(sc, val, f32x2{xin[r], xin[r + 1]});
+                            }
+                            if (ok0)
+                                C[o] = val.x;
+                            if (ok1)
+                                C[o + ldc32] = val.y;
+                        }
+                        if (ok0)
+                            mx = fmaxf(mx, fabsf(val.x));
+                        if (ok1)
+                            mx = fmaxf(mx, fabsf(val.y));
                     }
                 }
             }
@@ -563,7 +680,7 @@ int plan_gemm(int M, int N, int K, int batch, int *split)
     return best;
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int EP = EP_NONE>
 int launch_gemm(const GemmArgs &a, int akm, int bkm, hipStream_t stream)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -573,12 +690,21 @@ int launch_gemm(const GemmArgs &a, int akm, int bkm, hipStream_t stream)
     do {                                                                                                              \
         static bool attr_done = false;                                                                                \
         if (!attr_done) {                                                                                             \
-            (void)hipFuncSetAttribute((const void *)k_gemm<TM, TN, WM, WN, AK, BK>,                                   \
+            (void)hipFuncSetAttribute((const void *)k_gemm<TM, TN, WM, WN, AK, BK, EP>,                                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                    \
             attr_done = true;                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, AK, BK>), grid, block, lds_bytes, stream, a);                      \
+        hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, AK, BK, EP>), grid, block, lds_bytes, stream, a);                      \
     } while (0)
+    // fused epilogues exist for the operand layouts of the products that use them: a Linear's forward (both k-major) and its
+    // data gradient (dy k-major, W read as its transpose)
+    if constexpr (EP == EP_GELU_FWD || EP == EP_RESIDUAL) {
+        DCL_CHECK_ARG(akm && bkm, "this epilogue needs two k-major operands (a Linear's forward)");
+        DCL_GEMM_LAUNCH(true, true);
+    } else if constexpr (EP == EP_GELU_BWD) {
+        DCL_CHECK_ARG(akm && !bkm, "the GELU-backward epilogue needs a k-major A and a row-contiguous B (a Linear's data gradient)");
+        DCL_GEMM_LAUNCH(true, false);
+    } else {
     if (akm && bkm)
         DCL_GEMM_LAUNCH(true, true);
     else if (akm)
@@ -587,6 +713,7 @@ int launch_gemm(const GemmArgs &a, int akm, int bkm, hipStream_t stream)
         DCL_GEMM_LAUNCH(false, true);
     else
         DCL_GEMM_LAUNCH(false, false);
+    }
 #undef DCL_GEMM_LAUNCH
     DCL_LAUNCH_CHECK();
     return 0;
@@ -633,10 +760,11 @@ extern "C" int dcl_gemm_suggest_splitk(int M, int N, int K, int batch)
     return s;
 }
 
-extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t strideA, const float *B, int64_t ldb,
-                              int b_kmajor, int64_t strideB, int M, int N, int K, int batch, const float *a_amax,
-                              int a_count, const float *b_amax, int b_count, const float *bias, float *C, int64_t ldc, int64_t strideC,
-                              int accumulate, float *c_amax, int splitk, float *ws, float *a_rowsum, void *stream)
+static int gemm_impl(const float *A, int64_t lda, int a_kmajor, int64_t strideA, const float *B, int64_t ldb,
+                     int b_kmajor, int64_t strideB, int M, int N, int K, int batch, const float *a_amax,
+                     int a_count, const float *b_amax, int b_count, const float *bias, float *C, int64_t ldc, int64_t strideC,
+                     int accumulate, float *c_amax, int splitk, float *ws, float *a_rowsum, void *stream,
+                     int ep, float *C2, const float *aux, const float *rowscale, int rows_per_scale)
 {
     DCL_CHECK_ARG(!a_rowsum || (!a_kmajor && batch == 1), "a_rowsum needs a row-contiguous A and batch 1");
     DCL_CHECK_ARG(A && B && C && a_amax && b_amax, "null pointer");
@@ -653,23 +781,34 @@ extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t
     a.a_amax = a_amax, a.b_amax = b_amax, a.a_count = a_count, a.b_count = b_count;
     a.M = M, a.N = N, a.K = K, a.batch = batch, a.splitk = splitk;
     a.rowsum = a_rowsum ? (splitk > 1 ? ws + (long)M * N * batch * splitk : a_rowsum) : nullptr;
+    a.C2 = C2, a.aux = aux, a.rowscale = rowscale, a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
     if (splitk > 1) {
         a.C = ws, a.ldc = N, a.sC = (long)M * N, a.bias = nullptr, a.c_amax = nullptr, a.accumulate = 0;
     } else {
         a.C = C, a.ldc = ldc, a.sC = strideC, a.bias = bias, a.c_amax = c_amax, a.accumulate = accumulate;
     }
     int sfix = splitk;
-    const int c = plan_gemm(M, N, K, batch, &sfix);
+    int c = plan_gemm(M, N, K, batch, &sfix);
+    if (ep != EP_NONE && c == 0)
+        c = 4;          // the fused epilogues on 8 accumulator tiles per wave spill (144-172 B): 256 x 192 instead of 256 x 256
     a.tiles_m = (M + TILES[c].bm - 1) / TILES[c].bm;
     a.tiles_n = (N + TILES[c].bn - 1) / TILES[c].bn;
     int rc;
-    switch (c) {
-    case 0: rc = launch_gemm<2, 4, 4, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
-    case 1: rc = launch_gemm<2, 2, 4, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
-    case 2: rc = launch_gemm<2, 2, 2, 4>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
-    case 4: rc = launch_gemm<2, 3, 4, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
-    default: rc = launch_gemm<2, 2, 2, 2>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;
+#define DCL_GEMM_TILES(EPV)                                                                                      \
+    switch (c) {                                                                                                 \
+    case 0: rc = launch_gemm<2, (EPV == EP_NONE ? 4 : 3), 4, 2, EPV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break; \
+    case 1: rc = launch_gemm<2, 2, 4, 2, EPV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;                \
+    case 2: rc = launch_gemm<2, 2, 2, 4, EPV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;                \
+    case 4: rc = launch_gemm<2, 3, 4, 2, EPV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;                \
+    default: rc = launch_gemm<2, 2, 2, 2, EPV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;               \
     }
+    switch (ep) {
+    case EP_GELU_FWD: DCL_GEMM_TILES(EP_GELU_FWD); break;
+    case EP_GELU_BWD: DCL_GEMM_TILES(EP_GELU_BWD); break;
+    case EP_RESIDUAL: DCL_GEMM_TILES(EP_RESIDUAL); break;
+    default: DCL_GEMM_TILES(EP_NONE); break;
+    }
+#undef DCL_GEMM_TILES
     if (rc != 0)
         return rc;
     if (splitk > 1) {
@@ -685,4 +824,27 @@ extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t
         DCL_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t strideA, const float *B, int64_t ldb,
+                              int b_kmajor, int64_t strideB, int M, int N, int K, int batch, const float *a_amax,
+                              int a_count, const float *b_amax, int b_count, const float *bias, float *C, int64_t ldc, int64_t strideC,
+                              int accumulate, float *c_amax, int splitk, float *ws, float *a_rowsum, void *stream)
+{
+    return gemm_impl(A, lda, a_kmajor, strideA, B, ldb, b_kmajor, strideB, M, N, K, batch, a_amax, a_count, b_amax, b_count, bias,
+                     C, ldc, strideC, accumulate, c_amax, splitk, ws, a_rowsum, stream, EP_NONE, nullptr, nullptr, nullptr, 1);
+}
+
+extern "C" int dcl_gemm_f16x3_ep(const float *A, int64_t lda, int a_kmajor, const float *B, int64_t ldb, int b_kmajor, int M, int N,
+                                 int K, const float *a_amax, int a_count, const float *b_amax, int b_count, const float *bias,
+                                 float *C, int64_t ldc, float *c_amax, int ep, float *C2, const float *aux,
+                                 const float *rowscale, int rows_per_scale, void *stream)
+{
+    DCL_CHECK_ARG(ep >= EP_GELU_FWD && ep <= EP_RESIDUAL, "ep must be 1 (GELU forward), 2 (GELU backward) or 3 (residual)");
+    DCL_CHECK_ARG(ep != EP_GELU_FWD || C2, "the GELU-forward epilogue needs the second output C2");
+    DCL_CHECK_ARG(ep == EP_GELU_FWD || aux, "this epilogue needs its second input aux");
+    DCL_CHECK_ARG(!rowscale || rows_per_scale >= 32, "rows_per_scale must be >= 32 (a tile row group spans at most two samples)");
+    DCL_CHECK_ARG(ldc >= N && (int64_t)M * ldc < ((int64_t)1 << 30), "the fused epilogues address C with 32-bit element offsets: M * ldc < 2^30");
+    return gemm_impl(A, lda, a_kmajor, 0, B, ldb, b_kmajor, 0, M, N, K, 1, a_amax, a_count, b_amax, b_count, bias, C, ldc, 0, 0,
+                     c_amax, 1, nullptr, nullptr, stream, ep, C2, aux, rowscale, rows_per_scale);
 }

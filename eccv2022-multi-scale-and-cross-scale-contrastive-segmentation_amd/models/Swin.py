@@ -71,6 +71,16 @@ class DropPath(nn.Module):
         return _ScaledResidual.apply(shortcut, x, mask / keep, 1.0 / keep)
 
 
+    def factors(self, x):
+        """(scale, bound) for a fused ``shortcut + scale * branch``: the per-sample factors mask / keep as a [B] tensor (the same
+        draw as ``forward`` / ``add_to``) and 1 / keep; (None, 1.0) when the module is inactive."""
+        if self.drop_prob == 0.0 or not self.training:
+            return None, 1.0
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return (mask / keep).reshape(-1), 1.0 / keep
+
+
 class _ScaledResidual(torch.autograd.Function):
     """shortcut + x * scale (scale [B, 1, ...], no gradient); backward: the incoming gradient goes to the shortcut as it
     is, scaled to x -- with its absmax tag (|g scale| <= |g| / keep), so that the Linear behind x finds its operand scale
@@ -98,6 +108,15 @@ def _residual(shortcut, y, drop_path):
     return drop_path.add_to(shortcut, y) if isinstance(drop_path, DropPath) else shortcut + drop_path(y)
 
 
+def _factors(drop_path, x):
+    """(fusable, scale, bound): the residual sum can ride in a GEMM epilogue when drop_path is Identity or this module's DropPath."""
+    if isinstance(drop_path, DropPath):
+        if x.dim() < 3 or x.numel() // (x.shape[0] * x.shape[-1]) < 32:     # (the epilogue wants >= 32 rows per sample; checked
+            return False, None, 1.0                                          # BEFORE the mask is drawn: one draw per residual sum)
+        return (True,) + drop_path.factors(x)
+    return isinstance(drop_path, nn.Identity), None, 1.0
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
         super().__init__()
@@ -106,12 +125,29 @@ class Mlp(nn.Module):
         self.fc2 = TokenLinear(hidden_features or in_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
 
+    def _fusable(self, x):
+        from .ops import fused_mlp_ok
+        return (type(self.act) is nn.GELU and self.act.approximate == 'none' and (self.drop.p == 0.0 or not self.training)
+                and fused_mlp_ok(x, self.fc1, self.fc2))
+
     def forward(self, x):
+        if self._fusable(x):
+            from .ops import fused_mlp
+            return fused_mlp(x, self.fc1, self.fc2)         # GELU and its derivative inside the GEMM epilogues (ops._FusedMlp)
         h = self.fc1(x)
         # (the absmax tag of an f16x3 fc1's output also bounds fc2's input, and the tag of fc2's data gradient the
         # gradient GELU hands back to fc1)
         a = tagged_gelu(h) if type(self.act) is nn.GELU and self.act.approximate == 'none' else self.act(h)
         return self.drop(self.fc2(self.drop(a)))
+
+    def add_to(self, shortcut, x, drop_path):
+        """shortcut + drop_path(self(x)) (reference models/Swin.py:321); on the fused path the sum is fc2's epilogue."""
+        if self._fusable(x):
+            ok, scale, bound = _factors(drop_path, x)
+            if ok:
+                from .ops import fused_mlp
+                return fused_mlp(x, self.fc1, self.fc2, shortcut=shortcut, scale=scale, bound=bound)
+        return _residual(shortcut, self(x), drop_path)
 
 
 def window_partition(x, ws):
@@ -188,6 +224,18 @@ class SwinTransformerBlock(nn.Module):
                 and a.dim == 32 * a.num_heads and a.attn_drop.p == 0.0 and not torch.is_autocast_enabled()
                 and a.qkv.weight.dtype == torch.float32)
 
+    def _proj_residual(self, shortcut, att):
+        """shortcut + drop_path(proj_drop(proj(att))) (reference models/Swin.py:318); the sum in the projection GEMM's epilogue when
+        nothing sits between the two (no projection dropout)."""
+        a = self.attn
+        if a.proj_drop.p == 0.0 or not self.training:
+            from .ops import linear_residual, linear_residual_ok
+            if linear_residual_ok(att, a.proj):
+                ok, scale, bound = _factors(self.drop_path, att)
+                if ok:
+                    return linear_residual(att, a.proj, shortcut, scale=scale, bound=bound)
+        return _residual(shortcut, a.proj_drop(a.proj(att)), self.drop_path)
+
     def forward(self, x, mask_matrix):
         B, L, C = x.shape
         H, W, ws = self.H, self.W, self.window_size
@@ -208,9 +256,9 @@ class SwinTransformerBlock(nn.Module):
             qbuf = tag_of(qkv)
             if qbuf is not None:
                 tag(att, qbuf)              # a softmax-weighted mean of v rows (or of the bias row): |att| <= max|qkv|
-            x = _residual(shortcut, a.proj_drop(a.proj(att)), self.drop_path)
+            x = self._proj_residual(shortcut, att)
             n2, x = self.norm2.with_shortcut(x) if isinstance(self.norm2, FusedLayerNorm) else (self.norm2(x), x)
-            return _residual(x, self.mlp(n2), self.drop_path)
+            return self.mlp.add_to(x, n2, self.drop_path) if isinstance(self.mlp, Mlp) else _residual(x, self.mlp(n2), self.drop_path)
         x = self.norm1(x).view(B, H, W, C)
         pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
         if pad_r or pad_b:

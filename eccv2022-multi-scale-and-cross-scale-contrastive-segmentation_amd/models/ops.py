@@ -1287,6 +1287,191 @@ class _TokenLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
+def gemm_f16x3_ep(a, b, b_kmajor, M, N, K, out, a_amax, b_amax, ep, bias=None, c_amax=None, out2=None, aux=None,
+                  rowscale=None, rows_per_scale=1):
+    """dcl_gemm_f16x3_ep: out [M, N] = epilogue(a [M, K] (k-major rows) . b (+ bias)); b is W [N, K] (b_kmajor) or W [K, N] read as
+    its transpose.  ep 1: out = v, out2 = gelu(v); ep 2: out = v * gelu'(aux); ep 3: out = aux + rowscale[row // rows_per_scale] * v."""
+    from .. import _lib
+    p = _lib.ptr
+    _lib.check(_lib.lib().dcl_gemm_f16x3_ep(p(a), K, 1, p(b), K if b_kmajor else N, int(b_kmajor), M, N, K, p(a_amax),
+                                            a_amax.numel(), p(b_amax), b_amax.numel(), p(bias), p(out), N, p(c_amax), int(ep),
+                                            p(out2), p(aux), p(rowscale), int(rows_per_scale), _stream(out)), "dcl_gemm_f16x3_ep")
+    return out
+
+
+def _ep_gemm_ok(m, n, k):
+    """The fused-epilogue entry takes one pass over the contraction (no k-split) and 32-bit element offsets into C."""
+    from .. import _lib
+    return m * n < (1 << 30) and _lib.lib().dcl_gemm_suggest_splitk(m, n, k, 1) == 1
+
+
+class _TokenLinearResidual(torch.autograd.Function):
+    """shortcut + scale * (x W^T + b) in ONE launch: the residual sum of a Swin block's attention half (reference
+    models/Swin.py:318, shortcut + drop_path(proj(...))) rides in the projection GEMM's epilogue.  scale: [B] per-sample DropPath
+    factors (mask / keep) or None; bound = 1 / keep bounds |scale|."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, shortcut, scale, bound):
+        from . import amax as _am
+        n, k = weight.shape
+        x2 = _am.carry(x, x.reshape(-1, k))
+        m = x2.shape[0]
+        y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+        ca = _am.zeros(1, x.device)
+        gemm_f16x3_ep(x2, weight, True, m, n, k, y, _am.amax_of(x2), _am.amax_of(weight), 3, bias=bias, c_amax=ca,
+                      aux=shortcut, rowscale=scale, rows_per_scale=m // scale.numel() if scale is not None else 1)
+        _am.tag(y, ca)
+        ctx.save_for_backward(x2, weight, scale)
+        ctx.has_bias = bias is not None
+        ctx.xshape, ctx.bound = x.shape, float(bound)
+        return _am.carry(y, y.view(*x.shape[:-1], n))
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import amax as _am
+        x2, weight, scale = ctx.saved_tensors
+        n, k = weight.shape
+        gb2 = _scaled_rows(gy, n, scale, ctx.bound)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            g = linear_dgrad_f16x3(gb2, weight)
+            gx = _am.carry(g, g.view(ctx.xshape))
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            if want_gb:
+                gw, gb = linear_wgrad_f16x3(gb2, x2, want_bias=True)
+            else:
+                gw = linear_wgrad_f16x3(gb2, x2)
+        elif want_gb:
+            gb = gb2.sum(0)
+        return gx, gw, gb, (gy if ctx.needs_input_grad[3] else None), None, None
+
+
+def _scaled_rows(gy, n, scale, bound):
+    """gy as contiguous [M, n] rows, times the per-sample factors (the branch's share of a residual sum's gradient); the absmax
+    tag travels along (|g scale| <= |g| * bound)."""
+    from . import amax as _am
+    g2 = _am.carry(gy, gy.reshape(-1, n))
+    if not g2.is_contiguous():
+        g2 = _am.carry(g2, g2.contiguous())
+    if scale is None:
+        return g2
+    out = (g2.view(scale.numel(), -1, n) * scale.view(-1, 1, 1)).view(-1, n)
+    t = _am.tag_of(g2)
+    if t is not None:
+        _am.tag(out, t * bound)
+    return out
+
+
+class _FusedMlp(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) (+ shortcut, scaled per sample) of a Swin Mlp (reference models/Swin.py:62-76, :321) with the
+    element-wise passes inside the GEMMs: fc1's epilogue writes the pre-activation h AND gelu(h) (no GELU kernel), fc2's epilogue
+    adds the residual (no addcmul), and in the backward fc2's data gradient leaves its epilogue already multiplied by gelu'(h)
+    (no gelu_backward kernel) -- per block three passes over [tokens, 4 C] and one over [tokens, C] less."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, shortcut, scale, bound):
+        from . import amax as _am
+        hd, k = w1.shape
+        n = w2.shape[0]
+        x2 = _am.carry(x, x.reshape(-1, k))
+        m = x2.shape[0]
+        dev = x.device
+        h = torch.empty((m, hd), dtype=torch.float32, device=dev)
+        a = torch.empty((m, hd), dtype=torch.float32, device=dev)
+        ch = _am.zeros(1, dev)
+        gemm_f16x3_ep(x2, w1, True, m, hd, k, h, _am.amax_of(x2), _am.amax_of(w1), 1, bias=b1, c_amax=ch, out2=a)
+        _am.tag(a, ch)                          # |gelu(v)| <= |v|
+        if shortcut is not None:
+            y = torch.empty((m, n), dtype=torch.float32, device=dev)
+            cy = _am.zeros(1, dev)
+            gemm_f16x3_ep(a, w2, True, m, n, hd, y, ch, _am.amax_of(w2), 3, bias=b2, c_amax=cy, aux=shortcut, rowscale=scale,
+                          rows_per_scale=m // scale.numel() if scale is not None else 1)
+            _am.tag(y, cy)
+        else:
+            y = linear_f16x3(a, w2, b2)
+        ctx.save_for_backward(x2, h, a, w1, w2, scale)
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        ctx.xshape, ctx.bound, ctx.residual = x.shape, float(bound), shortcut is not None
+        return _am.carry(y, y.view(*x.shape[:-1], n))
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import amax as _am
+        x2, h, a, w1, w2, scale = ctx.saved_tensors
+        hd, k = w1.shape
+        n = w2.shape[0]
+        m = x2.shape[0]
+        g2 = _scaled_rows(gy, n, scale if ctx.residual else None, ctx.bound)
+        need = ctx.needs_input_grad
+        gx = gw1 = gb1 = gw2 = gb2 = None
+        # fc2: weight / bias gradient from (dy, a); data gradient with gelu'(h) applied in its epilogue = fc1's dy
+        if need[3]:
+            if ctx.has_b2 and need[4]:
+                gw2, gb2 = linear_wgrad_f16x3(g2, a, want_bias=True)
+            else:
+                gw2 = linear_wgrad_f16x3(g2, a)
+        elif ctx.has_b2 and need[4]:
+            gb2 = g2.sum(0)
+        if need[0] or need[1] or (ctx.has_b1 and need[2]):
+            gh = torch.empty((m, hd), dtype=torch.float32, device=gy.device)
+            cg = _am.zeros(1, gy.device)
+            gemm_f16x3_ep(g2, w2, False, m, hd, n, gh, _am.amax_of(g2), _am.amax_of(w2), 2, c_amax=cg, aux=h)
+            _am.tag(gh, cg)
+            if need[0]:
+                g = linear_dgrad_f16x3(gh, w1)
+                gx = _am.carry(g, g.view(ctx.xshape))
+            if need[1]:
+                if ctx.has_b1 and need[2]:
+                    gw1, gb1 = linear_wgrad_f16x3(gh, x2, want_bias=True)
+                else:
+                    gw1 = linear_wgrad_f16x3(gh, x2)
+            elif ctx.has_b1 and need[2]:
+                gb1 = gh.sum(0)
+        return gx, gw1, gb1, gw2, gb2, (gy if (ctx.residual and need[5]) else None), None, None
+
+
+FUSED_MLP = _dbg.fused_mlp  # module switch (A/B runs, tests of the unfused path): False = TokenLinear -> tagged_gelu -> TokenLinear
+
+
+def fused_mlp_ok(x, fc1, fc2):
+    """Both Linears of a Swin Mlp on the split-f16 GEMM with fused epilogues: the TokenLinear conditions for each, and
+    products that need no k-split."""
+    if not (FUSED_MLP and isinstance(fc1, TokenLinear) and isinstance(fc2, TokenLinear) and fc1.f16x3 and fc2.f16x3
+            and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+            and fc1.weight.dtype == torch.float32 and fc1.weight.requires_grad and fc2.weight.requires_grad
+            and _token_gemm_ok(x, fc1.weight)):
+        return False
+    hd, k = fc1.weight.shape
+    n = fc2.weight.shape[0]
+    m = x.numel() // k
+    # (few tokens per hidden column -- the last stage: the erf evaluations sit exposed at the end of long tiles and cost more than
+    # the cache-resident element-wise kernels they replace: +45 / +55 us per launch at 6 400 x 6 144, tools/probes/gemm_ep_time.py)
+    return (fc2.weight.shape[1] == hd and n % 32 == 0 and fc2.weight.is_contiguous() and m * max(n, hd) * 4 < (1 << 32)
+            and m >= 4 * hd and _ep_gemm_ok(m, hd, k) and _ep_gemm_ok(m, n, hd) and _ep_gemm_ok(m, hd, n))
+
+
+def fused_mlp(x, fc1, fc2, shortcut=None, scale=None, bound=1.0):
+    """fc2(gelu(fc1(x))), or shortcut + scale * that (scale [B] per-sample factors or None); see _FusedMlp."""
+    if shortcut is not None:
+        shortcut = shortcut.contiguous()
+    return _FusedMlp.apply(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, shortcut,
+                           scale.reshape(-1).contiguous() if scale is not None else None, bound)
+
+
+def linear_residual_ok(x, lin):
+    n, k = lin.weight.shape
+    return (FUSED_MLP and isinstance(lin, TokenLinear) and lin.f16x3 and x.is_cuda and x.dtype == torch.float32
+            and torch.is_grad_enabled() and not torch.is_autocast_enabled() and lin.weight.dtype == torch.float32
+            and lin.weight.requires_grad and _token_gemm_ok(x, lin.weight) and _ep_gemm_ok(x.numel() // k, n, k))
+
+
+def linear_residual(x, lin, shortcut, scale=None, bound=1.0):
+    """shortcut + scale * lin(x) with the sum in the GEMM's epilogue (see _TokenLinearResidual)."""
+    return _TokenLinearResidual.apply(x, lin.weight, lin.bias, shortcut.contiguous(),
+                                      scale.reshape(-1).contiguous() if scale is not None else None, bound)
+
+
 def _token_gemm_ok(x, weight):
     """Shapes the split-f16 GEMM takes for all three products of a Linear: every extent a multiple of 32 (each is the
     contraction of one of them), the token rows contiguous."""

@@ -368,6 +368,20 @@ int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t strideA, c
                                       Linear (column sums of dy) rides on its weight-gradient GEMM, whose A operand is dy^T */,
                    void *stream);
 
+/* The same product (batch 1, no k-split) with a fused epilogue, v = the product (+ bias); C2 / aux are [M, N] with C's ldc:
+ *   ep 1  GELU forward   C = v (the pre-activation, kept for the backward), C2 = gelu(v): Mlp.fc1 + act in one launch (reference
+ *                        models/Swin.py:62-76; nn.GELU(), erf form).  Both operands k-major (a Linear's forward).
+ *   ep 2  GELU backward  C = v * gelu'(aux), aux = the pre-activation: the data gradient of fc2 handed to fc1 as its dy.
+ *                        A k-major, B row-contiguous (a Linear's data gradient).
+ *   ep 3  residual       C = aux + rowscale[row / rows_per_scale] * v (rowscale NULL: 1): shortcut + drop_path(branch) with the
+ *                        per-sample factor of DropPath (Swin.py:318-321).  Both operands k-major.
+ * c_amax (optional) receives max|C|. */
+int dcl_gemm_f16x3_ep(const float *A, int64_t lda, int a_kmajor, const float *B, int64_t ldb, int b_kmajor, int M, int N, int K,
+                      const float *a_amax, int a_count, const float *b_amax, int b_count, const float *bias /* or NULL */,
+                      float *C, int64_t ldc, float *c_amax /* or NULL */, int ep, float *C2 /* ep 1 */,
+                      const float *aux /* ep 2, 3 */, const float *rowscale /* ep 3, or NULL */, int rows_per_scale,
+                      void *stream);
+
 /* out = a + b (+ c) (+ d), n floats: the gradient of a tensor with several consumers in one pass (HRNet exchange
  * modules: every branch output feeds all fuse rows, reference models/HRNet.py:264-287). */
 int dcl_add_n(const float *a, const float *b, const float *c /* or NULL */, const float *d /* or NULL */, int64_t n,

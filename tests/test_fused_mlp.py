@@ -1,0 +1,169 @@
+"""GPU tests of the GEMM's fused epilogues (csrc/dcl_gemm.hip, dcl_gemm_f16x3_ep) and of what the Swin port builds on them:
+fc1 + GELU, fc2's data gradient x gelu'(h), shortcut + drop_path(branch) in the projection / fc2 epilogue
+(reference models/Swin.py:62-76 Mlp, :318-321 the two residual sums of a block)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gelu64(v):
+    return 0.5 * v * (1.0 + torch.erf(v * 0.7071067811865476))
+
+
+def _dgelu64(v):
+    return 0.5 * (1.0 + torch.erf(v * 0.7071067811865476)) + v * torch.exp(-0.5 * v * v) * 0.3989422804014327
+
+
+@pytest.mark.parametrize("M,K,N", [(6400, 384, 1536), (2080, 96, 384), (25600, 192, 768), (1056, 1536, 6144)])
+def test_gemm_epilogues_against_fp64(M, K, N):
+    """The three epilogues of dcl_gemm_f16x3_ep against float64 on Swin Mlp shapes (interior and ragged tiles: 2080 and 1056 rows are
+    not multiples of any workgroup tile): values to 3e-6 of the result's maximum, the emitted absmax exact, bitwise reproducible."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import amax as am, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    v64 = x.double() @ w.double().t() + b.double()
+    # ep 1: pre-activation and GELU in one launch
+    for rep in range(2):
+        h, a = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+        ca = am.zeros(1, dev)
+        ops.gemm_f16x3_ep(x, w, True, M, N, K, h, am.amax_of(x), am.amax_of(w), 1, bias=b, c_amax=ca, out2=a)
+        if rep == 0:
+            h0, a0 = h.clone(), a.clone()
+    assert torch.equal(h, h0) and torch.equal(a, a0)
+    den = v64.abs().max()
+    assert ((h.double() - v64).abs().max() / den).item() < 3e-6
+    assert ((a.double() - _gelu64(v64)).abs().max() / den).item() < 3e-6
+    assert ca.item() == h.abs().max().item()
+    # ep 2: data gradient times gelu'(aux)
+    gy = torch.randn(M, N, generator=g).to(dev)            # dy of fc2's output side: here [M, N] . W [N, K] -> [M, K]
+    hh = (torch.randn(M, K, generator=g) * 1.5).to(dev)
+    out = torch.empty(M, K, device=dev)
+    cg = am.zeros(1, dev)
+    ops.gemm_f16x3_ep(gy, w, False, M, K, N, out, am.amax_of(gy), am.amax_of(w), 2, c_amax=cg, aux=hh)
+    want = (gy.double() @ w.double()) * _dgelu64(hh.double())
+    assert ((out.double() - want).abs().max() / want.abs().max()).item() < 3e-6
+    assert cg.item() == out.abs().max().item()
+    # ep 3: shortcut + per-sample factor * (product + bias)
+    B = 4 if M % 4 == 0 else 1
+    sc = torch.tensor([0.0, 1.0 / 0.7, 1.0 / 0.7, 0.0][:B]).to(dev)
+    short = torch.randn(M, N, generator=g).to(dev)
+    for scale in (None, sc):
+        y = torch.empty(M, N, device=dev)
+        cy = am.zeros(1, dev)
+        ops.gemm_f16x3_ep(x, w, True, M, N, K, y, am.amax_of(x), am.amax_of(w), 3, bias=b, c_amax=cy, aux=short, rowscale=scale,
+                          rows_per_scale=M // B)
+        f = 1.0 if scale is None else sc.double().repeat_interleave(M // B).view(-1, 1)
+        want = short.double() + f * v64
+        assert ((y.double() - want).abs().max() / want.abs().max()).item() < 3e-6
+        assert cy.item() == y.abs().max().item()
+        if scale is not None:
+            assert torch.equal(y[:M // B], short[:M // B])          # a dropped sample is the shortcut, bit for bit
+
+
+def test_gemm_epilogue_argument_errors():
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import amax as am, ops
+    dev = torch.device("cuda:0")
+    x, w = torch.randn(1024, 64, device=dev), torch.randn(96, 64, device=dev)
+    out = torch.empty(1024, 96, device=dev)
+    with pytest.raises(RuntimeError, match="second output"):
+        ops.gemm_f16x3_ep(x, w, True, 1024, 96, 64, out, am.amax_of(x), am.amax_of(w), 1)
+    with pytest.raises(RuntimeError, match="second input"):
+        ops.gemm_f16x3_ep(x, w, True, 1024, 96, 64, out, am.amax_of(x), am.amax_of(w), 3)
+    with pytest.raises(RuntimeError, match="k-major"):
+        ops.gemm_f16x3_ep(x, w, False, 1024, 96, 64, out, am.amax_of(x), am.amax_of(w), 3, aux=out)
+
+
+@pytest.mark.parametrize("residual,drop", [(False, 0.0), (True, 0.0), (True, 0.3)])
+def test_fused_mlp_matches_unfused_and_fp64(residual, drop):
+    """Mlp (+ residual sum, + DropPath) through ops._FusedMlp against the unfused chain TokenLinear -> GELU -> TokenLinear (->
+    addcmul) under the same mask draw, and both against float64: output, input / shortcut gradients, all four parameter gradients."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import ops
+    from mscs_amd.models.Swin import DropPath, Mlp
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, L, C = 4, 3200, 192
+    mlp = Mlp(C, 4 * C).to(dev).train()
+    dp = DropPath(drop).train() if drop else torch.nn.Identity()
+    x = torch.randn(B, L, C, device=dev)
+    s = torch.randn(B, L, C, device=dev)
+    gy = torch.randn(B, L, C, device=dev)
+    res = {}
+    for fused in (True, False):
+        ops.FUSED_MLP = fused
+        try:
+            mlp.zero_grad()
+            xi, si = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
+            torch.manual_seed(11)
+            assert mlp._fusable(xi) == fused
+            y = mlp.add_to(si, xi, dp) if residual else mlp(xi)
+            y.backward(gy)
+            res[fused] = [y.detach(), xi.grad] + ([si.grad] if residual else []) + [p.grad.clone() for p in mlp.parameters()]
+        finally:
+            ops.FUSED_MLP = True
+    # float64 (same mask: the factors are recovered from the unfused run's shortcut-free part when DropPath is active)
+    w1, b1, w2, b2 = [p.detach().double() for p in (mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias)]
+    x64 = x.double().requires_grad_(True)
+    s64 = s.double().requires_grad_(True)
+    h = x64 @ w1.t() + b1
+    br = _gelu64(h) @ w2.t() + b2
+    if residual:
+        torch.manual_seed(11)
+        f = torch.ones(B, 1, 1, dtype=torch.float64, device=dev)
+        if drop:
+            f = (x.new_empty((B, 1, 1)).bernoulli_(1.0 - drop) / (1.0 - drop)).double()
+        y64 = s64 + f * br
+    else:
+        y64 = br
+    gs = torch.autograd.grad(y64, [x64, s64] if residual else [x64], gy.double(), retain_graph=True)
+    names = ["y", "dx"] + (["dshortcut"] if residual else []) + ["dw1", "db1", "dw2", "db2"]
+    for i, n in enumerate(names):
+        a, b = res[True][i], res[False][i]
+        den = b.abs().max().item() + 1e-12
+        assert (a - b).abs().max().item() <= 2e-5 * den, (n, (a - b).abs().max().item() / den)
+    assert ((res[True][0].double() - y64).abs().max() / y64.abs().max()).item() < 3e-6
+    assert ((res[True][1].double() - gs[0]).abs().max() / gs[0].abs().max()).item() < 5e-6
+    if residual:
+        assert torch.equal(res[True][2], gy)                 # the shortcut's gradient is the incoming one, untouched
+        if drop:                                             # a dropped sample sends nothing into the branch
+            assert torch.equal(res[True][1].view(B, -1).abs().amax(1) == 0, f.view(-1) == 0)
+
+
+def test_swin_block_fused_epilogues_match_unfused_chain():
+    """A whole SwinTransformerBlock (HIP attention) with DropPath active: the block with the residual sums in the projection / fc2
+    epilogues and GELU inside the GEMMs against the same block on the unfused chain, same mask draws: output, input gradient, every
+    parameter gradient."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import ops
+    from mscs_amd.models.Swin import BasicLayer, SwinTransformerBlock
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    blk = SwinTransformerBlock(dim=96, num_heads=3, window_size=7, shift_size=3, drop_path=0.25).to(dev).train()
+    H, W = 40, 40
+    blk.H, blk.W = H, W
+    x = torch.randn(4, H * W, 96, device=dev)
+    mask = BasicLayer(dim=96, depth=2, num_heads=3)._shift_mask(H, W, dev)
+    res = {}
+    for fused in (True, False):
+        ops.FUSED_MLP = fused
+        try:
+            blk.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            torch.manual_seed(21)
+            y = blk(xi, mask)
+            (y * torch.cos(torch.arange(y.numel(), device=dev).view_as(y) * 0.37)).sum().backward()
+            res[fused] = (y.detach(), xi.grad, {k: p.grad.clone() for k, p in blk.named_parameters()})
+        finally:
+            ops.FUSED_MLP = True
+    ya, ga, pa = res[True]
+    yb, gb, pb = res[False]
+    assert (ya - yb).abs().max().item() <= 2e-5 * yb.abs().max().item()
+    assert (ga - gb).abs().max().item() <= 1e-4 * gb.abs().max().item()
+    for k in pa:
+        assert (pa[k] - pb[k]).abs().max().item() <= 1e-4 * max(pb[k].abs().max().item(), 1e-6), k
