@@ -34,6 +34,8 @@ SIGNATURES = {
     "dcl_infonce_zsweep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp],
     "dcl_infonce_possweep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_infonce_loss": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "dcl_infonce_zsweep_keep": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "dcl_infonce_pos_finish": [_vp, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "dcl_infonce_prep_stats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
     "dcl_infonce_bwd": [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "dcl_infonce_bwd_streamk_workgroups": [_i, _i],

@@ -31,7 +31,7 @@
 // A/B and bound probes (tools/probes/gemm_ab.sh); the product build leaves them at their defaults
 #ifndef DCL_GEMM_PROBE
 #define DCL_GEMM_PROBE 0        // bits: 1 no MFMAs, 2 no split + LDS stores, 4 no global loads, 8 no split (raw bits
-                                // stored), 16 split but no LDS stores (results wrong)
+                                // stored), 16 split but no LDS stores, 32 no result stores (results wrong)
 #endif
 #ifndef DCL_GEMM_PINGPONG
 #define DCL_GEMM_PINGPONG 1     // 0: every wave stages before its matrix work
@@ -488,7 +488,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
                             float val = acc[i][j][r] * inv + bv;
                             if (a.accumulate)
                                 val += *p;
-                            *p = val;
+                            if (!(DCL_GEMM_PROBE & 32))
+                                *p = val;
                             mx = fmaxf(mx, fabsf(val));
                         }
                     }

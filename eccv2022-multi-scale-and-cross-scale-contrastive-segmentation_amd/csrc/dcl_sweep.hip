@@ -75,6 +75,11 @@ struct SweepArgs {
     int sk_seq;            // launch number of this (flags, workspace) pair, never 0 (host: dcl_infonce_bwd_streamk)
     long long sk_timeout;  // s_memrealtime ticks (100 MHz) an owner waits for one partial tile before it gives up
     int sk_probe;          // timing probe (dcl_infonce_set_streamk(2)): no flag traffic, no waiting -- WRONG results
+    // MODE_Z, optional: keep the raw similarities of the POSITIVE columns, spos[i * spos_ld + (j - lo_i)] (row i's positive range
+    // is contiguous: class-major bank).  k_pos_finish then evaluates the positives' terms from them once Z_i is complete --
+    // the MODE_POS sweep (a second pass over ~1/K of the similarity matrix: A panels, chunks, MFMAs) disappears.
+    float *spos;
+    int spos_ld;
 };
 
 // One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to the wave-uniform LDS address
@@ -619,6 +624,8 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                     const float e = __builtin_amdgcn_exp2f(acc[r] * p.c1);
                     const bool inr = (unsigned)(jj - lo) < span;
                     zi += (jj < p.N2 && !inr) ? e : 0.f;
+                    if (p.spos && inr && jj < p.N2)         // (rows >= N1 have an empty range)
+                        p.spos[(size_t)i * p.spos_ld + (jj - lo)] = acc[r];
                 }
             }
         } else if (MODE == MODE_POS) {
@@ -902,6 +909,44 @@ __global__ __launch_bounds__(1024) void k_loss_reduce(const float *__restrict__ 
     }
 }
 
+// The positives' share of the forward, from the similarities MODE_Z kept (SweepArgs::spos): row i's
+//   rowloss_i = sum_p (s_ip / tau - log(e^{s_ip / tau} + Z_i)),   W_i = sum_p 1 / (e^{s_ip / tau} + Z_i),   Z_i = sum of the zpart slabs
+// -- exactly what MODE_POS computes per element (same exp2 / log / rcp), one wave per row, lanes along the positive range.
+__global__ __launch_bounds__(256) void k_pos_finish(const float *__restrict__ spos, int ld, int N1, int N1pad, int V1,
+                                                   const int32_t *__restrict__ rng_lo, const int32_t *__restrict__ rng_hi,
+                                                   float inv_tau, float c1, int intra, const float *__restrict__ zpart,
+                                                   int zsplits, float *__restrict__ Z, float *__restrict__ rowloss,
+                                                   float *__restrict__ W)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N1pad)
+        return;
+    float zi = 0.f;
+    for (int s = 0; s < zsplits; ++s)
+        zi += zpart[(size_t)s * N1pad + i];
+    int lo = 0, hi = 0;
+    if (i < N1) {
+        lo = rng_lo[i / V1];
+        hi = rng_hi[i / V1];
+    }
+    float rl = 0.f, ws = 0.f;
+    const float *row = spos + (size_t)i * ld;
+    for (int q = lane; q < hi - lo; q += 64) {
+        const float sv = row[q];
+        const float t = __builtin_amdgcn_exp2f(sv * c1) + zi;
+        const bool pos = !(intra && lo + q == i);
+        rl += pos ? (sv * inv_tau - logf(t)) : 0.f;
+        ws += pos ? __builtin_amdgcn_rcpf(t) : 0.f;
+    }
+    rl = wave_sum(rl);
+    ws = wave_sum(ws);
+    if (lane == 0) {
+        Z[i] = zi;
+        rowloss[i] = rl;
+        W[i] = ws;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_prep_stats(const float *__restrict__ Z,
                                                    const float *__restrict__ W,
                                                    const int32_t *__restrict__ rng_lo,
@@ -976,6 +1021,42 @@ extern "C" int dcl_infonce_zsweep(const float *A, int N1, int V1, const float *B
         hipLaunchKernelGGL((k_sweep<MODE_Z, false, true>), dim3(RB, nsplit), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL((k_sweep<MODE_Z, false, false>), dim3(RB, nsplit), dim3(256), 0, (hipStream_t)stream, p);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_infonce_zsweep_keep(const float *A, int N1, int V1, const float *B, int N2,
+                                       const int32_t *rng_lo, const int32_t *rng_hi, float inv_tau,
+                                       int nsplit, float *zpart, const void *Ah, const void *Bh, float *spos, int spos_ld,
+                                       void *stream)
+{
+    int rc = check_common(A, N1, V1, B, N2, rng_lo, rng_hi, nsplit);
+    if (rc)
+        return rc;
+    DCL_CHECK_ARG(zpart && spos && spos_ld > 0, "null output pointer");
+    DCL_CHECK_ARG((Ah == nullptr) == (Bh == nullptr), "Ah and Bh must be given together");
+    SweepArgs p = fwd_args(A, N1, V1, B, N2, rng_lo, rng_hi, inv_tau, 0, Ah, Bh);
+    p.nsplit = nsplit; p.zpart = zpart;
+    p.spos = spos; p.spos_ld = spos_ld;
+    const int RB = dcl_round_up(N1, BM) / BM;
+    if (Ah)
+        hipLaunchKernelGGL((k_sweep<MODE_Z, false, true>), dim3(RB, nsplit), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((k_sweep<MODE_Z, false, false>), dim3(RB, nsplit), dim3(256), 0, (hipStream_t)stream, p);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dcl_infonce_pos_finish(const float *spos, int spos_ld, int N1, int V1, const int32_t *rng_lo,
+                                      const int32_t *rng_hi, float inv_tau, int intra, int f16x3, const float *zpart,
+                                      int zsplits, float *Z, float *rowloss, float *W, void *stream)
+{
+    DCL_CHECK_ARG(spos && rng_lo && rng_hi && zpart && Z && rowloss && W, "null pointer");
+    DCL_CHECK_ARG(N1 > 0 && V1 > 0 && spos_ld > 0 && zsplits > 0, "bad sizes");
+    const float k = f16x3 ? F16_SCALE_SQ_INV : 1.0f;            // (as fwd_args: the kept values are 2^20 <a, b> in f16x3 mode)
+    const int N1pad = dcl_round_up(N1, BM);
+    hipLaunchKernelGGL(k_pos_finish, dim3((N1pad + 3) / 4), dim3(256), 0, (hipStream_t)stream, spos, spos_ld, N1, N1pad, V1,
+                       rng_lo, rng_hi, inv_tau * k, inv_tau * 1.4426950408889634f * k, intra, zpart, zsplits, Z, rowloss, W);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -60,6 +60,7 @@ class DebugConfig:
     side_stream_priority: Optional[int] = field(default_factory=lambda: _int('DCL_SIDE_PRIO'))  # HIP priority of the branch streams
     # ---- loss
     mfma_mode: Optional[str] = field(default_factory=lambda: os.environ.get('DCL_MFMA'))        # 'f32' | 'f16x3' override
+    keep_positives: bool = field(default_factory=lambda: _flag('DCL_KEEP_POSITIVES'))           # forward: one sweep + k_pos_finish
     sweep_streamk: Optional[int] = field(default_factory=lambda: _int('DCL_SWEEP_STREAMK'))     # 0 = column-split slabs
     sweep_slices: Optional[int] = field(default_factory=lambda: _int('DCL_SWEEP_SLICES'))       # 1 | 4 | 8 column slices of stream-K
     lib_path: Optional[str] = field(default_factory=lambda: os.environ.get('DCL_LIB_PATH'))     # probe builds of the library

@@ -83,6 +83,7 @@ class _Term:
     rng_hi: torch.Tensor = None
     rev_lo: torch.Tensor = None          # cross only: [T_b] positive ranges of b's slots in bank a
     rev_hi: torch.Tensor = None
+    max_span: int = 0                    # max over the anchor slots of rng_hi - rng_lo (host side, from the plan)
     Z: torch.Tensor = None
     W: torch.Tensor = None
     nsplit: int = 1
@@ -323,6 +324,7 @@ def _plan_terms_and_sample(cfg: EngineConfig, staged: StagedLabels, with_cross: 
         pa, pb = st.scales[t.a].plan, st.scales[t.b].plan
         lo, hi = positive_ranges(pa, pb)
         ids = [add(lo), add(hi)]
+        t.max_span = int((hi - lo).max()) if len(lo) else 0      # widest positive range of an anchor slot (host plan)
         if not t.intra:
             rlo, rhi = positive_ranges(pb, pa)
             ids += [add(rlo), add(rhi)]
@@ -650,6 +652,19 @@ def agree_or_raise(error: Optional[BaseException], device, group=None):
                            "aborting this step on every rank")
 
 
+KEEP_POSITIVES_MAX_SPAN = 2048     # floats per row of the kept-positives buffer (N1pad x span x 4 B: 80 MB at N1 = 9 804)
+
+
+def _keep_positives(t) -> bool:
+    """Single-segment term whose widest positive range is small enough to keep the positives' similarities in memory: the forward
+    is then ONE sweep over the bank (dcl_infonce_zsweep_keep + dcl_infonce_pos_finish) instead of the Z and POS sweeps.  A few
+    classes with thousands of views each (blocky labels) keep the two-sweep form: the buffer would approach the N x N matrix."""
+    from ..debug import cfg as _dbg
+    # (max_span is the host plan's figure for the rank-local ranges: only the default own segment qualifies)
+    return (_dbg.keep_positives and len(t.segs) == 1 and t.segs[0].rng_lo is t.rng_lo and t.pcount is None
+            and 0 < t.max_span <= KEEP_POSITIVES_MAX_SPAN)
+
+
 def run_forward_terms(st: StepState):
     """K4 for every term over its contrast segments; raw term losses land in st.loss_buf[idx]."""
     L = _lib.lib()
@@ -667,6 +682,24 @@ def run_forward_terms(st: StepState):
         t.W = torch.empty((N1pad,), dtype=torch.float32, device=dev)
         rowloss = torch.empty((N1pad,), dtype=torch.float32, device=dev)
         inv_tau = 1.0 / t.tau
+        if _keep_positives(t):
+            # one pass over the bank: the Z sweep keeps the positives' similarities, a row-wise kernel finishes them
+            sg = t.segs[0]
+            ld = (t.max_span + 3) & ~3
+            spos = torch.empty((N1pad, ld), dtype=torch.float32, device=dev)
+            ah = A.bank_h if sg.bank_h is not None else None
+            _lib.check(L.dcl_infonce_zsweep_keep(_lib.ptr(A.bank), N1, V1, _lib.ptr(sg.bank), sg.N, _lib.ptr(sg.rng_lo),
+                                                 _lib.ptr(sg.rng_hi), inv_tau, sg.nsplit, _lib.ptr(zpart), _lib.ptr(ah),
+                                                 _lib.ptr(sg.bank_h), _lib.ptr(spos), ld, stream), "dcl_infonce_zsweep_keep")
+            _lib.check(L.dcl_infonce_pos_finish(_lib.ptr(spos), ld, N1, V1, _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi), inv_tau,
+                                                1 if (t.intra and sg.own) else 0, 1 if sg.bank_h is not None else 0,
+                                                _lib.ptr(zpart), zs_total, _lib.ptr(t.Z), _lib.ptr(rowloss), _lib.ptr(t.W),
+                                                stream), "dcl_infonce_pos_finish")
+            _lib.check(L.dcl_infonce_loss(_lib.ptr(rowloss), _lib.ptr(sg.rng_lo), _lib.ptr(sg.rng_hi),
+                                          _lib.ptr(t.pcount), N1, V1, 1 if t.intra else 0,
+                                          _lib.ptr(st.loss_buf[idx:]), stream), "dcl_infonce_loss")
+            st.keepalive += [zpart, rowloss, spos]
+            continue
         off = 0
         for sg in t.segs:
             ah = A.bank_h if sg.bank_h is not None else None

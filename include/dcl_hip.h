@@ -151,6 +151,17 @@ int dcl_infonce_possweep(const float *A, int N1, int V1, const float *B, int N2,
                          float *W, const void *Ah, const void *Bh, void *stream);
 int dcl_infonce_loss(const float *rowloss, const int32_t *rng_lo, const int32_t *rng_hi,
                      const int32_t *pcount, int N1, int V1, int intra, float *loss, void *stream);
+/* One pass over the bank instead of two (single-segment terms): dcl_infonce_zsweep_keep = dcl_infonce_zsweep that also KEEPS the
+ * raw similarities of every row's positive columns, spos f32 [N1pad][spos_ld], spos_ld >= max_u (rng_hi[u] - rng_lo[u])
+ * (column j of row i at spos[i * spos_ld + j - rng_lo[i / V1]]; the positive range of a row is contiguous in the class-major
+ * bank); dcl_infonce_pos_finish then produces dcl_infonce_possweep's Z / rowloss / W from them (same per-element arithmetic;
+ * f16x3 = the sweep ran with Ah / Bh).  Reference: DenseContrastiveLossV2.py:173-192, _ms.py:132-161. */
+int dcl_infonce_zsweep_keep(const float *A, int N1, int V1, const float *B, int N2, const int32_t *rng_lo,
+                            const int32_t *rng_hi, float inv_tau, int nsplit, float *zpart, const void *Ah, const void *Bh,
+                            float *spos, int spos_ld, void *stream);
+int dcl_infonce_pos_finish(const float *spos, int spos_ld, int N1, int V1, const int32_t *rng_lo, const int32_t *rng_hi,
+                           float inv_tau, int intra, int f16x3, const float *zpart, int zsplits, float *Z, float *rowloss,
+                           float *W, void *stream);
 
 /* ---- K5 ---------------------------------------------------------------------------------
  * InfoNCE backward.  With G_ij = dL/ds_ij:

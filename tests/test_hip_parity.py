@@ -440,6 +440,98 @@ def test_c_abi_direct_infonce_cross(dev, oracle):
     _check_grad(dp2.sum(0)[:N2].cpu().numpy(), d2)
 
 
+@pytest.mark.parametrize("f16x3", [False, True])
+@pytest.mark.parametrize("intra", [0, 1])
+def test_one_sweep_forward_equals_two_sweep_forward(dev, f16x3, intra):
+    """dcl_infonce_zsweep_keep + dcl_infonce_pos_finish (one pass over the bank; the positives' similarities kept) against
+    dcl_infonce_zsweep + dcl_infonce_possweep on ragged class-sorted banks (a class absent from the contrast bank, ranges that
+    cross chunk and column-split boundaries, N not a multiple of anything): the same zpart and Z bit for bit, rowloss / W to
+    fp32 summation order."""
+    from mscs_amd import _lib
+    import ctypes
+    L = _lib.lib()
+    rs = np.random.RandomState(5)
+    V = 9
+    cls1 = np.sort(rs.randint(0, 9, size=61))
+    cls2 = cls1 if intra else np.sort(rs.choice([0, 1, 2, 3, 5, 6, 7, 8], size=47))      # class 4 absent from the contrast bank
+    N1, N2 = len(cls1) * V, len(cls2) * V
+    F1 = rs.randn(N1, 256).astype(np.float32); F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+    F2 = F1 if intra else rs.randn(N2, 256).astype(np.float32)
+    F2 = F2 / np.linalg.norm(F2, axis=1, keepdims=True)
+    lo = np.array([np.flatnonzero(cls2 == c)[0] * V if (cls2 == c).any() else 0 for c in cls1], np.int32)
+    hi = np.array([(np.flatnonzero(cls2 == c)[-1] + 1) * V if (cls2 == c).any() else 0 for c in cls1], np.int32)
+
+    def bank(F):
+        pad = (-F.shape[0]) % 128
+        return torch.from_numpy(np.concatenate([F, np.zeros((pad, 256), np.float32)])).to(dev)
+    A, B = bank(F1), bank(F2)
+    Ah = Bh = None
+    if f16x3:
+        def halves(b):
+            x = b.double() * 1024.0
+            h = x.to(torch.float16)
+            l = (x - h.double()).to(torch.float16)
+            return torch.cat([h, l], 1).contiguous()
+        Ah, Bh = halves(A), halves(B)
+    lo_d, hi_d = torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev)
+    N1pad = A.shape[0]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = _lib.ptr
+    tau = 0.1
+    for ns in (1, 3):
+        zp0 = torch.empty(ns * N1pad, device=dev); zp1 = torch.empty(ns * N1pad, device=dev)
+        Z0, rl0, W0 = (torch.empty(N1pad, device=dev) for _ in range(3))
+        Z1, rl1, W1 = (torch.empty(N1pad, device=dev) for _ in range(3))
+        _lib.check(L.dcl_infonce_zsweep(p(A), N1, V, p(B), N2, p(lo_d), p(hi_d), 1 / tau, ns, p(zp0), p(Ah), p(Bh), st), "z")
+        _lib.check(L.dcl_infonce_possweep(p(A), N1, V, p(B), N2, p(lo_d), p(hi_d), 1 / tau, intra, p(zp0), ns, 0, p(Z0), p(rl0),
+                                          p(W0), p(Ah), p(Bh), st), "pos")
+        ld = (int((hi - lo).max()) + 3) & ~3
+        spos = torch.full((N1pad, ld), float("nan"), device=dev)
+        _lib.check(L.dcl_infonce_zsweep_keep(p(A), N1, V, p(B), N2, p(lo_d), p(hi_d), 1 / tau, ns, p(zp1), p(Ah), p(Bh),
+                                             p(spos), ld, st), "zkeep")
+        _lib.check(L.dcl_infonce_pos_finish(p(spos), ld, N1, V, p(lo_d), p(hi_d), 1 / tau, intra, int(f16x3), p(zp1), ns,
+                                            p(Z1), p(rl1), p(W1), st), "finish")
+        assert torch.equal(zp0, zp1) and torch.equal(Z0, Z1)
+        # every positive was written exactly where the finish kernel reads it, nothing else was touched
+        span = torch.from_numpy(np.repeat(hi - lo, V)).to(dev)
+        cols = torch.arange(ld, device=dev).view(1, -1)
+        assert torch.equal(~torch.isnan(spos[:N1]), cols < span.view(-1, 1)) and torch.isnan(spos[N1:]).all()
+        assert torch.allclose(rl0[:N1], rl1[:N1], rtol=2e-6, atol=2e-5) and torch.allclose(W0[:N1], W1[:N1], rtol=2e-6, atol=1e-9)
+        assert (rl1[N1:] == 0).all() and (W1[N1:] == 0).all()
+
+
+def test_keep_positives_switch_gives_the_same_loss_and_gradients(dev):
+    """The loss module with the one-sweep forward (default) and with the two-sweep forward (debug.cfg.keep_positives = False):
+    same sampling, loss and feature gradients to round-off, on a three-scale cross-scale configuration."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.debug import cfg as dbg
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    from mscs_amd.losses import engine
+    conf = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "min_views_per_class": 5, "max_views_per_class": 60,
+            "max_features_total": 3000, "scales": 3, "weights": [1.0, 0.7, 0.4], "cross_scale_contrast": True}
+    g = torch.Generator().manual_seed(2)
+    label = torch.randint(0, 19, (3, 96, 192), generator=g).to(dev)
+    feats = [torch.randn(3, 64, 96 // s, 192 // s, generator=g).to(dev) for s in (1, 2, 4)]
+    outs = {}
+    keep = dbg.keep_positives
+    try:
+        for flag in (True, False):
+            dbg.keep_positives = flag
+            mod = DenseContrastiveLossV2_ms(dict(conf)).to(dev)
+            fs = [f.clone().requires_grad_(True) for f in feats]
+            torch.manual_seed(9)
+            loss = mod(label, fs)
+            loss.backward()
+            used = [engine._keep_positives(t) for t in mod.last_state.terms] if hasattr(mod, "last_state") else None
+            outs[flag] = (loss.detach(), [f.grad for f in fs], used)
+    finally:
+        dbg.keep_positives = keep
+    assert outs[True][2] and all(outs[True][2]) and not any(outs[False][2])
+    assert torch.allclose(outs[True][0], outs[False][0], rtol=2e-6)
+    for a, b in zip(outs[True][1], outs[False][1]):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item() + 1e-12
+
+
 def test_k1_k2_direct_odd_sizes(dev, oracle):
     """K1/K2 through ctypes at sizes that are not multiples of the stride or the segment length."""
     from mscs_amd import _lib
