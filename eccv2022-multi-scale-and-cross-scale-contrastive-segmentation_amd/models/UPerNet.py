@@ -114,6 +114,17 @@ class FPN(nn.Module):
             nn.Dropout2d(self.dropout),
             nn.Conv2d(self.fpn_num_ch, self.num_classes, kernel_size=1))
 
+    def _classify(self, y):
+        """conv_last[1:] = Dropout2d -> conv1x1 (reference models/UPerNet.py:66-68); the channel dropout folded into per-sample
+        weights of the 1x1 convolution when it is active (models/ops.py dropout2d_conv1x1)."""
+        tail = list(self.conv_last)[1:]
+        if len(tail) == 2 and isinstance(tail[0], nn.Dropout2d):
+            from .ops import dropout2d_conv1x1
+            return dropout2d_conv1x1(y, tail[0], tail[1])
+        for layer in tail:
+            y = layer(y)
+        return y
+
     def forward(self, conv_out):
         c5 = conv_out[-1]
         size5 = c5.shape[2:]
@@ -148,12 +159,10 @@ class FPN(nn.Module):
             else:
                 for layer in list(block)[1:]:
                     y = layer(y)
-            x = y
-            for layer in list(self.conv_last)[1:]:
-                x = layer(x)
+            x = self._classify(y)
         else:
             fused = upsample_concat(parts, self.align_corners)
-            x = self.conv_last(fused)
+            x = self._classify(self.conv_last[0](fused))
         if self.return_features:
             return x, pyramid, fused
         return x

@@ -167,3 +167,30 @@ def test_swin_block_fused_epilogues_match_unfused_chain():
     assert (ga - gb).abs().max().item() <= 1e-4 * gb.abs().max().item()
     for k in pa:
         assert (pa[k] - pb[k]).abs().max().item() <= 1e-4 * max(pb[k].abs().max().item(), 1e-6), k
+
+
+def test_dropout2d_folded_into_the_classifier_matches_the_two_modules():
+    """ops.dropout2d_conv1x1 (channel factors in per-sample weights) against conv(F.dropout2d(x)) under the same generator state:
+    the same channels dropped, output and all gradients to fp32 round-off; eval mode and p = 0 run the modules as they are."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    drop = torch.nn.Dropout2d(0.1).train()
+    conv = torch.nn.Conv2d(512, 150, 1).to(dev)
+    x = torch.randn(4, 512, 40, 48, device=dev)
+    gy = torch.randn(4, 150, 40, 48, device=dev)
+    res = []
+    for folded in (True, False):
+        conv.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        torch.manual_seed(77)
+        y = ops.dropout2d_conv1x1(xi, drop, conv) if folded else conv(drop(xi))
+        y.backward(gy)
+        res.append((y.detach(), xi.grad, conv.weight.grad.clone(), conv.bias.grad.clone()))
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    dropped = (res[0][1].abs().amax((2, 3)) == 0)
+    assert dropped.any() and torch.equal(dropped, res[1][1].abs().amax((2, 3)) == 0)       # whole channels, the same ones
+    drop.eval()
+    assert torch.equal(ops.dropout2d_conv1x1(x, drop, conv), conv(x))
