@@ -56,6 +56,7 @@ class DebugConfig:
     # backward on a side stream: 0 off, 1 on, 2 on with the fine part's weight gradient first (A/B: 96.4 / 96.0 / 95.6 ms)
     gemm_gemm_tile: Optional[int] = field(default_factory=lambda: _int('DCL_GEMM_TILE'))       # 1..4: force a workgroup tile
     fold_dropout2d: bool = field(default_factory=lambda: _flag('DCL_FOLD_DROPOUT2D'))           # Dropout2d -> conv1x1 as per-sample weights
+    token_laterals: bool = field(default_factory=lambda: _flag('DCL_TOKEN_LATERALS'))           # UPerNet laterals read Swin outputs token-major
     fused_mlp: bool = field(default_factory=lambda: _flag('DCL_FUSED_MLP'))                     # Swin Mlp / residual sums in GEMM epilogues
     coalesced_sync_bn: bool = field(default_factory=lambda: _flag('DCL_SYNCBN_COALESCE'))       # stacked SyncBN exchanges
     side_stream_priority: Optional[int] = field(default_factory=lambda: _int('DCL_SIDE_PRIO'))  # HIP priority of the branch streams

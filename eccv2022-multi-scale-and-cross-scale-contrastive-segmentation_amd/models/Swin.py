@@ -46,6 +46,35 @@ def to_2tuple(x):
     return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
 
 
+class TokenMap:
+    """A backbone output kept TOKEN-MAJOR: ``tokens`` [B, H * W, C] -- what the stage's output LayerNorm wrote -- standing for the
+    [B, C, H, W] map the reference returns (models/Swin.py:452-455: view, permute, contiguous).  A consumer that is a 1x1
+    convolution reads the tokens as they are (a GEMM does not care which operand index is contiguous; models/ops.py
+    conv1x1_from_tokens) and its data gradient comes back token-major, which is what the LayerNorm's backward wants: the layout
+    copies of both directions disappear.  Anybody else calls ``nchw()`` and gets the reference's tensor (made once).  Only handed
+    out when the owner of the backbone asks for it (SwinTransformer.token_outputs, set by models/UPerNet.py for its own decoder)."""
+
+    def __init__(self, tokens, H, W):
+        self.tokens, self.H, self.W = tokens, int(H), int(W)
+        self._nchw = None
+
+    @property
+    def shape(self):
+        b, _, c = self.tokens.shape
+        return torch.Size((b, c, self.H, self.W))
+
+    def nchw(self):
+        if self._nchw is None:
+            t = self.tokens
+            self._nchw = carry(t, t.view(-1, self.H, self.W, t.shape[-1]).permute(0, 3, 1, 2).contiguous())
+        return self._nchw
+
+
+def as_nchw(x):
+    """A backbone output as the reference's NCHW tensor (TokenMap or tensor)."""
+    return x.nchw() if isinstance(x, TokenMap) else x
+
+
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm semantics)."""
 
@@ -457,9 +486,15 @@ class SwinTransformer(nn.Module):
             x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww)
             if i in self.out_indices:
                 x_out = getattr(self, f'norm{i}')(x_out)
-                # (same values in another order: the norm's absmax tag travels with the NCHW copy the decoder convolves)
-                outs.append(carry(x_out, x_out.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous()))
+                tm = TokenMap(x_out, H, W)
+                # token_outputs: every level but the last stays token-major (the decoder's lateral 1x1 convolutions read tokens;
+                # the last level feeds pooling / 3x3 convolutions).  Otherwise the reference's NCHW tensors (same values in
+                # another order: the norm's absmax tag travels with the copy the decoder convolves)
+                keep = self.token_outputs and self.training and torch.is_grad_enabled() and x_out.is_cuda and i != max(self.out_indices)
+                outs.append(tm if keep else tm.nchw())
         return tuple(outs)
+
+    token_outputs = False      # set by the owner (models/UPerNet.py); see TokenMap
 
     def train(self, mode=True):
         super().train(mode)

@@ -17,7 +17,8 @@ from ..utils import DATASETS_INFO, printlog
 from .fused_bn import FusedBatchNorm2d, bn_act
 from .ops import upsample_bilinear, upsample_concat
 from .Projector import Projector
-from .Swin import SwinTransformer
+from ..debug import cfg as _dbg
+from .Swin import SwinTransformer, as_nchw
 from .Swin import backbone_config as backbone_config_swin
 
 
@@ -125,15 +126,28 @@ class FPN(nn.Module):
             y = layer(y)
         return y
 
+    def _lateral(self, block, x):
+        """fpn_in[k](backbone level) (reference models/UPerNet.py:88-92).  A level handed over token-major (models/Swin.TokenMap) goes
+        into the 1x1 convolution as it lies: no NCHW copy forward, no copy back in front of the backbone norm's backward."""
+        from .Swin import TokenMap
+        if isinstance(x, TokenMap):
+            from .ops import conv1x1_from_tokens, conv1x1_from_tokens_ok
+            if (isinstance(block, _ConvBNAct) and len(block) in (2, 3) and isinstance(block[1], FusedBatchNorm2d)
+                    and (len(block) == 2 or isinstance(block[2], nn.ReLU)) and conv1x1_from_tokens_ok(x.tokens, block[0], x.H, x.W)):
+                return bn_act(block[1], conv1x1_from_tokens(x.tokens, block[0], x.H, x.W), relu=len(block) == 3)
+            x = x.nchw()
+        return block(x)
+
     def forward(self, conv_out):
-        c5 = conv_out[-1]
+        from .Swin import as_nchw
+        c5 = as_nchw(conv_out[-1])
         size5 = c5.shape[2:]
         ppm = [c5] + [conv(upsample_bilinear(pool(c5), size5, False))
                       for pool, conv in zip(self.ppm_pooling, self.ppm_conv)]
         feature = self.ppm_last_conv(torch.cat(ppm, 1))
         pyramid = [feature]
         for i in range(2, self.fpn_num_lvl + 1):
-            lateral = self.fpn_in[-i + 1](conv_out[-i])
+            lateral = self._lateral(self.fpn_in[-i + 1], conv_out[-i])
             feature = upsample_bilinear(feature, lateral.shape[2:], self.align_corners, add=lateral)
             pyramid.append(self.fpn_out[-i + 1](feature))
         pyramid.reverse()                                       # [P2 .. P5]
@@ -293,6 +307,10 @@ class UPerNet(nn.Module):
             self._conv_packs.refresh()
         if x.is_cuda and self.training:
             self._linear_tags.refresh()
+        # the decoder's lateral convolutions read the backbone levels token-major (models/Swin.TokenMap; graph key `token_laterals`,
+        # default on): every other reader below goes through as_nchw
+        self.backbone.token_outputs = bool(self.config.get('token_laterals', True)) and self.config.get('hip_decoder', True) \
+            and _dbg.token_laterals
         feats = self.backbone(x)
         logits, fpn_feats, fused = self.fpn(feats)
         # graph key `lazy_logits` (extension, default off = the reference's return values): the logits of both heads stay
@@ -307,17 +325,19 @@ class UPerNet(nn.Module):
         logits = up(logits)
         interm = None
         if self.get_intermediate and self.aux_head is not None:
-            interm = up(self._aux(feats[self.aux_in_index]))
+            interm = up(self._aux(as_nchw(feats[self.aux_in_index])))
         if self.projector_model is not None:
             if self.use_ms_projector:
                 if self.projector_position == 'backbone':
-                    proj = self.projector_model(feats[:self.ms_projector_scales])
+                    proj = self.projector_model([as_nchw(f) for f in feats[:self.ms_projector_scales]])
                 else:
                     proj = self.projector_model(fpn_feats)
             else:
                 proj = self.projector_model(fused.materialize() if hasattr(fused, 'materialize') else fused)
             if self.return_features:
                 return (interm, logits, proj) if self.get_intermediate else (logits, proj)
+        if self.return_backbone_feats:
+            feats = [as_nchw(f) for f in feats]
         if self.get_intermediate:
             return (interm, logits, list(feats)) if self.return_backbone_feats else (interm, logits)
         return (logits, list(feats)[::-1]) if self.return_backbone_feats else logits

@@ -1077,6 +1077,67 @@ class _Conv1x1Gemm(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _Conv1x1FromTokens(torch.autograd.Function):
+    """1x1 convolution (no bias) of a map given TOKEN-MAJOR, result NCHW: y[b] [Co, HW] = W [Co, C] . tok[b]^T with tok [B, HW, C]
+    -- a Swin stage output as its LayerNorm wrote it (models/Swin.TokenMap) feeding a lateral convolution of the UPerNet decoder
+    (reference models/Swin.py:452-455 permute + contiguous, then models/UPerNet.py:88-92 fpn_in).  All three products are batched
+    split-f16 GEMMs on the operands as they lie: forward (W k-major, tokens k-major), data gradient dtok[b] [HW, C] = dy[b]^T W
+    (both row-contiguous; written token-major, i.e. contiguous for the LayerNorm's backward), weight gradient dW = sum_b dy[b] tok[b]
+    (dy k-major over the pixels, tokens row-contiguous).  No layout copy in either direction."""
+
+    @staticmethod
+    def forward(ctx, tok, weight, H, W):
+        from . import amax as _am
+        b, hw, c = tok.shape
+        co = weight.shape[0]
+        y = torch.empty((b, co, H, W), dtype=torch.float32, device=tok.device)
+        ca = _am.zeros(1, tok.device)
+        gemm_f16x3(weight, True, c, tok, True, c, co, hw, c, y, hw, _am.amax_of(weight), _am.amax_of(tok), batch=b,
+                   strides=(0, hw * c, co * hw), c_amax=ca)
+        _am.tag(y, ca)
+        ctx.save_for_backward(tok, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import amax as _am
+        tok, weight = ctx.saved_tensors
+        b, hw, c = tok.shape
+        co = weight.shape[0]
+        g = _am.carry(gy, gy.contiguous())
+        gt = gw = None
+        if ctx.needs_input_grad[0]:
+            gt = torch.empty_like(tok)
+            cg = _am.zeros(1, tok.device)
+            gemm_f16x3(g, False, hw, weight, False, c, hw, c, co, gt, c, _am.amax_of(g), _am.amax_of(weight), batch=b,
+                       strides=(co * hw, 0, hw * c), c_amax=cg)
+            _am.tag(gt, cg)
+        if ctx.needs_input_grad[1]:
+            part = torch.empty((b, co, c), dtype=torch.float32, device=tok.device)
+            gemm_f16x3(g, True, hw, tok, False, c, co, c, hw, part, c, _am.amax_of(g), _am.amax_of(tok), batch=b,
+                       strides=(co * hw, hw * c, co * c))
+            gw = (part.sum(0) if b > 1 else part[0]).view_as(weight)
+        return gt, gw, None, None
+
+
+def conv1x1_from_tokens_ok(tok, conv, H, W):
+    if not (GEMM_CONV1X1 and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and tok.is_cuda and tok.dtype == torch.float32 and tok.dim() == 3 and tok.is_contiguous()
+            and conv.weight.dtype == torch.float32 and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
+        return False
+    b, hw, c = tok.shape
+    co = conv.out_channels
+    return (hw == H * W and c == conv.in_channels and c % 32 == 0 and hw % 32 == 0 and co % 4 == 0
+            and max(co, c) * hw * 4 < (1 << 32) and gemm_supported(co, hw, c, c, True, c, True)
+            and gemm_supported(hw, c, co, hw, False, c, False) and gemm_supported(co, c, hw, hw, True, c, False))
+
+
+def conv1x1_from_tokens(tok, conv, H, W):
+    """conv(tokens as an NCHW map) -> [B, Co, H, W]; see _Conv1x1FromTokens."""
+    return _Conv1x1FromTokens.apply(tok, conv.weight, int(H), int(W))
+
+
 class _FeatureDropoutConv1x1(torch.autograd.Function):
     """conv1x1(dropout2d(x)) without the two passes over x: Dropout2d multiplies whole channels by a per-(sample, channel) factor
     m (0 or 1 / (1 - p)), and a 1x1 convolution is linear in its input channels, so y_n = (W . diag(m_n)) x_n -- the factor moves

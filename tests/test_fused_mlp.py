@@ -194,3 +194,44 @@ def test_dropout2d_folded_into_the_classifier_matches_the_two_modules():
     assert dropped.any() and torch.equal(dropped, res[1][1].abs().amax((2, 3)) == 0)       # whole channels, the same ones
     drop.eval()
     assert torch.equal(ops.dropout2d_conv1x1(x, drop, conv), conv(x))
+
+
+@pytest.mark.parametrize("B,H,W,C", [(4, 40, 48, 192), (2, 32, 32, 96), (3, 20, 24, 384)])
+def test_lateral_convolution_reads_tokens(B, H, W, C):
+    """UPerNet's lateral block (conv1x1 -> BN -> ReLU) on a backbone level kept token-major (models/Swin.TokenMap -> ops.
+    conv1x1_from_tokens) against the same block on the reference's NCHW copy, and the 1x1 convolution alone against float64:
+    output, token gradient (token-major, contiguous), weight and norm-parameter gradients."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import ops
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d
+    from mscs_amd.models.Swin import TokenMap
+    from mscs_amd.models.UPerNet import FPN, _conv1x1_bn_relu
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    block = ops.use_gemm_conv1x1(_conv1x1_bn_relu(C, 512, FusedBatchNorm2d)).to(dev).train()
+    tok = torch.randn(B, H * W, C, device=dev)
+    gy = torch.randn(B, 512, H, W, device=dev)
+    assert ops.conv1x1_from_tokens_ok(tok, block[0], H, W)
+    res = []
+    for tokens in (True, False):
+        block.zero_grad()
+        ti = tok.clone().requires_grad_(True)
+        tm = TokenMap(ti, H, W)
+        y = FPN._lateral(None, block, tm if tokens else tm.nchw())
+        y.backward(gy)
+        assert ti.grad.is_contiguous()
+        res.append((y.detach(), ti.grad) + tuple(p.grad.clone() for p in block.parameters()))
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 3e-5 * b.abs().max().item() + 1e-9
+    # the convolution alone against float64
+    ti = tok.clone().requires_grad_(True)
+    w = block[0].weight
+    w.grad = None
+    y = ops.conv1x1_from_tokens(ti, block[0], H, W)
+    y.backward(gy)
+    w64 = w.detach().double().view(512, C)
+    y64 = torch.einsum("oc,bpc->bop", w64, tok.double()).view(B, 512, H, W)
+    gt64 = torch.einsum("bop,oc->bpc", gy.double().view(B, 512, -1), w64)
+    gw64 = torch.einsum("bop,bpc->oc", gy.double().view(B, 512, -1), tok.double())
+    for got, want in ((y, y64), (ti.grad, gt64), (w.grad.view(512, C), gw64)):
+        assert ((got.double() - want).abs().max() / want.abs().max()).item() < 3e-6
