@@ -83,6 +83,8 @@ SIGNATURES = {
     "dcl_gemm_set_tile": [_i],
     "dcl_gemm_f16x3": [_vp, _i64, _i, _i64, _vp, _i64, _i, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i64, _i64, _i,
                        _vp, _i, _vp, _vp, _vp],
+    "dcl_gemm_f16x3_ascaled": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i64, _vp, _i, _vp, _vp, _vp, _i, _i,
+                               _vp, _vp],
     "dcl_gemm_f16x3_ep": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _i,
                           _vp],
     "dcl_add_n": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],

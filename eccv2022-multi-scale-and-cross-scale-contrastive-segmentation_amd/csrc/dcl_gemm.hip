@@ -84,6 +84,12 @@ struct GemmArgs {
     const float *aux;
     const float *rowscale;
     int rows_per_scale;
+    // A-operand scale (template parameter ASC): element (row, k) of A is multiplied by a_scale[t / a_scale_group], t = the TOKEN
+    // index of the element = its row for a k-major A (a Linear's data gradient: A = dy) and its k for a row-contiguous A (the
+    // weight gradient: A = dy^T).  The per-sample factor of DropPath on a branch's gradient (Swin.py:318-321: dy_branch = dy *
+    // mask / keep) rides in the power-of-two scale of the f16 split: no pass over dy.  Row-contiguous A: a_scale_group % 32 == 0.
+    const float *a_scale;
+    int a_scale_group;
 };
 
 enum { EP_NONE = 0, EP_GELU_FWD = 1, EP_GELU_BWD = 2, EP_RESIDUAL = 3 };
@@ -200,19 +206,21 @@ struct Stager {
             v[j] = __builtin_bit_cast(float4, w);
         }
     }
+    // rs: optional per-row scales of this thread's 8 rows (k-major operands with an A-operand scale), else s for all
     static __device__ __forceinline__ void store(const StageState &q, char *__restrict__ hi, float s,
-                                                 const float4 (&v)[8])
+                                                 const float4 (&v)[8], const float *rs = nullptr)
     {
         if constexpr (KM) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 uint2 h, l;
+                const float sj = rs ? rs[j] : s;
                 if (DCL_GEMM_PROBE & 8) {
                     h = uint2{__float_as_uint(v[j].x), __float_as_uint(v[j].y)};
                     l = uint2{__float_as_uint(v[j].z), __float_as_uint(v[j].w)};
                 } else {
-                    split2g(v[j].x, v[j].y, s, h.x, l.x);
-                    split2g(v[j].z, v[j].w, s, h.y, l.y);
+                    split2g(v[j].x, v[j].y, sj, h.x, l.x);
+                    split2g(v[j].z, v[j].w, sj, h.y, l.y);
                 }
                 if (DCL_GEMM_PROBE & 16) {
                     asm volatile("" ::"v"(h.x), "v"(h.y), "v"(l.x), "v"(l.y));
@@ -244,7 +252,7 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int TM, int TN, int WM, int WN, bool AKM, bool BKM, int EP = EP_NONE>
+template <int TM, int TN, int WM, int WN, bool AKM, bool BKM, int EP = EP_NONE, bool ASC = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
@@ -305,6 +313,34 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
         Stager<BN, BKM>::init(q, stB ? tid - BM : 0, a.ldb, col0, a.N);
     const unsigned gstep = q.step;
     unsigned goff = (unsigned)kbeg * gstep;
+    // A-operand scale: k-major A -> one factor per staged row (this thread's 8 rows, fixed for the launch); row-contiguous A ->
+    // one factor per k-step (32 consecutive tokens of one sample), fetched one k-step before the split that uses it
+    // (row-contiguous A: the factors -- at most 64, checked by the entry point -- sit in one VGPR, lane l = factor l, and are picked
+    // with v_readlane by a scalar index that is advanced with the k-steps: no memory operation inside the k loop.  A scalar load per
+    // k-step made the compiler wait on lgkmcnt, the counter of the LDS fragment reads as well.)
+    float arow[8];
+    float atab = 0.f, ak_cur = 1.f;
+    int aidx = 0, arem = 0;                 // sample of the NEXT k-step to be stored, and that k-step's first token within it
+    if constexpr (ASC) {
+        if constexpr (AKM) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = min(row0 + (tid >> 3) + j * (BM / 8), a.M - 1);
+                arow[j] = stA ? sa * a.a_scale[r / a.a_scale_group] : sa;
+            }
+        } else {
+            const int nfac = (a.K + a.a_scale_group - 1) / a.a_scale_group;
+            atab = lane < nfac ? a.a_scale[lane] : 0.f;
+            aidx = __builtin_amdgcn_readfirstlane((kbeg * 32) / a.a_scale_group);
+            arem = __builtin_amdgcn_readfirstlane(kbeg * 32 - aidx * a.a_scale_group);
+            ak_cur = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, atab), min(aidx, 63)));
+            arem += 32;
+            if (arem >= a.a_scale_group) {
+                arem -= a.a_scale_group;
+                ++aidx;
+            }
+        }
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -329,22 +365,33 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
         goff += gstep;
     };
     float rs[4] = {0.f, 0.f, 0.f, 0.f};     // row sums of this thread's four A rows over the k rows it staged
-    auto store = [&](int stage, const float4 (&v)[8]) {
+    // ak: (ASC, row-contiguous A) the factor of the k-step being stored
+    auto store = [&](int stage, const float4 (&v)[8], float ak = 1.f) {
         if (DCL_GEMM_PROBE & 2)
             return;
         char *base = lds + stage * STAGE;
         if (!AKM && stA && a.rowsum) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                rs[0] += v[j].x;
-                rs[1] += v[j].y;
-                rs[2] += v[j].z;
-                rs[3] += v[j].w;
+                if constexpr (ASC) {
+                    rs[0] = fmaf(ak, v[j].x, rs[0]);
+                    rs[1] = fmaf(ak, v[j].y, rs[1]);
+                    rs[2] = fmaf(ak, v[j].z, rs[2]);
+                    rs[3] = fmaf(ak, v[j].w, rs[3]);
+                } else {
+                    rs[0] += v[j].x;
+                    rs[1] += v[j].y;
+                    rs[2] += v[j].z;
+                    rs[3] += v[j].w;
+                }
             }
         }
-        if (stA)
-            Stager<BM, AKM>::store(q, base, sa, v);
-        else if (stB)
+        if (stA) {
+            if constexpr (ASC && AKM)
+                Stager<BM, AKM>::store(q, base, sa, v, arow);
+            else
+                Stager<BM, AKM>::store(q, base, ASC ? sa * ak : sa, v);
+        } else if (stB)
             Stager<BN, BKM>::store(q, base + A_BYTES, sb, v);
     };
 
@@ -353,7 +400,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
     // compiler's vmcnt bookkeeping across the rotated loop waits for the NEWEST loads at every store (vmcnt(7..0) where
     // vmcnt(15..8) would do), and asm loads the compiler cannot see are not safe at 250+ live registers.
     load(v0);
-    store(0, v0);
+    store(0, v0, ak_cur);
     load(v0);
     lds_barrier();
 
@@ -361,9 +408,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
     auto kstep = [&](int k, float4 (&va)[8]) {
         const int cur = (k - kbeg) & 1;
         const bool more = k + 1 < kend;
+        float ak = 1.f;
+        if constexpr (ASC && !AKM) {            // factor of k-step k + 1, the one stored in this trip
+            ak = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, atab), min(aidx, 63)));
+            arem += 32;
+            if (arem >= a.a_scale_group) {
+                arem -= a.a_scale_group;
+                ++aidx;
+            }
+        }
         if (early) {
             if (more)
-                store(cur ^ 1, va);
+                store(cur ^ 1, va, ak);
             load(va);
         }
         const char *st = lds + cur * STAGE;
@@ -443,7 +499,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
 #endif
         if (!early) {
             if (more)
-                store(cur ^ 1, va);
+                store(cur ^ 1, va, ak);
             load(va);
         }
         lds_barrier();
@@ -681,7 +737,7 @@ int plan_gemm(int M, int N, int K, int batch, int *split)
     return best;
 }
 
-template <int TM, int TN, int WM, int WN, int EP = EP_NONE>
+template <int TM, int TN, int WM, int WN, int EP = EP_NONE, bool ASC = false>
 int launch_gemm(const GemmArgs &a, int akm, int bkm, hipStream_t stream)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -691,11 +747,11 @@ int launch_gemm(const GemmArgs &a, int akm, int bkm, hipStream_t stream)
     do {                                                                                                              \
         static bool attr_done = false;                                                                                \
         if (!attr_done) {                                                                                             \
-            (void)hipFuncSetAttribute((const void *)k_gemm<TM, TN, WM, WN, AK, BK, EP>,                                   \
+            (void)hipFuncSetAttribute((const void *)k_gemm<TM, TN, WM, WN, AK, BK, EP, ASC>,                                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                    \
             attr_done = true;                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, AK, BK, EP>), grid, block, lds_bytes, stream, a);                      \
+        hipLaunchKernelGGL((k_gemm<TM, TN, WM, WN, AK, BK, EP, ASC>), grid, block, lds_bytes, stream, a);                      \
     } while (0)
     // fused epilogues exist for the operand layouts of the products that use them: a Linear's forward (both k-major) and its
     // data gradient (dy k-major, W read as its transpose)
@@ -705,6 +761,13 @@ int launch_gemm(const GemmArgs &a, int akm, int bkm, hipStream_t stream)
     } else if constexpr (EP == EP_GELU_BWD) {
         DCL_CHECK_ARG(akm && !bkm, "the GELU-backward epilogue needs a k-major A and a row-contiguous B (a Linear's data gradient)");
         DCL_GEMM_LAUNCH(true, false);
+    } else if constexpr (ASC) {
+        // the A-operand scale exists for the two products of a Linear's backward: dy k-major / dy^T row-contiguous, W row-contiguous
+        DCL_CHECK_ARG(!bkm, "the A-operand scale needs a row-contiguous B (a Linear's data / weight gradient)");
+        if (akm)
+            DCL_GEMM_LAUNCH(true, false);
+        else
+            DCL_GEMM_LAUNCH(false, false);
     } else {
     if (akm && bkm)
         DCL_GEMM_LAUNCH(true, true);
@@ -765,8 +828,14 @@ static int gemm_impl(const float *A, int64_t lda, int a_kmajor, int64_t strideA,
                      int b_kmajor, int64_t strideB, int M, int N, int K, int batch, const float *a_amax,
                      int a_count, const float *b_amax, int b_count, const float *bias, float *C, int64_t ldc, int64_t strideC,
                      int accumulate, float *c_amax, int splitk, float *ws, float *a_rowsum, void *stream,
-                     int ep, float *C2, const float *aux, const float *rowscale, int rows_per_scale)
+                     int ep, float *C2, const float *aux, const float *rowscale, int rows_per_scale,
+                     const float *a_scale = nullptr, int a_scale_group = 1)
 {
+    DCL_CHECK_ARG(!a_scale || (a_scale_group >= 1 && batch == 1 && (a_kmajor || a_scale_group % 32 == 0)),
+                  "A-operand scale: batch 1, group >= 1, and a multiple of 32 for a row-contiguous A");
+    DCL_CHECK_ARG(!a_scale || ep == EP_NONE || ep == EP_GELU_BWD, "A-operand scale: plain or GELU-backward epilogue only");
+    DCL_CHECK_ARG(!a_scale || a_kmajor || (K + a_scale_group - 1) / a_scale_group <= 64,
+                  "A-operand scale on a row-contiguous A: at most 64 factors");
     DCL_CHECK_ARG(!a_rowsum || (!a_kmajor && batch == 1), "a_rowsum needs a row-contiguous A and batch 1");
     DCL_CHECK_ARG(A && B && C && a_amax && b_amax, "null pointer");
     DCL_CHECK_ARG(batch >= 1 && splitk >= 1 && a_count >= 1 && b_count >= 1, "batch, splitk and the absmax counts must be >= 1");
@@ -783,6 +852,7 @@ static int gemm_impl(const float *A, int64_t lda, int a_kmajor, int64_t strideA,
     a.M = M, a.N = N, a.K = K, a.batch = batch, a.splitk = splitk;
     a.rowsum = a_rowsum ? (splitk > 1 ? ws + (long)M * N * batch * splitk : a_rowsum) : nullptr;
     a.C2 = C2, a.aux = aux, a.rowscale = rowscale, a.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    a.a_scale = a_scale, a.a_scale_group = a_scale_group;
     if (splitk > 1) {
         a.C = ws, a.ldc = N, a.sC = (long)M * N, a.bias = nullptr, a.c_amax = nullptr, a.accumulate = 0;
     } else {
@@ -795,19 +865,27 @@ static int gemm_impl(const float *A, int64_t lda, int a_kmajor, int64_t strideA,
     a.tiles_m = (M + TILES[c].bm - 1) / TILES[c].bm;
     a.tiles_n = (N + TILES[c].bn - 1) / TILES[c].bn;
     int rc;
-#define DCL_GEMM_TILES(EPV)                                                                                      \
+#define DCL_GEMM_TILES(EPV, ASCV)                                                                                \
     switch (c) {                                                                                                 \
-    case 0: rc = launch_gemm<2, (EPV == EP_NONE ? 4 : 3), 4, 2, EPV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break; \
-    case 1: rc = launch_gemm<2, 2, 4, 2, EPV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;                \
-    case 2: rc = launch_gemm<2, 2, 2, 4, EPV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;                \
-    case 4: rc = launch_gemm<2, 3, 4, 2, EPV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;                \
-    default: rc = launch_gemm<2, 2, 2, 2, EPV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;               \
+    case 0: rc = launch_gemm<2, (EPV == EP_NONE ? 4 : 3), 4, 2, EPV, ASCV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break; \
+    case 1: rc = launch_gemm<2, 2, 4, 2, EPV, ASCV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;          \
+    case 2: rc = launch_gemm<2, 2, 2, 4, EPV, ASCV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;          \
+    case 4: rc = launch_gemm<2, 3, 4, 2, EPV, ASCV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;          \
+    default: rc = launch_gemm<2, 2, 2, 2, EPV, ASCV>(a, a_kmajor, b_kmajor, (hipStream_t)stream); break;         \
     }
-    switch (ep) {
-    case EP_GELU_FWD: DCL_GEMM_TILES(EP_GELU_FWD); break;
-    case EP_GELU_BWD: DCL_GEMM_TILES(EP_GELU_BWD); break;
-    case EP_RESIDUAL: DCL_GEMM_TILES(EP_RESIDUAL); break;
-    default: DCL_GEMM_TILES(EP_NONE); break;
+    if (a_scale) {
+        if (ep == EP_GELU_BWD) {
+            DCL_GEMM_TILES(EP_GELU_BWD, true);
+        } else {
+            DCL_GEMM_TILES(EP_NONE, true);
+        }
+    } else {
+        switch (ep) {
+        case EP_GELU_FWD: DCL_GEMM_TILES(EP_GELU_FWD, false); break;
+        case EP_GELU_BWD: DCL_GEMM_TILES(EP_GELU_BWD, false); break;
+        case EP_RESIDUAL: DCL_GEMM_TILES(EP_RESIDUAL, false); break;
+        default: DCL_GEMM_TILES(EP_NONE, false); break;
+        }
     }
 #undef DCL_GEMM_TILES
     if (rc != 0)
@@ -834,6 +912,18 @@ extern "C" int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t
 {
     return gemm_impl(A, lda, a_kmajor, strideA, B, ldb, b_kmajor, strideB, M, N, K, batch, a_amax, a_count, b_amax, b_count, bias,
                      C, ldc, strideC, accumulate, c_amax, splitk, ws, a_rowsum, stream, EP_NONE, nullptr, nullptr, nullptr, 1);
+}
+
+extern "C" int dcl_gemm_f16x3_ascaled(const float *A, int64_t lda, int a_kmajor, const float *B, int64_t ldb, int b_kmajor, int M,
+                                      int N, int K, const float *a_amax, int a_count, const float *b_amax, int b_count,
+                                      float *C, int64_t ldc, float *c_amax, int splitk, float *ws, float *a_rowsum,
+                                      const float *a_scale, int a_scale_group, int ep, const float *aux, void *stream)
+{
+    DCL_CHECK_ARG(a_scale, "null a_scale");
+    DCL_CHECK_ARG(ep == EP_NONE || (ep == EP_GELU_BWD && aux && splitk == 1), "ep must be 0, or 2 (GELU backward) with aux and no k-split");
+    DCL_CHECK_ARG(ep == EP_NONE || (ldc >= N && (int64_t)M * ldc < ((int64_t)1 << 30)), "the fused epilogue addresses C with 32-bit element offsets");
+    return gemm_impl(A, lda, a_kmajor, 0, B, ldb, b_kmajor, 0, M, N, K, 1, a_amax, a_count, b_amax, b_count, nullptr, C, ldc, 0, 0,
+                     c_amax, splitk, ws, a_rowsum, stream, ep, nullptr, aux, nullptr, 1, a_scale, a_scale_group);
 }
 
 extern "C" int dcl_gemm_f16x3_ep(const float *A, int64_t lda, int a_kmajor, const float *B, int64_t ldb, int b_kmajor, int M, int N,

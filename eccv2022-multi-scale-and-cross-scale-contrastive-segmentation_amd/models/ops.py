@@ -1330,6 +1330,21 @@ def gemm_f16x3(a, a_kmajor, lda, b, b_kmajor, ldb, M, N, K, out, ldc, a_amax, b_
     return out
 
 
+def gemm_f16x3_ascaled(a, a_kmajor, lda, b, ldb, M, N, K, out, a_amax, b_amax, a_scale, group, c_amax=None, a_rowsum=None,
+                       ep=0, aux=None):
+    """dcl_gemm_f16x3_ascaled: out [M, N] = (A with a per-token factor) . B, B row-contiguous ([K, N] read as its transpose);
+    a_scale [tokens / group] multiplies row t of a k-major A or k row t of a row-contiguous A (see include/dcl_hip.h)."""
+    from .. import _lib
+    L = _lib.lib()
+    splitk = 1 if ep else L.dcl_gemm_suggest_splitk(M, N, K, 1)
+    ws = torch.empty(L.dcl_gemm_workspace_floats(M, N, 1, splitk), dtype=torch.float32, device=out.device) if splitk > 1 else None
+    p = _lib.ptr
+    _lib.check(L.dcl_gemm_f16x3_ascaled(p(a), lda, int(a_kmajor), p(b), ldb, 0, M, N, K, p(a_amax), a_amax.numel(), p(b_amax),
+                                        b_amax.numel(), p(out), N, p(c_amax), splitk, p(ws), p(a_rowsum), p(a_scale), int(group),
+                                        int(ep), p(aux), _stream(out)), "dcl_gemm_f16x3_ascaled")
+    return out
+
+
 def linear_f16x3(x2, weight, bias=None, tag_out=True):
     """y [M, N] = x2 [M, K] weight[N, K]^T + bias (the forward of nn.Linear on contiguous rows)."""
     from . import amax as _am
@@ -1343,18 +1358,21 @@ def linear_f16x3(x2, weight, bias=None, tag_out=True):
     return y
 
 
-def linear_dgrad_f16x3(gy2, weight):
-    """dx [M, K] = gy2 [M, N] weight[N, K]."""
+def linear_dgrad_f16x3(gy2, weight, scale=None, group=1):
+    """dx [M, K] = (gy2 [M, N], rows scaled by scale[row // group]) weight[N, K]."""
     from . import amax as _am
     m, n = gy2.shape
     k = weight.shape[1]
     gx = torch.empty((m, k), dtype=torch.float32, device=gy2.device)
     ca = _am.zeros(1, gy2.device)
-    gemm_f16x3(gy2, True, n, weight, False, k, m, k, n, gx, k, _am.amax_of(gy2), _am.amax_of(weight), c_amax=ca)
+    if scale is not None:
+        gemm_f16x3_ascaled(gy2, True, n, weight, k, m, k, n, gx, _am.amax_of(gy2), _am.amax_of(weight), scale, group, c_amax=ca)
+    else:
+        gemm_f16x3(gy2, True, n, weight, False, k, m, k, n, gx, k, _am.amax_of(gy2), _am.amax_of(weight), c_amax=ca)
     return _am.tag(gx, ca)
 
 
-def linear_wgrad_f16x3(gy2, x2, want_bias=False):
+def linear_wgrad_f16x3(gy2, x2, want_bias=False, scale=None, group=1):
     """dW [N, K] = gy2 [M, N]^T x2 [M, K] (contraction over the M rows, k-split slabs summed in fixed order); with
     ``want_bias`` also db [N] = the column sums of gy2, accumulated by the threads that stage the dy^T operand (no extra
     pass over gy2): returns (dW, db)."""
@@ -1363,7 +1381,10 @@ def linear_wgrad_f16x3(gy2, x2, want_bias=False):
     k = x2.shape[1]
     gw = torch.empty((n, k), dtype=torch.float32, device=gy2.device)
     gb = torch.empty((n,), dtype=torch.float32, device=gy2.device) if want_bias else None
-    gemm_f16x3(gy2, False, n, x2, False, k, n, k, m, gw, k, _am.amax_of(gy2), _am.amax_of(x2), a_rowsum=gb)
+    if scale is not None:       # rows of gy2 (the contraction index here) scaled by scale[row // group], the bias gradient too
+        gemm_f16x3_ascaled(gy2, False, n, x2, k, n, k, m, gw, _am.amax_of(gy2), _am.amax_of(x2), scale, group, a_rowsum=gb)
+    else:
+        gemm_f16x3(gy2, False, n, x2, False, k, n, k, m, gw, k, _am.amax_of(gy2), _am.amax_of(x2), a_rowsum=gb)
     return (gw, gb) if want_bias else gw
 
 
@@ -1455,20 +1476,40 @@ class _TokenLinearResidual(torch.autograd.Function):
         from . import amax as _am
         x2, weight, scale = ctx.saved_tensors
         n, k = weight.shape
-        gb2 = _scaled_rows(gy, n, scale, ctx.bound)
+        gb2, sc, grp = _branch_grad(gy, n, scale, ctx.bound)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            g = linear_dgrad_f16x3(gb2, weight)
+            g = linear_dgrad_f16x3(gb2, weight, sc, grp)
             gx = _am.carry(g, g.view(ctx.xshape))
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if want_gb:
-                gw, gb = linear_wgrad_f16x3(gb2, x2, want_bias=True)
+                gw, gb = linear_wgrad_f16x3(gb2, x2, want_bias=True, scale=sc, group=grp)
             else:
-                gw = linear_wgrad_f16x3(gb2, x2)
+                gw = linear_wgrad_f16x3(gb2, x2, scale=sc, group=grp)
         elif want_gb:
-            gb = gb2.sum(0)
+            gb = _scaled_rows(gy, n, scale, ctx.bound).sum(0)
         return gx, gw, gb, (gy if ctx.needs_input_grad[3] else None), None, None
+
+
+ASCALE_IN_GEMM = _dbg.gemm_ascale     # the per-sample factor of a branch's gradient as an operand scale of the backward GEMMs
+
+
+def _branch_grad(gy, n, scale, bound):
+    """(rows, scale, group) for the backward GEMMs of a branch whose output was scaled per sample: the incoming gradient as
+    contiguous [M, n] rows UNSCALED plus the factors for dcl_gemm_f16x3_ascaled when the GEMMs can apply them (whole k-steps of 32
+    tokens per sample, factors that keep the scaled operand inside the f16 split's range), else the scaled rows and no factors."""
+    from . import amax as _am
+    if scale is None:
+        return _scaled_rows(gy, n, None, bound), None, 1
+    g2 = _am.carry(gy, gy.reshape(-1, n))
+    if not g2.is_contiguous():
+        g2 = _am.carry(g2, g2.contiguous())
+    grp = g2.shape[0] // scale.numel()
+    if ASCALE_IN_GEMM and grp % 32 == 0 and grp * scale.numel() == g2.shape[0] and bound <= 3.9 and g2.shape[0] % 32 == 0 \
+            and scale.numel() <= 64:
+        return g2, scale, grp
+    return _scaled_rows(gy, n, scale, bound), None, 1
 
 
 def _scaled_rows(gy, n, scale, bound):
@@ -1526,21 +1567,24 @@ class _FusedMlp(torch.autograd.Function):
         hd, k = w1.shape
         n = w2.shape[0]
         m = x2.shape[0]
-        g2 = _scaled_rows(gy, n, scale if ctx.residual else None, ctx.bound)
+        g2, sc, grp = _branch_grad(gy, n, scale if ctx.residual else None, ctx.bound)
         need = ctx.needs_input_grad
         gx = gw1 = gb1 = gw2 = gb2 = None
         # fc2: weight / bias gradient from (dy, a); data gradient with gelu'(h) applied in its epilogue = fc1's dy
         if need[3]:
             if ctx.has_b2 and need[4]:
-                gw2, gb2 = linear_wgrad_f16x3(g2, a, want_bias=True)
+                gw2, gb2 = linear_wgrad_f16x3(g2, a, want_bias=True, scale=sc, group=grp)
             else:
-                gw2 = linear_wgrad_f16x3(g2, a)
+                gw2 = linear_wgrad_f16x3(g2, a, scale=sc, group=grp)
         elif ctx.has_b2 and need[4]:
-            gb2 = g2.sum(0)
+            gb2 = _scaled_rows(gy, n, scale if ctx.residual else None, ctx.bound).sum(0)
         if need[0] or need[1] or (ctx.has_b1 and need[2]):
             gh = torch.empty((m, hd), dtype=torch.float32, device=gy.device)
             cg = _am.zeros(1, gy.device)
-            gemm_f16x3_ep(g2, w2, False, m, hd, n, gh, _am.amax_of(g2), _am.amax_of(w2), 2, c_amax=cg, aux=h)
+            if sc is not None:
+                gemm_f16x3_ascaled(g2, True, n, w2, hd, m, hd, n, gh, _am.amax_of(g2), _am.amax_of(w2), sc, grp, c_amax=cg, ep=2, aux=h)
+            else:
+                gemm_f16x3_ep(g2, w2, False, m, hd, n, gh, _am.amax_of(g2), _am.amax_of(w2), 2, c_amax=cg, aux=h)
             _am.tag(gh, cg)
             if need[0]:
                 g = linear_dgrad_f16x3(gh, w1)

@@ -387,6 +387,15 @@ int dcl_gemm_f16x3(const float *A, int64_t lda, int a_kmajor, int64_t strideA, c
  *   ep 3  residual       C = aux + rowscale[row / rows_per_scale] * v (rowscale NULL: 1): shortcut + drop_path(branch) with the
  *                        per-sample factor of DropPath (Swin.py:318-321).  Both operands k-major.
  * c_amax (optional) receives max|C|. */
+/* dcl_gemm_f16x3 (batch 1) with a per-token factor on the A operand: element (row, k) of A times a_scale[t / a_scale_group], t = the
+ * element's row for a k-major A (a Linear's data gradient, A = dy [tokens, N]) or its k for a row-contiguous A (the weight
+ * gradient, A = dy^T; a_scale_group % 32 == 0).  DropPath's per-sample factor on a branch's gradient (reference
+ * models/Swin.py:318-321) costs no pass over dy: it is folded into the scale of the f16 split.  B row-contiguous.  a_rowsum (weight
+ * gradient: the bias gradient) sums the SCALED rows.  ep 0, or 2 = the GELU-backward epilogue of dcl_gemm_f16x3_ep (aux). */
+int dcl_gemm_f16x3_ascaled(const float *A, int64_t lda, int a_kmajor, const float *B, int64_t ldb, int b_kmajor, int M, int N, int K,
+                           const float *a_amax, int a_count, const float *b_amax, int b_count, float *C, int64_t ldc,
+                           float *c_amax /* or NULL */, int splitk, float *ws /* or NULL */, float *a_rowsum /* or NULL */,
+                           const float *a_scale, int a_scale_group, int ep, const float *aux /* ep 2 */, void *stream);
 int dcl_gemm_f16x3_ep(const float *A, int64_t lda, int a_kmajor, const float *B, int64_t ldb, int b_kmajor, int M, int N, int K,
                       const float *a_amax, int a_count, const float *b_amax, int b_count, const float *bias /* or NULL */,
                       float *C, int64_t ldc, float *c_amax /* or NULL */, int ep, float *C2 /* ep 1 */,

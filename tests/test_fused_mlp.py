@@ -235,3 +235,30 @@ def test_lateral_convolution_reads_tokens(B, H, W, C):
     gw64 = torch.einsum("bop,bpc->oc", gy.double().view(B, 512, -1), tok.double())
     for got, want in ((y, y64), (ti.grad, gt64), (w.grad.view(512, C), gw64)):
         assert ((got.double() - want).abs().max() / want.abs().max()).item() < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(4 * 1600, 768, 3072), (8 * 800, 192, 192), (4 * 6400, 384, 96)])
+def test_gemm_with_a_per_token_factor_on_the_gradient(M, N, K):
+    """dcl_gemm_f16x3_ascaled behind linear_dgrad_f16x3 / linear_wgrad_f16x3: dy's rows times a per-sample factor (DropPath's mask /
+    keep, zeros included) inside the data-gradient and the weight-gradient GEMM (k-split slabs, bias gradient as scaled row sums)
+    against float64 on the explicitly scaled dy, and bitwise against ... itself (deterministic)."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N)
+    B = 4 if M % 1600 == 0 and M // 4 % 32 == 0 else 8
+    gy = torch.randn(M, N, generator=g).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    sc = torch.tensor(([0.0, 1 / 0.7, 1 / 0.7, 0.0] * 2)[:B]).to(dev)
+    grp = M // B
+    gs64 = gy.double() * sc.double().repeat_interleave(grp).view(-1, 1)
+    for rep in range(2):
+        gx = ops.linear_dgrad_f16x3(gy, w, sc, grp)
+        gw, gb = ops.linear_wgrad_f16x3(gy, x, want_bias=True, scale=sc, group=grp)
+        if rep == 0:
+            keep = (gx.clone(), gw.clone(), gb.clone())
+    assert all(torch.equal(a, b) for a, b in zip(keep, (gx, gw, gb)))
+    for got, want in ((gx, gs64 @ w.double()), (gw, gs64.t() @ x.double()), (gb, gs64.sum(0))):
+        assert ((got.double() - want).abs().max() / want.abs().max()).item() < 3e-6
+    assert (gx[:grp] == 0).all()                             # a dropped sample's rows: exact zeros
