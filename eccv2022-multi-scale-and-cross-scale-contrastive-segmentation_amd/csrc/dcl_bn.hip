@@ -199,6 +199,9 @@ struct BnFused {
     float *dbeta, *dgamma;      // backward outputs (may be NULL)
     const float *pivot;         // forward: [C] shift of the partial sums (k_bn_stats), NULL = 0
     unsigned long long *mask_out;   // forward, RELU: packed y > 0 bits for the backward (see relu_mask_words), or NULL
+    int xmask;                      // backward apply: the norm's INPUT is a ReLU output (conv -> ReLU -> norm, the projection heads:
+                                    // reference models/Projector.py:46-51) -- dx is zeroed where x <= 0, i.e. the ReLU's backward
+                                    // rides in this kernel (which reads x anyway) instead of a pass of its own
 };
 
 // Packed ReLU mask of an [N*C, HW] tensor with HW % 256 == 0: the 64 consecutive 16-byte vectors a wave handles give
@@ -565,6 +568,12 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                 o.y = k * (g.y - mg - (xx.y - m) * is * mgx);
                 o.z = k * (g.z - mg - (xx.z - m) * is * mgx);
                 o.w = k * (g.w - mg - (xx.w - m) * is * mgx);
+                if (f.xmask) {
+                    o.x = xx.x > 0.f ? o.x : 0.f;
+                    o.y = xx.y > 0.f ? o.y : 0.f;
+                    o.z = xx.z > 0.f ? o.z : 0.f;
+                    o.w = xx.w > 0.f ? o.w : 0.f;
+                }
                 gv[u] = g;
                 xv[u] = o;
                 if (j0 + u * BN_THREADS < nv)
@@ -595,7 +604,9 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                     g = (rec ? bn_eval(x[q], asc, ash) : y[q]) > 0.f ? g : 0.f;
                 if (dres)
                     dres[q] = g;
-                const float o = k * (g - mg - (x[q] - m) * is * mgx);
+                float o = k * (g - mg - (x[q] - m) * is * mgx);
+                if (f.xmask)
+                    o = x[q] > 0.f ? o : 0.f;
                 dx[q] = o;
                 am = fmaxf(am, fabsf(o));
             }
@@ -885,11 +896,14 @@ extern "C" int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const flo
                                       float *amax, void *stream)
 {
     DCL_CHECK_ARG(dy && x && mean && invstd && part && part_local && dx && count > 0, "bad arguments");
+    const int xmask = (relu >> 2) & 1;          // relu + 4: the norm's input is a ReLU output, dx = 0 where x <= 0 (see BnFused)
+    relu &= 3;
     DCL_CHECK_ARG(relu != 2 || (y && HW % 256 == 0), "relu = 2: y is the packed mask, HW % 256 == 0");
     const unsigned long long *mask = relu == 2 ? (const unsigned long long *)y : nullptr;
     if (mask)
         y = nullptr;
     BnFused f{};
+    f.xmask = xmask;
     f.part = part;
     f.part_local = part_local;
     f.ns = pick_slices(N, C);

@@ -58,6 +58,7 @@ class DebugConfig:
     fold_dropout2d: bool = field(default_factory=lambda: _flag('DCL_FOLD_DROPOUT2D'))           # Dropout2d -> conv1x1 as per-sample weights
     token_laterals: bool = field(default_factory=lambda: _flag('DCL_TOKEN_LATERALS'))           # UPerNet laterals read Swin outputs token-major
     gemm_ascale: bool = field(default_factory=lambda: _flag('DCL_GEMM_ASCALE'))                 # DropPath's factor as an operand scale of the backward GEMMs
+    relu_then_bn: bool = field(default_factory=lambda: _flag('DCL_RELU_THEN_BN'))               # projector ReLU's backward inside the norm's
     fused_mlp: bool = field(default_factory=lambda: _flag('DCL_FUSED_MLP'))                     # Swin Mlp / residual sums in GEMM epilogues
     coalesced_sync_bn: bool = field(default_factory=lambda: _flag('DCL_SYNCBN_COALESCE'))       # stacked SyncBN exchanges
     side_stream_priority: Optional[int] = field(default_factory=lambda: _int('DCL_SIDE_PRIO'))  # HIP priority of the branch streams

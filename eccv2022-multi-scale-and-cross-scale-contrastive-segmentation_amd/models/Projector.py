@@ -96,12 +96,29 @@ class Projector(nn.Module):
     nhwc = True          # training on the GPU: the embedding maps are written pixel-major (channels-last strides, same shape
                          # and values as the reference's tensor; models/ops.py _Conv1x1ToNHWC) -- what K3 / K6 gather / scatter
 
+    @staticmethod
+    def _hidden(head: nn.Sequential, x: torch.Tensor):
+        """head[:-1](x).  A hidden layer is conv -> ReLU(inplace) -> BatchNorm (reference models/Projector.py:46-51); with this
+        package's fused norm the ReLU's backward rides in the norm's backward kernel (models/fused_bn.py relu_then_bn)."""
+        from .fused_bn import FusedBatchNorm2d, relu_then_bn
+        layers = list(head[:-1])
+        i = 0
+        while i < len(layers):
+            if (i + 1 < len(layers) and isinstance(layers[i], nn.ReLU) and layers[i].inplace
+                    and isinstance(layers[i + 1], FusedBatchNorm2d) and x.is_cuda):
+                x = relu_then_bn(layers[i + 1], x)
+                i += 2
+            else:
+                x = layers[i](x)
+                i += 1
+        return x
+
     def _run_head(self, head: nn.Sequential, x: torch.Tensor):
         if self.lazy and self.training and x.is_cuda and x.dtype == torch.float32:
-            return LazyProjection(head[:-1](x), head[-1])
+            return LazyProjection(self._hidden(head, x), head[-1])
         if self.nhwc and self.training and x.is_cuda and torch.is_grad_enabled():
             from .ops import conv1x1_nhwc_supported, conv1x1_to_nhwc
-            hidden = head[:-1](x)
+            hidden = self._hidden(head, x)
             if conv1x1_nhwc_supported(hidden, head[-1]):
                 return conv1x1_to_nhwc(hidden, head[-1])
             return head[-1](hidden)

@@ -53,8 +53,9 @@ def _check_equal_batch(n, device):
 class _FusedBNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, sync, amax,
-                token=None, pre=None):
+                token=None, pre=None, xmask=False):
         ctx.token = token
+        ctx.xmask = bool(xmask)     # x is a ReLU output whose backward this norm's backward performs (relu_then_bn)
         L = _lib.lib()
         N, C, H, W = x.shape
         HW = H * W
@@ -121,7 +122,7 @@ class _FusedBNFunction(torch.autograd.Function):
         relu = (2 if ctx.packed_mask else 1) if ctx.relu else 0         # 2: `y` is the packed sign mask
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
-        if (ctx.world == 1 and _onepass_stream(dev) and (relu != 1 or y is None)
+        if (ctx.world == 1 and _onepass_stream(dev) and (relu != 1 or y is None) and not ctx.xmask
                 and L.dcl_bn_bwd_onepass_supported(N, C, HW, relu)):
             # one kernel that reads dy and x ONCE (csrc/dcl_bn_onepass.hip): persistent workgroups keep their share of a
             # channel in registers across the statistics exchange.  Only on the device's default stream of a single-rank
@@ -139,7 +140,7 @@ class _FusedBNFunction(torch.autograd.Function):
                 _amax.tag(dx, amax)
             if ctx.token is not None:
                 ctx.token.dres, dres = dres, None
-            return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+            return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
         _lib.check(L.dcl_bn_bwd_reduce_part(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), N, C, HW, relu,
                                             _lib.ptr(part), st), "dcl_bn_bwd_reduce_part")
@@ -156,15 +157,15 @@ class _FusedBNFunction(torch.autograd.Function):
         amax = _amax.zeros(_amax.SLOTS, dev) if ctx.emit_amax else None
         _lib.check(L.dcl_bn_bwd_apply_fused(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(part_all),
-                                            _lib.ptr(part), ctx.count, N, C, HW, relu, _lib.ptr(dx), _lib.ptr(dres),
-                                            _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(amax), st),
+                                            _lib.ptr(part), ctx.count, N, C, HW, relu + (4 if ctx.xmask else 0), _lib.ptr(dx),
+                                            _lib.ptr(dres), _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(amax), st),
                    "dcl_bn_bwd_apply_fused")
         if amax is not None:
             _amax.tag(dx, amax)
         if ctx.token is not None:
             # the residual's gradient travels through the token to the convolution that shares the input
             ctx.token.dres, dres = dres, None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 ONEPASS = _dbg.bn_onepass         # one-kernel backward on the default stream (DCL_BN_ONEPASS=0: the two-kernel form)
@@ -412,7 +413,8 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
                 and not (FORCE_GROUP or (self.sync and _world() > 1 and _dbg.coalesced_sync_bn)))
 
-    def forward(self, x, residual=None, relu=False, grad_token=None):
+    def forward(self, x, residual=None, relu=False, grad_token=None, input_relu=False):
+        """``input_relu`` (relu_then_bn only): x is the output of a ReLU whose backward is left to this norm's backward kernel."""
         if self._fusable(x, residual):
             # partial max|y| side output (64 slots) for the f16x3 convolutions that consume y (models/amax.py)
             amax = _amax.zeros(_amax.SLOTS, x.device) if self.emit_amax else None
@@ -424,8 +426,9 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
             y = _FusedBNFunction.apply(x, residual, self.weight, self.bias, self.running_mean,
                                        self.running_var, self.num_batches_tracked, float(self.eps),
                                        float(self.momentum), bool(relu), bool(self.sync), amax,
-                                       grad_token if residual is not None else None, pre)
+                                       grad_token if residual is not None else None, pre, bool(input_relu))
             return _amax.tag(y, amax) if amax is not None else y
+        assert not input_relu, "input_relu is only valid on the fused path (relu_then_bn checks it)"
         if self.sync and self.training and _world() > 1:
             # convert_sync_batchnorm only flips the flag of a FusedBatchNorm2d: nn.BatchNorm2d.forward below would
             # silently normalise with THIS rank's statistics
@@ -436,6 +439,30 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
         if residual is not None:
             y = y + residual
         return F.relu(y, inplace=True) if relu else y
+
+
+class _ReluMaskedDownstream(torch.autograd.Function):
+    """In-place ReLU whose backward is the IDENTITY: only for relu_then_bn, where the norm behind it zeroes its input gradient
+    wherever this output is 0 (dcl_bn_bwd_apply_fused, relu + 4) -- the three-tensor threshold_backward pass disappears."""
+
+    @staticmethod
+    def forward(ctx, t):
+        ctx.mark_dirty(t)
+        return t.relu_()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def relu_then_bn(bn, t):
+    """bn(relu_(t)): the order of the projection heads' hidden layers (reference models/Projector.py:46-51: conv -> ReLU -> BN).
+    On the fused training path of a single norm the ReLU's backward rides in the norm's backward kernel; else the two modules run
+    as they are.  ``t`` is overwritten (as nn.ReLU(inplace=True) does)."""
+    if (isinstance(bn, FusedBatchNorm2d) and bn._fusable(t, None) and torch.is_grad_enabled() and t.requires_grad
+            and _dbg.relu_then_bn and not (FORCE_GROUP)):
+        return bn(_ReluMaskedDownstream.apply(t), input_relu=True)
+    return bn(F.relu(t, inplace=True))
 
 
 def bn_act(bn, x, residual=None, relu=True, grad_token=None):

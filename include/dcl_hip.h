@@ -281,7 +281,9 @@ int dcl_bn_apply_fused(const float *x, const float *res, const float *part, doub
                                           for the backward -- see below */,
                        void *stream);
 /* relu = 2 in the two backward calls: `y` is the packed mask dcl_bn_apply_fused wrote (1/32 of y's size), not y
- * itself -- what the backward of a norm + residual + ReLU needs from y is only y > 0. */
+ * itself -- what the backward of a norm + residual + ReLU needs from y is only y > 0.
+ * dcl_bn_bwd_apply_fused only, relu + 4: the norm's INPUT x is the output of a ReLU (conv -> ReLU -> norm, the projection heads,
+ * reference models/Projector.py:46-51): dx is zeroed where x <= 0 -- the ReLU's backward inside this kernel, which reads x anyway. */
 /* dcl_bn_apply_fused with an explicit number `ns` of partial sums per channel, part f32 [C][ns][2], from any producer: the
  * epilogue of the convolution in front of the norm (dcl_conv3x3_bnstats_f16x3, ns = dcl_conv3x3_bnstats_tiles(...): the
  * statistics pass over the convolution's output disappears; reference models/HRNet.py:77-93 conv -> bn) or

@@ -262,3 +262,44 @@ def test_gemm_with_a_per_token_factor_on_the_gradient(M, N, K):
     for got, want in ((gx, gs64 @ w.double()), (gw, gs64.t() @ x.double()), (gb, gs64.sum(0))):
         assert ((got.double() - want).abs().max() / want.abs().max()).item() < 3e-6
     assert (gx[:grp] == 0).all()                             # a dropped sample's rows: exact zeros
+
+
+@pytest.mark.parametrize("shape", [(4, 512, 40, 48), (3, 96, 17, 23), (2, 48, 128, 256)])
+def test_relu_then_bn_matches_the_two_modules(shape):
+    """fused_bn.relu_then_bn (conv output -> in-place ReLU -> FusedBatchNorm2d with the ReLU's backward inside the norm's backward
+    kernel: dcl_bn_bwd_apply_fused, relu + 4) against ReLU + the same norm run as separate autograd nodes, and against
+    nn.BatchNorm2d in float64: output, input gradient (zero exactly where the input was <= 0), dgamma, dbeta."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.debug import cfg as dbg
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d, relu_then_bn
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    C = shape[1]
+    bn = FusedBatchNorm2d(C).to(dev).train()
+    torch.nn.init.normal_(bn.weight, 1.0, 0.3)
+    torch.nn.init.normal_(bn.bias, 0.0, 0.3)
+    x = torch.randn(*shape, device=dev)
+    gy = torch.randn(*shape, device=dev)
+    res = []
+    keep = dbg.relu_then_bn
+    try:
+        for fused in (True, False):
+            dbg.relu_then_bn = fused
+            bn.zero_grad()
+            bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+            xi = x.clone().requires_grad_(True)
+            y = relu_then_bn(bn, xi * 1.0)
+            y.backward(gy)
+            res.append((y.detach(), xi.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_var.clone()))
+    finally:
+        dbg.relu_then_bn = keep
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item() + 1e-9
+    assert torch.equal(res[0][1] == 0, x <= 0) or ((res[0][1] == 0) & (x > 0)).sum().item() < 4     # (a true zero gradient is possible)
+    ref = torch.nn.BatchNorm2d(C).to(dev).double().train()
+    ref.load_state_dict({k: v.double() for k, v in bn.state_dict().items() if "running" not in k and "num" not in k}, strict=False)
+    x64 = x.double().requires_grad_(True)
+    y64 = ref(torch.relu(x64))
+    y64.backward(gy.double())
+    for got, want in ((res[0][0], y64), (res[0][1], x64.grad), (res[0][2], ref.weight.grad), (res[0][3], ref.bias.grad)):
+        assert ((got.double() - want).abs().max() / want.abs().max()).item() < 2e-5
