@@ -575,8 +575,13 @@ __global__ __launch_bounds__(256) void k_tapup_bwd(const float *__restrict__ dy,
 template <int NW4>
 __global__ __launch_bounds__(256) void k_tapup_bwd_w(const float *__restrict__ dy, int Co, int H, int W, int h, int w, Axis ay,
                                                     Axis ax, int trl, int tiles_r, int FR, int WP, float *__restrict__ dz,
-                                                    long long sn, long long sc)
+                                                    long long sn, long long sc, int planes, int ppw)
 {
+    // Round 4: a workgroup takes `ppw` consecutive planes of its row tile (the weight tables -- axis_weight has a division per
+    // entry -- are built once for all of them), and the vertical pass reads dy as float4s with every row of a footprint in
+    // flight: one item = (low-resolution row, four columns), up to 8 x 16 bytes per thread outstanding.  Before, a thread had
+    // four 4-byte loads in flight and half the threads idled on a 128-column map: 3.5 ms per launch on 16 x 512 x 128 x 128 where
+    // the bytes take 0.1 (the kernel was bound by the latency of ~20 dependent load groups per workgroup).
     constexpr int PADL = 4, TS = (NW4 + 1) | 1;            // weight row of a column: TS float4s (odd: conflict-free b128 reads)
     extern __shared__ __attribute__((aligned(16))) float tap_lds[];
     f32x4 *wt = (f32x4 *)tap_lds;                           // [TAP_TRL][FR] {w(ky = 0), w(1), w(2), 0}
@@ -584,8 +589,7 @@ __global__ __launch_bounds__(256) void k_tapup_bwd_w(const float *__restrict__ d
     float *Vt = (float *)(wf + (size_t)w * TS);             // [3 * TAP_TRL][WP], column X at PADL + X
     int *a4s = (int *)(Vt + (size_t)3 * TAP_TRL * WP);      // [w] window start (padded index, multiple of 4)
     int *ylo = a4s + w;                                     // [TAP_TRL] first dy row of a low-resolution row's footprint
-    const int tile = blockIdx.x % tiles_r, plane = blockIdx.x / tiles_r;
-    const int n = plane / Co, co = plane - n * Co;
+    const int tile = blockIdx.x % tiles_r, plane0 = (blockIdx.x / tiles_r) * ppw;
     const int r_a = tile * trl, nr = min(r_a + trl, h) - r_a;
     const int t = threadIdx.x;
     for (int e = t; e < TAP_TRL * FR; e += 256) {
@@ -622,7 +626,41 @@ __global__ __launch_bounds__(256) void k_tapup_bwd_w(const float *__restrict__ d
         out_range(ax, c, w, W, xs_lo, xs_hi);
         ((float *)wf)[e] = (m < 4 * NW4 + 2 && Xs >= xs_lo && Xs <= xs_hi) ? axis_weight(ax, Xs, w, c) : 0.f;
     }
+    for (int pp = 0; pp < ppw && plane0 + pp < planes; ++pp) {
+    const int plane = plane0 + pp;
+    const int n = plane / Co, co = plane - n * Co;
+    __syncthreads();                        // the previous plane's horizontal pass has read Vt (first trip: the tables are built)
     const float *g = dy + (size_t)plane * H * W;
+    if ((W & 3) == 0) {
+        const int W4 = W >> 2;
+        for (int item = t; item < TAP_TRL * W4; item += 256) {
+            const int rr = item / W4, x4 = item - rr * W4;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+            if (rr < nr) {
+                const int y0 = ylo[rr];
+                const f32x4 *wr = wt + rr * FR;
+                const float *gc = g + 4 * x4;
+                for (int j = 0; j < FR; j += 8) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)             // (rows past the footprint: clamped address, never used)
+                        v[u] = *(const f32x4 *)(gc + (size_t)min(max(y0 + min(j + u, FR - 1), 0), H - 1) * W);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (j + u < FR) {
+                            const f32x4 q = wr[j + u];
+                            a0 += q.x * v[u];
+                            a1 += q.y * v[u];
+                            a2 += q.z * v[u];
+                        }
+                    }
+                }
+            }
+            *(f32x4 *)(Vt + (size_t)(0 * TAP_TRL + rr) * WP + PADL + 4 * x4) = a0;
+            *(f32x4 *)(Vt + (size_t)(1 * TAP_TRL + rr) * WP + PADL + 4 * x4) = a1;
+            *(f32x4 *)(Vt + (size_t)(2 * TAP_TRL + rr) * WP + PADL + 4 * x4) = a2;
+        }
+    } else
     for (int X = t; X < W; X += 256) {
 #pragma unroll
         for (int rr = 0; rr < TAP_TRL; ++rr) {
@@ -690,6 +728,7 @@ __global__ __launch_bounds__(256) void k_tapup_bwd_w(const float *__restrict__ d
         op[tapstride] = o1;
         op[2 * tapstride] = o2;
     }
+    }   // planes of this workgroup
 }
 
 // conservative bound of the low-resolution window a run of `n_out` consecutive output coordinates (+ one on either side)
@@ -747,6 +786,7 @@ extern "C" int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1, i
 }
 
 static int g_tapup_bwd_form = 2;        // 2 = k_tapup_bwd_w (windowed horizontal pass), 1 = k_tapup_bwd
+static int g_tapup_bwd_ppw = 4;         // planes per workgroup of k_tapup_bwd_w (dcl_tapup_set_bwd_form(16 + p): p = 1, 2, 4, 8)
 
 static int tapup_bwd_impl(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
                           float *dz, void *stream, bool query);
@@ -827,12 +867,17 @@ static int tapup_bwd_impl(const float *dy, int N, int Co, int H, int W, int h, i
         if (query)
             return 0;
         const int tiles2 = (h + TAP_TRL - 1) / TAP_TRL;
-        const long long blocks2 = (long long)N * Co * tiles2;
-        DCL_CHECK_ARG(blocks2 < (1LL << 31), "too many tiles");
+        // planes per workgroup: 4 while that still leaves ~8 workgroups per CU
+        const long long planes = (long long)N * Co;
+        int ppw = g_tapup_bwd_ppw;
+        while (ppw > 1 && (planes + ppw - 1) / ppw * tiles2 < 2048)
+            ppw >>= 1;
+        const long long blocks2 = (planes + ppw - 1) / ppw * tiles2;
+        DCL_CHECK_ARG(blocks2 < (1LL << 31) && planes < (1LL << 31), "too many tiles");
 #define DCL_TAPUP_CASE(K)                                                                                                   \
     case K:                                                                                                                 \
         hipLaunchKernelGGL(k_tapup_bwd_w<K>, dim3((unsigned)blocks2), dim3(256), lds2, (hipStream_t)stream, dy, Co, H, W, h, w, \
-                           ay, ax, TAP_TRL, tiles2, FR, WP, dz, sn, sc);                                                     \
+                           ay, ax, TAP_TRL, tiles2, FR, WP, dz, sn, sc, (int)planes, ppw);                                   \
         break;
         switch (nw4) {
             DCL_TAPUP_CASE(2)
@@ -858,6 +903,10 @@ static int tapup_bwd_impl(const float *dy, int N, int Co, int H, int W, int h, i
 
 extern "C" int dcl_tapup_set_bwd_form(int form)
 {
+    if (form > 16 && form <= 24) {          // tuning hook: planes per workgroup of the second form
+        g_tapup_bwd_ppw = form - 16;
+        return 0;
+    }
     if (form != 1 && form != 2)
         return DCL_EINVAL;
     g_tapup_bwd_form = form;

@@ -1,6 +1,7 @@
 """Tap-up backward: first form against the windowed form -- bitwise-near agreement, fp64 check of both on a small case, timing."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mscs_amd
 from mscs_amd import _lib
 L = _lib.lib()
@@ -39,4 +40,26 @@ for (n, co, H, W, h, w) in [(12, 720, 128, 256, 32, 64), (12, 720, 128, 256, 16,
         res.setdefault(form, []).append(round(e0.elapsed_time(e1) / 5, 3))
     gb = (dy.numel() + 9 * co * n * h * w) * 4 / 1e9
     print((n, co, H, W, h, w), "ms form1", res[1], "form2", res[2], "algorithmic GB", round(gb, 2))
+# planes per workgroup of the windowed form (dcl_tapup_set_bwd_form(16 + p))
 L.dcl_tapup_set_bwd_form(2)
+for (n, co, H, W, h, w) in [(12, 720, 128, 256, 32, 64), (12, 720, 128, 256, 16, 32), (16, 512, 128, 128, 32, 32), (16, 512, 128, 128, 16, 16),
+                            (16, 512, 160, 160, 40, 40), (16, 512, 160, 160, 20, 20)]:
+    dy = torch.randn(n, co, H, W, device=dev)
+    out = []
+    ref = None
+    for p in (1, 2, 4, 8, 1, 2, 4, 8):
+        L.dcl_tapup_set_bwd_form(16 + p)
+        dz = torch.empty((9 * co, n * h * w), device=dev)
+        L.dcl_tapup_bwd(_lib.ptr(dy), n, co, H, W, h, w, 0, 1, _lib.ptr(dz), st)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = dz.clone()
+        assert torch.equal(ref, dz), "planes per workgroup changed the result"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            L.dcl_tapup_bwd(_lib.ptr(dy), n, co, H, W, h, w, 0, 1, _lib.ptr(dz), st)
+        e1.record(); torch.cuda.synchronize()
+        out.append((p, round(e0.elapsed_time(e1) / 5, 3)))
+    print((n, co, H, W, h, w), "ms by planes per workgroup", out, "dy GB", round(dy.numel() * 4 / 1e9, 2))
+L.dcl_tapup_set_bwd_form(16 + 4)
