@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void k_normalize_bwd_scatter(
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
             am = fmaxf(am, __shfl_xor(am, o, 64));
-        if (lane == 0)
+        // (a plain load first: atomics on the two cache lines of a tag retire one after the other, one per sampled row adds up;
+        // a stale read only costs an atomic that changes nothing)
+        if (lane == 0 && am > __builtin_nontemporal_load(amax + (row & (DCL_AMAX_SLOTS - 1))))
             atomicMax((unsigned int *)(amax + (row & (DCL_AMAX_SLOTS - 1))), __float_as_uint(am));
     }
 }
