@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_normalize_bwd_scatter(
             am = fmaxf(am, __shfl_xor(am, o, 64));
         // (a plain load first: atomics on the two cache lines of a tag retire one after the other, one per sampled row adds up;
         // a stale read only costs an atomic that changes nothing)
-        if (lane == 0 && am > __builtin_nontemporal_load(amax + (row & (DCL_AMAX_SLOTS - 1))))
+        if (lane == 0)
             atomicMax((unsigned int *)(amax + (row & (DCL_AMAX_SLOTS - 1))), __float_as_uint(am));
     }
 }

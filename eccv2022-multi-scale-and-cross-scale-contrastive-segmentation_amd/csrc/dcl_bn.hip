@@ -170,8 +170,7 @@ __device__ __forceinline__ void block_amax(float m, float *dst)
 #pragma unroll
         for (int w = 1; w < BN_THREADS / 64; ++w)
             m = fmaxf(m, wmax[w]);
-        if (m > __builtin_nontemporal_load(dst))        // (skipped once the slot holds at least as much: dcl_layernorm.hip block_amax_ln)
-            atomicMax((unsigned int *)dst, __float_as_uint(m));
+        atomicMax((unsigned int *)dst, __float_as_uint(m));
     }
 }
 
