@@ -73,6 +73,11 @@ def _gemm(a):
     return 2.0 * m * n * k * batch, 4.0 * batch * (m * k + n * k + m * n), f"{batch}x[{m}x{k}].[{n}x{k}]^T"
 
 
+def _gemm_ep(a):            # dcl_gemm_f16x3_ep(A, lda, akm, B, ldb, bkm, M, N, K, ...): + one more [M, N] tensor read or written
+    m, n, k = a[6], a[7], a[8]
+    return 2.0 * m * n * k, 4.0 * (m * k + n * k + 2.0 * m * n), f"[{m}x{k}].[{n}x{k}]^T"
+
+
 def _sweep(factor):
     def f(a):
         n1, n2 = a[1], a[4]
@@ -146,7 +151,10 @@ MODELS = {
     "dcl_wgrad3x3_f16x3": (_wgrad3x3, "mfma", None),
     "dcl_wgrad1x1_f16x3": (_wgrad1x1, "mfma", None),
     "dcl_gemm_f16x3": (_gemm, "mfma", "k_gemm"),
+    "dcl_gemm_f16x3_ep": (_gemm_ep, "mfma", "k_gemm"),
+    "dcl_gemm_f16x3_ascaled": (_gemm_ep, "mfma", "k_gemm"),
     "dcl_infonce_zsweep": (_sweep(2.0), "mfma", "k_sweep<MODE_Z>"),
+    "dcl_infonce_zsweep_keep": (_sweep(2.0), "mfma", "k_sweep<MODE_Z>"),
     "dcl_infonce_bwd_streamk": (_sweep(4.0), "mfma", "k_sweep<MODE_BWD,stream-K>"),
     "dcl_infonce_bwd": (_sweep(4.0), "mfma", "k_sweep<MODE_BWD>"),
     "dcl_bn_stats_part": (_bn_stats, "hbm", "k_bn_stats"),

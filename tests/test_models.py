@@ -423,3 +423,42 @@ def test_drop_path_fused_residual_matches_two_step_form():
     dp.eval()
     s, x = torch.randn(2, 3), torch.randn(2, 3)
     assert torch.equal(dp.add_to(s, x), s + x) and torch.equal(DropPath(0.0).train().add_to(s, x), s + x)
+
+
+def test_token_map_and_cpu_fallbacks_of_the_round4_fusions():
+    """Host-side logic of the round-4 Swin / UPerNet fusions on CPU tensors: TokenMap.nchw() is the reference's view -> permute ->
+    contiguous; DropPath.factors draws what DropPath.forward draws; dropout2d_conv1x1 and relu_then_bn run the plain modules when
+    the fused path does not apply (CPU), and a TokenMap lateral falls back to the NCHW tensor."""
+    import mscs_amd  # noqa: F401
+    from mscs_amd.models import ops
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d, relu_then_bn
+    from mscs_amd.models.Swin import DropPath, TokenMap, as_nchw
+    from mscs_amd.models.UPerNet import FPN, _conv1x1_bn_relu
+    torch.manual_seed(0)
+    tok = torch.randn(2, 6 * 5, 8)
+    tm = TokenMap(tok, 6, 5)
+    assert tuple(tm.shape) == (2, 8, 6, 5)
+    assert torch.equal(tm.nchw(), tok.view(2, 6, 5, 8).permute(0, 3, 1, 2).contiguous()) and tm.nchw() is tm.nchw()
+    assert as_nchw(tm) is tm.nchw() and as_nchw(tok) is tok
+    dp = DropPath(0.4).train()
+    x = torch.randn(6, 3, 4)
+    torch.manual_seed(5)
+    y = dp(x)
+    torch.manual_seed(5)
+    scale, bound = dp.factors(x)
+    assert torch.allclose(y, x * scale.view(-1, 1, 1)) and abs(bound - 1 / 0.6) < 1e-12
+    assert DropPath(0.0).train().factors(x) == (None, 1.0) and dp.eval().factors(x) == (None, 1.0)
+    drop, conv = torch.nn.Dropout2d(0.5).train(), torch.nn.Conv2d(8, 3, 1)
+    xi = torch.randn(2, 8, 4, 4)
+    torch.manual_seed(3)
+    a = ops.dropout2d_conv1x1(xi, drop, conv)
+    torch.manual_seed(3)
+    assert torch.equal(a, conv(drop(xi)))
+    bn = FusedBatchNorm2d(8).train()
+    t = torch.randn(2, 8, 4, 4)
+    ref = torch.nn.BatchNorm2d(8).train()(torch.relu(t))
+    assert torch.allclose(relu_then_bn(bn, t.clone()), ref, atol=1e-6)
+    block = _conv1x1_bn_relu(8, 4, FusedBatchNorm2d).train()
+    out = FPN._lateral(None, block, TokenMap(tok, 6, 5))
+    block2_in = tok.view(2, 6, 5, 8).permute(0, 3, 1, 2).contiguous()
+    assert out.shape == (2, 4, 6, 5) and torch.isfinite(out).all() and out.shape == block(block2_in).shape
