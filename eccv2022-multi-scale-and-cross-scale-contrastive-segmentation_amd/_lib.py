@@ -75,6 +75,7 @@ SIGNATURES = {
     "dcl_amax_sum2": [_vp, _i, _vp, _i, _vp, _vp],
     "dcl_tapup_fwd": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "dcl_tapup_bwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "dcl_tapup_bwd_amax": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "dcl_tapup_set_bwd_form": [_i],
     "dcl_tapup_supported": [_i, _i, _i, _i, _i, _i, _i],
     "dcl_gemm_supported": [_i, _i, _i, _i64, _i, _i64, _i],

@@ -315,6 +315,7 @@ struct TapSrc {
 
 constexpr int TAP_RC = 32;         // output rows per workgroup (forward)
 constexpr int TAP_TW = 256;        // output columns per workgroup = threads
+constexpr size_t TAP_FWD_LDS_MAX = 128 * 1024;     // source windows of a forward tile (dynamic LDS; above 64 KB one workgroup per CU)
 
 // Forward.  One workgroup = one (n, co) plane x 32 output rows x 256 output columns.  The low-resolution windows of BOTH
 // sources (9 taps each) that the tile's shifted coordinates interpolate from are staged once (a duplicate of the last
@@ -488,10 +489,27 @@ constexpr int TAP_TRL = 4;         // low-resolution rows per workgroup (backwar
 // LDS and the horizontal pass gathers each (tap, row, column) of dz from its footprint with column weights from a second
 // table.  (The other order -- lanes along the low-resolution columns read dy rows with a stride of the scale factor --
 // is 4- to 8-way bank conflicted on ten times the volume.)
+// max|dz| of a workgroup -> one integer atomic max (values >= 0).  The backward GEMMs take their operand scale from it: the
+// a-priori bound 4 s_y s_x max|dy| is 16-256 x the real maximum (the signs of dy under a norm cancel), i.e. 4-8 bits of the
+// f16 split given away -- visible as 1.2e-2 in the conv_last weight gradient of the UPerNet fixture once the 2x map took this route.
+__device__ __forceinline__ void tap_block_amax(float m, float *dst)
+{
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0)
+        wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax((unsigned int *)dst, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
 __global__ __launch_bounds__(256) void k_tapup_bwd(const float *__restrict__ dy, int Co, int H, int W, int h, int w,
                                                   Axis ay, Axis ax, int trl, int tiles_r, int gr, int kxn,
-                                                  float *__restrict__ dz, long long sn, long long sc)
+                                                  float *__restrict__ dz, long long sn, long long sc, float *__restrict__ amax)
 {
+    float am = 0.f;
     extern __shared__ __attribute__((aligned(16))) float tap_lds[];
     float *wt = tap_lds;                                  // [gr][3][TAP_TRL] row weights
     float *wxt = wt + (size_t)gr * 3 * TAP_TRL;           // [w][kxn] column weights of shifted coordinate xlo[c] + k
@@ -559,7 +577,10 @@ __global__ __launch_bounds__(256) void k_tapup_bwd(const float *__restrict__ dy,
                 a += wc[k] * vrow[Xd];
         }
         out[tap * tapstride + (size_t)(r_a + rr) * w + c] = a;
+        am = fmaxf(am, fabsf(a));
     }
+    if (amax)
+        tap_block_amax(am, amax);
 }
 
 // Backward, second form (the default wherever its column window fits NW4 <= 8 float4s).  Same tiles and summation structure;
@@ -575,8 +596,9 @@ __global__ __launch_bounds__(256) void k_tapup_bwd(const float *__restrict__ dy,
 template <int NW4>
 __global__ __launch_bounds__(256) void k_tapup_bwd_w(const float *__restrict__ dy, int Co, int H, int W, int h, int w, Axis ay,
                                                     Axis ax, int trl, int tiles_r, int FR, int WP, float *__restrict__ dz,
-                                                    long long sn, long long sc, int planes, int ppw)
+                                                    long long sn, long long sc, int planes, int ppw, float *__restrict__ amax)
 {
+    float am = 0.f;
     // Round 4: a workgroup takes `ppw` consecutive planes of its row tile (the weight tables -- axis_weight has a division per
     // entry -- are built once for all of them), and the vertical pass reads dy as float4s with every row of a footprint in
     // flight: one item = (low-resolution row, four columns), up to 8 x 16 bytes per thread outstanding.  Before, a thread had
@@ -727,8 +749,11 @@ __global__ __launch_bounds__(256) void k_tapup_bwd_w(const float *__restrict__ d
         op[0] = o0;
         op[tapstride] = o1;
         op[2 * tapstride] = o2;
+        am = fmaxf(am, fmaxf(fabsf(o0), fmaxf(fabsf(o1), fabsf(o2))));
     }
     }   // planes of this workgroup
+    if (amax)
+        tap_block_amax(am, amax);
 }
 
 // conservative bound of the low-resolution window a run of `n_out` consecutive output coordinates (+ one on either side)
@@ -775,7 +800,14 @@ extern "C" int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1, i
         zfloats += 9 * s[i].wr * s[i].wc;
     }
     const size_t lds = (size_t)(tabfloats + zfloats) * sizeof(float);
-    DCL_CHECK_ARG(lds <= 64 * 1024, "source maps too large for the tap-up tile (LDS): convolve the up-sampled map instead");
+    DCL_CHECK_ARG(lds <= TAP_FWD_LDS_MAX, "source maps too large for the tap-up tile (LDS): convolve the up-sampled map instead");
+    if (lds > 64 * 1024) {              // (a source only 2x coarser than the output: 95 KB for the 32 x 256 tile, one workgroup per CU)
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void *)k_tapup_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAP_FWD_LDS_MAX);
+            attr_done = true;
+        }
+    }
     const int tiles_y = (H + TAP_RC - 1) / TAP_RC, tiles_x = (W + TAP_TW - 1) / TAP_TW;
     const long long blocks = (long long)N * Co * tiles_y * tiles_x;
     DCL_CHECK_ARG(blocks < (1LL << 31), "too many tiles");
@@ -789,13 +821,20 @@ static int g_tapup_bwd_form = 2;        // 2 = k_tapup_bwd_w (windowed horizonta
 static int g_tapup_bwd_ppw = 4;         // planes per workgroup of k_tapup_bwd_w (dcl_tapup_set_bwd_form(16 + p): p = 1, 2, 4, 8)
 
 static int tapup_bwd_impl(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
-                          float *dz, void *stream, bool query);
+                          float *dz, void *stream, bool query, float *amax = nullptr);
 
 extern "C" int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners,
                              int channel_major, float *dz, void *stream)
 {
     DCL_CHECK_ARG(dy && dz && N > 0 && Co > 0 && H > 0 && W > 0 && h > 0 && w > 0, "bad arguments");
     return tapup_bwd_impl(dy, N, Co, H, W, h, w, align_corners, channel_major, dz, stream, false);
+}
+
+extern "C" int dcl_tapup_bwd_amax(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners,
+                                  int channel_major, float *dz, float *dz_amax, void *stream)
+{
+    DCL_CHECK_ARG(dy && dz && dz_amax && N > 0 && Co > 0 && H > 0 && W > 0 && h > 0 && w > 0, "bad arguments");
+    return tapup_bwd_impl(dy, N, Co, H, W, h, w, align_corners, channel_major, dz, stream, false, dz_amax);
 }
 
 static size_t tapup_fwd_lds(const int *hs, const int *ws, int nsrc, int H, int W)
@@ -815,7 +854,7 @@ extern "C" int dcl_tapup_supported(int h0, int w0, int h1, int w1, int H, int W,
         return 0;
     const int hs[2] = {h0, h1}, ws[2] = {w0, w1};
     const int nsrc = (h1 > 0 && w1 > 0) ? 2 : 1;
-    if (tapup_fwd_lds(hs, ws, nsrc, H, W) > 64 * 1024)
+    if (tapup_fwd_lds(hs, ws, nsrc, H, W) > TAP_FWD_LDS_MAX)
         return 0;
     for (int i = 0; i < nsrc; ++i)
         if (tapup_bwd_impl(nullptr, 1, 1, H, W, hs[i], ws[i], align_corners, 1, nullptr, nullptr, true) != 0)
@@ -824,7 +863,7 @@ extern "C" int dcl_tapup_supported(int h0, int w0, int h1, int w1, int H, int W,
 }
 
 static int tapup_bwd_impl(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
-                          float *dz, void *stream, bool query)
+                          float *dz, void *stream, bool query, float *amax)
 {
     const Axis ay = make_axis(h, H, align_corners), ax = make_axis(w, W, align_corners);
     const int kxn = tap_footprint(w, W);
@@ -877,7 +916,7 @@ static int tapup_bwd_impl(const float *dy, int N, int Co, int H, int W, int h, i
 #define DCL_TAPUP_CASE(K)                                                                                                   \
     case K:                                                                                                                 \
         hipLaunchKernelGGL(k_tapup_bwd_w<K>, dim3((unsigned)blocks2), dim3(256), lds2, (hipStream_t)stream, dy, Co, H, W, h, w, \
-                           ay, ax, TAP_TRL, tiles2, FR, WP, dz, sn, sc, (int)planes, ppw);                                   \
+                           ay, ax, TAP_TRL, tiles2, FR, WP, dz, sn, sc, (int)planes, ppw, amax);                             \
         break;
         switch (nw4) {
             DCL_TAPUP_CASE(2)
@@ -896,7 +935,7 @@ static int tapup_bwd_impl(const float *dy, int N, int Co, int H, int W, int h, i
         return form1_fits ? 0 : DCL_EUNSUPPORTED;
     DCL_CHECK_ARG(form1_fits, "maps too wide for the tap-up backward tile (LDS)");
     hipLaunchKernelGGL(k_tapup_bwd, dim3((unsigned)blocks), dim3(256), lds_for(trl), (hipStream_t)stream, dy, Co, H, W, h, w, ay,
-                       ax, trl, tiles_r, gr, kxn, dz, sn, sc);
+                       ax, trl, tiles_r, gr, kxn, dz, sn, sc, amax);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -59,6 +59,9 @@ class DebugConfig:
     token_laterals: bool = field(default_factory=lambda: _flag('DCL_TOKEN_LATERALS'))           # UPerNet laterals read Swin outputs token-major
     gemm_ascale: bool = field(default_factory=lambda: _flag('DCL_GEMM_ASCALE'))                 # DropPath's factor as an operand scale of the backward GEMMs
     relu_then_bn: bool = field(default_factory=lambda: _flag('DCL_RELU_THEN_BN'))               # projector ReLU's backward inside the norm's
+    head_split_min_scale: int = field(default_factory=lambda: 0 if _int('DCL_HEAD_SPLIT_MIN_SCALE') is None else _int('DCL_HEAD_SPLIT_MIN_SCALE'))
+    # 0 = automatic (models/ops.py conv3x3_over_upsampled: >= 4x coarser maps, and 2x coarser ones with >= 256 channels, go through the
+    # tap products of the head split); 4 = round 3's rule; 2 = every map at least 2x coarser
     fused_mlp: bool = field(default_factory=lambda: _flag('DCL_FUSED_MLP'))                     # Swin Mlp / residual sums in GEMM epilogues
     coalesced_sync_bn: bool = field(default_factory=lambda: _flag('DCL_SYNCBN_COALESCE'))       # stacked SyncBN exchanges
     side_stream_priority: Optional[int] = field(default_factory=lambda: _int('DCL_SIDE_PRIO'))  # HIP priority of the branch streams

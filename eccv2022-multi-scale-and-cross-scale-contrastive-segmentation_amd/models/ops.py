@@ -791,14 +791,19 @@ class _CoarseTaps(torch.autograd.Function):
             hw = h * w
             P = n * hw
             dz = torch.empty((n, 9 * Co, hw) if img else (9 * Co, P), dtype=torch.float32, device=dy.device)
-            _lib.check(L.dcl_tapup_bwd(_lib.ptr(dy), n, Co, H, W, h, w, 1 if align else 0, 0 if img else 1, _lib.ptr(dz), st),
-                       "dcl_tapup_bwd")
             gx = None
             if ctx.ams is not None:
                 wam, xams = ctx.ams
-                # |dz| <= (weight a low-resolution pixel receives from the up-sampled map) x max|dy|: the bilinear weights of
-                # one source pixel sum to s_y s_x in the interior and to < 2 s per axis at a clamped border
-                dzam = dyam * float(4 * -(-H // h) * -(-W // w))
+                # max|dz| measured by the gather's adjoint itself (round 4).  Until then the a-priori bound 4 s_y s_x max|dy| (the
+                # bilinear weights of one source pixel sum to s_y s_x in the interior, < 2 s per axis at a clamped border) set the
+                # operand scale of the two GEMMs below: 16-256 x the real maximum, 4-8 bits of the f16 split
+                dzam = _am.zeros(1, dy.device)
+                _lib.check(L.dcl_tapup_bwd_amax(_lib.ptr(dy), n, Co, H, W, h, w, 1 if align else 0, 0 if img else 1, _lib.ptr(dz),
+                                                _lib.ptr(dzam), st), "dcl_tapup_bwd_amax")
+            else:
+                _lib.check(L.dcl_tapup_bwd(_lib.ptr(dy), n, Co, H, W, h, w, 1 if align else 0, 0 if img else 1, _lib.ptr(dz), st),
+                           "dcl_tapup_bwd")
+            if ctx.ams is not None:
                 if img:
                     if ctx.needs_input_grad[5 + i]:
                         # dx[n] [C_b, h w] = W_b^T dz[n]: both operands row-contiguous (the contraction 9 Co may be ragged); the
@@ -981,7 +986,10 @@ class LazyConcat:
         return self._full
 
 
-def conv3x3_over_upsampled(ts, align_corners, weight, bias, min_scale=4):
+HEAD_SPLIT_MIN_SCALE = _dbg.head_split_min_scale
+
+
+def conv3x3_over_upsampled(ts, align_corners, weight, bias, min_scale=None):
     """``conv2d(cat([ts[0]] + [up(t) for t in ts[1:]], 1), weight, bias, padding=1)`` (bilinear ``up`` to ts[0]'s size)
     without up-sampling the maps that are at least ``min_scale`` times coarser than ts[0]:
 
@@ -999,11 +1007,25 @@ def conv3x3_over_upsampled(ts, align_corners, weight, bias, min_scale=4):
     for t in ts:
         offs.append(off)
         off += t.shape[1]
-    is_fine = [t is t0 or t.shape[-1] * min_scale > W for t in ts]
+    if min_scale is None:
+        min_scale = HEAD_SPLIT_MIN_SCALE
+
+    def goes_coarse(t):
+        # >= 4x coarser: always.  2x coarser: the tap products of such a map are 9/4 of an output map per output channel and
+        # cross HBM five times per step (written and read forward, written and read twice backward) -- worth it for a wide map
+        # (UPerNet's 512-channel P3: config 4 79.1 -> 74.3 ms, config 5 218.3 -> 210.5), not for HRNet's 96-channel branch
+        # (89.4 -> 95.2 ms: 2.5 GB of tap products for a third of the fine convolution's work).  min_scale forces either rule.
+        if min_scale:
+            return t.shape[-1] * min_scale <= W
+        return t.shape[-1] * 4 <= W or (t.shape[-1] * 2 <= W and t.shape[1] >= 256)
+    is_fine = [t is t0 or not goes_coarse(t) for t in ts]
     fine = [t for t, f in zip(ts, is_fine) if f]
-    coarse = [t for t, f in zip(ts, is_fine) if not f]
     fine_ranges = tuple((o, o + t.shape[1]) for t, o, f in zip(ts, offs, is_fine) if f)
-    coarse_offs = tuple(o for o, f in zip(offs, is_fine) if not f)
+    # coarse maps coarsest first: the tap gather takes them in pairs, and a map only 2x coarser (min_scale = 2) fills a forward
+    # tile's LDS window by itself -- it goes last, alone or behind a small one
+    order = sorted((i for i, f in enumerate(is_fine) if not f), key=lambda i: ts[i].shape[-1])
+    coarse = [ts[i] for i in order]
+    coarse_offs = tuple(offs[i] for i in order)
     if coarse:
         # the tap gather's tiles are sized by LDS: ask the library BEFORE committing to the split form (it would otherwise
         # raise mid-step, for some shapes only in the backward) and convolve the materialised concatenation instead

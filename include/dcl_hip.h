@@ -331,6 +331,10 @@ int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1 /* may be NUL
                   int W, int align_corners, int channel_major, float *y, int accumulate, void *stream);
 int dcl_tapup_bwd(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
                   float *dz, void *stream);
+/* dcl_tapup_bwd that also max-es max|dz| into dz_amax[0] (zero-initialised by the caller; integer atomic max): the operand scale of
+ * the backward GEMMs that consume dz (an a-priori bound from max|dy| is 16-256x too large: bits of the f16 split given away). */
+int dcl_tapup_bwd_amax(const float *dy, int N, int Co, int H, int W, int h, int w, int align_corners, int channel_major,
+                       float *dz, float *dz_amax, void *stream);
 /* tuning hook: 2 (default) = windowed horizontal pass (k_tapup_bwd_w), 1 = the first form (also the fallback for column
  * windows beyond 8 float4s). */
 int dcl_tapup_set_bwd_form(int form);

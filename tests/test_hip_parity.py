@@ -1580,6 +1580,47 @@ def test_head_conv_over_upsampled_matches_fp64(dev, align, chans, H, W, Co, bias
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("chans,H,W,Co,min_scale", [((32, 256, 64), 64, 96, 64, None), ((48, 96, 192), 40, 72, 32, 2),
+                                                    ((16, 256), 128, 256, 32, None)])
+def test_head_conv_over_upsampled_two_x_level(dev, align, chans, H, W, Co, min_scale):
+    """The map that is only 2x coarser than the output through the tap products as well (round 4: automatic for >= 256 channels --
+    UPerNet's P3 -- or forced with min_scale = 2): three coarse maps (pairs (8x, 4x) and the 2x map alone), and a 128 x 256 output
+    whose 2x source fills a forward tile's LDS window beyond 64 KB (one workgroup per CU).  Against float64 as the test above."""
+    import torch.nn.functional as F
+    from mscs_amd.models import ops
+    torch.manual_seed(4)
+    n = 2
+    ts = [torch.randn(n, c, max(H >> i, 1), max(W >> i, 1), device=dev).requires_grad_(True) for i, c in enumerate(chans)]
+    wt = (torch.randn(Co, sum(chans), 3, 3, device=dev) * 0.05).requires_grad_(True)
+    gy = torch.randn(n, Co, H, W, device=dev)
+    seen = []
+    orig = ops._HeadSplit.apply
+    try:
+        ops._HeadSplit.apply = staticmethod(lambda *a: (seen.append(len(a) - 7), orig(*a))[1])
+        y = ops.conv3x3_over_upsampled(ts, align, wt, None, min_scale=min_scale)
+    finally:
+        ops._HeadSplit.apply = orig
+    assert seen == [len(chans) - 1]                 # every map but the full-resolution one went through the tap products
+    y.backward(gy)
+    got = [y.detach()] + [t.grad for t in ts] + [wt.grad]
+    ts64 = [t.detach().double().requires_grad_(True) for t in ts]
+    w64 = wt.detach().double().requires_grad_(True)
+    cat = torch.cat([ts64[0]] + [F.interpolate(t, size=(H, W), mode="bilinear", align_corners=align) for t in ts64[1:]], 1)
+    y64 = F.conv2d(cat, w64, None, padding=1)
+    y64.backward(gy.double())
+    ref = [y64.detach()] + [t.grad for t in ts64] + [w64.grad]
+    # the library's own fp32 distance from float64 on the same formulation: 2 M outputs of ~2 400 products each put its maximum at
+    # a few 1e-6 as well -- the bar is 3e-6 or twice the library's error, whichever is larger
+    with torch.no_grad():
+        cat32 = torch.cat([ts[0]] + [F.interpolate(t, size=(H, W), mode="bilinear", align_corners=align) for t in ts[1:]], 1)
+        e_lib = ((F.conv2d(cat32, wt, None, padding=1).double() - y64).abs().max() / y64.abs().max()).item()
+    for k, (a, r) in enumerate(zip(got, ref)):
+        err = ((a.double() - r).abs().max() / r.abs().max()).item()
+        assert err < (max(3e-6, 2 * e_lib) if k == 0 else 1e-5), (k, err, e_lib)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("align", [True, False])
 def test_head_conv_over_upsampled_any_map_order(dev, align):
     """UPerNet's fusion convolution concatenates [P2, P5, P4, P3] (reference models/UPerNet.py:96-101): the coarse maps sit
     BETWEEN the fine ones in the weight's input channels.  conv3x3_over_upsampled against float64 for that order (output,
