@@ -362,11 +362,16 @@ def roofline_gemm_kernel(args, dev, iters=10):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * m * c * 4 * c
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": f"k_gemm<2,4,4,2> (dcl_gemm_f16x3): Swin stage-3 Mlp.fc1 forward, [{m} x {c}] . [{4 * c} x {c}]^T + bias",
+    # FETCH_SIZE / WRITE_SIZE per launch (KiB) of exactly these two shapes: profiles/r04_gemm_pmc.csv (tools/pmc_gemm.sh, separate
+    # --pmc passes); 2 x FETCH + WRITE = bytes that crossed L2 <-> fabric
+    pmc = {(16384, 384): (30987.6, 98340.6), (25600, 768): (255298.3, 307241.5)}.get((m, c))
+    traffic = (2 * pmc[0] + pmc[1]) * 1024 if pmc else None
+    out = {"traffic_source": "constant from profiles/r04_gemm_pmc.csv (separate rocprofv3 --pmc passes of this launch)"} if pmc else {}
+    return {**out, "bound": "mfma", "kernel": f"k_gemm (dcl_gemm_f16x3): Swin stage-3 Mlp.fc1 forward, [{m} x {c}] . [{4 * c} x {c}]^T + bias",
             "achieved": round(achieved, 2), "peak": round(MFMA_F16X3_BWD_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_F16X3_BWD_PEAK_TFLOPS, 4),
             "peak_note": "2 M N K algorithmic FLOP issued as 3 f16 MFMA passes (split-f16, fp32-equivalent): 2.5 PFLOP/s / 3",
-            "traffic": None, "algorithmic_bytes": 4 * (m * c + 4 * c * c + m * 4 * c), "launch_ms": round(ms, 4)}
+            "traffic": traffic, "algorithmic_bytes": 4 * (m * c + 4 * c * c + m * 4 * c), "launch_ms": round(ms, 4)}
 
 
 def roofline_bwd_kernel(mod, iters=10):
