@@ -107,6 +107,9 @@ def parse():
     ap.add_argument("--feature-layout", choices=["nchw", "nhwc"], default="nchw",
                     help="loss workload: memory layout of the synthetic embedding maps (nhwc = channels-last strides, what "
                          "this package's projector hands out in training; nchw = a plain contiguous map)")
+    ap.add_argument("--detail-file", default=None,
+                    help="write the FULL record (per-shape tables, roofline_other / roofline_hbm, notes) to this JSON file; it always "
+                         "goes to stderr as one 'bench-detail: {...}' line.  stdout carries the compact line only (<= 4 KB)")
     ap.add_argument("--kernel-table", default=None,
                     help="write the in-step per-kernel table (the rows behind `roofline*`) to this JSON file")
     ap.add_argument("--no-reference-config", action="store_true",
@@ -659,6 +662,9 @@ def time_train_step(args, dev, rank, world):
     mod = mgr.loss.loss_classes["DenseContrastiveLossV2_ms"]
     extra = {"contrastive_loss_fwd_bwd_ms": round(loss_only_ms(mod, dev, args), 3),
              "metrics_in_step": not args.no_metrics,
+             # one resident batch, its "label complete" event fired before the timed region: the label stage of step i + 1 overlaps
+             # step i's tail, which a dataloader-fed run cannot do for the first ~1.5 ms of a step
+             "timed_batch": "resident; label_ready pre-fired",
              # what the manager resolved (the timed config itself holds reference keys only unless a --materialize-* /
              # --plain-config flag wrote an explicit `false`): logits kept at 1/4 resolution for the fused up-sampling +
              # cross-entropy / arg-max kernels
@@ -734,6 +740,74 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
+
+LINE_LIMIT = 4096       # the driver keeps a ~9 KB stdout tail (a 23.7 KB line was recorded as "parsed": null)
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches", "launch_ms", "step_ms", "algorithmic_flops",
+              "algorithmic_bytes", "traffic")
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config", "contrastive_loss_fwd_bwd_ms", "roofline", "roofline_step", "roofline_sweep", "cpu_baseline",
+             "eager_gpu_step_ms", "speedup_vs_eager_gpu_step", "eager_gpu_step_ms_miopen_find", "plain_config_ms_per_step",
+             "metrics_in_step", "lazy_logits", "lazy_projector", "fused_optimizer", "config_keys_beyond_reference", "peak_mem_gb",
+             "timed_batch", "detail")
+
+
+def _short_kernel(name):
+    """'k_conv3x3_il<3,4> (dcl_conv3x3_f16x3): all 242 launches ...' -> 'k_conv3x3_il<3,4> (dcl_conv3x3_f16x3)'"""
+    cut = name.find("):")
+    name = name[:cut + 1] if cut > 0 else name
+    return name[:96]
+
+
+def _slim_roofline(r):
+    if not r:
+        return r
+    e = {k: r[k] for k in _ROOF_KEYS if k in r}
+    e["kernel"] = _short_kernel(str(e.get("kernel", "")))
+    for k in ("algorithmic_flops", "algorithmic_bytes", "traffic"):
+        if isinstance(e.get(k), float):
+            e[k] = float(f"{e[k]:.5g}")
+    return e
+
+
+def compact_line(full):
+    """The ONE stdout line the driver parses: BASELINE.json's metric, one `roofline`, `roofline_step`, the similarity sweep's
+    roofline (the kernel north_star names), a `cpu_baseline` and the comparator ratios -- no per-shape tables, no prose.
+    Everything else (`roofline_other`, `roofline_hbm`, shapes, notes) is the detail record (stderr / --detail-file).
+    Guaranteed <= LINE_LIMIT bytes: optional keys are dropped, last first, until it fits."""
+    line = {k: full[k] for k in _TOP_KEYS if k in full}
+    if "config" in line:
+        line["config"] = {"workload": str(full["config"].get("workload", ""))[:300]}
+    for k in ("roofline", "roofline_step"):
+        if k in line:
+            line[k] = _slim_roofline(line[k])
+    sweep = [r for r in full.get("roofline_other", []) if "k_sweep" in str(r.get("kernel", ""))]
+    if sweep and "roofline_sweep" not in line and "k_sweep" not in str(full.get("roofline", {}).get("kernel", "")):
+        line["roofline_sweep"] = _slim_roofline(sweep[0])
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample_seconds", "model_seconds", "loss_seconds")
+                                if k in cb}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample_short") or cb.get("sample", ""))[:200]
+    drop = ["peak_mem_gb", "config_keys_beyond_reference", "fused_optimizer", "lazy_projector", "lazy_logits", "metrics_in_step",
+            "eager_gpu_step_ms_miopen_find", "detail", "roofline_sweep", "timed_batch"]
+    text = json.dumps(line)
+    while len(text) >= LINE_LIMIT and drop:
+        line.pop(drop.pop(0), None)
+        text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:
+        raise RuntimeError(f"bench line is {len(text)} bytes (limit {LINE_LIMIT}): {sorted(line)}")
+    return text
+
+
+def emit(full, args):
+    """detail record -> stderr (+ --detail-file), compact line -> stdout, LAST."""
+    detail = json.dumps(full)
+    if getattr(args, "detail_file", None):
+        with open(args.detail_file, "w") as f:
+            f.write(detail + "\n")
+        full = dict(full, detail=args.detail_file)
+    print("bench-detail: " + detail, file=sys.stderr, flush=True)
+    print(compact_line(full), flush=True)
 
 
 def main():
@@ -829,13 +903,17 @@ def main():
             lsec, cores, lsample = cpu_baseline_loss(args)
             if workload == "loss":
                 out["cpu_baseline"] = {"value": round(1.0 / lsec, 5), "unit": unit, "cores": cores,
-                                       "kind": "port", "sample": lsample, "sample_seconds": round(lsec, 2)}
+                                       "kind": "port", "sample": lsample, "sample_seconds": round(lsec, 2),
+                                       "sample_short": f"one whole DCV2_ms evaluation fwd+bwd ({args.scales} scales + cross-scale, batch "
+                                                       f"{args.batch}, {args.height}x{args.width}), eager torch fp32, measured once"}
             else:
                 msec, msample = cpu_baseline_model(args)
                 out["cpu_baseline"] = {"value": round(args.batch / (msec + lsec), 5), "unit": unit, "cores": cores,
                                        "kind": "port", "sample": msample + "; " + lsample,
                                        "model_seconds": round(msec, 2), "loss_seconds": round(lsec, 2),
-                                       "sample_seconds": round(msec + lsec, 2)}
+                                       "sample_seconds": round(msec + lsec, 2),
+                                       "sample_short": f"one whole step: HRNet-W48 fwd+bwd over all {args.batch} images (micro-batches "
+                                                       f"of 4) + SGD + one full DCV2_ms evaluation, torch CPU fp32, measured once"}
         if workload == "step" and world == 1 and not args.no_reference_config and not args.plain_config:
             # the same step with this package's opt-in behaviour switched OFF by explicit `false` keys: full-resolution logits,
             # the projector's [n, d, h, w] maps (pixel-major strides), torch's foreach optimizer -- what a user gets who calls the
@@ -867,7 +945,7 @@ def main():
                 out["eager_gpu_step_ms_miopen_find"] = round(tuned_ms, 1)
                 out["speedup_vs_eager_gpu_step_miopen_find"] = round(tuned_ms / ms_per_step, 2)
                 out["eager_miopen_find_total_s"] = round(time.perf_counter() - t0, 1)
-        print(json.dumps(out), flush=True)
+        emit(out, args)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
