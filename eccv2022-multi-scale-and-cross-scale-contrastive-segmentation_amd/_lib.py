@@ -58,12 +58,17 @@ SIGNATURES = {
     "dcl_bn_apply_parts": [_vp, _vp, _vp, _i, ctypes.c_double, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                            _vp, _vp, _vp],
     "dcl_bn_compact_parts": [_vp, _i, _i, _vp, _vp],
+    "dcl_conv3x3_f16x3_multi": [_vp, _i, _vp],
     "dcl_conv3x3_bnstats_tiles": [_i, _i, _i, _i, _i],
     "dcl_conv3x3_s2_smallcin": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "dcl_conv3x3_bnstats_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_bwd_reduce_part": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "dcl_bn_bwd_apply_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp,
                                _vp, _vp, _vp],
+    "dcl_bn_stats_part_multi": [_vp, _i, _vp],
+    "dcl_bn_apply_fused_multi": [_vp, _i, _i, _i, _vp],
+    "dcl_bn_bwd_reduce_part_multi": [_vp, _i, _vp],
+    "dcl_bn_bwd_apply_fused_multi": [_vp, _i, _i, _vp],
     "dcl_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "dcl_bn_bwd_onepass_supported": [_i, _i, _i, _i],

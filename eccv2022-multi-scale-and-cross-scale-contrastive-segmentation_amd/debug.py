@@ -25,6 +25,8 @@ class DebugConfig:
     fuse_residual_grad: bool = field(default_factory=lambda: _flag('DCL_FUSE_RESIDUAL_GRAD'))   # GradToken path
     branch_streams: bool = field(default_factory=lambda: _flag('DCL_BRANCH_STREAMS'))           # one HIP stream per branch
     defer_join: bool = field(default_factory=lambda: _flag('DCL_DEFER_JOIN'))                   # no join between modules
+    merge_branches: bool = field(default_factory=lambda: _flag('DCL_MERGE_BRANCHES'))           # branches 1.. of an exchange module: one launch
+    # per kernel stage and block depth (models/merged.py, csrc k_conv3x3_il_multi / k_bn_*_multi); 0 = one stream per branch
     stage_continuity: bool = field(default_factory=lambda: _flag('DCL_STAGE_CONTINUITY'))       # ... nor between stages
     fanout_on_branch_stream: bool = field(default_factory=lambda: _flag('DCL_FANOUT_STREAM'))
     branch_stream_map: List[int] = field(default_factory=lambda: [

@@ -1,0 +1,209 @@
+"""One launch per kernel stage for the coarse branches of an HRNet exchange module (mscs_amd/models/merged.py; C ABI
+dcl_conv3x3_f16x3_multi, dcl_bn_*_multi -- reference models/HRNet.py:263-287, :77-93): the job-table kernels run the bodies of
+the single-layer kernels, so everything must agree BITWISE with the stream-per-branch schedule."""
+import ctypes
+import importlib
+
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import mscs_amd  # noqa: F401
+    return torch.device("cuda:0")
+
+
+def _module(nb, dev, seed=5):
+    from mscs_amd.models import fused_bn
+    from mscs_amd.models.ops import use_direct_conv1x1, use_direct_conv3x3
+    hm = importlib.import_module("mscs_amd.models.HRNet")
+    torch.manual_seed(seed)
+    ch = [48, 96, 192, 384][:nb]
+    mod = hm.HighResolutionModule(nb, hm.BasicBlock, [4] * nb, ch, ch, 'SUM', True, norm_layer=fused_bn.FusedBatchNorm2d)
+    use_direct_conv3x3(mod)
+    use_direct_conv1x1(mod)
+    return hm, mod.to(dev).train(), ch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb,hw", [(4, (64, 96)), (3, (32, 64)), (4, (128, 256))])
+def test_merged_branches_are_bitwise_the_per_branch_schedule(dev, nb, hw):
+    """Whole exchange module, merged coarse branches (default) against one stream per branch: outputs, input gradients, every
+    parameter gradient and the running statistics bitwise equal.  (64, 96): the coarsest maps have H W % 256 != 0 (the norms'
+    backward reads y), (128, 256): packed sign masks on every branch."""
+    hm, mod, ch = _module(nb, dev)
+    state = {k: v.clone() for k, v in mod.state_dict().items()}
+    xs0 = [torch.randn(2, c, hw[0] >> i, hw[1] >> i, device=dev) for i, c in enumerate(ch)]
+    res = []
+    keep = hm._MERGE_BRANCHES
+    try:
+        for merged in (False, True, True):
+            mod.load_state_dict(state)
+            mod.zero_grad(set_to_none=True)
+            xs = [x.clone().requires_grad_(True) for x in xs0]
+            hm._MERGE_BRANCHES = merged
+            assert mod._mergeable(xs) == merged
+            outs = mod(list(xs))
+            sum((o * torch.cos(torch.arange(o.numel(), device=dev).view(o.shape) * 0.37)).mean() for o in outs).backward()
+            torch.cuda.synchronize()
+            res.append(([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
+                        [p.grad.clone() for p in mod.parameters()], [b.clone() for b in mod.buffers()]))
+    finally:
+        hm._MERGE_BRANCHES = keep
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert len(a) == len(b)
+            for t, u in zip(a, b):
+                assert torch.equal(t, u)
+
+
+@pytest.mark.gpu
+def test_merged_schedule_is_reproducible_run_to_run(dev):
+    """Six repetitions of a whole exchange module (forward + backward, two streams) on the same inputs: every output and gradient
+    bitwise equal.  (An issue order that alternated the two streams block by block failed this 40 times in 63.)"""
+    hm, mod, ch = _module(4, dev, seed=21)
+    state = {k: v.clone() for k, v in mod.state_dict().items()}
+    xs0 = [torch.randn(2, c, 128 >> i, 256 >> i, device=dev) for i, c in enumerate(ch)]
+    first = None
+    for rep in range(6):
+        mod.load_state_dict(state)
+        mod.zero_grad(set_to_none=True)
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        assert mod._mergeable(xs)
+        outs = mod(list(xs))
+        sum((o * torch.cos(torch.arange(o.numel(), device=dev).view(o.shape) * 0.37)).mean() for o in outs).backward()
+        torch.cuda.synchronize()
+        got = [o.detach().clone() for o in outs] + [x.grad.clone() for x in xs] + [p.grad.clone() for p in mod.parameters()]
+        if first is None:
+            first = got
+        else:
+            for a, b in zip(first, got):
+                assert torch.equal(a, b), rep
+
+
+@pytest.mark.gpu
+def test_merged_branches_on_one_stream_and_without_residual_tokens(dev):
+    """The serialised form (no branch streams: what bench.py's kernel table replays) and the form without GradTokens run the same
+    launches: bitwise the default."""
+    hm, mod, ch = _module(4, dev, seed=11)
+    state = {k: v.clone() for k, v in mod.state_dict().items()}
+    xs0 = [torch.randn(3, c, 32 >> i, 64 >> i, device=dev) for i, c in enumerate(ch)]
+    keep = (hm._BRANCH_STREAMS, hm._FUSE_RESIDUAL_GRAD)
+    res = []
+    try:
+        for streams, tokens in ((True, True), (False, True), (True, False)):
+            hm._BRANCH_STREAMS, hm._FUSE_RESIDUAL_GRAD = streams, tokens
+            mod.load_state_dict(state)
+            mod.zero_grad(set_to_none=True)
+            xs = [x.clone().requires_grad_(True) for x in xs0]
+            assert mod._mergeable(xs)
+            outs = mod._run_branches(list(xs))
+            sum(o.square().mean() for o in outs).backward()
+            torch.cuda.synchronize()
+            res.append(([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
+                        [p.grad.clone() for p in mod.parameters() if p.grad is not None]))
+    finally:
+        hm._BRANCH_STREAMS, hm._FUSE_RESIDUAL_GRAD = keep
+    for a, b in zip(res[0][0] + res[0][1] + res[0][2], res[1][0] + res[1][1] + res[1][2]):
+        assert torch.equal(a, b)
+    # without tokens the residual gradient is added by autograd instead of in the data-gradient epilogue: fp32 round-off
+    for a, b in zip(res[0][0], res[2][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][1] + res[0][2], res[2][1] + res[2][2]):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-12
+
+
+@pytest.mark.gpu
+def test_c_abi_multi_convolution_equals_single_launches_on_ragged_shapes(dev):
+    """dcl_conv3x3_f16x3_multi through the C ABI: four jobs of different, ragged geometry (tiles cut by the image border, 1..4
+    jobs, addends) against dcl_conv3x3_f16x3 with the same (3, P) tile -- bitwise -- and against float64."""
+    from mscs_amd import _lib
+    from mscs_amd.models import ops
+    from mscs_amd.models.amax import amax_of
+    from mscs_amd.models.merged import ConvJob
+    L = _lib.lib()
+    torch.manual_seed(3)
+    shapes = [(2, 96, 96, 19, 40), (1, 192, 96, 7, 33), (3, 48, 192, 16, 32), (2, 384, 96, 5, 9)]
+    for njobs in (1, 2, 4):
+        for p in (2, 4):
+            T = []
+            for (n, ci, co, h, w) in shapes[:njobs]:
+                x = torch.randn(n, ci, h, w, device=dev)
+                wt = torch.randn(co, ci, 3, 3, device=dev) * 0.1
+                ad = torch.randn(n, co, h, w, device=dev)
+                xa, wa = amax_of(x), amax_of(wt)
+                wp = ops.conv3x3_pack(wt, wa)
+                single = ops.conv3x3_launch(x, wp, co, xa, wa, torch.empty(n, co, h, w, device=dev), tile_r=3, tile_p=p, addend=ad)
+                T.append((x, wt, ad, xa, wa, wp, single, torch.empty(n, co, h, w, device=dev)))
+            arr = (ConvJob * njobs)()
+            for k, (x, wt, ad, xa, wa, wp, single, out) in enumerate(T):
+                n, ci, h, w = x.shape
+                arr[k] = ConvJob(x.data_ptr(), wp.data_ptr(), xa.data_ptr(), wa.data_ptr(), ad.data_ptr(), None, out.data_ptr(),
+                                 n, ci, wt.shape[0], h, w, xa.numel(), p, 0)
+            _lib.check(L.dcl_conv3x3_f16x3_multi(ctypes.addressof(arr), njobs, _lib.stream_ptr(dev)), "multi")
+            torch.cuda.synchronize()
+            for (x, wt, ad, xa, wa, wp, single, out) in T:
+                assert torch.equal(out, single)
+                ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1) + ad.double()
+                assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
+    # a job the (3, P) tile does not cover is refused, not mis-computed
+    x = torch.randn(1, 48, 8, 32, device=dev)
+    wt = torch.randn(48, 48, 3, 3, device=dev)
+    xa, wa = amax_of(x), amax_of(wt)
+    wp = ops.conv3x3_pack(wt, wa)
+    out = torch.empty(1, 48, 8, 32, device=dev)
+    arr = (ConvJob * 1)()
+    arr[0] = ConvJob(x.data_ptr(), wp.data_ptr(), xa.data_ptr(), wa.data_ptr(), None, None, out.data_ptr(), 1, 48, 48, 8, 32, 1, 0, 0)
+    assert L.dcl_conv3x3_f16x3_multi(ctypes.addressof(arr), 1, _lib.stream_ptr(dev)) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_res", [False, True])
+def test_merged_norms_equal_the_single_layer_op_and_float64(dev, with_res):
+    """bn_act_merged (4 kernel stages, job tables) against FusedBatchNorm2d layer by layer -- outputs, running statistics, input /
+    residual / parameter gradients bitwise -- and the outputs against a float64 batch norm.  Shapes cover the flat (small
+    planes) and per-plane grid forms, H W % 4 != 0 and the packed-mask / y-reading backward."""
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d
+    from mscs_amd.models.merged import bn_act_merged, bn_merged_ok
+    torch.manual_seed(9)
+    shapes = [(2, 96, 64, 64), (3, 192, 16, 32), (2, 384, 5, 7), (2, 48, 128, 128)]
+    bns = [FusedBatchNorm2d(c).to(dev).train() for (_, c, _, _) in shapes]
+    for bn in bns:
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_()
+    state = [{k: v.clone() for k, v in bn.state_dict().items()} for bn in bns]
+    xs0 = [torch.randn(*s, device=dev) * 2 + 0.3 for s in shapes]
+    rs0 = [torch.randn(*s, device=dev) for s in shapes]
+    gs = [torch.randn(*s, device=dev) for s in shapes]
+
+    def run(merged):
+        for bn, st in zip(bns, state):
+            bn.load_state_dict(st)
+            bn.zero_grad(set_to_none=True)
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        rs = [r.clone().requires_grad_(True) for r in rs0] if with_res else None
+        if merged:
+            assert bn_merged_ok(bns, xs, rs)
+            ys = bn_act_merged(bns, xs, residuals=rs, relu=True)
+        else:
+            ys = [bn(x, residual=(rs[k] if rs else None), relu=True) for k, (bn, x) in enumerate(zip(bns, xs))]
+        torch.autograd.backward(ys, gs)
+        torch.cuda.synchronize()
+        out = [y.detach().clone() for y in ys] + [x.grad.clone() for x in xs] + ([r.grad.clone() for r in rs] if rs else [])
+        for bn in bns:
+            out += [bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone(),
+                    bn.num_batches_tracked.clone()]
+        return out
+
+    a, b = run(False), run(True)
+    for t, u in zip(a, b):
+        assert torch.equal(t, u)
+    for k, (x, r) in enumerate(zip(xs0, rs0)):
+        xd = x.double()
+        m, v = xd.mean((0, 2, 3), keepdim=True), xd.var((0, 2, 3), unbiased=False, keepdim=True)
+        ref = (xd - m) / (v + 1e-5).sqrt() * bns[k].weight.double().view(1, -1, 1, 1) + bns[k].bias.double().view(1, -1, 1, 1)
+        ref = (ref + r.double() if with_res else ref).clamp_min(0)
+        assert (b[k].double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
