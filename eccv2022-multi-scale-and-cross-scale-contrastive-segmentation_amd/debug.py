@@ -25,8 +25,14 @@ class DebugConfig:
     fuse_residual_grad: bool = field(default_factory=lambda: _flag('DCL_FUSE_RESIDUAL_GRAD'))   # GradToken path
     branch_streams: bool = field(default_factory=lambda: _flag('DCL_BRANCH_STREAMS'))           # one HIP stream per branch
     defer_join: bool = field(default_factory=lambda: _flag('DCL_DEFER_JOIN'))                   # no join between modules
-    merge_branches: bool = field(default_factory=lambda: _flag('DCL_MERGE_BRANCHES'))           # branches 1.. of an exchange module: one launch
-    # per kernel stage and block depth (models/merged.py, csrc k_conv3x3_il_multi / k_bn_*_multi); 0 = one stream per branch
+    merge_branches: bool = field(default_factory=lambda: _flag('DCL_MERGE_BRANCHES', False))    # branches 1.. of an exchange module: one
+    # launch per kernel stage and block depth (models/merged.py, csrc k_conv3x3_il_multi / k_bn_*_multi).  OFF by default: built,
+    # bitwise-tested (tests/test_merged_branches.py) and measured -- the three coarse convolutions of a stage-4 depth take 130 us as
+    # one launch against 213 us in a row (tools/probes/conv_multi_time.py), the serialised kernel time of a step drops by 6.9 ms and
+    # its launches from 2 813 to ~1 900, and the step gets SLOWER, 89.5 / 89.7 against 87.6 ms (alternating runs on one box,
+    # profiles/r05_ab_merge_branches.json): with one stream per branch those partial-chip kernels already run beside each other and
+    # beside branch 0, and the merged schedule puts the three coarse weight gradients (each a full-chip launch) of a depth in a row on
+    # ONE stream -- its dependency chain per module is 2.3x the longest per-branch chain
     stage_continuity: bool = field(default_factory=lambda: _flag('DCL_STAGE_CONTINUITY'))       # ... nor between stages
     fanout_on_branch_stream: bool = field(default_factory=lambda: _flag('DCL_FANOUT_STREAM'))
     branch_stream_map: List[int] = field(default_factory=lambda: [

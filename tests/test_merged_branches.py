@@ -31,7 +31,7 @@ def _module(nb, dev, seed=5):
 @pytest.mark.gpu
 @pytest.mark.parametrize("nb,hw", [(4, (64, 96)), (3, (32, 64)), (4, (128, 256))])
 def test_merged_branches_are_bitwise_the_per_branch_schedule(dev, nb, hw):
-    """Whole exchange module, merged coarse branches (default) against one stream per branch: outputs, input gradients, every
+    """Whole exchange module, merged coarse branches against one stream per branch (the default): outputs, input gradients, every
     parameter gradient and the running statistics bitwise equal.  (64, 96): the coarsest maps have H W % 256 != 0 (the norms'
     backward reads y), (128, 256): packed sign masks on every branch."""
     hm, mod, ch = _module(nb, dev)
@@ -72,9 +72,14 @@ def test_merged_schedule_is_reproducible_run_to_run(dev):
         mod.load_state_dict(state)
         mod.zero_grad(set_to_none=True)
         xs = [x.clone().requires_grad_(True) for x in xs0]
-        assert mod._mergeable(xs)
-        outs = mod(list(xs))
-        sum((o * torch.cos(torch.arange(o.numel(), device=dev).view(o.shape) * 0.37)).mean() for o in outs).backward()
+        keep = hm._MERGE_BRANCHES
+        hm._MERGE_BRANCHES = True
+        try:
+            assert mod._mergeable(xs)
+            outs = mod(list(xs))
+            sum((o * torch.cos(torch.arange(o.numel(), device=dev).view(o.shape) * 0.37)).mean() for o in outs).backward()
+        finally:
+            hm._MERGE_BRANCHES = keep
         torch.cuda.synchronize()
         got = [o.detach().clone() for o in outs] + [x.grad.clone() for x in xs] + [p.grad.clone() for p in mod.parameters()]
         if first is None:
@@ -91,9 +96,10 @@ def test_merged_branches_on_one_stream_and_without_residual_tokens(dev):
     hm, mod, ch = _module(4, dev, seed=11)
     state = {k: v.clone() for k, v in mod.state_dict().items()}
     xs0 = [torch.randn(3, c, 32 >> i, 64 >> i, device=dev) for i, c in enumerate(ch)]
-    keep = (hm._BRANCH_STREAMS, hm._FUSE_RESIDUAL_GRAD)
+    keep = (hm._BRANCH_STREAMS, hm._FUSE_RESIDUAL_GRAD, hm._MERGE_BRANCHES)
     res = []
     try:
+        hm._MERGE_BRANCHES = True
         for streams, tokens in ((True, True), (False, True), (True, False)):
             hm._BRANCH_STREAMS, hm._FUSE_RESIDUAL_GRAD = streams, tokens
             mod.load_state_dict(state)
@@ -106,7 +112,7 @@ def test_merged_branches_on_one_stream_and_without_residual_tokens(dev):
             res.append(([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
                         [p.grad.clone() for p in mod.parameters() if p.grad is not None]))
     finally:
-        hm._BRANCH_STREAMS, hm._FUSE_RESIDUAL_GRAD = keep
+        hm._BRANCH_STREAMS, hm._FUSE_RESIDUAL_GRAD, hm._MERGE_BRANCHES = keep
     for a, b in zip(res[0][0] + res[0][1] + res[0][2], res[1][0] + res[1][1] + res[1][2]):
         assert torch.equal(a, b)
     # without tokens the residual gradient is added by autograd instead of in the data-gradient epilogue: fp32 round-off
