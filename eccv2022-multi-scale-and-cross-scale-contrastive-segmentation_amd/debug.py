@@ -25,6 +25,7 @@ class DebugConfig:
     fuse_residual_grad: bool = field(default_factory=lambda: _flag('DCL_FUSE_RESIDUAL_GRAD'))   # GradToken path
     branch_streams: bool = field(default_factory=lambda: _flag('DCL_BRANCH_STREAMS'))           # one HIP stream per branch
     defer_join: bool = field(default_factory=lambda: _flag('DCL_DEFER_JOIN'))                   # no join between modules
+    merge_from: int = field(default_factory=lambda: 1 if _int('DCL_MERGE_FROM') is None else _int('DCL_MERGE_FROM'))   # first merged branch
     merge_branches: bool = field(default_factory=lambda: _flag('DCL_MERGE_BRANCHES', False))    # branches 1.. of an exchange module: one
     # launch per kernel stage and block depth (models/merged.py, csrc k_conv3x3_il_multi / k_bn_*_multi).  OFF by default: built,
     # bitwise-tested (tests/test_merged_branches.py) and measured -- the three coarse convolutions of a stage-4 depth take 130 us as

@@ -81,6 +81,7 @@ _DEFER_JOIN = _dbg.defer_join
 _STAGE_CONTINUITY = _dbg.stage_continuity
 _FANOUT_ON_BRANCH_STREAM = _dbg.fanout_on_branch_stream
 _BRANCH_STREAM_MAP = list(_dbg.branch_stream_map)     # stream per branch (0 = the main stream); default: one each
+_MERGE_FROM = _dbg.merge_from
 _MERGE_BRANCHES = _dbg.merge_branches                  # branches 1.. of a module: one launch per kernel stage and depth (models/merged.py)
 
 
@@ -303,14 +304,15 @@ class HighResolutionModule(nn.Module):
         """Branches 1 .. n-1 can run as ONE launch per kernel stage and block depth (models/merged.py): plain BasicBlock chains
         of equal length on the fused norms and the (3, P) direct convolution tiles (W48: 96 / 192 / 384 channels), at least two
         of them.  Decided per call from the module structure and the inputs; anything else takes the stream-per-branch path."""
-        if not (_MERGE_BRANCHES and not _BRANCH_STREAM_MAP and self.num_branches >= 3 and x[0].is_cuda and self.training):
+        m0 = _MERGE_FROM
+        if not (_MERGE_BRANCHES and not _BRANCH_STREAM_MAP and self.num_branches >= m0 + 2 and x[0].is_cuda and self.training):
             return False
-        chains = [list(br) for br in self.branches[1:]]
+        chains = [list(br) for br in self.branches[m0:]]
         if len({len(c) for c in chains}) != 1:
             return False
         if not all(type(blk) is BasicBlock and blk.downsample is None and blk.stride == 1 for c in chains for blk in c):
             return False
-        xs = list(x[1:])
+        xs = list(x[m0:])
         for d in range(len(chains[0])):
             blocks = [c[d] for c in chains]
             if not (conv_multi_ok([b.conv1 for b in blocks], xs) and conv_multi_ok([b.conv2 for b in blocks], xs)
@@ -323,15 +325,17 @@ class HighResolutionModule(nn.Module):
         stage of a depth one launch over all of them (convolution, norm statistics, norm apply; the same in the backward:
         autograd sees one node per stage).  Reference models/HRNet.py:263-267 (`x[i] = self.branches[i](x[i])`)."""
         nb = self.num_branches
+        m0 = _MERGE_FROM                # first branch of the merged group (1: all but the finest)
         dev = x[0].device
         main = torch.cuda.current_stream(dev)
-        chains = [list(br) for br in self.branches[1:]]
-        cur = list(x[1:])
+        chains = [list(br) for br in self.branches[m0:]]
+        cur = list(x[m0:])
         cs = None                       # (_BRANCH_STREAMS off -- the serialised replay of bench.py's kernel table: same launches, one stream)
+        side = _side_streams(dev, nb - 1) if _BRANCH_STREAMS else None
         if _BRANCH_STREAMS:
-            cs = _side_streams(dev, nb - 1)[0]
+            cs = side[m0 - 1]
             need_main = False
-            for k in range(1, nb):
+            for k in range(m0, nb):
                 src = getattr(x[k], '_dcl_stream', None) if _DEFER_JOIN else None
                 if src is None:
                     need_main = True
@@ -358,13 +362,28 @@ class HighResolutionModule(nn.Module):
         # max, identical inputs by checksum; no cross-stream block in the allocator's history; gone without the caching
         # allocator and with everything on one stream) -- 0 of 63 runs differ in this order, 40 of 63 in the alternating one
         # (tools/probes/dbg_merged.py).  The GPU queues fill either way: the host runs ahead of the device.
+        # (branches 1 .. m0-1, if any, on their own streams as in the per-branch schedule)
+        mid = [None] * (m0 - 1)
+        for k in range(m0 - 1, 0, -1):
+            if side is None:
+                mid[k - 1] = self.branches[k](x[k])
+                continue
+            if not (_DEFER_JOIN and getattr(x[k], '_dcl_stream', None) is side[k - 1]):
+                side[k - 1].wait_stream(main)
+            with torch.cuda.stream(side[k - 1]):
+                _amax_record_stream(x[k], side[k - 1])
+                mid[k - 1] = self.branches[k](x[k])
         out0 = self.branches[0](x[0])
         if cs is not None:
             main.wait_stream(cs)
             for t in cur:
                 _amax_record_stream(t, main)
+            for k in range(1, m0):
+                main.wait_stream(side[k - 1])
+                _amax_record_stream(mid[k - 1], main)
         self._coarse_stream = cs
-        return [out0] + cur
+        self._coarse_from = m0
+        return [out0] + mid + cur
 
     def _run_branches(self, x):
         """The branches of a module are independent until the fuse layers: on CUDA each runs on its own HIP stream
@@ -421,7 +440,7 @@ class HighResolutionModule(nn.Module):
                 al = [fan_out(x[0], nrow)]
                 for j in range(1, self.num_branches):
                     # (merged coarse branches: their outputs' gradient sums run on the group's stream, in order with its backward)
-                    cs = getattr(self, '_coarse_stream', None)
+                    cs = getattr(self, '_coarse_stream', None) if j >= getattr(self, '_coarse_from', 1) else None
                     with torch.cuda.stream(cs if cs is not None else side_f[j - 1]):
                         al.append(fan_out(x[j], nrow))
             else:
