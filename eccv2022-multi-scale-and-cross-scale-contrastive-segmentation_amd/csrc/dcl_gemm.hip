@@ -597,8 +597,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a)
                             } else {
                                 f32x2 sc = sp2(1.f);
                                 if (a.rowscale) {
-                                    sc.x = a.rowscale[q0 + (rem0 + dr >= a.rows_per_scale ? 1 : 0)];
-                                    sc.y = a.rowscale[q0 + (rem0 + dr + 1 >= a.rows_per_scale ? 1 : 0)];
+                                    // (rows past M in a partial tile: clamped to the last sample's factor, never read past the
+                                    // [M / rows_per_scale] array; their results are not stored)
+                                    const int qmax = (a.M - 1) / a.rows_per_scale;
+                                    sc.x = a.rowscale[min(q0 + (rem0 + dr >= a.rows_per_scale ? 1 : 0), qmax)];
+                                    sc.y = a.rowscale[min(q0 + (rem0 + dr + 1 >= a.rows_per_scale ? 1 : 0), qmax)];
                                 }
                                 val = pk_fma(sc, val, f32x2{xin[r], xin[r + 1]});
                             }

@@ -775,6 +775,19 @@ int tap_footprint(int in_size, int out_size)
 
 }  // namespace
 
+// LDS a workgroup of the current device may ask for with the dynamic-size opt-in (gfx950: 160 KiB per CU)
+static size_t tapup_device_lds_limit()
+{
+    int devid = 0, v = 0;
+    if (hipGetDevice(&devid) != hipSuccess)
+        return 64 * 1024;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, devid) == hipSuccess && v > 0)
+        return (size_t)v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, devid) == hipSuccess && v > 0)
+        return (size_t)v;
+    return 64 * 1024;
+}
+
 extern "C" int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1, int h1, int w1, int N, int Co, int H, int W,
                              int align_corners, int channel_major, float *y, int accumulate, void *stream)
 {
@@ -802,10 +815,22 @@ extern "C" int dcl_tapup_fwd(const float *z0, int h0, int w0, const float *z1, i
     const size_t lds = (size_t)(tabfloats + zfloats) * sizeof(float);
     DCL_CHECK_ARG(lds <= TAP_FWD_LDS_MAX, "source maps too large for the tap-up tile (LDS): convolve the up-sampled map instead");
     if (lds > 64 * 1024) {              // (a source only 2x coarser than the output: 95 KB for the 32 x 256 tile, one workgroup per CU)
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void *)k_tapup_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAP_FWD_LDS_MAX);
-            attr_done = true;
+        // the opt-in is per DEVICE (a second GPU in the process needs its own), and a device without that much LDS must say no
+        // here, not in the launch
+        static bool attr_done[64] = {};
+        int devid = 0;
+        if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64)
+            devid = 0;
+        if (!attr_done[devid]) {
+            DCL_CHECK_ARG(lds <= tapup_device_lds_limit(), "tap-up tile needs more LDS than this device offers");
+            const hipError_t e = hipFuncSetAttribute((const void *)k_tapup_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)TAP_FWD_LDS_MAX);
+            if (e != hipSuccess) {
+                dcl_set_error("dcl_tapup_fwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d): %s", (int)TAP_FWD_LDS_MAX,
+                              hipGetErrorString(e));
+                return (int)e;
+            }
+            attr_done[devid] = true;
         }
     }
     const int tiles_y = (H + TAP_RC - 1) / TAP_RC, tiles_x = (W + TAP_TW - 1) / TAP_TW;
@@ -854,7 +879,8 @@ extern "C" int dcl_tapup_supported(int h0, int w0, int h1, int w1, int H, int W,
         return 0;
     const int hs[2] = {h0, h1}, ws[2] = {w0, w1};
     const int nsrc = (h1 > 0 && w1 > 0) ? 2 : 1;
-    if (tapup_fwd_lds(hs, ws, nsrc, H, W) > TAP_FWD_LDS_MAX)
+    const size_t need = tapup_fwd_lds(hs, ws, nsrc, H, W);
+    if (need > TAP_FWD_LDS_MAX || (need > 64 * 1024 && need > tapup_device_lds_limit()))
         return 0;
     for (int i = 0; i < nsrc; ++i)
         if (tapup_bwd_impl(nullptr, 1, 1, H, W, hs[i], ws[i], align_corners, 1, nullptr, nullptr, true) != 0)

@@ -807,15 +807,52 @@ def _streamk_workspace(dev, G: int):
 
 
 def _streamk_note_launches(dev):
-    """After the stream-K launches of a backward pass: asynchronous copy of the error word to the host + an event."""
+    """After the stream-K launches of a backward pass: asynchronous copy of the error word to the host + an event.  On several
+    ranks the word is first all-reduced (MAX, 4 bytes, asynchronous): one rank's invalid gradient reaches every rank through the
+    gradient all-reduce, so every rank has to see the error (``streamk_check`` then raises on all of them, not on one whose
+    peers would hang in their next collective)."""
     got = _SK_WS.get((dev.index, _lib.stream_ptr(dev)))
     if got is None:
         return
     G = got[4]
-    got[3].copy_(got[1][G:G + 1], non_blocking=True)
+    word = got[1][G:G + 1]
+    if _dist_world() > 1:
+        import torch.distributed as dist
+        word = word.clone()
+        work = dist.all_reduce(word, op=dist.ReduceOp.MAX, async_op=True)
+        work.wait()                             # (orders the current stream behind the collective; does not block the host on RCCL)
+    got[3].copy_(word, non_blocking=True)
     ev = got[2] or torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
     got[2] = ev
+
+
+def streamk_check(wait: bool = True):
+    """Raise ``StreamKTimeout`` if a stream-K backward launch of THIS backward pass (or an earlier one) reported a timed-out
+    hand-over -- to be called after ``loss.backward()`` and BEFORE the gradients are consumed: the managers register it as a
+    pre-step hook of their optimizer (BaseManager.load_optimiser), so an invalid gradient is never applied.  ``wait``: wait for
+    the event behind the error word's copy; that copy sits right behind the loss's sweeps at the very START of the backward
+    pass, so by the time the host has enqueued the rest of the backward it has normally completed (no stall in a GPU-bound
+    step).  The error switches stream-K off for the process (column-split ``dcl_infonce_bwd`` from then on), so repeating the
+    step is safe.  On several ranks the word is the maximum over the ranks: all of them raise."""
+    for key, got in list(_SK_WS.items()):
+        ev, host = got[2], got[3]
+        if ev is None:
+            continue
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            continue
+        n = int(host[0])
+        if n != 0:
+            _lib.lib().dcl_infonce_set_streamk(0)
+            _SK_WS.pop(key, None)
+            raise StreamKTimeout(
+                f"stream-K backward: {n} hand-over(s) between persistent workgroups timed out (a contributor workgroup never "
+                "became resident: CU mask, another persistent kernel, several ranks on one device?).  The feature gradients of "
+                "this backward pass are invalid and must not be applied.  Stream-K is now OFF for this process "
+                "(dcl_infonce_set_streamk(0)): repeat the step -- it uses the column-split backward; set DCL_SWEEP_STREAMK=0 to "
+                "start that way.")
 
 
 def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_meta, need):

@@ -26,6 +26,7 @@ from .. import losses as _losses
 from .. import models as _models
 from ..datasets import SyntheticSegmentation
 from ..losses import LossWrapper
+from ..losses.engine import StreamKTimeout
 from ..utils import DATASETS_INFO, printlog
 from ..utils.config import parse_config
 from ..utils.lr_functions import LRFcts
@@ -260,6 +261,10 @@ class BaseManager:
                                                weight_decay=tcfg.get('weight_decay', 0.01), **fused)
         else:
             raise ValueError(f"optimizer {optim} not recognized")
+        # an invalid gradient of the contrastive loss (stream-K backward: a timed-out hand-over, losses/engine.py) must never
+        # reach the parameters: checked right before every update (the error word was copied to the host at the START of the
+        # backward pass, so this normally does not wait)
+        self.optimiser.register_step_pre_hook(lambda *_a, **_k: self._check_backward())
         if tcfg['lr_batchwise']:
             total = sum(len(self.data_loaders[self.train_schedule[e]]) for e in range(tcfg['epochs']))
         else:
@@ -270,6 +275,11 @@ class BaseManager:
     # ------------------------------------------------------------------ loops
     def forward_step(self, img, lbl, **kwargs):
         raise NotImplementedError
+
+    def _check_backward(self):
+        if self.device.type == 'cuda':
+            from ..losses.engine import streamk_check
+            streamk_check()
 
     def train(self):
         tcfg = self.config['train']
@@ -310,7 +320,17 @@ class BaseManager:
             self.optimiser.zero_grad()
             ret = self.forward_step(img, lbl, label_ready=ready)
             ret['loss'].backward()
-            self.optimiser.step()
+            try:
+                self.optimiser.step()
+            except StreamKTimeout as e:
+                # raised by the pre-step hook BEFORE anything was applied (on every rank: the error word is all-reduced).  The
+                # library has switched to the column-split backward: repeat the step on the same batch.  (The repeated forward
+                # updates the norms' running statistics and draws the sampling permutations a second time.)
+                printlog(f'[warning] {e}\n          repeating step {self.global_step}')
+                self.optimiser.zero_grad()
+                ret = self.forward_step(img, lbl, label_ready=ready)
+                ret['loss'].backward()
+                self.optimiser.step()
             if self.scheduler is not None and self.config['train']['lr_batchwise']:
                 self.scheduler.step()
             if batch_num == 2 and self.debugging:

@@ -259,6 +259,61 @@ def test_deterministic_bitwise(dev):
         assert torch.equal(a, b)
 
 
+def test_streamk_error_word_is_seen_before_the_gradients_are_applied(dev):
+    """a timed-out stream-K hand-over must be detected in the SAME step, before optimizer.step().  The error word
+    (flags[G], counted up by the kernel, never reset) is planted by hand; the backward pass copies it to the host right behind
+    its sweeps, `streamk_check()` -- the managers' optimizer pre-step hook -- raises StreamKTimeout and switches the process to
+    the column-split backward, whose gradients equal the stream-K ones (2e-6 of max); a clean pass raises nothing."""
+    from mscs_amd import _lib
+    from mscs_amd.losses import DenseContrastiveLossV2_ms
+    from mscs_amd.losses import engine
+    L = _lib.lib()
+    label, feats = _random_case(33, 3, 128, 256, 20, 64, (4, 8))
+    cfg = {"dataset": "CITYSCAPES", "experiment": 1, "temperature": 0.1, "scales": 2, "weights": [1.0, 0.5],
+           "cross_scale_contrast": True}
+    mod = DenseContrastiveLossV2_ms(cfg)
+    if (mod.DCV2_scale0.mfma_mode or "f16x3") != "f16x3":
+        pytest.skip("stream-K is the f16x3 backward")
+
+    def run():
+        fs = [f.to(dev).requires_grad_(True) for f in feats]
+        torch.manual_seed(1)
+        mod(label.to(dev), fs).backward()
+        return [f.grad.clone() for f in fs]
+    L.dcl_infonce_set_streamk(1)
+    try:
+        good = run()
+        engine.streamk_check()                                  # clean pass: nothing to report
+        assert engine._SK_WS, "the stream-K backward did not run (workspace missing)"
+        for got in engine._SK_WS.values():
+            got[1][got[4]:got[4] + 1].fill_(3)                  # "three hand-overs timed out"
+        run()
+        with pytest.raises(engine.StreamKTimeout):
+            engine.streamk_check()
+        assert not engine._SK_WS                               # workspace dropped, stream-K off: the repeated step is column-split
+        again = run()
+        engine.streamk_check()
+        assert not engine._SK_WS
+        for a, b in zip(good, again):
+            assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
+        # the hook the managers install: optimizer.step() raises BEFORE touching the parameters
+        L.dcl_infonce_set_streamk(1)
+        w = torch.nn.Parameter(torch.ones(4, device=dev))
+        opt = torch.optim.SGD([w], lr=1.0)
+        opt.register_step_pre_hook(lambda *_a, **_k: engine.streamk_check())
+        run()
+        for got in engine._SK_WS.values():
+            got[1][got[4]:got[4] + 1].fill_(1)
+        run()
+        w.grad = torch.ones_like(w)
+        with pytest.raises(engine.StreamKTimeout):
+            opt.step()
+        assert torch.equal(w.detach(), torch.ones(4, device=dev))
+    finally:
+        L.dcl_infonce_set_streamk(1)
+        engine._SK_WS.clear()
+
+
 @pytest.mark.parametrize("n,H,W,cap", [(2, 128, 256, 10000), (3, 64, 128, 700), (12, 256, 512, 10000), (2, 128, 128, 90)])
 def test_streamk_backward_equals_column_split_backward(dev, n, H, W, cap):
     """dcl_infonce_bwd_streamk (persistent workgroups over the (row block, chunk) sequence, finished tiles) against
