@@ -63,6 +63,7 @@ class _FusedBNFunction(torch.autograd.Function):
         st = _stream()
         world = _world() if sync else 1
         count = float(N * HW * world)
+        exch = None
         if pre is not None:
             # partial sums from the epilogue of the convolution that produced x (models/ops.py conv3x3_launch_bnstats): one
             # per pixel tile of that launch, same shift (the running mean) -- no statistics pass over x
@@ -74,7 +75,7 @@ class _FusedBNFunction(torch.autograd.Function):
                 _check_equal_batch(N, dev)
                 one = torch.empty((C * 2,), dtype=torch.float32, device=dev)
                 _lib.check(L.dcl_bn_compact_parts(_lib.ptr(part), C, ns, _lib.ptr(one), st), "dcl_bn_compact_parts")
-                _all_reduce(one)
+                exch = _all_reduce_async(one)
                 part, ns = one, 1
         else:
             ns = L.dcl_bn_num_slices(N, C)
@@ -87,14 +88,15 @@ class _FusedBNFunction(torch.autograd.Function):
             _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(running_mean), _lib.ptr(pivot),
                                            st), "dcl_bn_stats_part")
             if world > 1:
-                import torch.distributed as dist
                 _check_equal_batch(N, dev)
-                _all_reduce(part)
+                exch = _all_reduce_async(part)
         y = torch.empty_like(x)
         # The backward needs y only for the ReLU mask.  Without a residual it recomputes y > 0 from x (one tensor less
         # to read, twice); with one, the apply kernel packs the sign bits (1/32 of y) and the backward reads those.
         need_y = relu and res is not None
         mask = torch.empty(N * C * HW // 64, dtype=torch.int64, device=dev) if need_y and HW % 256 == 0 and _PACKED_RELU_MASK else None
+        if exch is not None:
+            exch.wait()                 # stream-side wait, right before the consumer of the sums
         _lib.check(L.dcl_bn_apply_parts(_lib.ptr(x), _lib.ptr(res), _lib.ptr(part), ns, count, eps, momentum,
                                         _lib.ptr(weight), _lib.ptr(bias), N, C, HW, 1 if relu else 0, _lib.ptr(y),
                                         _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(running_mean),
@@ -145,16 +147,17 @@ class _FusedBNFunction(torch.autograd.Function):
                                             _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), N, C, HW, relu,
                                             _lib.ptr(part), st), "dcl_bn_bwd_reduce_part")
         # dx needs the sums over ALL ranks; dbeta / dgamma stay this rank's sums (DDP averages parameter gradients)
-        part_all = part
+        part_all, exch = part, None
         if ctx.world > 1:
-            import torch.distributed as dist
             part_all = part.clone()
-            _all_reduce(part_all)
+            exch = _all_reduce_async(part_all)
         dx = torch.empty_like(x)
         want_res = ctx.has_res and (ctx.needs_input_grad[1] or ctx.token is not None)
         dres = torch.empty_like(x) if want_res else None
         # partial max|dx| (64 slots) for the consumer (the data / weight gradient of the convolution in front of this norm)
         amax = _amax.zeros(_amax.SLOTS, dev) if ctx.emit_amax else None
+        if exch is not None:
+            exch.wait()
         _lib.check(L.dcl_bn_bwd_apply_fused(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(part_all),
                                             _lib.ptr(part), ctx.count, N, C, HW, relu + (4 if ctx.xmask else 0), _lib.ptr(dx),
@@ -189,14 +192,40 @@ def _onepass_workspace(dev):
     return ent[0], seq
 
 
-COLLECTIVES = {"count": 0}        # SyncBatchNorm exchanges issued by this process (tests / tools read it)
+# SyncBatchNorm exchanges issued by this process, and how many of them made the HOST wait (tests / tools read it): on RCCL the
+# wait of an all-reduce orders the calling STREAM behind the collective and returns at once -- 0 host waits; gloo (the CPU
+# stand-in of the two-rank tests) completes on the host
+COLLECTIVES = {"count": 0, "host_waits": 0}
 FORCE_GROUP = False               # tests: take the grouped schedule on ONE rank too (the exchange itself is skipped)
 
 
+class _Exchange:
+    """An all-reduce in flight (reference semantics: nn.SyncBatchNorm over the process group, BaseManager.py:447-455).  Issued
+    with ``async_op=True`` right behind the kernel that produced the partial sums: RCCL runs it on its own stream; ``wait()``
+    -- called right before the kernel that consumes the sums, after the host-side preparation of that launch -- makes the
+    calling stream wait for it with a stream event.  The host never blocks on RCCL."""
+    __slots__ = ("work", "host")
+
+    def __init__(self, t):
+        import torch.distributed as dist
+        COLLECTIVES["count"] += 1
+        self.host = dist.get_backend() != "nccl"
+        self.work = dist.all_reduce(t, async_op=True)
+
+    def wait(self):
+        if self.work is not None:
+            if self.host:
+                COLLECTIVES["host_waits"] += 1
+            self.work.wait()
+            self.work = None
+
+
+def _all_reduce_async(t):
+    return _Exchange(t)
+
+
 def _all_reduce(t):
-    import torch.distributed as dist
-    COLLECTIVES["count"] += 1
-    dist.all_reduce(t)
+    _Exchange(t).wait()
 
 
 class _FusedBNGroupFunction(torch.autograd.Function):

@@ -18,7 +18,7 @@ import torch
 
 from .. import _lib
 from . import amax as _amax
-from .fused_bn import _PACKED_RELU_MASK, _all_reduce, _check_equal_batch, _world
+from .fused_bn import _PACKED_RELU_MASK, _all_reduce_async, _check_equal_batch, _world
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 
@@ -193,7 +193,7 @@ class _BNMergedFn(torch.autograd.Function):
             saved += [x, (mask if mask is not None else y) if need_y else None, ws[k], bs[k]]
         _lib.check(L.dcl_bn_stats_part_multi(ctypes.addressof(arr), n, st), "dcl_bn_stats_part_multi")
         if world > 1:
-            _all_reduce(stack)
+            _all_reduce_async(stack).wait()
         _lib.check(L.dcl_bn_apply_fused_multi(ctypes.addressof(arr), n, world, 1 if relu else 0, st), "dcl_bn_apply_fused_multi")
         ctx.save_for_backward(*saved, small)
         ctx.meta, ctx.masks, ctx.world, ctx.csum = meta, masks, world, csum
@@ -244,7 +244,7 @@ class _BNMergedFn(torch.autograd.Function):
         if ctx.world > 1:
             # dx needs the sums over ALL ranks; dbeta / dgamma stay this rank's sums (DDP averages parameter gradients)
             total = local.clone()
-            _all_reduce(total)
+            _all_reduce_async(total).wait()
             for k in range(n):
                 arr[k].part_all = total[offs[k]:].data_ptr()
         _lib.check(L.dcl_bn_bwd_apply_fused_multi(ctypes.addressof(arr), n, ctx.world, st), "dcl_bn_bwd_apply_fused_multi")

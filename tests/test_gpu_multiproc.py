@@ -151,7 +151,7 @@ def _train_worker(rank, world, port, out_dir, global_negatives, backbone="hrnet1
     direct = sum(isinstance(m, DirectConv2d) for m in mgr.model.modules())
     from mscs_amd.models import fused_bn
     torch.save({"params": flat, "metrics": mgr.metrics, "direct_convs": direct, "syncbn_collectives": fused_bn.COLLECTIVES["count"],
-                "steps": mgr.global_step,
+                "syncbn_host_waits": fused_bn.COLLECTIVES["host_waits"], "backend": backend, "steps": mgr.global_step,
                 "segs": [len(t.segs) for t in mgr.loss.loss_classes["DenseContrastiveLossV2_ms"].last_state.terms]},
                os.path.join(out_dir, f"train{rank}.pt"))
     dist.barrier()
@@ -188,6 +188,10 @@ def test_ddp_hrnet48_direct_kernels_and_branch_streams_two_ranks_one_gpu(tmp_pat
     # exchange per block depth (64 instead of 208 per direction)
     per_step = a["syncbn_collectives"] / max(1, a["steps"])
     assert per_step <= 340, per_step
+    # every exchange is issued asynchronously and awaited on the STREAM right before its consumer (fused_bn._Exchange): on RCCL
+    # (DCL_TEST_BACKEND=nccl, a node with two GPUs) the host never waits; gloo -- the stand-in on one-GPU boxes -- completes
+    # every collective on the host
+    assert a["syncbn_host_waits"] == (0 if a["backend"] == "nccl" else a["syncbn_collectives"])
 
 
 def _conv_stats_worker(rank, world, port, out_dir, backend):
