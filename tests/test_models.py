@@ -266,6 +266,21 @@ def test_train_mode_matches_reference_on_gpu(name):
     for k in ("dx", "pgrad", "pgrad_first4"):
         assert hip[k] <= 8.0 * lib[k] + 2e-4, (k, hip[k], lib[k], hip.get("pgrad_where"))
     assert max(hip["out"]) <= 5e-3 and hip["dx"] <= 5e-2 and hip["pgrad"] <= 5e-2 and hip["running"] <= 1e-3, hip
+    # Regression guard (round 5, review item 8): this path is deterministic -- three runs on the MI355X gave the same figures to
+    # the last digit, while the stock kernels moved between 1.3e-2 and 2.4e-2 (dx, W48) from run to run -- so each fixture's
+    # gradient distances to float64 are held to 1.3x what the per-product-verified arithmetic gives today.  A layer whose
+    # gradient degrades by 1e-2 of its tensor's maximum no longer hides under the 5e-2 cap.
+    if name in WHOLE_MODEL_GRADIENT_DISTANCE:
+        for k, v in WHOLE_MODEL_GRADIENT_DISTANCE[name].items():
+            assert hip[k] <= 1.3 * v, (name, k, hip[k], v)
+
+
+# measured on the MI355X, round 5 (relative to each tensor's maximum, against the reference code in float64)
+WHOLE_MODEL_GRADIENT_DISTANCE = {
+    "G11_train_hrnet48_ms4": {"dx": 1.61e-2, "pgrad": 1.52e-2, "pgrad_first4": 2.28e-2},
+    "G11_train_upernet_swinL_fpn": {"dx": 2.58e-2, "pgrad": 1.49e-2, "pgrad_first4": 2.85e-2},
+    "G11_train_upernet_swinT_fpn": {"dx": 1.22e-2, "pgrad": 2.03e-2, "pgrad_first4": 1.66e-2},
+}
 
 
 def _module_under_test(name, dev):
@@ -348,19 +363,28 @@ def _module_errors(name, dev, tag):
     # the same maximum with, per tensor, its single worst OUTPUT CHANNEL (dim 0) left out: one ReLU decision at an activation
     # within fp32 round-off of zero moves one pixel of one channel's dy by a full gradient value -- and with it every weight of
     # that channel -- in any fp32 implementation (tools/probes/g13_fpn_cmp.py)
+    # ONE (layer, output channel) is left out -- the layer that holds the single worst entry, all of that layer's tensors (weight,
+    # the norm's scale / shift behind it), that entry's channel -- not the worst channel of every tensor: every other channel of
+    # every tensor keeps the plain bar, and the test names the layer it expects
     pos = np.arange(0, sum(g.numel() for g in grads), step)
     starts = np.cumsum([0] + [g.numel() for g in grads])
+    pnames = [k for k, _ in mod.named_parameters()]
+    iw = int(np.searchsorted(starts, pos[int(np.argmax(rel))], side="right")) - 1
+    layer = pnames[iw].split(".")[0]
+    cbad = int((pos[int(np.argmax(rel))] - starts[iw]) // max(1, grads[iw].numel() // grads[iw].shape[0]))
     worst = 0.0
     for i, g in enumerate(grads):
         m = (pos >= starts[i]) & (pos < starts[i + 1])
         if not m.any():
             continue
-        ch = (pos[m] - starts[i]) // max(1, g.numel() // g.shape[0])
         r_i = rel[m]
-        bad = ch[np.argmax(r_i)]
-        keep = ch != bad
-        worst = max(worst, float(r_i[keep].max()) if keep.any() else 0.0)
+        if pnames[i].split(".")[0] == layer and g.shape[0] > cbad:
+            ch = (pos[m] - starts[i]) // max(1, g.numel() // g.shape[0])
+            r_i = r_i[ch != cbad]
+        if r_i.size:
+            worst = max(worst, float(r_i.max()))
     res["pgrad_wo1"] = worst
+    res["pgrad_wo1_where"] = f"{layer}[{cbad}]"
     stats = torch.cat([b.flatten().float().cpu() for k, b in mod.named_buffers()
                        if k.endswith("running_mean") or k.endswith("running_var")] + [torch.zeros(1)])
     ref = z[tag + "running_sample"]
@@ -397,6 +421,7 @@ def test_building_blocks_train_mode_pinned_against_fp64_on_gpu(name):
     # 3e-7), which puts 1.2e-2 into the weights of that one output channel.  The bar holds for every other channel of every tensor;
     # the flipped channel may be off by a gradient value (3e-2 of the tensor's max).
     if name.endswith("upernet_fpn"):
+        assert r["pgrad_wo1_where"].startswith("conv_last"), r         # the flipped activation is the fusion convolution's
         assert r["pgrad_wo1"] <= pg_bar and r["pgrad"] <= 3e-2, r
         r = dict(r, pgrad=r["pgrad_wo1"])
     assert max(r["out"]) <= 5e-5 and max(r["dx"]) <= 1e-3 and r["pgrad"] <= pg_bar and r["running"] <= 2e-5, r
