@@ -57,11 +57,8 @@ SIGNATURES = {
                            _vp, _vp, _vp],
     "dcl_bn_apply_parts": [_vp, _vp, _vp, _i, ctypes.c_double, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                            _vp, _vp, _vp],
-    "dcl_bn_compact_parts": [_vp, _i, _i, _vp, _vp],
     "dcl_conv3x3_f16x3_multi": [_vp, _i, _vp],
-    "dcl_conv3x3_bnstats_tiles": [_i, _i, _i, _i, _i],
     "dcl_conv3x3_s2_smallcin": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
-    "dcl_conv3x3_bnstats_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_bwd_reduce_part": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "dcl_bn_bwd_apply_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp,
                                _vp, _vp, _vp],
@@ -71,10 +68,6 @@ SIGNATURES = {
     "dcl_bn_bwd_apply_fused_multi": [_vp, _i, _i, _vp],
     "dcl_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "dcl_bn_bwd_onepass_supported": [_i, _i, _i, _i],
-    "dcl_bn_onepass_workspace_bytes": [],
-    "dcl_bn_bwd_onepass": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                           _vp],
     "dcl_upsample_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_upsample_bilinear_bwd": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "dcl_amax_sum2": [_vp, _i, _vp, _i, _vp, _vp],
@@ -168,7 +161,6 @@ def lib():
         l.dcl_last_kernel.restype = ctypes.c_char_p
         l.dcl_last_kernel.argtypes = []
         l.dcl_gemm_workspace_floats.restype = ctypes.c_int64
-        l.dcl_bn_onepass_workspace_bytes.restype = ctypes.c_int64
         l.dcl_last_error.argtypes = []
         from .debug import cfg as _dbg       # A/B switches of the tuning tools: one object, read once
         _dbg.apply_to_library(l)

@@ -258,43 +258,11 @@ __device__ __forceinline__ void bn_apply_body(const float *__restrict__ x,
     // slice loop, the double-precision square root and the division by itself made this prologue the whole kernel
     // (25.7 us for 19 MB).  Same arithmetic, same order: bitwise the same statistics.
     __shared__ float bc[2];
-    __shared__ double wsum[2][BN_THREADS / 64];
-    const bool wide = f.part && f.ns > 64;
-    if (wide) {
-        // many partial sums per channel (one per pixel tile of the producing convolution, dcl_conv3x3_bnstats_f16x3: up to
-        // ~1 500): every thread adds its strided share in double, the waves reduce by butterfly, thread 0 adds the four wave
-        // sums -- a fixed order, bitwise reproducible; the serial loop below would make this prologue the kernel
-        double da = 0.0, db = 0.0;
-        for (int s = threadIdx.x; s < f.ns; s += BN_THREADS) {
-            da += f.part[((size_t)c * f.ns + s) * 2 + 0];
-            db += f.part[((size_t)c * f.ns + s) * 2 + 1];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            da += __shfl_xor(da, o, 64);
-            db += __shfl_xor(db, o, 64);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            wsum[0][threadIdx.x >> 6] = da;
-            wsum[1][threadIdx.x >> 6] = db;
-        }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
     if (f.part) {
         // statistics of channel c from the partial sums (k_bn_combine's arithmetic), written out once per channel
         float a, b;
-        if (wide) {
-            double da = 0.0, db = 0.0;
-            for (int w = 0; w < BN_THREADS / 64; ++w) {
-                da += wsum[0][w];
-                db += wsum[1][w];
-            }
-            a = (float)da;
-            b = (float)db;
-        } else {
-            part_sums(f.part, c, f.ns, a, b);
-        }
+        part_sums(f.part, c, f.ns, a, b);
         const double ms = (double)a / f.count;                 // mean of the shifted values
         double var = (double)b / f.count - ms * ms;
         var = var > 0.0 ? var : 0.0;
@@ -911,59 +879,17 @@ extern "C" int dcl_bn_apply_fused(const float *x, const float *res, const float 
                          running_mean, running_var, batches_tracked, amax, pivot, relu_mask, stream);
 }
 
-// The same with an explicit number of partial sums per channel: part f32 [C][ns][2] from ANY producer -- the epilogue of the
-// convolution in front of the norm (dcl_conv3x3_bnstats_f16x3: ns = its pixel tiles) or dcl_bn_compact_parts (ns = 1).
+// The same with an explicit number of partial sums per channel: part f32 [C][ns][2] from any producer (ns <= 64: a serial
+// fixed-order sum per workgroup).
 extern "C" int dcl_bn_apply_parts(const float *x, const float *res, const float *part, int ns, double count, float eps,
                                   float momentum, const float *gamma, const float *beta, int N, int C, int HW,
                                   int relu, float *y, float *mean, float *invstd, float *running_mean,
                                   float *running_var, int64_t *batches_tracked, float *amax, const float *pivot,
                                   void *relu_mask, void *stream)
 {
-    DCL_CHECK_ARG(ns > 0, "ns must be positive");
+    DCL_CHECK_ARG(ns > 0 && ns <= 64, "1 .. 64 partial sums per channel");
     return bn_apply_impl(x, res, part, ns, count, eps, momentum, gamma, beta, N, C, HW, relu, y, mean, invstd,
                          running_mean, running_var, batches_tracked, amax, pivot, relu_mask, stream);
-}
-
-namespace {
-// out[c][0][{0, 1}] = fixed-order double sums of part[c][0 .. ns)[{0, 1}]: one workgroup per channel (the prologue arithmetic
-// of k_bn_apply's wide form).  For SyncBatchNorm: what crosses the ranks is then 2 floats per channel.
-__global__ __launch_bounds__(BN_THREADS) void k_bn_compact_parts(const float *__restrict__ part, int ns, float *__restrict__ out)
-{
-    __shared__ double wsum[2][BN_THREADS / 64];
-    const int c = blockIdx.x;
-    double da = 0.0, db = 0.0;
-    for (int s = threadIdx.x; s < ns; s += BN_THREADS) {
-        da += part[((size_t)c * ns + s) * 2 + 0];
-        db += part[((size_t)c * ns + s) * 2 + 1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        da += __shfl_xor(da, o, 64);
-        db += __shfl_xor(db, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        wsum[0][threadIdx.x >> 6] = da;
-        wsum[1][threadIdx.x >> 6] = db;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        da = db = 0.0;
-        for (int w = 0; w < BN_THREADS / 64; ++w) {
-            da += wsum[0][w];
-            db += wsum[1][w];
-        }
-        out[c * 2 + 0] = (float)da;
-        out[c * 2 + 1] = (float)db;
-    }
-}
-}  // namespace
-
-extern "C" int dcl_bn_compact_parts(const float *part, int C, int ns, float *out, void *stream)
-{
-    DCL_CHECK_ARG(part && out && C > 0 && ns > 0, "bad arguments");
-    hipLaunchKernelGGL(k_bn_compact_parts, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, part, ns, out);
-    DCL_LAUNCH_CHECK();
-    return 0;
 }
 
 static int bn_apply_impl(const float *x, const float *res, const float *part, int ns, double count, float eps,

@@ -75,13 +75,6 @@ struct ConvArgs {
     int tiles_x, tiles_y, nchunk, groups;
     int phases;                     // 1: data gradient of a stride-2 convolution, one output parity class per workgroup
     int onetap;                     // 1: 1x1 convolution (weights packed with one tap)
-    // batch-norm statistics of the OUTPUT in the epilogue (ST instantiations; dcl_conv3x3_bnstats_f16x3): per pixel tile and
-    // channel the sums of (y - pivot) and (y - pivot)^2 over the tile's valid pixels, part[(c * ntile + tile) * 2 + {0, 1}] --
-    // the layout dcl_bn_apply_parts combines in its prologue (k_bn_stats' partial sums with one "slice" per pixel tile)
-    float *stat_part;
-    const float *stat_pivot;        // [Cout] shift of the sums (the norm layer's running mean)
-    float *stat_pivot_out;          // [Cout] copy of the pivot actually used (the running mean is updated by the apply kernel)
-    int stat_ntile;                 // pixel tiles of the launch = tiles_x * tiles_y * N
 };
 
 constexpr float F16_TARGET = 16384.0f;      // operands are scaled so that their absmax lands in (2^13, 2^14]
@@ -155,18 +148,9 @@ __device__ __forceinline__ void static_for(F &&f)
 // P rows x R tiles).  For the 48 / 64-channel layers -- three or four K chunks, tile (R, P) = (2, 2) -- every wave
 // streaming BOTH channel tiles' weight fragments is 1 KiB from L1 per ~3 MFMAs and wave, 85 B / clk at two workgroups per
 // CU against the L1's 64: the (1, 4) wave of WS = 2 does the same 108 MFMAs per chunk on half the fragments.
-// ST ("statistics"): the epilogue also reduces the tile's outputs to per-channel sums for the batch norm that follows the
-// convolution (reference models/HRNet.py:77-93: conv -> bn), so that the norm needs no statistics pass over y
-// (k_bn_stats: 309 launches and 3.7 ms of a W48 step).  The accumulator layout has the 32 pixels of a tile row across the
-// lanes and 16 channels in the registers, so after the in-lane sums over the wave's P rows the 16 per-channel values of a
-// lane half are reduced ACROSS its 32 lanes by a transposing butterfly: at each of the first four steps a lane keeps half
-// of its values and adds the partner lane's copy of exactly those (16 -> 8 -> 4 -> 2 -> 1 values: 15 + 1 shuffles per
-// quantity instead of 16 x 5), leaving channel slot li / 2 in lane li; the workgroup's waves that share channels are
-// combined through LDS in wave order.  Fixed order everywhere: bitwise reproducible.
-template <int R, int P, int S, int MODE = 0, bool IL = false, int WS = 1, bool ST = false>
+template <int R, int P, int S, int MODE = 0, bool IL = false, int WS = 1>
 __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bid)
 {
-    static_assert(!ST || (S == 1 && MODE == 0), "epilogue statistics: stride-1 3x3 tiles");
     constexpr bool PH = MODE == 1, T1 = MODE == 2;
     constexpr int WR = 4 / WS;                    // waves along the rows
     static_assert(WS == 1 || (WS == 2 && IL), "wave split: interleaved stride-1 tiles only");
@@ -654,77 +638,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bid)
                 }
             }
         }
-    if constexpr (ST) {
-        // red[wave][r][slot = 16 h + li / 2][2]
-        float *red = (float *)lds;
-        __syncthreads();                                    // every wave has left the patch buffers
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int cob = (T0 + r) * 32 + 4 * h;
-            float s1[16], s2[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int ch = cob + (q & 3) + 8 * (q >> 2);
-                const bool chok = ch < a.Cout;
-                const float pv = a.stat_pivot[chok ? ch : a.Cout - 1];
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const int row = y0 + P * wrow + p;
-                    const float v = (chok && row < a.Ho && col < a.Wo) ? acc[r][p][q] * inv - pv : 0.f;
-                    t1 += v;
-                    t2 += v * v;
-                }
-                s1[q] = t1;
-                s2[q] = t2;
-            }
-            // transposing butterfly over the 32 lanes of this half: step with lane bit b (16, 8, 4, 2) pairs value k with
-            // value k + n / 2 -- the lane keeps the one its bit selects and adds the partner's copy of it
-#pragma unroll
-            for (int n = 16, b = 16; n > 1; n >>= 1, b >>= 1) {
-                const bool up = (li & b) != 0;
-#pragma unroll
-                for (int k = 0; k < n / 2; ++k) {
-                    const float keep1 = up ? s1[k + n / 2] : s1[k], send1 = up ? s1[k] : s1[k + n / 2];
-                    const float keep2 = up ? s2[k + n / 2] : s2[k], send2 = up ? s2[k] : s2[k + n / 2];
-                    s1[k] = keep1 + __shfl_xor(send1, b, 64);
-                    s2[k] = keep2 + __shfl_xor(send2, b, 64);
-                }
-            }
-            s1[0] += __shfl_xor(s1[0], 1, 64);
-            s2[0] += __shfl_xor(s2[0], 1, 64);
-            // lane li now holds register slot q = li >> 1 of its half: bit 4 of li chose q bit 3, ..., bit 1 chose q bit 0
-            if (!(li & 1)) {
-                float *o = red + ((wave * R + r) * 32 + 16 * h + (li >> 1)) * 2;
-                o[0] = s1[0];
-                o[1] = s2[0];
-            }
-        }
-        __syncthreads();
-        // one thread per (channel group of this workgroup, tile r, slot): the waves that share the channels, in wave order
-        constexpr int NG = WS;                              // channel groups per workgroup (WS = 2: waves w % 2)
-        if (tid < NG * R * 32) {
-            const int g = tid / (R * 32), rs = tid - g * (R * 32), r = rs >> 5, slot = rs & 31;
-            const int hh = slot >> 4, q = slot & 15;
-            const int ch = ((cg * WS + g) * R + r) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
-            if (ch < a.Cout) {
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < WR; ++wv) {
-                    const int w2 = wv * WS + g;              // wave = wrow * WS + (wave % WS)
-                    const float *o = red + ((w2 * R + r) * 32 + slot) * 2;
-                    t1 += o[0];
-                    t2 += o[1];
-                }
-                const int tile = (n * a.tiles_y + ty) * a.tiles_x + tx;
-                float *o = a.stat_part + ((size_t)ch * a.stat_ntile + tile) * 2;
-                o[0] = t1;
-                o[1] = t2;
-                if (tile == 0 && a.stat_pivot_out)
-                    a.stat_pivot_out[ch] = a.stat_pivot[ch];
-            }
-        }
-    }
 }
 
 template <int R, int P, int S>
@@ -759,19 +672,6 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_il_s2(ConvArgs a)
     conv_body<R, 1, 2, 0, true>(a, (int)blockIdx.x);
 }
 
-// the same two kernels with the batch-norm statistics of the output in the epilogue (conv_body, ST)
-template <int R, int P>
-__global__ __launch_bounds__(256, 1) void k_conv3x3_il_st(ConvArgs a)
-{
-    conv_body<R, P, 1, 0, true, 1, true>(a, (int)blockIdx.x);
-}
-
-template <int R, int P>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_il_ws2_st(ConvArgs a)
-{
-    conv_body<R, P, 1, 0, true, 2, true>(a, (int)blockIdx.x);
-}
-
 template <int R, int P>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_phases(ConvArgs a)
 {
@@ -782,14 +682,6 @@ template <int R, int P>
 __global__ __launch_bounds__(256, 1) void k_conv1x1(ConvArgs a)
 {
     conv_body<R, P, 1, 2>(a, (int)blockIdx.x);
-}
-
-// same body compiled for two workgroups per CU (<= 256 registers): the (2, 2) tile of the 48-channel shape, whose
-// three-chunk K loop is too short to hide a workgroup's own prologue / epilogue
-template <int R, int P, int S>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_o2(ConvArgs a)
-{
-    conv_body<R, P, S>(a, (int)blockIdx.x);
 }
 
 
@@ -1328,26 +1220,6 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
     }
     if (a.phases == 2)
         return DCL_EUNSUPPORTED;
-    if (a.stat_part) {
-        // epilogue statistics: the interleaved stride-1 tiles of the BasicBlock shapes ((3, P) and the wave-split (2, 2) tile)
-        a.stat_ntile = a.tiles_x * a.tiles_y * a.N;
-        const bool plain = S == 1 && !a.phases && !a.onetap && (a.Cin & 15) == 0 && a.up == 1;
-        if constexpr (S == 1 && R == 3) {
-            if (plain && g_conv_interleave) {
-                hipLaunchKernelGGL((k_conv3x3_il_st<R, P>), grid, dim3(256), 0, stream, a);
-                dcl_note_kernel("k_conv3x3_il_st<%d,%d>", R, P);
-                return 0;
-            }
-        }
-        if constexpr (S == 1 && R == 2 && P == 2) {
-            if (plain && g_conv_interleave == 2) {
-                hipLaunchKernelGGL((k_conv3x3_il_ws2_st<1, 4>), grid, dim3(256), 0, stream, a);
-                dcl_note_kernel("k_conv3x3_il_ws2_st<1,4>");
-                return 0;
-            }
-        }
-        return DCL_EUNSUPPORTED;
-    }
     if constexpr (S == 1) {
         if (a.phases == 1) {
             hipLaunchKernelGGL((k_conv3x3_phases<R, P>), grid, dim3(256), 0, stream, a);
@@ -1355,9 +1227,13 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
             return 0;
         }
         if (a.onetap) {
-            hipLaunchKernelGGL((k_conv1x1<R, P>), grid, dim3(256), 0, stream, a);
-            dcl_note_kernel("k_conv1x1<%d,%d>", R, P);
-            return 0;
+            if constexpr (R == 3 && P == 4) {
+                return DCL_EUNSUPPORTED;        // (conv_f16x3 never asks: P = 2 for one-tap (3, .) tiles)
+            } else {
+                hipLaunchKernelGGL((k_conv1x1<R, P>), grid, dim3(256), 0, stream, a);
+                dcl_note_kernel("k_conv1x1<%d,%d>", R, P);
+                return 0;
+            }
         }
     }
     if constexpr (S == 1 && R == 2 && P == 2) {
@@ -1370,16 +1246,22 @@ static int launch_conv(const ConvArgs &a0, hipStream_t stream)
             hipLaunchKernelGGL((k_conv3x3_il_o2<R, P>), grid, dim3(256), 0, stream, a);
             dcl_note_kernel("k_conv3x3_il_o2<%d,%d>", R, P);
         } else {
-            hipLaunchKernelGGL((k_conv3x3_o2<R, P, S>), grid, dim3(256), 0, stream, a);
-            dcl_note_kernel("k_conv3x3_o2<%d,%d,%d>", R, P, S);
+            // (channel counts that are not multiples of 16 -- hrnet18: the fenced tile at one workgroup per CU; its two-per-CU
+            // build kept 12 B of scratch)
+            hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
+            dcl_note_kernel("k_conv3x3<%d,%d,%d>", R, P, S);
         }
     } else if constexpr (S == 1) {
         if (g_conv_interleave && (a.Cin & 15) == 0 && a.up == 1) {
             hipLaunchKernelGGL((k_conv3x3_il<R, P>), grid, dim3(256), 0, stream, a);
             dcl_note_kernel("k_conv3x3_il<%d,%d>", R, P);
         } else {
-            hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
-            dcl_note_kernel("k_conv3x3<%d,%d,%d>", R, P, S);
+            if constexpr (R == 3 && P == 4) {
+                return DCL_EUNSUPPORTED;        // (see conv_f16x3: (3, 4) only on the interleaved staging)
+            } else {
+                hipLaunchKernelGGL((k_conv3x3<R, P, S>), grid, dim3(256), 0, stream, a);
+                dcl_note_kernel("k_conv3x3<%d,%d,%d>", R, P, S);
+            }
         }
     } else {
         if constexpr (S == 2 && P == 1) {
@@ -1496,42 +1378,11 @@ extern "C" int dcl_conv3x3_set_up2_phases(int on)
     return 0;
 }
 
-struct ConvStats {
-    const float *pivot;
-    float *part, *pivot_out;
-};
 static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout, const float *xamax,
                       int xcount, const float *wamax, const float *addend, const float *bias, float *y, int stride,
-                      int in_up, int Hout, int Wout, int tile_r, int tile_p, int onetap, void *stream,
-                      const ConvStats *stats = nullptr);
+                      int in_up, int Hout, int Wout, int tile_r, int tile_p, int onetap, void *stream);
 static void auto_tile(int N, int Cout, int Ho, int Wo, int nchunk, int stride, int phases, int onetap, int tile_r, int tile_p,
                       int &R, int &P);
-static bool stats_tile(int R, int P, int Cin) { return (Cin & 15) == 0 && ((R == 3 && g_conv_interleave) || (R == 2 && P == 2 && g_conv_interleave == 2)); }
-
-// Pixel tiles (= partial sums per channel) of dcl_conv3x3_bnstats_f16x3 on this shape, 0 = no kernel with epilogue
-// statistics for it (the caller runs dcl_conv3x3_f16x3 and the norm's own statistics pass).
-extern "C" int dcl_conv3x3_bnstats_tiles(int N, int Cin, int Cout, int H, int W)
-{
-    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
-        return 0;
-    int R, P;
-    auto_tile(N, Cout, H, W, (Cin + 15) / 16, 1, 0, 0, 0, 0, R, P);
-    if (!stats_tile(R, P, Cin))
-        return 0;
-    const int WRP = (R == 2 && P == 2) ? 8 : 4 * P;          // rows per workgroup (the (2, 2) tile runs as 2 x 2 waves of (1, 4))
-    return ((W + TW - 1) / TW) * ((H + WRP - 1) / WRP) * N;
-}
-
-extern "C" int dcl_conv3x3_bnstats_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
-                                         const float *xamax, int xcount, const float *wamax, const float *addend,
-                                         const float *bias, float *y, const float *pivot, float *part, float *pivot_out,
-                                         void *stream)
-{
-    DCL_CHECK_ARG(pivot && part && pivot_out, "null statistics pointer");
-    DCL_CHECK_ARG(dcl_conv3x3_bnstats_tiles(N, Cin, Cout, H, W) > 0, "no epilogue-statistics kernel for this shape");
-    const ConvStats st{pivot, part, pivot_out};
-    return conv_f16x3(x, N, Cin, H, W, wp, Cout, xamax, xcount, wamax, addend, bias, y, 1, 1, H, W, 0, 0, 0, stream, &st);
-}
 
 extern "C" int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
                                  const float *xamax, int xcount, const float *wamax, const float *addend,
@@ -1670,7 +1521,7 @@ static void auto_tile(int N, int Cout, int Ho, int Wo, int nchunk, int stride, i
 
 static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout, const float *xamax,
                       int xcount, const float *wamax, const float *addend, const float *bias, float *y, int stride,
-                      int in_up, int Hout, int Wout, int tile_r, int tile_p, int onetap, void *stream, const ConvStats *stats)
+                      int in_up, int Hout, int Wout, int tile_r, int tile_p, int onetap, void *stream)
 {
     DCL_CHECK_ARG(x && wp && xamax && wamax && y, "null pointer");
     DCL_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && xcount > 0, "bad shape");
@@ -1729,15 +1580,14 @@ static int conv_f16x3(const float *x, int N, int Cin, int H, int W, const void *
     a.nchunk = (Cin + 15) / 16;
     int R, P;
     auto_tile(N, Cout, a.Ho, a.Wo, a.nchunk, stride, a.phases, onetap, tile_r, tile_p, R, P);
-    a.stat_part = stats ? stats->part : nullptr;
-    a.stat_pivot = stats ? stats->pivot : nullptr;
-    a.stat_pivot_out = stats ? stats->pivot_out : nullptr;
-    a.stat_ntile = 0;
+    // the (3, 4) tile exists on the interleaved staging only (its fenced and one-tap instantiations spilled: 288 / 104 B of scratch)
+    if (R == 3 && P == 4 && !(g_conv_interleave && (Cin & 15) == 0 && a.up == 1 && !onetap && stride == 1))
+        P = 2;
     hipStream_t s = (hipStream_t)stream;
 #define DCL_CONV_CASE(r, p, st)                                                                              \
     if (R == r && P == p && stride == st) {                                                                  \
         if (launch_conv<r, p, st>(a, s) != 0) {                                                              \
-            dcl_set_error("dcl_conv3x3: no epilogue-statistics kernel for tile (%d, %d), stride %d", r, p, st); \
+            dcl_set_error("dcl_conv3x3: no kernel for tile (%d, %d), stride %d on this input", r, p, st);     \
             return DCL_EUNSUPPORTED;                                                                         \
         }                                                                                                    \
         DCL_LAUNCH_CHECK();                                                                                  \

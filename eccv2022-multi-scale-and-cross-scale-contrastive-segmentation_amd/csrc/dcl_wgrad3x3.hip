@@ -552,7 +552,7 @@ static void wgrad_plan(int N, int Cin, int Cout, int H, int W, int &nco, int &nc
 
 extern "C" int dcl_wgrad3x3_set_tile(int nco, int nci)
 {
-    if (nco < 0 || nco > 5 || nco == 4 || nci < 0 || nci > 2)
+    if (nco < 0 || nco > 5 || nco == 4 || nci < 0 || nci > 2 || (nco == 3 && nci == 2))      // (the six-tile wave spilled: retired)
         return DCL_EINVAL;
     g_tile_nco = nco;
     g_tile_nci = nci;
@@ -694,7 +694,6 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
         else                                                                     \
             hipLaunchKernelGGL((k_wgrad3x3<o, i, false>), grid, dim3(256), 0, s, a); \
     }
-    DCL_WG_CASE(3, 2)
     DCL_WG_CASE(2, 2)
     DCL_WG_CASE(1, 2)
     DCL_WG_CASE(3, 1)

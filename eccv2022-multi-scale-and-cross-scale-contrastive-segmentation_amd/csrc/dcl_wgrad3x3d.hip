@@ -851,7 +851,6 @@ void dcl_wgrad_dma_launch(const WgradArgs &a, int nco, int nci, dim3 grid, hipSt
 #define DCL_WGD_CASE(o, i)       \
     if (nco == o && nci == i)    \
         hipLaunchKernelGGL((k_wgrad3x3d<o, i>), grid, dim3(256), 0, s, a);
-    DCL_WGD_CASE(3, 2)
     DCL_WGD_CASE(2, 2)
     DCL_WGD_CASE(1, 2)
     DCL_WGD_CASE(3, 1)

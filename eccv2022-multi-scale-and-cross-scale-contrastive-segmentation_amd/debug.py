@@ -41,17 +41,8 @@ class DebugConfig:
     fuse_order: bool = field(default_factory=lambda: _flag('DCL_FUSE_ORDER'))                   # stride-2 chains last
     fanout: bool = field(default_factory=lambda: _flag('DCL_FANOUT'))                           # one-kernel gradient sums
     upsample_tag: bool = field(default_factory=lambda: _flag('DCL_UPSAMPLE_TAG'))               # absmax tags of up-sampled maps
-    conv_bn_stats: bool = field(default_factory=lambda: _flag('DCL_CONV_BN_STATS', False))       # BN statistics in the conv epilogue:
-    # OFF by default.  Built and parity-tested (csrc/dcl_conv3x3.hip ST, tests/test_dropin_paths.py); it removes 208 k_bn_stats
-    # launches and 2.3 ms of their kernel time from a W48 step and costs ~0.7 ms in the convolution epilogues and the apply
-    # kernels' wider prologue -- and the step gets SLOWER, 91.1-91.3 against 90.5-90.7 ms (alternating runs on one box,
-    # gpurun_out/r4c): the statistics pass is an HBM-bound kernel that overlaps the other branches' matrix kernels, the epilogue
-    # work sits inside the matrix kernels that bound the step
     small_cin_stem: bool = field(default_factory=lambda: _flag('DCL_SMALL_CIN_STEM'))            # fp32 kernel for the 3-channel stem conv
     packed_relu_mask: bool = field(default_factory=lambda: _flag('DCL_BN_MASK'))                # packed sign mask in the BN backward
-    bn_onepass: bool = field(default_factory=lambda: _flag('DCL_BN_ONEPASS', False))            # one-kernel BN backward (default stream);
-    # OFF by default: its teams of persistent workgroups wait for members that the branch streams' kernels keep off the CUs
-    # (step 104.4 vs 95.5 ms), and alone it only ties the two-kernel form until its barrier is pipelined
     gemm_conv1x1: bool = field(default_factory=lambda: _flag('DCL_GEMM_CONV1X1'))               # wide 1x1 convolutions on dcl_gemm_f16x3
     lib_conv1x1_addend: bool = field(default_factory=lambda: _flag('DCL_LIB_CONV1X1_ADDEND'))   # big 1x1 data gradients: residual
     # gradient accumulated by the library GEMM (beta = 1)

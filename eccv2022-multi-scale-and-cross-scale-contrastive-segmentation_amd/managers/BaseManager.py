@@ -148,8 +148,16 @@ class BaseManager:
             # UpsampledLogits) and the projection heads' last 1x1 convolution is evaluated on the sampled pixels only
             # (models/Projector.LazyProjection).  Same losses and gradients (tests/test_hip_parity.py); a config that says
             # `false` -- or code that calls the model classes directly -- gets the reference's tensors.
+            defaulted = [k for k in ('lazy_logits', 'lazy_projector') if k not in graph]
             graph.setdefault('lazy_logits', True)
             graph.setdefault('lazy_projector', True)
+            if defaulted:
+                # (said out loud, so that a subclass / hook that reads ret['output'] or ret['feats'] as plain tensors
+                # knows why it sees UpsampledLogits / LazyProjection objects and which key turns them off)
+                printlog(f"[mscs_amd] graph.{' / graph.'.join(defaulted)} not in the config: defaulting to true under this manager -- "
+                         "the model's training outputs are UpsampledLogits (logits at 1/4 resolution) and LazyProjection "
+                         "(projector rows on the sampled pixels) objects, consumed by this package's LossWrapper and metrics; "
+                         "write `false` for the reference's tensors (INTEGRATION.md, 'Runtime behaviour')")
         model_class = getattr(_models, graph['model'])
         self.model = model_class(config=graph, experiment=self.experiment)
         self.return_features = getattr(self.model, 'projector_model', None) is not None \

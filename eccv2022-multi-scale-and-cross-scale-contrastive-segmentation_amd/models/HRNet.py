@@ -96,19 +96,6 @@ def _side_streams(device, n):
     return have[:n]
 
 
-def _stats_bn(bn):
-    """The norm layer as a ``stats_for`` argument of DirectConv2d (None unless it is the fused norm)."""
-    return bn if isinstance(bn, FusedBatchNorm2d) else None
-
-
-def _conv_with_stats(conv, x, bn):
-    """conv(x) for a convolution whose result goes straight into ``bn`` (reference models/HRNet.py:77-93): the direct
-    kernels leave the norm's partial sums in their epilogue (csrc/dcl_conv3x3.hip, ST), so bn runs without a statistics pass."""
-    if isinstance(conv, DirectConv2d) and isinstance(bn, FusedBatchNorm2d):
-        return conv(x, stats_for=bn)
-    return conv(x)
-
-
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -131,10 +118,10 @@ class BasicBlock(nn.Module):
         if _FUSE_RESIDUAL_GRAD and self.downsample is None and isinstance(self.conv1, DirectConv2d) \
                 and isinstance(self.bn2, FusedBatchNorm2d) and self.conv1.fuses_residual_grad(x):
             tok = GradToken()
-            out = bn_act(self.bn1, self.conv1(x, grad_token=tok, stats_for=_stats_bn(self.bn1)))
+            out = bn_act(self.bn1, self.conv1(x, grad_token=tok))
         else:
-            out = bn_act(self.bn1, _conv_with_stats(self.conv1, x, self.bn1))
-        return bn_act(self.bn2, _conv_with_stats(self.conv2, out, self.bn2), residual=identity, grad_token=tok)
+            out = bn_act(self.bn1, self.conv1(x))
+        return bn_act(self.bn2, self.conv2(out), residual=identity, grad_token=tok)
 
 
 class Bottleneck(nn.Module):
@@ -164,7 +151,7 @@ class Bottleneck(nn.Module):
             out = bn_act(self.bn1, self.conv1(x, grad_token=tok))
         else:
             out = bn_act(self.bn1, self.conv1(x))
-        out = bn_act(self.bn2, _conv_with_stats(self.conv2, out, self.bn2))
+        out = bn_act(self.bn2, self.conv2(out))
         return bn_act(self.bn3, self.conv3(out), residual=identity, grad_token=tok)
 
 

@@ -53,7 +53,7 @@ def _check_equal_batch(n, device):
 class _FusedBNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, sync, amax,
-                token=None, pre=None, xmask=False):
+                token=None, xmask=False):
         ctx.token = token
         ctx.xmask = bool(xmask)     # x is a ReLU output whose backward this norm's backward performs (relu_then_bn)
         L = _lib.lib()
@@ -64,32 +64,18 @@ class _FusedBNFunction(torch.autograd.Function):
         world = _world() if sync else 1
         count = float(N * HW * world)
         exch = None
-        if pre is not None:
-            # partial sums from the epilogue of the convolution that produced x (models/ops.py conv3x3_launch_bnstats): one
-            # per pixel tile of that launch, same shift (the running mean) -- no statistics pass over x
-            part, ns, pivot = pre
-            ws = torch.empty((2 * C,), dtype=torch.float32, device=dev)
-            mean, invstd = ws[:C], ws[C:]
-            if world > 1:
-                # SyncBatchNorm: 2 floats per channel cross the ranks (fixed-order sums of the tiles)
-                _check_equal_batch(N, dev)
-                one = torch.empty((C * 2,), dtype=torch.float32, device=dev)
-                _lib.check(L.dcl_bn_compact_parts(_lib.ptr(part), C, ns, _lib.ptr(one), st), "dcl_bn_compact_parts")
-                exch = _all_reduce_async(one)
-                part, ns = one, 1
-        else:
-            ns = L.dcl_bn_num_slices(N, C)
-            # one workspace: [part C*ns*2 | mean C | invstd C | pivot C]; the per-slice partial sums are combined in the
-            # prologue of the apply kernel (no combine / finalize launches); SyncBatchNorm = all-reduce of `part` in
-            # between.  The sums are shifted by the running mean (identical on every rank) against cancellation.
-            ws = torch.empty((C * ns * 2 + 3 * C,), dtype=torch.float32, device=dev)
-            part, mean, invstd = ws[:C * ns * 2], ws[C * ns * 2:C * ns * 2 + C], ws[C * ns * 2 + C:C * ns * 2 + 2 * C]
-            pivot = ws[C * ns * 2 + 2 * C:]
-            _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(running_mean), _lib.ptr(pivot),
-                                           st), "dcl_bn_stats_part")
-            if world > 1:
-                _check_equal_batch(N, dev)
-                exch = _all_reduce_async(part)
+        ns = L.dcl_bn_num_slices(N, C)
+        # one workspace: [part C*ns*2 | mean C | invstd C | pivot C]; the per-slice partial sums are combined in the
+        # prologue of the apply kernel (no combine / finalize launches); SyncBatchNorm = all-reduce of `part` in
+        # between.  The sums are shifted by the running mean (identical on every rank) against cancellation.
+        ws = torch.empty((C * ns * 2 + 3 * C,), dtype=torch.float32, device=dev)
+        part, mean, invstd = ws[:C * ns * 2], ws[C * ns * 2:C * ns * 2 + C], ws[C * ns * 2 + C:C * ns * 2 + 2 * C]
+        pivot = ws[C * ns * 2 + 2 * C:]
+        _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(running_mean), _lib.ptr(pivot),
+                                       st), "dcl_bn_stats_part")
+        if world > 1:
+            _check_equal_batch(N, dev)
+            exch = _all_reduce_async(part)
         y = torch.empty_like(x)
         # The backward needs y only for the ReLU mask.  Without a residual it recomputes y > 0 from x (one tensor less
         # to read, twice); with one, the apply kernel packs the sign bits (1/32 of y) and the backward reads those.
@@ -124,25 +110,6 @@ class _FusedBNFunction(torch.autograd.Function):
         relu = (2 if ctx.packed_mask else 1) if ctx.relu else 0         # 2: `y` is the packed sign mask
         dbeta = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
         dgamma = torch.empty((C,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
-        if (ctx.world == 1 and _onepass_stream(dev) and (relu != 1 or y is None) and not ctx.xmask
-                and L.dcl_bn_bwd_onepass_supported(N, C, HW, relu)):
-            # one kernel that reads dy and x ONCE (csrc/dcl_bn_onepass.hip): persistent workgroups keep their share of a
-            # channel in registers across the statistics exchange.  Only on the device's default stream of a single-rank
-            # run: never more than one such kernel may be in flight (its teams wait for all their members)
-            dx = torch.empty_like(x)
-            want_res = ctx.has_res and (ctx.needs_input_grad[1] or ctx.token is not None)
-            dres = torch.empty_like(x) if want_res else None
-            amax = _amax.zeros(_amax.SLOTS, dev) if ctx.emit_amax else None
-            ws, seq = _onepass_workspace(dev)
-            _lib.check(L.dcl_bn_bwd_onepass(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(invstd),
-                                            _lib.ptr(weight), _lib.ptr(bias), ctx.count, N, C, HW, relu, _lib.ptr(dx),
-                                            _lib.ptr(dres), _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(amax),
-                                            _lib.ptr(ws), seq, st), "dcl_bn_bwd_onepass")
-            if amax is not None:
-                _amax.tag(dx, amax)
-            if ctx.token is not None:
-                ctx.token.dres, dres = dres, None
-            return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
         _lib.check(L.dcl_bn_bwd_reduce_part(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(mean),
                                             _lib.ptr(invstd), _lib.ptr(weight), _lib.ptr(bias), N, C, HW, relu,
                                             _lib.ptr(part), st), "dcl_bn_bwd_reduce_part")
@@ -168,28 +135,7 @@ class _FusedBNFunction(torch.autograd.Function):
         if ctx.token is not None:
             # the residual's gradient travels through the token to the convolution that shares the input
             ctx.token.dres, dres = dres, None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
-
-
-ONEPASS = _dbg.bn_onepass         # one-kernel backward on the default stream (DCL_BN_ONEPASS=0: the two-kernel form)
-_ONEPASS_WS = {}
-
-
-def _onepass_stream(dev):
-    return ONEPASS and torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev)
-
-
-def _onepass_workspace(dev):
-    """(slot workspace of the device -- all bits set = every slot empty --, launch number): see dcl_bn_bwd_onepass."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    ent = _ONEPASS_WS.get(key)
-    if ent is None:
-        n = int(_lib.lib().dcl_bn_onepass_workspace_bytes())
-        with torch.cuda.stream(torch.cuda.default_stream(dev)):
-            ent = _ONEPASS_WS[key] = [torch.full((n // 4,), -1, dtype=torch.int32, device=dev), 0]
-    seq = ent[1]
-    ent[1] += 1
-    return ent[0], seq
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 # SyncBatchNorm exchanges issued by this process, and how many of them made the HOST wait (tests / tools read it): on RCCL the
@@ -405,7 +351,11 @@ def can_group_static(bns):
     issue different all-reduce sequences and hang."""
     if len(bns) < 2 or not _dbg.coalesced_sync_bn:
         return False
-    if not all(isinstance(bn, FusedBatchNorm2d) and bn.training for bn in bns):
+    # (the conditions of FusedBatchNorm2d._fusable that depend on the MODEL only -- affine, running statistics, a fixed
+    # momentum, no autocast -- belong here too: a model that fails them takes the per-norm schedule on every rank instead of
+    # raising "not a contiguous float32 CUDA tensor" from the stacked one, ADVICE r04)
+    if not all(isinstance(bn, FusedBatchNorm2d) and bn.training and bn.affine and bn.track_running_stats
+               and bn.momentum is not None for bn in bns) or torch.is_autocast_enabled():
         return False
     return FORCE_GROUP or (_world() >= 2 and all(bn.sync for bn in bns))
 
@@ -434,28 +384,15 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 and (residual is None or (residual.shape == x.shape and residual.is_contiguous()
                                           and residual.dtype == torch.float32)))
 
-    def takes_conv_stats(self, x):
-        """True when this norm, applied to the output of a convolution of ``x``'s kind, can take its partial sums from that
-        convolution's epilogue: the fused training path, and not the stacked SyncBatchNorm schedule of several ranks (whose
-        members run dcl_bn_stats_part into one exchange buffer, _FusedBNGroupFunction)."""
-        return (self.training and self.affine and self.track_running_stats and self.momentum is not None
-                and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
-                and not (FORCE_GROUP or (self.sync and _world() > 1 and _dbg.coalesced_sync_bn)))
-
     def forward(self, x, residual=None, relu=False, grad_token=None, input_relu=False):
         """``input_relu`` (relu_then_bn only): x is the output of a ReLU whose backward is left to this norm's backward kernel."""
         if self._fusable(x, residual):
             # partial max|y| side output (64 slots) for the f16x3 convolutions that consume y (models/amax.py)
             amax = _amax.zeros(_amax.SLOTS, x.device) if self.emit_amax else None
-            pre = getattr(x, '_dcl_bnstats', None)
-            if pre is not None:
-                # (version of x when the convolution wrote it, part, tiles, pivot copy, the running mean the sums are shifted by)
-                ok = pre[0] == x._version and pre[4] == self.running_mean.data_ptr() and pre[1].device == x.device
-                pre = pre[1:4] if ok else None
             y = _FusedBNFunction.apply(x, residual, self.weight, self.bias, self.running_mean,
                                        self.running_var, self.num_batches_tracked, float(self.eps),
                                        float(self.momentum), bool(relu), bool(self.sync), amax,
-                                       grad_token if residual is not None else None, pre, bool(input_relu))
+                                       grad_token if residual is not None else None, bool(input_relu))
             return _amax.tag(y, amax) if amax is not None else y
         assert not input_relu, "input_relu is only valid on the fused path (relu_then_bn checks it)"
         if self.sync and self.training and _world() > 1:

@@ -37,12 +37,6 @@ def _conv3x3(a):
     return flops, byts, f"{n}x({ci}->{co})x{h}x{w}" + (" s2" if stride == 2 else "") + (" s2-dgrad" if in_up == 2 else "")
 
 
-def _conv3x3_bnstats(a):
-    # (x, N, Cin, H, W, wp, Cout, xamax, xcount, wamax, addend, bias, y, pivot, part, pivot_out, stream): stride 1
-    n, ci, h, w, co = a[1], a[2], a[3], a[4], a[6]
-    return 2.0 * n * co * ci * 9 * h * w, 4.0 * n * (ci + co) * h * w, f"{n}x({ci}->{co})x{h}x{w} +bn-stats"
-
-
 def _conv_smallcin(a):      # (x, N, Cin, H, W, w, Cout, bias, y): the stem's 3-channel stride-2 convolution, HBM-bound
     n, ci, h, w, co = a[1], a[2], a[3], a[4], a[6]
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
@@ -167,7 +161,6 @@ def _bn_multi(stage):       # (jobs, njobs, ...): models/merged.py BnJob; bytes 
 # entry point -> (work model, bound, fixed kernel symbol or None = ask dcl_last_kernel)
 MODELS = {
     "dcl_conv3x3_f16x3": (_conv3x3, "mfma", None),
-    "dcl_conv3x3_bnstats_f16x3": (_conv3x3_bnstats, "mfma", None),
     "dcl_conv3x3_s2_smallcin": (_conv_smallcin, "hbm", "k_conv3x3_s2_smallcin"),
     "dcl_conv1x1_f16x3": (_conv1x1, "mfma", None),
     "dcl_wgrad3x3_f16x3": (_wgrad3x3, "mfma", None),

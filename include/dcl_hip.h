@@ -284,16 +284,12 @@ int dcl_bn_apply_fused(const float *x, const float *res, const float *part, doub
  * itself -- what the backward of a norm + residual + ReLU needs from y is only y > 0.
  * dcl_bn_bwd_apply_fused only, relu + 4: the norm's INPUT x is the output of a ReLU (conv -> ReLU -> norm, the projection heads,
  * reference models/Projector.py:46-51): dx is zeroed where x <= 0 -- the ReLU's backward inside this kernel, which reads x anyway. */
-/* dcl_bn_apply_fused with an explicit number `ns` of partial sums per channel, part f32 [C][ns][2], from any producer: the
- * epilogue of the convolution in front of the norm (dcl_conv3x3_bnstats_f16x3, ns = dcl_conv3x3_bnstats_tiles(...): the
- * statistics pass over the convolution's output disappears; reference models/HRNet.py:77-93 conv -> bn) or
- * dcl_bn_compact_parts (ns = 1).  ns > 64: the workgroup's threads share the prologue's sum (fixed order). */
+/* dcl_bn_apply_fused with an explicit number `ns` (1 .. 64) of partial sums per channel, part f32 [C][ns][2], from any producer
+ * (reference models/HRNet.py:77-93 conv -> bn: the norm after a convolution). */
 int dcl_bn_apply_parts(const float *x, const float *res, const float *part, int ns, double count, float eps, float momentum,
                        const float *gamma, const float *beta, int N, int C, int HW, int relu, float *y, float *mean,
                        float *invstd, float *running_mean, float *running_var, int64_t *batches_tracked,
                        float *amax, const float *pivot, void *relu_mask, void *stream);
-/* out f32 [C][2] = fixed-order (double) sums of part f32 [C][ns][2]: SyncBatchNorm exchanges 2 floats per channel */
-int dcl_bn_compact_parts(const float *part, int C, int ns, float *out, void *stream);
 int dcl_bn_bwd_reduce_part(const float *dy, const float *x, const float *y, const float *mean, const float *invstd,
                            const float *gamma, const float *beta, int N, int C, int HW, int relu, float *part,
                            void *stream);
@@ -376,20 +372,6 @@ int dcl_tapup_set_bwd_form(int form);
 /* 1 when dcl_tapup_fwd on the sources [h0, w0] (+ [h1, w1]; h1 = 0: one source) and dcl_tapup_bwd of each fit their LDS tiles for
  * an [H, W] output, else 0: asked before a step commits to the split head (no failure mid-step / only in the backward). */
 int dcl_tapup_supported(int h0, int w0, int h1, int w1, int H, int W, int align_corners);
-
-/* ---- one-kernel batch-norm backward (csrc/dcl_bn_onepass.hip) -------------------------------------------------------
- * dcl_bn_bwd_reduce_part + dcl_bn_bwd_apply_fused of a single-rank norm in ONE launch that reads dy and x once: 256 persistent
- * workgroups keep their share of a channel in registers across the per-channel statistics exchange (teams of H W / 1024
- * workgroups of one XCD, relaxed agent-scope counters).  Shapes: H W % 1024 == 0, H W / 1024 in {1, 2, 4, 8, 16, 32}, N <= 12
- * (dcl_bn_bwd_onepass_supported); relu: 0 none, 1 the mask is recomputed from x (y = NULL), 2 y is the packed sign mask.
- * ws: dcl_bn_onepass_workspace_bytes() bytes, every byte 0xFF ONCE by the caller; seq = 0, 1, 2, ... the launch number on that
- * workspace.  The teams wait for all their members: launch it on ONE stream only (never two instances in flight). */
-int dcl_bn_bwd_onepass_supported(int N, int C, int HW, int relu);
-int64_t dcl_bn_onepass_workspace_bytes(void);
-int dcl_bn_bwd_onepass(const float *dy, const float *x, const void *y_or_mask, const float *mean, const float *invstd,
-                       const float *gamma, const float *beta, double count, int N, int C, int HW, int relu, float *dx,
-                       float *dres /* or NULL */, float *dbeta /* or NULL */, float *dgamma /* or NULL */,
-                       float *amax /* DCL_AMAX_SLOTS or NULL */, void *ws, int64_t seq, void *stream);
 
 /* ---- split-f16 GEMM, f32 in / out (csrc/dcl_gemm.hip) ------------------------------------------------------------
  * C[b][m][n] = (accumulate ? C : 0) + bias[n] + sum_k A[b](m, k) * B[b](n, k),  b < batch, at fp32-equivalent accuracy
@@ -500,23 +482,11 @@ typedef struct dcl_conv_job {
     int N, Cin, Cout, H, W, xcount, tile_p, reserved;
 } dcl_conv_job;
 int dcl_conv3x3_f16x3_multi(const dcl_conv_job *jobs, int njobs, void *stream);
-/* The same convolution (stride 1, automatic tile) with the batch-norm statistics of its OUTPUT reduced in the epilogue: per
- * pixel tile t and output channel c, part[(c * ntile + t) * 2 + {0, 1}] = sum over the tile's pixels of (y - pivot[c]),
- * (y - pivot[c])^2 -- the partial sums dcl_bn_apply_parts(ns = ntile) combines, so the norm that follows the convolution
- * (reference models/HRNet.py:77-93) needs no statistics pass over y.  ntile = dcl_conv3x3_bnstats_tiles(N, Cin, Cout, H, W);
- * 0 = no such kernel for the shape (Cin % 16 != 0, or a tile other than the BasicBlock tiles): use dcl_conv3x3_f16x3 +
- * dcl_bn_stats_part.  pivot f32 [Cout]: the norm's running mean; pivot_out f32 [Cout] receives a copy (the apply kernel
- * updates the running mean).  Fixed summation order: bitwise reproducible. */
 /* 3x3 / stride 2 / pad 1 convolution with 1 .. 4 input channels on plain fp32 FMAs (the stem's conv1 on the image, reference
  * models/HRNet.py:404-405): x [N, Cin, H, W], w [Cout, Cin, 3, 3] (unpacked), bias [Cout] or NULL, y [N, Cout, (H - 1) / 2 + 1,
  * (W - 1) / 2 + 1].  The tile kernels would pad the contraction to 16 channels. */
 int dcl_conv3x3_s2_smallcin(const float *x, int N, int Cin, int H, int W, const float *w, int Cout, const float *bias,
                             float *y, void *stream);
-int dcl_conv3x3_bnstats_tiles(int N, int Cin, int Cout, int H, int W);
-int dcl_conv3x3_bnstats_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout,
-                              const float *xamax, int xcount, const float *wamax, const float *addend,
-                              const float *bias, float *y, const float *pivot, float *part, float *pivot_out,
-                              void *stream);
 
 /* tuning hook: in_up = 2 (data gradient of a stride-2 convolution) -- 2 (default, round 4): one workgroup stages a patch of the
  * stored gradient once and computes all four parity classes of its output tile (9 taps per staged patch, k_conv3x3_pm); 1: every

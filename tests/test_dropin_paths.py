@@ -283,88 +283,6 @@ def test_head_split_falls_back_when_the_tap_gather_does_not_fit(dev, monkeypatch
 
 # (n, Cin, Cout, H, W): shapes whose automatic tile is one of the BasicBlock tiles (the epilogue-statistics kernels): the four
 # branch shapes at a reduced batch, ragged rows / columns (H, W not multiples of the tile) and a ragged last channel tile
-@pytest.mark.parametrize("shape", [(4, 48, 48, 128, 256), (6, 96, 96, 61, 100), (12, 192, 192, 32, 64), (12, 384, 384, 16, 32),
-                                   (12, 96, 80, 64, 120), (3, 48, 48, 99, 250)],
-                         ids=lambda s: "x".join(map(str, s)))
-def test_conv_epilogue_batchnorm_statistics(dev, shape):
-    """dcl_conv3x3_bnstats_f16x3: the per-tile partial sums of (y - pivot), (y - pivot)^2 the convolution's epilogue leaves
-    for the norm behind it (reference models/HRNet.py:77-93 conv -> bn), against float64 sums over the convolution's own
-    output: ragged tiles (rows / columns / channels past the edge must not count), every tile of the BasicBlock shapes;
-    the output itself is bitwise the plain kernel's; two runs are bitwise equal."""
-    from mscs_amd.models import ops
-    from mscs_amd.models.amax import amax_of
-    n, ci, co, h, w = shape
-    gen = torch.Generator(device=dev).manual_seed(0)
-    x = torch.randn(n, ci, h, w, device=dev, generator=gen).relu_()
-    wt = torch.randn(co, ci, 3, 3, device=dev, generator=gen) * 0.1
-    pivot = torch.randn(co, device=dev, generator=gen) * 0.3
-    ntile = ops.conv3x3_bnstats_tiles(x, co)
-    assert ntile > 0
-    wam, xam = amax_of(wt), amax_of(x)
-    wp = ops.conv3x3_pack(wt, wam)
-    ref = torch.empty(n, co, h, w, device=dev)
-    ops.conv3x3_launch(x, wp, co, xam, wam, ref)
-    outs = []
-    for _ in range(2):
-        y = torch.full((n, co, h, w), float("nan"), device=dev)
-        part, pv = ops.conv3x3_launch_bnstats(x, wp, co, xam, wam, y, pivot, ntile)
-        outs.append((y, part.clone(), pv.clone()))
-    y, part, pv = outs[0]
-    assert torch.equal(y, ref) and torch.equal(pv, pivot)
-    assert torch.equal(outs[1][0], y) and torch.equal(outs[1][1], part)
-    d = y.double() - pivot.double().view(1, co, 1, 1)
-    s1, s2 = d.sum((0, 2, 3)), (d * d).sum((0, 2, 3))
-    got = part.view(co, ntile, 2).double().sum(1)
-    assert torch.isfinite(part).all()
-    scale1 = d.abs().sum((0, 2, 3))
-    assert ((got[:, 0] - s1).abs() <= 2e-6 * scale1 + 1e-12).all(), (got[:, 0] - s1).abs().max().item()
-    assert ((got[:, 1] - s2).abs() <= 2e-6 * s2 + 1e-12).all(), ((got[:, 1] - s2).abs() / s2).max().item()
-
-
-@pytest.mark.parametrize("ch,hw", [(48, (128, 256)), (96, (61, 104)), (192, (32, 64))])
-def test_basic_block_with_epilogue_statistics_equals_the_two_pass_norm(dev, ch, hw):
-    """BasicBlock (conv -> bn -> relu -> conv -> bn -> + identity -> relu, reference models/HRNet.py:77-93) in training mode
-    with the norms' statistics taken from the convolutions' epilogues against the same block with the norms' own
-    statistics pass: output, running statistics, input and parameter gradients to 2e-5 of max (the two differ in the order
-    of the fp32 partial sums only); and that the epilogue path really ran."""
-    from mscs_amd import _lib
-    from mscs_amd.models import ops
-    from mscs_amd.models.HRNet import BasicBlock
-    from mscs_amd.models.fused_bn import FusedBatchNorm2d
-    from mscs_amd.utils.kernel_timer import KernelTimer
-    gen = torch.Generator().manual_seed(0)
-    nb = 4 if ch == 48 else 12
-    x0 = torch.randn(nb, ch, *hw, generator=gen).to(dev)
-    up = torch.randn(nb, ch, *hw, generator=gen).to(dev)
-    res = {}
-    for on in (False, True):
-        torch.manual_seed(0)
-        blk = BasicBlock(ch, ch, norm_layer=FusedBatchNorm2d).to(dev).train()
-        ops.use_direct_conv3x3(blk)
-        with torch.no_grad():
-            for bn in (blk.bn1, blk.bn2):
-                bn.weight.uniform_(0.5, 1.5)
-                bn.bias.uniform_(-0.3, 0.3)
-                bn.running_mean.uniform_(-0.2, 0.2)
-        x = x0.clone().requires_grad_(True)
-        keep = ops.CONV_BN_STATS
-        ops.CONV_BN_STATS = on
-        try:
-            with KernelTimer(["dcl_conv3x3_bnstats_f16x3", "dcl_bn_stats_part", "dcl_conv3x3_f16x3"]) as kt:
-                y = blk(x)
-                y.backward(up)
-                torch.cuda.synchronize()
-        finally:
-            ops.CONV_BN_STATS = keep
-        names = [c[0] for c in kt.calls]
-        assert names.count("dcl_conv3x3_bnstats_f16x3") == (2 if on else 0)
-        assert names.count("dcl_bn_stats_part") == (0 if on else 2)
-        res[on] = [y.detach(), x.grad] + [p.grad for p in blk.parameters()] + \
-                  [blk.bn1.running_mean, blk.bn1.running_var, blk.bn2.running_mean, blk.bn2.running_var]
-    for a, b in zip(res[False], res[True]):
-        assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item()
-
-
 @pytest.mark.parametrize("shape", [(2, 3, 64, 64, 128), (1, 3, 64, 33, 47), (2, 1, 16, 17, 40), (1, 4, 70, 20, 64), (12, 3, 64, 512, 1024)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_stem_small_cin_stride2_convolution_against_fp64(dev, shape):

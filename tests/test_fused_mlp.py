@@ -84,7 +84,7 @@ def test_fused_mlp_matches_unfused_and_fp64(residual, drop):
     """Mlp (+ residual sum, + DropPath) through ops._FusedMlp against the unfused chain TokenLinear -> GELU -> TokenLinear (->
     addcmul) under the same mask draw, and both against float64: output, input / shortcut gradients, all four parameter gradients."""
     import mscs_amd  # noqa: F401
-    from mscs_amd.models import ops
+    from mscs_amd.models import ops, ops_linear
     from mscs_amd.models.Swin import DropPath, Mlp
     dev = torch.device("cuda:0")
     torch.manual_seed(5)
@@ -96,7 +96,7 @@ def test_fused_mlp_matches_unfused_and_fp64(residual, drop):
     gy = torch.randn(B, L, C, device=dev)
     res = {}
     for fused in (True, False):
-        ops.FUSED_MLP = fused
+        ops_linear.FUSED_MLP = fused
         try:
             mlp.zero_grad()
             xi, si = x.clone().requires_grad_(True), s.clone().requires_grad_(True)
@@ -106,7 +106,7 @@ def test_fused_mlp_matches_unfused_and_fp64(residual, drop):
             y.backward(gy)
             res[fused] = [y.detach(), xi.grad] + ([si.grad] if residual else []) + [p.grad.clone() for p in mlp.parameters()]
         finally:
-            ops.FUSED_MLP = True
+            ops_linear.FUSED_MLP = True
     # float64 (same mask: the factors are recovered from the unfused run's shortcut-free part when DropPath is active)
     w1, b1, w2, b2 = [p.detach().double() for p in (mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias)]
     x64 = x.double().requires_grad_(True)
@@ -140,7 +140,7 @@ def test_swin_block_fused_epilogues_match_unfused_chain():
     epilogues and GELU inside the GEMMs against the same block on the unfused chain, same mask draws: output, input gradient, every
     parameter gradient."""
     import mscs_amd  # noqa: F401
-    from mscs_amd.models import ops
+    from mscs_amd.models import ops, ops_linear
     from mscs_amd.models.Swin import BasicLayer, SwinTransformerBlock
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
@@ -151,7 +151,7 @@ def test_swin_block_fused_epilogues_match_unfused_chain():
     mask = BasicLayer(dim=96, depth=2, num_heads=3)._shift_mask(H, W, dev)
     res = {}
     for fused in (True, False):
-        ops.FUSED_MLP = fused
+        ops_linear.FUSED_MLP = fused
         try:
             blk.zero_grad()
             xi = x.clone().requires_grad_(True)
@@ -160,7 +160,7 @@ def test_swin_block_fused_epilogues_match_unfused_chain():
             (y * torch.cos(torch.arange(y.numel(), device=dev).view_as(y) * 0.37)).sum().backward()
             res[fused] = (y.detach(), xi.grad, {k: p.grad.clone() for k, p in blk.named_parameters()})
         finally:
-            ops.FUSED_MLP = True
+            ops_linear.FUSED_MLP = True
     ya, ga, pa = res[True]
     yb, gb, pb = res[False]
     assert (ya - yb).abs().max().item() <= 2e-5 * yb.abs().max().item()
@@ -173,7 +173,7 @@ def test_dropout2d_folded_into_the_classifier_matches_the_two_modules():
     """ops.dropout2d_conv1x1 (channel factors in per-sample weights) against conv(F.dropout2d(x)) under the same generator state:
     the same channels dropped, output and all gradients to fp32 round-off; eval mode and p = 0 run the modules as they are."""
     import mscs_amd  # noqa: F401
-    from mscs_amd.models import ops
+    from mscs_amd.models import ops, ops_linear
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     drop = torch.nn.Dropout2d(0.1).train()
@@ -202,7 +202,7 @@ def test_lateral_convolution_reads_tokens(B, H, W, C):
     conv1x1_from_tokens) against the same block on the reference's NCHW copy, and the 1x1 convolution alone against float64:
     output, token gradient (token-major, contiguous), weight and norm-parameter gradients."""
     import mscs_amd  # noqa: F401
-    from mscs_amd.models import ops
+    from mscs_amd.models import ops, ops_linear
     from mscs_amd.models.fused_bn import FusedBatchNorm2d
     from mscs_amd.models.Swin import TokenMap
     from mscs_amd.models.UPerNet import FPN, _conv1x1_bn_relu
@@ -243,7 +243,7 @@ def test_gemm_with_a_per_token_factor_on_the_gradient(M, N, K):
     keep, zeros included) inside the data-gradient and the weight-gradient GEMM (k-split slabs, bias gradient as scaled row sums)
     against float64 on the explicitly scaled dy, and bitwise against ... itself (deterministic)."""
     import mscs_amd  # noqa: F401
-    from mscs_amd.models import ops
+    from mscs_amd.models import ops, ops_linear
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(N)
     B = 4 if M % 1600 == 0 and M // 4 % 32 == 0 else 8

@@ -192,58 +192,3 @@ def test_ddp_hrnet48_direct_kernels_and_branch_streams_two_ranks_one_gpu(tmp_pat
     # (DCL_TEST_BACKEND=nccl, a node with two GPUs) the host never waits; gloo -- the stand-in on one-GPU boxes -- completes
     # every collective on the host
     assert a["syncbn_host_waits"] == (0 if a["backend"] == "nccl" else a["syncbn_collectives"])
-
-
-def _conv_stats_worker(rank, world, port, out_dir, backend):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ["DCL_SYNCBN_COALESCE"] = "0"          # per-norm exchanges: the schedule in which a norm may take conv statistics
-    import mscs_amd  # noqa: F401
-    from mscs_amd.models import fused_bn, ops
-    from mscs_amd.models.fused_bn import FusedBatchNorm2d
-    dev = torch.device("cuda", _device_of(rank, backend))
-    torch.cuda.set_device(dev)
-    dist.init_process_group(backend, rank=rank, world_size=world)
-    g = torch.Generator().manual_seed(9)
-    n, c, h, w = 8, 96, 64, 128                      # per rank 4 x 96 x 64 x 128: the (3, 4) tile of the epilogue-statistics kernel
-    x = torch.randn(n, c, h, w, generator=g)
-    wt = torch.randn(c, c, 3, 3, generator=g) * 0.05
-    gy = torch.randn(n, c, h, w, generator=g)
-    half = slice(4 * rank, 4 * rank + 4)
-    res = {}
-    for on in (False, True):
-        conv = torch.nn.Conv2d(c, c, 3, 1, 1, bias=False).to(dev)
-        ops.use_direct_conv3x3(conv)
-        bn = FusedBatchNorm2d(c).to(dev)
-        bn.sync = True
-        with torch.no_grad():
-            conv.weight.copy_(wt)
-        xi = x[half].to(dev).requires_grad_(True)
-        ops.CONV_BN_STATS = on
-        before = fused_bn.COLLECTIVES["count"]
-        y = bn(conv(xi, stats_for=bn), relu=True)
-        y.backward(gy[half].to(dev))
-        torch.cuda.synchronize()
-        res[on] = {"y": y.detach().cpu(), "dx": xi.grad.cpu(), "dw": conv.weight.grad.cpu(), "rm": bn.running_mean.cpu(),
-                   "rv": bn.running_var.cpu(), "collectives": fused_bn.COLLECTIVES["count"] - before,
-                   "took_stats": getattr(conv, "_bnstats", "x") is None}
-    torch.save(res, os.path.join(out_dir, f"cs{rank}.pt"))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.timeout(300)
-def test_conv_epilogue_statistics_under_syncbn_two_ranks(tmp_path):
-    """SyncBatchNorm fed by the convolution's epilogue statistics (DCL_CONV_BN_STATS, per-norm exchange schedule): the tiles'
-    partial sums are compacted to 2 floats per channel (dcl_bn_compact_parts), all-reduced, and the apply kernel runs with
-    ns = 1 -- same outputs, gradients and running statistics as the norm's own statistics pass on both ranks, one
-    collective per direction either way."""
-    port = _free_port()
-    mp.spawn(_conv_stats_worker, args=(2, port, str(tmp_path), _backend()), nprocs=2, join=True)
-    for q in range(2):
-        r = torch.load(os.path.join(str(tmp_path), f"cs{q}.pt"))
-        a, b = r[False], r[True]
-        assert a["collectives"] == 2 and b["collectives"] == 2
-        for key in ("y", "dx", "dw", "rm", "rv"):
-            assert (a[key] - b[key]).abs().max().item() <= 2e-5 * max(a[key].abs().max().item(), 1e-6), (q, key)
