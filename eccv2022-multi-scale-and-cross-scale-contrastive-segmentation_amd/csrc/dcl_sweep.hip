@@ -26,6 +26,16 @@
 
 namespace {
 
+// Bound probes (tools/probes/sweep_ab.sh builds variants of the library with -DDCL_SWEEP_PROBE=<bits>, sweep_ab.py times them next to
+// the shipped one in one process; 0 in the product; results wrong, times meaningful).  Forward sweeps: 1 = no chunk DMA after the
+// first, 2 = no exp epilogue, 4 = no LDS operand reads, 8 = one A row for every lane (no strided panel loads).  Pipelined backward:
+// 16 = every chunk DMA re-reads chunk 0, 32 = no exp / split epilogue, 64 = no transposing reads, 128 = no S operand reads,
+// 256 = no workgroup barrier per chunk.  Round 5, N = 9 804 (profiles/r05_sweep_probes.txt): forward 148 us -> 130 / 146 / 146 /
+// 119, all four 98; backward 310 us -> 303 / 282 / 297 / 270 / 311, all 241: no single resource gates either sweep, the bare MFMA
+// stream is at 0.49-0.60 of the nominal f16x3 roofline (the clock drops to ~1.75 GHz in these loops).
+#ifndef DCL_SWEEP_PROBE
+#define DCL_SWEEP_PROBE 0
+#endif
 constexpr int CP = DCL_CP;              // 256 channels (padded)
 constexpr int ROWF = CP + 4;            // LDS row stride in floats (1040 B)
 constexpr int CJ = 32;                  // bank rows (similarity columns) per chunk
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
         }
         dma_wait_barrier<0>();          // every wave holds its fragments: the buffers may take the first chunks
     } else if (F16) {
-        const _Float16 *arow = p.Ah + (size_t)i * (2 * CP) + 8 * h;
+        const _Float16 *arow = p.Ah + (size_t)((DCL_SWEEP_PROBE & 8) ? 0 : i) * (2 * CP) + 8 * h;
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
             ahi[kb] = *(const half8 *)(arow + 16 * kb);
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
         const int nrows_c = (p.N2 + BM - 1) / BM * BM;             // rows of the column-statistics array
         auto gsw = [](unsigned r) { return ((r & 3u) << 2) | ((r >> 2) & 3u); };
         auto dma_piece = [&](int slot, int j0s, int row) {
-            dma_row(p.Bh + (size_t)(j0s + row) * (2 * CP) + ((unsigned)lane ^ gsw(row)) * 8,
+            dma_row(p.Bh + (size_t)(((DCL_SWEEP_PROBE & 16) ? 0 : j0s) + row) * (2 * CP) + ((unsigned)lane ^ gsw(row)) * 8,
                     lds + slot * PBUF + row * CP);
         };
         auto dma_stats = [&](int slot, int j0s) {       // every wave copies the same piece: uniform DMA count per wave
@@ -422,6 +432,8 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             constexpr bool with_dma = decltype(WITH_DMA)::value;
             const char *sb = lb + (unsigned)sslot * PBUFB;
             auto rd = [&](int kb, half8 &hi8, half8 &lo8) {
+                if ((DCL_SWEEP_PROBE & 128) && kb > 1)
+                    return;
                 const char *a = sb + (s_off ^ ((unsigned)kb << 5));
                 hi8 = *(const half8 *)a;
                 lo8 = *(const half8 *)(a + 512);
@@ -447,10 +459,15 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                     const int r0 = kb - 1;
                     const float w0 = USE_COL ? cs[jrow(r0, h) * 4 + 1] : 0.f;
                     const float w1 = USE_COL ? cs[jrow(r0 + 1, h) * 4 + 1] : 0.f;
-                    const float v0 = __builtin_amdgcn_exp2f(eacc[r0] * p.c1) * (rcW + w0);
-                    const float v1 = __builtin_amdgcn_exp2f(eacc[r0 + 1] * p.c1) * (rcW + w1);
+                    const float v0 = (DCL_SWEEP_PROBE & 32) ? eacc[r0] : __builtin_amdgcn_exp2f(eacc[r0] * p.c1) * (rcW + w0);
+                    const float v1 = (DCL_SWEEP_PROBE & 32) ? eacc[r0 + 1] : __builtin_amdgcn_exp2f(eacc[r0 + 1] * p.c1) * (rcW + w1);
                     unsigned hi, lo2;
-                    split2(v0, v1, hG, hi, lo2);
+                    if (DCL_SWEEP_PROBE & 32) {
+                        hi = __float_as_uint(v0);
+                        lo2 = __float_as_uint(v1);
+                    } else {
+                        split2(v0, v1, hG, hi, lo2);
+                    }
                     hhv[r0 >> 3][(r0 & 7) >> 1] = hi;
                     hlv[r0 >> 3][(r0 & 7) >> 1] = lo2;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -486,7 +503,10 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             // chunk c + 1 (issued two iterations ago) has landed once at most the NV DMAs of chunk c + 2 are still
             // outstanding; behind the barrier every wave has also left the second product of chunk c - 1, whose buffer
             // takes chunk c + 3 during this iteration's S recompute
-            dma_wait_barrier<NV>();
+            if (DCL_SWEEP_PROBE & 256)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NV) : "memory");
+            else
+                dma_wait_barrier<NV>();
             const int dslot = (k + 3) & 3, dj0 = min(c + 3, c1 - 1) * CJ;
             const int nxt = (k + 1) & 3;                       // past the last chunk: stale data, result unused
             const float *cs = cst + (k & 3) * CSTF;
@@ -528,6 +548,8 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             const char *hb = lb + (unsigned)(k & 3) * PBUFB;
             union TR { half8 v; fp16x4 q[2]; };
             auto read_b = [&](int st, TR &bh, TR &bl) {
+                if ((DCL_SWEEP_PROBE & 64) && st > 1)
+                    return;
                 const int kb = st >> 3, ct = st & 7;
                 const char *pa = hb + kb * 16384 + (pa_off ^ ((unsigned)ct << 6));
                 const char *pb = hb + kb * 16384 + (pb_off ^ ((unsigned)ct << 6));
@@ -561,7 +583,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
         dma_wait_barrier<0>();  // chunk c has landed (asm LDS-DMA: waited for by hand); everyone left chunk c-1
         const float *cur = lds + ((c - c0) & 1) * BUF;
         const float *buf = cur;
-        if (c + 1 < c1)
+        if (c + 1 < c1 && !(DCL_SWEEP_PROBE & 1))
             stage(lds + ((c + 1 - c0) & 1) * BUF, (c + 1) * CJ);
         const int j0 = c * CJ;
 
@@ -585,9 +607,9 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // prologue reads of k-block 0
 #pragma unroll
             for (int kb = 0; kb < 16; ++kb) {
-                const int kn = kb < 15 ? kb + 1 : 15;
-                const half8 nh = *(const half8 *)(bt + 16 * kn);
-                const half8 nl = *(const half8 *)(bt + CP + 16 * kn);
+                const int kn = (DCL_SWEEP_PROBE & 4) ? 0 : (kb < 15 ? kb + 1 : 15);
+                const half8 nh = (DCL_SWEEP_PROBE & 4) ? bh : *(const half8 *)(bt + 16 * kn);
+                const half8 nl = (DCL_SWEEP_PROBE & 4) ? bl : *(const half8 *)(bt + CP + 16 * kn);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ahi[kb], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, alo[kb], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ahi[kb], acc, 0, 0, 0);
@@ -616,7 +638,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
             if (plain) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    zi += __builtin_amdgcn_exp2f(acc[r] * p.c1);
+                    zi += (DCL_SWEEP_PROBE & 2) ? acc[r] : __builtin_amdgcn_exp2f(acc[r] * p.c1);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
