@@ -6,7 +6,7 @@
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/../.. && pwd)}
 PKG=$ROOT/eccv2022-multi-scale-and-cross-scale-contrastive-segmentation_amd
-OUT=$ROOT/tools/probes/_build
+OUT=$ROOT/tools/probes/variants
 VARIANTS="${VARIANTS:-1 2 4 8 3 6 7 15}"
 if [ "$1" = wbuild ]; then
   mkdir -p $OUT
