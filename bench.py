@@ -292,7 +292,7 @@ PMC_STEP = {
     "k_sweep<MODE_Z>": (104508.6, 21137.7),             # (since it keeps the positives' similarities: 21 MB written per launch)
     "k_sweep<MODE_BWD,stream-K>": (60944.6, 71687.9),
 }
-PMC_STEP_SOURCE = "profiles/r04_step_pmc_fetch.csv, r04_step_pmc_write.csv"
+PMC_STEP_SOURCE = "profiles/r05_step_pmc_fetch.csv, r05_step_pmc_write.csv (round 4's passes of the same kernels: equal to 0.01 %)"
 
 
 def roofline_from_rows(rows, args):
@@ -448,10 +448,10 @@ def roofline_bwd_kernel(mod, iters=10):
 PMC_HEAD_WGRAD = (3514955.5 + 19856.5, 26330.0 + 3645.0)   # k_wgrad3x3d<3,1,true> + its slab reduction, 12 x (144 -> 720) x 128 x 256
 PMC_HEAD_FWD = (516063.4, 1228800.0)                        # k_conv3x3_il<3,4> on the same layer (profiles/r03_head_wgrad_pmc.csv)
 PMC_F16X3 = (104540.5, 128128.0)      # KiB per launch (FETCH_SIZE, WRITE_SIZE), profiles/r02_loss_pmc_*.csv
-PMC_F16X3_SK = (60279.9, 71687.9)     # stream-K kernel with 4 column slices, KiB per launch: profiles/r04_loss_pmc_fetch.csv / _write.csv
+PMC_F16X3_SK = (60279.9, 71687.9)     # stream-K kernel with 4 column slices, KiB per launch: profiles/r05_loss_pmc_fetch.csv / _write.csv (60285.2 there)
                                       # (one slice, round 3's partition, same run: 281075.0 / 42504.0 -- r04_loss_pmc_*_1slice.csv)
 PMC_SOURCE = "profiles/r02_loss_pmc_fetch.csv, r02_loss_pmc_write.csv"
-PMC_SOURCE_SK = "profiles/r04_loss_pmc_fetch.csv, r04_loss_pmc_write.csv"
+PMC_SOURCE_SK = "profiles/r05_loss_pmc_fetch.csv, r05_loss_pmc_write.csv"
 
 
 def cpu_baseline_loss(args):

@@ -10,7 +10,7 @@
     ops_swin     LayerNorm, window attention
     ops_logits   fused up-sampling + cross-entropy (UpsampledLogits)
 
-Module switches (A/B runs, tests) live in the module that reads them: ``ops_resize.HIP_UPSAMPLE``, ``ops_conv.CONV_BN_STATS``,
+Module switches (A/B runs, tests) live in the module that reads them: ``ops_resize.HIP_UPSAMPLE``,
 ``ops_linear.FUSED_MLP`` ... -- assigning to the copy in THIS namespace changes nothing."""
 from . import ops_common, ops_resize, ops_linear, ops_conv, ops_conv1x1, ops_head, ops_swin, ops_logits
 
