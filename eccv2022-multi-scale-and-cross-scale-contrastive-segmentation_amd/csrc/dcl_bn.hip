@@ -21,6 +21,15 @@ constexpr int BN_THREADS = 256;
 #endif
 constexpr int BN_UNROLL = DCL_BN_UNROLL;       // 16-byte vectors per thread in the element-wise kernels
 
+// Probe builds (tools/probes/bn_coherence.sh, -DDCL_BN_PROBE=<bits>; 0 in the product): 1 = the per-slice partial sums are read
+// with agent-scope VECTOR loads instead of the scalar loads the compiler picks for uniform addresses, 2 = the per-channel mean /
+// invstd / gamma / beta of the backward kernels as well.
+#ifndef DCL_BN_PROBE
+#define DCL_BN_PROBE 0
+#endif
+__device__ __forceinline__ float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ldc(const float *p) { return (DCL_BN_PROBE & 2) ? ld_agent(p) : *p; }
+
 __device__ inline void block_reduce2(float &a, float &b, float *sh)
 {
     a = wave_sum(a);
@@ -35,6 +44,25 @@ __device__ inline void block_reduce2(float &a, float &b, float *sh)
     b = sh[4] + sh[5] + sh[6] + sh[7];
 }
 
+// the same for double accumulators (the statistics kernel: every thread's running sums and the workgroup's reduction are kept in
+// double; what is rounded to float is the ONE partial sum a workgroup writes)
+__device__ inline void block_reduce2(double &a, double &b, double *sh)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        sh[w] = a;
+        sh[4 + w] = b;
+    }
+    __syncthreads();
+    a = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    b = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+}
+
 // grid (C, nslice): workgroup (c, s) reduces planes n = s, s + nslice, ... of channel c.
 // part[(c * nslice + s) * 2 + {0,1}] = {sum x, sum x^2}
 // Shifted sums: with a pivot p[c] (the layer's running mean: the same value on every rank, and close to the batch
@@ -47,11 +75,14 @@ __device__ __forceinline__ void bn_stats_body(const float *__restrict__ x, int N
                                               const float *__restrict__ pivot_src,
                                               float *__restrict__ pivot_out, const int c, const int s)
 {
-    __shared__ float sh[8];
+    __shared__ double sh[8];
     const float pv = pivot_src ? pivot_src[c] : 0.f;
     if (pivot_out && s == 0 && threadIdx.x == 0)
         pivot_out[c] = pv;
-    float a = 0.f, b = 0.f;
+    // sixteen values at a time are summed pairwise in float; the running sums of a thread are doubles (two conversions and two
+    // double additions per sixteen elements: nothing beside the loads) -- with float running sums the variance of a channel whose
+    // pivot is far from the batch mean lost 2-3e-5 of its value on 32 768-element planes (E[d^2] - E[d]^2 cancels)
+    double a = 0.0, b = 0.0;
     const int hw4 = (HW & 3) ? 0 : (HW >> 2);      // 16-B loads only when every plane base is 16-B aligned
     for (int n = s; n < N; n += nslice) {
         const float *p = x + ((size_t)n * C + c) * HW;
@@ -63,29 +94,29 @@ __device__ __forceinline__ void bn_stats_body(const float *__restrict__ x, int N
             v1.x -= pv; v1.y -= pv; v1.z -= pv; v1.w -= pv;
             v2.x -= pv; v2.y -= pv; v2.z -= pv; v2.w -= pv;
             v3.x -= pv; v3.y -= pv; v3.z -= pv; v3.w -= pv;
-            a += ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)) +
-                 (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w)));
-            b += ((v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w)) +
-                 ((v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w)) +
-                 (((v2.x * v2.x + v2.y * v2.y) + (v2.z * v2.z + v2.w * v2.w)) +
-                  ((v3.x * v3.x + v3.y * v3.y) + (v3.z * v3.z + v3.w * v3.w)));
+            a += (double)(((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)) +
+                          (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w))));
+            b += (double)(((v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w)) +
+                          ((v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w)) +
+                          (((v2.x * v2.x + v2.y * v2.y) + (v2.z * v2.z + v2.w * v2.w)) +
+                           ((v3.x * v3.x + v3.y * v3.y) + (v3.z * v3.z + v3.w * v3.w))));
         }
         for (; i < hw4; i += BN_THREADS) {
             f32x4 v = p4[i];
             v.x -= pv; v.y -= pv; v.z -= pv; v.w -= pv;
-            a += (v.x + v.y) + (v.z + v.w);
-            b += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            a += (double)((v.x + v.y) + (v.z + v.w));
+            b += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
         }
         for (int i = (hw4 << 2) + threadIdx.x; i < HW; i += BN_THREADS) {
             const float v = p[i] - pv;
-            a += v;
-            b += v * v;
+            a += (double)v;
+            b += (double)(v * v);
         }
     }
     block_reduce2(a, b, sh);
     if (threadIdx.x == 0) {
-        part[((size_t)c * nslice + s) * 2 + 0] = a;
-        part[((size_t)c * nslice + s) * 2 + 1] = b;
+        part[((size_t)c * nslice + s) * 2 + 0] = (float)a;
+        part[((size_t)c * nslice + s) * 2 + 1] = (float)b;
     }
 }
 
@@ -183,13 +214,17 @@ __device__ __forceinline__ void block_amax(float m, float *dst)
 
 // y = x * sc + sh: ONE definition of the affine form, so that the backward's recomputed ReLU mask (y > 0 without
 // reading y) sees bit-identical values
+__device__ __forceinline__ float bn_shift(float beta, float mean, float sc) { return __builtin_fmaf(-mean, sc, beta); }
 __device__ __forceinline__ void bn_affine(const float *invstd, const float *gamma, const float *beta,
                                           const float *mean, int c, float &sc, float &sh)
 {
-    sc = invstd[c] * (gamma ? gamma[c] : 1.f);
-    sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    sc = ldc(invstd + c) * (gamma ? ldc(gamma + c) : 1.f);
+    sh = bn_shift(beta ? ldc(beta + c) : 0.f, ldc(mean + c), sc);
 }
-__device__ __forceinline__ float bn_eval(float x, float sc, float sh) { return x * sc + sh; }
+// (explicit fused operations: written as x * sc + sh the compiler is free to contract -- or not -- per call site, and it did decide
+// differently for the forward and the backward kernels once packed FP32 was switched off: masks then disagree wherever y rounds
+// to the other side of zero, 6e-3 of max in the input gradient of the layer-1 fixture)
+__device__ __forceinline__ float bn_eval(float x, float sc, float sh) { return __builtin_fmaf(x, sc, sh); }
 
 // "Fused" mode of the apply kernels: the per-slice partial sums `part` (all-reduced across ranks by the caller for
 // SyncBatchNorm) are combined in every workgroup's prologue instead of by a k_bn_combine launch -- same fixed
@@ -226,8 +261,14 @@ __device__ __forceinline__ void part_sums(const float *part, int c, int ns, floa
     for (int s = 0; s < ns; s += 8) {
         float2 v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            v[i] = p[min(s + i, ns - 1)];
+        for (int i = 0; i < 8; ++i) {
+            if (DCL_BN_PROBE & 1) {
+                const float *q = (const float *)(p + min(s + i, ns - 1));
+                v[i] = float2{ld_agent(q), ld_agent(q + 1)};
+            } else {
+                v[i] = p[min(s + i, ns - 1)];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (s + i < ns) {
@@ -292,7 +333,7 @@ __device__ __forceinline__ void bn_apply_body(const float *__restrict__ x,
                 f.batches_tracked[0] += 1;
         }
         sc = invstd_f * (gamma ? gamma[c] : 1.f);
-        sh = (beta ? beta[c] : 0.f) - mean_f * sc;
+        sh = bn_shift(beta ? beta[c] : 0.f, mean_f, sc);
     } else {
         bn_affine(invstd, gamma, beta, mean, c, sc, sh);
     }
@@ -402,7 +443,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const float *__restrict__ dy,
                                                    const unsigned long long *__restrict__ mask, const int c, const int s)
 {
     __shared__ float sh[8];
-    const float m = mean[c], is = invstd[c];
+    const float m = ldc(mean + c), is = ldc(invstd + c);
     // y == NULL (ReLU without residual): the mask y > 0 is recomputed from x -- one tensor less to read
     float asc, ash;
     bn_affine(invstd, gamma, beta, mean, c, asc, ash);
@@ -508,11 +549,11 @@ __device__ __forceinline__ void bn_bwd_apply_body(const float *__restrict__ dy,
     const unsigned nv = flat ? (unsigned)N * (unsigned)hw4 : (unsigned)hw4;
     const unsigned j0 = bx * (BN_UNROLL * BN_THREADS) + threadIdx.x;
     float am = 0.f;
-    const float m = mean[c], is = invstd[c];
+    const float m = ldc(mean + c), is = ldc(invstd + c);
     float asc, ash;                                   // y == NULL: ReLU mask recomputed from x (see the reduce)
     bn_affine(invstd, gamma, beta, mean, c, asc, ash);
     const bool rec = RELU && y == nullptr && mask == nullptr;
-    const float k = is * (gamma ? gamma[c] : 1.f);
+    const float k = is * (gamma ? ldc(gamma + c) : 1.f);
     float mg = 0.f, mgx = 0.f;
     __shared__ float bc[2];                 // (one thread computes, see k_bn_apply)
     if (threadIdx.x == 0) {

@@ -83,6 +83,7 @@ _FANOUT_ON_BRANCH_STREAM = _dbg.fanout_on_branch_stream
 _BRANCH_STREAM_MAP = list(_dbg.branch_stream_map)     # stream per branch (0 = the main stream); default: one each
 _MERGE_FROM = _dbg.merge_from
 _MERGE_BRANCHES = _dbg.merge_branches                  # branches 1.. of a module: one launch per kernel stage and depth (models/merged.py)
+_MERGE_INTERLEAVE = False       # tests / tools/probes/dbg_merged.py: branch 0's block d right behind the coarse group's depth d
 
 
 def _side_streams(device, n):
@@ -334,6 +335,8 @@ class HighResolutionModule(nn.Module):
                 for t in cur:
                     _amax_record_stream(t, cs)
         on_cs = (lambda: torch.cuda.stream(cs)) if cs is not None else contextlib.nullcontext
+        inter = _MERGE_INTERLEAVE and m0 == 1 and len(self.branches[0]) == len(chains[0])
+        cur0 = x[0]
         for d in range(len(chains[0])):
             blocks = [c[d] for c in chains]
             with on_cs():
@@ -343,12 +346,11 @@ class HighResolutionModule(nn.Module):
                 a = bn_act_merged([blk.bn1 for blk in blocks], z, relu=True)
                 z2 = conv3x3_group([blk.conv2 for blk in blocks], a)
                 cur = bn_act_merged([blk.bn2 for blk in blocks], z2, residuals=cur, relu=True, tokens=toks)
-        # Branch 0 AFTER the whole coarse chain, not block by block in between.  Issued alternately (coarse depth d, block d of
-        # branch 0, ...) the autograd engine also alternates between the two streams in the backward, and on this stack that
-        # order gave run-to-run differences in the output of single norm-backward kernels (one to three channels of dx, 1e-4 of
-        # max, identical inputs by checksum; no cross-stream block in the allocator's history; gone without the caching
-        # allocator and with everything on one stream) -- 0 of 63 runs differ in this order, 40 of 63 in the alternating one
-        # (tools/probes/dbg_merged.py).  The GPU queues fill either way: the host runs ahead of the device.
+            if inter:
+                cur0 = self.branches[0][d](cur0)
+        # Branch 0 after the whole coarse chain (or, _MERGE_INTERLEAVE, block by block in between: the order in which the autograd
+        # engine alternates between the two streams node by node -- it exposed the packed-FP32-beside-MFMA fault that csrc/Makefile's
+        # NOPK now avoids; kept as a test order).  The GPU queues fill either way: the host runs ahead.
         # (branches 1 .. m0-1, if any, on their own streams as in the per-branch schedule)
         mid = [None] * (m0 - 1)
         for k in range(m0 - 1, 0, -1):
@@ -360,7 +362,7 @@ class HighResolutionModule(nn.Module):
             with torch.cuda.stream(side[k - 1]):
                 _amax_record_stream(x[k], side[k - 1])
                 mid[k - 1] = self.branches[k](x[k])
-        out0 = self.branches[0](x[0])
+        out0 = cur0 if inter else self.branches[0](x[0])
         if cs is not None:
             main.wait_stream(cs)
             for t in cur:

@@ -1,0 +1,149 @@
+"""Does the norm backward (packed-FP32 code) return different bits when ANOTHER kernel shares its compute units?
+
+    [DCL_LIB_PATH=variant.so] python tools/probes/pk_coresident.py [iters=N]
+
+Stream A: the backward of one FusedBatchNorm2d (+ residual + ReLU, 2 x 48 x 64 x 96: the shape and form of the launches that differ
+in tools/probes/dbg_dx.py) again and again on the same inputs, every dx compared bitwise with the one computed alone.  Stream B,
+concurrently: nothing | the f16x3 convolution (matrix pipe) | norm statistics (vector ALU, no matrix instructions) | a plain
+ATen element-wise kernel."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import mscs_amd  # noqa: F401,E402
+from mscs_amd.models import fused_bn, ops  # noqa: E402
+from mscs_amd.models.amax import amax_of  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+NB = next((int(a[3:]) for a in sys.argv if a.startswith("nb=")), 8)
+iters = next((int(a[6:]) for a in sys.argv if a.startswith("iters=")), 60)
+bn = fused_bn.FusedBatchNorm2d(48).to(dev).train()
+with torch.no_grad():
+    bn.weight.uniform_(0.5, 1.5)
+    bn.bias.uniform_(-0.5, 0.5)
+x = torch.randn(2, 48, 64, 96, device=dev, requires_grad=True)
+res = torch.randn(2, 48, 64, 96, device=dev)
+dy = torch.randn(2, 48, 64, 96, device=dev) * 1e-4
+y = bn(x, residual=res, relu=True)
+ref = torch.autograd.grad(y, x, dy, retain_graph=True)[0].clone()
+torch.cuda.synchronize()
+
+# stream B's work
+cx = torch.randn(12, 96, 64, 128, device=dev).relu_()
+cw = torch.randn(96, 96, 3, 3, device=dev) * 0.03
+sx, sw = amax_of(cx), amax_of(cw)
+wp = ops.conv3x3_pack(cw, sw)
+cout = torch.empty_like(cx)
+bx = torch.randn(12, 96, 64, 128, device=dev)
+L = mscs_amd._lib.lib() if hasattr(mscs_amd, "_lib") else None
+from mscs_amd import _lib  # noqa: E402
+L = _lib.lib()
+ns = L.dcl_bn_num_slices(12, 96)
+part = torch.empty(96 * ns * 2, device=dev)
+rm = torch.zeros(96, device=dev)
+piv = torch.empty(96, device=dev)
+
+
+def b_conv():
+    ops.conv3x3_launch(cx, wp, 96, sx, sw, cout)
+
+
+def b_stats():
+    _lib.check(L.dcl_bn_stats_part(_lib.ptr(bx), 12, 96, 64 * 128, _lib.ptr(part), _lib.ptr(rm), _lib.ptr(piv), _lib.stream_ptr(dev)), "stats")
+
+
+def b_aten():
+    torch.mul(bx, 1.0001, out=cout)
+
+
+gy96 = torch.randn(12, 96, 64, 128, device=dev)
+gy192 = torch.randn(12, 192, 32, 64, device=dev)
+x192 = torch.randn(12, 192, 32, 64, device=dev).relu_()
+
+
+def b_wgrad96():
+    ops.conv3x3_wgrad(cx, gy96)
+
+
+def b_wgrad192():
+    ops.conv3x3_wgrad(x192, gy192)
+
+
+# the coarse branches of an exchange module, merged launches (models/merged.py): forward once, backward again and again
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_merged_branches import _module  # noqa: E402
+hm, mod, ch = _module(4, dev)
+hm._MERGE_BRANCHES = True
+mxs = [torch.randn(2, c, 64 >> i, 96 >> i, device=dev, requires_grad=True) for i, c in enumerate(ch)]
+sb = torch.cuda.Stream(dev)
+sb.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(sb):
+    from mscs_amd.models.merged import conv3x3_group, bn_act_merged
+    blocks = [br[0] for br in mod.branches[1:]]
+    z = conv3x3_group([b.conv1 for b in blocks], mxs[1:], [None] * 3)
+    a = bn_act_merged([b.bn1 for b in blocks], z, relu=True)
+    z2 = conv3x3_group([b.conv2 for b in blocks], a)
+    outm = bn_act_merged([b.bn2 for b in blocks], z2, residuals=mxs[1:], relu=True, tokens=[None] * 3)
+    gouts = [torch.randn_like(o) for o in outm]
+torch.cuda.synchronize()
+
+
+def b_merged_bwd():
+    torch.autograd.grad(outm, mxs[1:] + [p for b in blocks for p in b.parameters()], gouts, retain_graph=True)
+
+
+sa = torch.cuda.Stream(dev)
+CASES = (("nothing", None), ("f16x3 convolution (MFMA)", b_conv), ("weight gradient 96 ch (LDS-DMA + MFMA)", b_wgrad96),
+         ("weight gradient 192 ch", b_wgrad192), ("merged coarse-block backward", b_merged_bwd),
+         ("norm statistics (VALU)", b_stats), ("ATen mul", b_aten), ("merged coarse-block backward", b_merged_bwd))
+c48 = torch.randn(12, 48, 128, 256, device=dev).relu_()
+w48 = torch.randn(48, 48, 3, 3, device=dev) * 0.05
+s48x, s48w = amax_of(c48), amax_of(w48)
+wp48 = ops.conv3x3_pack(w48, s48w)
+o48 = torch.empty_like(c48)
+g48 = torch.randn(12, 48, 128, 256, device=dev)
+lx = torch.randn(16384, 384, device=dev)
+lw = torch.randn(1536, 384, device=dev) * 0.05
+
+
+def b_conv48():
+    ops.conv3x3_launch(c48, wp48, 48, s48x, s48w, o48)
+
+
+def b_wgrad48():
+    ops.conv3x3_wgrad(c48, g48)
+
+
+def b_gemm():
+    ops.linear_f16x3(lx, lw)
+
+
+if "mfma" in sys.argv:
+    CASES = (("convolution 48 ch, two workgroups per CU (32x32x16)", b_conv48), ("GEMM 16384 x 384 -> 1536 (32x32x16)", b_gemm),
+             ("weight gradient 48 ch (16x16x32)", b_wgrad48), ("weight gradient 96 ch (16x16x32)", b_wgrad96))
+if "wgrad" in sys.argv:
+    CASES = (("weight gradient 96 ch (LDS-DMA + MFMA)", b_wgrad96), ("weight gradient 192 ch", b_wgrad192))
+print("library:", os.environ.get("DCL_LIB_PATH", "product"))
+for name, fb in CASES:
+    bad = total = 0
+    worst = 0.0
+    for it in range(iters):
+        outs = []
+        if fb is not None:
+            with torch.cuda.stream(sb):
+                for _ in range(NB):
+                    fb()
+        with torch.cuda.stream(sa):
+            for _ in range(12):
+                outs.append(torch.autograd.grad(y, x, dy, retain_graph=True)[0])
+        torch.cuda.synchronize()
+        for o in outs:
+            total += 1
+            if not torch.equal(o, ref):
+                bad += 1
+                worst = max(worst, ((o - ref).abs().max() / ref.abs().max()).item())
+    print(f"stream B = {name}: {bad} of {total} norm backwards differ from the one computed alone (worst {worst:.1e} of max)", flush=True)
