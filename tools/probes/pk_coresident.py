@@ -103,6 +103,20 @@ va, vb, vc = (torch.randn(2, 48, 64, 96, device=dev) for _ in range(3))
 if "aten" in sys.argv:
     def victim():
         return torch.addcmul(va, vb, vc, value=0.37).mul_(1.7).add_(vb, alpha=-0.21)
+elif "bnfwd" in sys.argv:                       # the norm's forward (statistics + apply with residual and ReLU)
+    def victim():
+        with torch.no_grad():
+            return bn(x, residual=res, relu=True)
+elif "bnplain" in sys.argv:                     # backward of a norm + ReLU without residual (mask recomputed from x)
+    y2 = bn(x, relu=True)
+
+    def victim():
+        return torch.autograd.grad(y2, x, dy, retain_graph=True)[0]
+elif "upsample" in sys.argv:                    # bilinear up-sampling + add (csrc/dcl_resize.hip)
+    ub = torch.randn(2, 48, 128, 192, device=dev)
+
+    def victim():
+        return ops.upsample_bilinear(va, (128, 192), True) + 0
 else:
     def victim():
         return torch.autograd.grad(y, x, dy, retain_graph=True)[0]
