@@ -42,6 +42,9 @@ class DebugConfig:
     fanout: bool = field(default_factory=lambda: _flag('DCL_FANOUT'))                           # one-kernel gradient sums
     upsample_tag: bool = field(default_factory=lambda: _flag('DCL_UPSAMPLE_TAG'))               # absmax tags of up-sampled maps
     small_cin_stem: bool = field(default_factory=lambda: _flag('DCL_SMALL_CIN_STEM'))            # fp32 kernel for the 3-channel stem conv
+    deterministic_stem_wgrad: bool = field(default_factory=lambda: _flag('DCL_DETERMINISTIC_STEM_WGRAD'))   # the stem's weight gradient
+    # on the split-f16 kernel (input channels zero-padded to 16) instead of the library's atomic split-K kernel: the training step is
+    # bitwise reproducible with it (tests/test_step_reproducible.py)
     packed_relu_mask: bool = field(default_factory=lambda: _flag('DCL_BN_MASK'))                # packed sign mask in the BN backward
     gemm_conv1x1: bool = field(default_factory=lambda: _flag('DCL_GEMM_CONV1X1'))               # wide 1x1 convolutions on dcl_gemm_f16x3
     lib_conv1x1_addend: bool = field(default_factory=lambda: _flag('DCL_LIB_CONV1X1_ADDEND'))   # big 1x1 data gradients: residual

@@ -121,6 +121,7 @@ def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0, addend=No
     return out
 
 
+DETERMINISTIC_STEM_WGRAD = _dbg.deterministic_stem_wgrad     # (DCL_DETERMINISTIC_STEM_WGRAD=0: ATen / MIOpen for input-channel counts below 16)
 SMALL_CIN_STEM = _dbg.small_cin_stem     # the stem's 3 -> 64 stride-2 convolution on its own fp32 kernel (DCL_SMALL_CIN_STEM=0: tile kernel)
 
 
@@ -277,6 +278,16 @@ class _Conv3x3Direct(torch.autograd.Function):
                     gw = torch.bmm(gy.view(n, -1, h * w), x.view(n, ci, h * w).transpose(1, 2)).sum(0).view_as(weight)
             elif conv3x3_wgrad_supported(x, weight.shape[0], ctx.stride):
                 gw = conv3x3_wgrad(x, gy, ctx.stride)
+            elif DETERMINISTIC_STEM_WGRAD and weight.shape[1] < 16 and weight.shape[0] % 16 == 0 \
+                    and (x.shape[3] % 8 == 0 or ctx.stride == 1):
+                # the stem's 3-channel input (reference models/HRNet.py:333-338): the library's kernel for this shape splits the
+                # pixels and adds the pieces with ATOMICS (igemm_wrw ... gkgs) -- the one launch of a training step whose result
+                # changed from run to run (tools/probes/step_repro.py: after one step this weight differed by 8e-8, everything else
+                # was bitwise equal; after three steps every tensor differed).  Input channels zero-padded to 16, then the
+                # split-f16 weight-gradient kernel in its fixed summation order.
+                xp = x.new_zeros((x.shape[0], 16, x.shape[2], x.shape[3]))
+                xp[:, :weight.shape[1]] = x
+                gw = conv3x3_wgrad(xp, gy, ctx.stride)[:, :weight.shape[1]].contiguous()
             else:
                 st = ctx.stride
                 gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [st, st], [1, 1], [1, 1], False,
