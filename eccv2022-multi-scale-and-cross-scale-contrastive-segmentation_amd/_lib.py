@@ -59,6 +59,8 @@ SIGNATURES = {
                            _vp, _vp, _vp],
     "dcl_conv3x3_f16x3_multi": [_vp, _i, _vp],
     "dcl_conv3x3_s2_smallcin": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "dcl_wgrad3x3_s2_smallcin_workspace": [_i],
+    "dcl_wgrad3x3_s2_smallcin": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "dcl_bn_bwd_reduce_part": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "dcl_bn_bwd_apply_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp,
                                _vp, _vp, _vp],

@@ -1366,6 +1366,183 @@ extern "C" int dcl_conv3x3_s2_smallcin(const float *x, int N, int Cin, int H, in
     return 0;
 }
 
+// ---- stem: weight gradient of the same layer (3x3 / stride 2 / pad 1, Cin * 9 <= 32 taps, Cout <= 64), fp32 on the matrix pipe.
+//   dw[co][ci][ky][kx] = sum over (n, oy, ox) of gy[n][co][oy][ox] * x[n][ci][2 oy + ky - 1][2 ox + kx - 1]
+// is a GEMM  D[co][tap] += A[co][pixel] B[pixel][tap]  with the PIXELS as the contraction: v_mfma_f32_32x32x2f32 takes two pixels per
+// instruction (lane (i, k): A = gy of channel i at pixel k of the pair, B = tap i of that pixel), products and sums in fp32.  The
+// library's kernel for this shape (igemm_wrw ... gkgs, 0.41 ms at batch 12 x 512 x 1024) splits the pixels and adds the pieces with
+// atomics -- the one launch of a training step whose result changed from run to run; the traffic (75 MB of image, 403 MB of gradient)
+// is worth 0.1 ms.  Persistent workgroups: workgroup b takes the 128-pixel row segments b, b + G, b + 2 G, ... (a FIXED assignment),
+// stages gy [Cout][128] and the three image rows [Cin][3][258] of a segment in LDS with coalesced loads, its four waves take 32
+// pixels each and keep their 32 x 32 accumulators (one per 32 output channels) across all segments; at the end the waves' tiles are
+// added in LDS in wave order and the workgroup writes ONE slab; k_wgrad_stem_sum adds the slabs in index order in double.
+namespace {
+constexpr int SW_PIX = 128, SW_XW = 2 * SW_PIX + 2;      // staged image row: columns 2 ox0 - 1 .. 2 ox0 + 256
+constexpr int SW_GS = SW_PIX + 1;                        // LDS row stride of the staged gradient (odd: channel rows fall into different banks)
+
+template <int MT>                                        // MT = Cout / 32 (1 | 2)
+__global__ __launch_bounds__(256, 2) void k_wgrad_stem(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ part,
+                                                      int N, int Cin, int H, int W, int Cout, int Ho, int Wo, int segs_x, long nseg)
+{
+    __shared__ float gl[32 * MT * SW_GS];
+    __shared__ float xl[3 * 3 * SW_XW + 32];
+    __shared__ float red[3][32 * MT][33];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, k = lane >> 5, i = lane & 31;
+    // tap of this lane: i = ci * 9 + ky * 3 + kx (lanes with i >= Cin * 9 feed zeros)
+    const int ntap = Cin * 9;
+    const int tci = i / 9, tky = (i % 9) / 3, tkx = i % 3;
+    const bool tap_ok = i < ntap;
+    const int xoff = tap_ok ? (tci * 3 + tky) * SW_XW + tkx : 0;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            acc[m][q] = 0.f;
+    const size_t gplane = (size_t)Ho * Wo, xplane = (size_t)H * W;
+    // Staging registers: a segment's values are loaded UNCONDITIONALLY from clamped addresses (a branch around a load makes the
+    // compiler wait for it on the spot: 40 dependent round trips per segment, 0.60 ms for the whole launch) while the previous
+    // segment's matrix instructions run, and written to LDS -- zeros where the mask says "outside" -- behind a barrier.
+    constexpr int GN = 32 * MT * SW_PIX / 256;                 // gradient values per thread and segment (16 | 32)
+    constexpr int XN = (3 * 3 * SW_XW + 255) / 256;            // image values per thread and segment (10)
+    float gr[GN], xr[XN];
+    unsigned gmask = 0, xmask = 0;
+    auto issue = [&](long sg) {
+        const int sx = (int)(sg % segs_x);
+        const long r = sg / segs_x;
+        const int oy = (int)(r % Ho), n = (int)(r / Ho);
+        const int ox0 = sx * SW_PIX;
+        gmask = 0, xmask = 0;
+        const float *gb = gy + (size_t)n * Cout * gplane + (size_t)oy * Wo + ox0;
+#pragma unroll
+        for (int u = 0; u < GN; ++u) {
+            const int e = tid + 256 * u, c = e >> 7, pp = e & (SW_PIX - 1);
+            const bool ok = c < Cout && ox0 + pp < Wo;
+            gmask |= ok ? (1u << u) : 0u;
+            gr[u] = gb[ok ? (size_t)c * gplane + pp : 0];
+        }
+        const float *xb = x + (size_t)n * Cin * xplane;
+#pragma unroll
+        for (int u = 0; u < XN; ++u) {
+            const int e = tid + 256 * u, row = e / SW_XW, c = e - row * SW_XW;
+            const int ci = row / 3, ky = row - 3 * ci;
+            const int yy = 2 * oy + ky - 1, xx = 2 * ox0 + c - 1;
+            const bool ok = row < Cin * 3 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            xmask |= ok ? (1u << u) : 0u;
+            xr[u] = xb[ok ? (size_t)ci * xplane + (size_t)yy * W + xx : 0];
+        }
+    };
+    long s = blockIdx.x;
+    if (s < nseg)
+        issue(s);
+    for (; s < nseg; s += gridDim.x) {
+        __syncthreads();                                 // the previous segment's operand reads are done
+#pragma unroll
+        for (int u = 0; u < GN; ++u) {
+            const int e = tid + 256 * u;
+            gl[(e >> 7) * SW_GS + (e & (SW_PIX - 1))] = ((gmask >> u) & 1) ? gr[u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < XN; ++u) {
+            const int e = tid + 256 * u;
+            if (e < 3 * 3 * SW_XW)
+                xl[e] = ((xmask >> u) & 1) ? xr[u] : 0.f;
+        }
+        __syncthreads();
+        if (s + gridDim.x < nseg)
+            issue(s + gridDim.x);                        // the next segment's loads fly during this one's matrix instructions
+        // this wave's 32 pixels, two per instruction: pixel p = 32 wave + 2 t + k
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+            const int p = 32 * wave + 2 * t + k;
+            const float b = tap_ok ? xl[xoff + 2 * p] : 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(gl[(32 * m + i) * SW_GS + p], b, acc[m], 0, 0, 0);
+        }
+    }
+    // waves 1 .. 3 hand their tiles to wave 0 through LDS, added in wave order; accumulator register q of lane (k, i) is row
+    // (q & 3) + 8 (q >> 2) + 4 k (output channel), column i (tap)
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                red[wave - 1][32 * m + (q & 3) + 8 * (q >> 2) + 4 * k][i] = acc[m][q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *dst = part + (size_t)blockIdx.x * 32 * MT * 32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = 32 * m + (q & 3) + 8 * (q >> 2) + 4 * k;
+                dst[row * 32 + i] = ((acc[m][q] + red[0][row][i]) + red[1][row][i]) + red[2][row][i];
+            }
+    }
+}
+
+// one workgroup per output channel: thread (g, t) adds the slabs g, g + 8, g + 16, ... of tap t in double (eight loads in flight per
+// trip: one thread per output walking all 512 slabs was 512 dependent round trips, 0.3 ms), the eight partial sums are added in
+// order g = 0 .. 7 -- a fixed order either way
+__global__ __launch_bounds__(256) void k_wgrad_stem_sum(const float *__restrict__ part, int nslab, int rows, int ntap, int Cout,
+                                                       float *__restrict__ dw)
+{
+    __shared__ double ps[8][32];
+    const int co = blockIdx.x, t = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double acc = 0.0;
+    const float *p = part + (size_t)co * 32 + t;
+    const size_t stride = (size_t)rows * 32;
+    for (int sl = g; sl < nslab; sl += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = p[(size_t)min(sl + 8 * u, nslab - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (sl + 8 * u < nslab)
+                acc += (double)v[u];
+    }
+    ps[g][t] = acc;
+    __syncthreads();
+    if (g == 0 && t < ntap) {
+        double a = ps[0][t];
+#pragma unroll
+        for (int u = 1; u < 8; ++u)
+            a += ps[u][t];
+        dw[co * ntap + t] = (float)a;                    // dw is [Cout][Cin][3][3] = [Cout][ntap]
+    }
+}
+}  // namespace
+
+extern "C" int dcl_wgrad3x3_s2_smallcin_workspace(int Cout)
+{
+    return 512 * ((Cout + 31) / 32) * 32 * 32;           // floats: one [Cout rounded up][32] slab per workgroup, 512 workgroups
+}
+
+extern "C" int dcl_wgrad3x3_s2_smallcin(const float *x, int N, int Cin, int H, int W, const float *gy, int Cout, float *part,
+                                        float *dw, void *stream)
+{
+    DCL_CHECK_ARG(x && gy && part && dw && N > 0 && H > 0 && W > 0, "bad arguments");
+    DCL_CHECK_ARG(Cin >= 1 && Cin * 9 <= 32, "this kernel takes up to 3 input channels (27 taps in one 32-column tile)");
+    DCL_CHECK_ARG(Cout >= 1 && Cout <= 64, "this kernel takes up to 64 output channels");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int segs_x = (Wo + SW_PIX - 1) / SW_PIX;
+    const long nseg = (long)segs_x * Ho * N;
+    const int G = (int)(nseg < 512 ? nseg : 512);        // two workgroups per CU
+    const int MT = (Cout + 31) / 32;
+    if (MT == 1)
+        hipLaunchKernelGGL(k_wgrad_stem<1>, dim3(G), dim3(256), 0, (hipStream_t)stream, x, gy, part, N, Cin, H, W, Cout, Ho, Wo, segs_x, nseg);
+    else
+        hipLaunchKernelGGL(k_wgrad_stem<2>, dim3(G), dim3(256), 0, (hipStream_t)stream, x, gy, part, N, Cin, H, W, Cout, Ho, Wo, segs_x, nseg);
+    dcl_note_kernel("k_wgrad_stem");
+    hipLaunchKernelGGL(k_wgrad_stem_sum, dim3(Cout), dim3(256), 0, (hipStream_t)stream, part, G, 32 * MT, Cin * 9, Cout, dw);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dcl_conv3x3_set_min_workgroups(int n)
 {
     g_conv_min_wgs = n > 0 ? n : 96;

@@ -189,6 +189,24 @@ def conv3x3_wgrad(x, gy, stride=1):
     return dw
 
 
+def stem_wgrad_supported(x, cout, stride):
+    return stride == 2 and x.shape[1] * 9 <= 32 and cout <= 64 and x.is_contiguous() and x.dtype == torch.float32
+
+
+def stem_wgrad(x, gy):
+    """dw [Co, Ci, 3, 3] of conv2d(x, w, stride=2, padding=1) for Ci <= 3 input channels (the stem's convolution on the image) on
+    csrc/dcl_conv3x3.hip k_wgrad_stem: fp32 products on the matrix pipe, fixed summation order."""
+    from .. import _lib
+    L = _lib.lib()
+    n, ci, h, w = x.shape
+    co = gy.shape[1]
+    part = torch.empty(L.dcl_wgrad3x3_s2_smallcin_workspace(co), dtype=torch.float32, device=x.device)
+    dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)
+    _lib.check(L.dcl_wgrad3x3_s2_smallcin(_lib.ptr(x), n, ci, h, w, _lib.ptr(gy), co, _lib.ptr(part), _lib.ptr(dw), _stream(x)),
+               "dcl_wgrad3x3_s2_smallcin")
+    return dw
+
+
 class _Conv3x3Direct(torch.autograd.Function):
     """3x3 / stride 1 / pad 1 convolution on the f16x3 (fp32-equivalent) kernels: forward and data gradient through
     csrc/dcl_conv3x3.hip, weight gradient through csrc/dcl_wgrad3x3.hip (channel counts that are not multiples
@@ -278,13 +296,15 @@ class _Conv3x3Direct(torch.autograd.Function):
                     gw = torch.bmm(gy.view(n, -1, h * w), x.view(n, ci, h * w).transpose(1, 2)).sum(0).view_as(weight)
             elif conv3x3_wgrad_supported(x, weight.shape[0], ctx.stride):
                 gw = conv3x3_wgrad(x, gy, ctx.stride)
-            elif DETERMINISTIC_STEM_WGRAD and weight.shape[1] < 16 and weight.shape[0] % 16 == 0 \
-                    and (x.shape[3] % 8 == 0 or ctx.stride == 1):
-                # the stem's 3-channel input (reference models/HRNet.py:333-338): the library's kernel for this shape splits the
+            elif DETERMINISTIC_STEM_WGRAD and stem_wgrad_supported(x, weight.shape[0], ctx.stride):
+                # the stem's 3-channel input (reference models/HRNet.py:404-405): the library's kernel for this shape splits the
                 # pixels and adds the pieces with ATOMICS (igemm_wrw ... gkgs) -- the one launch of a training step whose result
                 # changed from run to run (tools/probes/step_repro.py: after one step this weight differed by 8e-8, everything else
-                # was bitwise equal; after three steps every tensor differed).  Input channels zero-padded to 16, then the
-                # split-f16 weight-gradient kernel in its fixed summation order.
+                # was bitwise equal; after three steps every tensor differed)
+                gw = stem_wgrad(x, gy)
+            elif DETERMINISTIC_STEM_WGRAD and weight.shape[1] < 16 and weight.shape[0] % 16 == 0 \
+                    and (x.shape[3] % 8 == 0 or ctx.stride == 1):
+                # other narrow inputs: channels zero-padded to 16, then the split-f16 weight-gradient kernel (fixed summation order too)
                 xp = x.new_zeros((x.shape[0], 16, x.shape[2], x.shape[3]))
                 xp[:, :weight.shape[1]] = x
                 gw = conv3x3_wgrad(xp, gy, ctx.stride)[:, :weight.shape[1]].contiguous()

@@ -43,6 +43,12 @@ def _conv_smallcin(a):      # (x, N, Cin, H, W, w, Cout, bias, y): the stem's 3-
     return 2.0 * n * co * ci * 9 * ho * wo, 4.0 * n * (ci * h * w + co * ho * wo), f"{n}x({ci}->{co})x{h}x{w} s2"
 
 
+def _wgrad_smallcin(a):     # (x, N, Cin, H, W, gy, Cout, part, dw): the stem's weight gradient, HBM-bound
+    n, ci, h, w, co = a[1], a[2], a[3], a[4], a[6]
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    return 2.0 * n * co * ci * 9 * ho * wo, 4.0 * n * (ci * h * w + co * ho * wo), f"{n}x({ci}->{co})x{h}x{w} s2 wgrad"
+
+
 def _conv1x1(a):
     n, ci, h, w, co = a[1], a[2], a[3], a[4], a[6]
     return 2.0 * n * co * ci * h * w, 4.0 * n * (ci + co) * h * w + (4.0 * n * co * h * w if a[10] else 0.0), \
@@ -162,6 +168,7 @@ def _bn_multi(stage):       # (jobs, njobs, ...): models/merged.py BnJob; bytes 
 MODELS = {
     "dcl_conv3x3_f16x3": (_conv3x3, "mfma", None),
     "dcl_conv3x3_s2_smallcin": (_conv_smallcin, "hbm", "k_conv3x3_s2_smallcin"),
+    "dcl_wgrad3x3_s2_smallcin": (_wgrad_smallcin, "hbm", "k_wgrad_stem"),
     "dcl_conv1x1_f16x3": (_conv1x1, "mfma", None),
     "dcl_wgrad3x3_f16x3": (_wgrad3x3, "mfma", None),
     "dcl_wgrad1x1_f16x3": (_wgrad1x1, "mfma", None),

@@ -487,6 +487,14 @@ int dcl_conv3x3_f16x3_multi(const dcl_conv_job *jobs, int njobs, void *stream);
  * (W - 1) / 2 + 1].  The tile kernels would pad the contraction to 16 channels. */
 int dcl_conv3x3_s2_smallcin(const float *x, int N, int Cin, int H, int W, const float *w, int Cout, const float *bias,
                             float *y, void *stream);
+/* Weight gradient of that layer (the backward of nn.Conv2d(3, 64, 3, 2, 1) at reference models/HRNet.py:404-405; replaces
+ * aten::convolution_backward, whose kernel for this shape adds its pixel splits with atomics): x [N, Cin, H, W] with Cin * 9 <= 32,
+ * gy [N, Cout, (H - 1) / 2 + 1, (W - 1) / 2 + 1] with Cout <= 64, dw [Cout, Cin, 3, 3]; fp32 products on the matrix pipe
+ * (v_mfma_f32_32x32x2f32), a FIXED summation order (bitwise reproducible).  part: workspace of
+ * dcl_wgrad3x3_s2_smallcin_workspace(Cout) floats. */
+int dcl_wgrad3x3_s2_smallcin_workspace(int Cout);
+int dcl_wgrad3x3_s2_smallcin(const float *x, int N, int Cin, int H, int W, const float *gy, int Cout, float *part, float *dw,
+                             void *stream);
 
 /* tuning hook: in_up = 2 (data gradient of a stride-2 convolution) -- 2 (default, round 4): one workgroup stages a patch of the
  * stored gradient once and computes all four parity classes of its output tile (9 taps per staged patch, k_conv3x3_pm); 1: every

@@ -1803,3 +1803,24 @@ def test_gemm_f16x3_linear_triplet_at_swin_shapes(dev):
         e_lib = ((l.double() - r).abs().max() / r.abs().max()).item()
         assert e_mine < 3e-6 and e_mine <= 2 * e_lib + 1e-7, (e_mine, e_lib)
         assert torch.equal(a, a2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64, 128), (1, 3, 32, 37, 50), (3, 1, 64, 20, 300), (2, 2, 48, 9, 7), (1, 3, 64, 512, 1024)])
+def test_stem_weight_gradient_matches_fp64_and_is_reproducible(dev, shape):
+    """csrc k_wgrad_stem (weight gradient of the stem's 3-channel stride-2 convolution, reference models/HRNet.py:404-405) against
+    aten::convolution_backward in float64 -- 2e-6 of max: fp32 products and sums -- over odd sizes, ragged segments, 1 .. 3 input and
+    32 .. 64 output channels; and bitwise equal from call to call (the library kernel it replaces uses atomics)."""
+    from mscs_amd.models import ops
+    n, ci, co, h, w = shape
+    g = torch.Generator(device="cpu").manual_seed(n * 1000 + h)
+    x = torch.randn(n, ci, h, w, generator=g).to(dev)
+    gy = torch.randn(n, co, (h - 1) // 2 + 1, (w - 1) // 2 + 1, generator=g).to(dev)
+    assert ops.stem_wgrad_supported(x, co, 2)
+    dw = ops.stem_wgrad(x, gy)
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), torch.zeros(co, ci, 3, 3, device=dev, dtype=torch.float64), None,
+                                              [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    assert ((dw.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    for _ in range(3):
+        assert torch.equal(ops.stem_wgrad(x, gy), dw)
+
