@@ -497,6 +497,7 @@ static bool use_dma(int Cin, int H, int W) { return g_variant != 0 && (size_t)Ci
 
 // dcl_wgrad3x3_s2.hip
 bool dcl_wgrad_s2_supported(int H, int W);
+void dcl_wgrad_s2_set_dma(int on);
 int dcl_wgrad_s2_slabs(int N, int Cin, int Cout, int H, int W, int force_nco, int force_nci);
 void dcl_wgrad_s2_launch(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax,
                          int xcount, const float *gamax, int gcount, float *part, int force_nco, int force_nci,
@@ -564,6 +565,7 @@ extern "C" int dcl_wgrad3x3_set_variant(int variant)
     if (variant < -1 || variant > 2 || variant == 1)     // 1 was the retired kernel
         return DCL_EINVAL;
     g_variant = variant;
+    dcl_wgrad_s2_set_dma(variant != 0);      // the stride-2 kernel's LDS-DMA form follows the same switch
     return 0;
 }
 
@@ -599,7 +601,10 @@ extern "C" int dcl_wgrad3x3_set_strip_group(int on)
 
 extern "C" int dcl_wgrad3x3_set_stride2(int native)
 {
+    if (native < 0 || native > 2)
+        return DCL_EINVAL;
     g_s2_native = native ? 1 : 0;
+    dcl_wgrad_s2_set_dma(native != 2);       // 2: the round-4 kernel (every operand loaded in MFMA order)
     return 0;
 }
 

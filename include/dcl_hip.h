@@ -518,8 +518,10 @@ int dcl_wgrad3x3_set_tile(int nco, int nci);
  * loads both operands itself in MFMA order (csrc/dcl_wgrad3x3.hip; also the fallback for tensors beyond 4 GiB per
  * image and for the zero-inserted stride-2 form).  Changes dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_variant(int variant);
-/* tuning hook (stride 2): 1 (default) = GEMM over the output pixels (csrc/dcl_wgrad3x3_s2.hip, needs W % 16 == 0),
- * 0 = the stride-1 kernels on a zero-inserted dy.  Changes dcl_wgrad3x3_splits(). */
+/* tuning hook (stride 2): 1 (default) = GEMM over the output pixels (csrc/dcl_wgrad3x3_s2.hip, needs W % 16 == 0), the x rows
+ * staged by LDS-DMA (k_wgrad3x3_s2d, round 5; one ci tile per wave); 2 = the same GEMM with every operand loaded in MFMA order
+ * (k_wgrad3x3_s2, round 4: bitwise the same result); 0 = the stride-1 kernels on a zero-inserted dy.  Changes
+ * dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_stride2(int native);
 /* tuning hook (per-wave kernels): pixel splits per tile pair, 0 = automatic.  Changes dcl_wgrad3x3_splits(). */
 int dcl_wgrad3x3_set_splits(int nx);

@@ -1824,3 +1824,30 @@ def test_stem_weight_gradient_matches_fp64_and_is_reproducible(dev, shape):
     for _ in range(3):
         assert torch.equal(ops.stem_wgrad(x, gy), dw)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 48, 96, 32, 64), (2, 48, 48, 20, 48), (1, 32, 96, 7, 16), (3, 16, 48, 33, 80), (1, 96, 192, 64, 128),
+                                   (2, 32, 32, 12, 32)])
+def test_stride2_weight_gradient_lds_dma_form_is_bitwise_the_load_form(dev, shape):
+    """csrc k_wgrad3x3_s2d (x rows of the stride-2 weight gradient staged by LDS-DMA, round 5; reference models/HRNet.py:216-261
+    fuse layers) runs the arithmetic of k_wgrad3x3_s2 in the same order: bitwise equal results over odd heights, ragged strips,
+    one to three co tiles per wave; and 2e-6 of max from float64."""
+    from mscs_amd import _lib
+    from mscs_amd.models import ops
+    n, ci, co, h, w = shape
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(h * 100 + w)
+    x = torch.randn(n, ci, h, w, generator=g).to(dev)
+    gy = torch.randn(n, co, (h - 1) // 2 + 1, w // 2, generator=g).to(dev)
+    try:
+        assert L.dcl_wgrad3x3_set_stride2(2) == 0
+        old = ops.conv3x3_wgrad(x, gy, 2)
+        assert L.dcl_wgrad3x3_set_stride2(1) == 0
+        new = ops.conv3x3_wgrad(x, gy, 2)
+    finally:
+        L.dcl_wgrad3x3_set_stride2(1)
+    assert torch.equal(old, new)
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.double(), torch.zeros(co, ci, 3, 3, device=dev, dtype=torch.float64), None,
+                                              [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    assert ((new.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+
