@@ -279,6 +279,7 @@ PMC_STEP = {
     "k_conv3x3_il_s2<3>": (26060.2, 19677.4),
     "k_conv3x3_il_s2<2>": (43989.6, 21174.9),
     "k_wgrad3x3_s2<3,1>": (62257.5, 6607.0),
+    "k_wgrad3x3_s2d<3,1>": (64579.9, 6607.6),           # (round 5: x rows by LDS-DMA; the halo pieces are whole 16-byte fetches)
     "k_bn_bwd_apply<true>": (46719.6, 70047.6),
     "k_bn_bwd_reduce<true>": (46581.0, 13.1),
     "k_bn_apply<true,true>": (49313.1, 50776.2),
