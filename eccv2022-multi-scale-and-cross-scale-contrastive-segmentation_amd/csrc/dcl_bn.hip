@@ -44,25 +44,6 @@ __device__ inline void block_reduce2(float &a, float &b, float *sh)
     b = sh[4] + sh[5] + sh[6] + sh[7];
 }
 
-// the same for double accumulators (the statistics kernel: every thread's running sums and the workgroup's reduction are kept in
-// double; what is rounded to float is the ONE partial sum a workgroup writes)
-__device__ inline void block_reduce2(double &a, double &b, double *sh)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) {
-        sh[w] = a;
-        sh[4 + w] = b;
-    }
-    __syncthreads();
-    a = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-    b = (sh[4] + sh[5]) + (sh[6] + sh[7]);
-}
-
 // grid (C, nslice): workgroup (c, s) reduces planes n = s, s + nslice, ... of channel c.
 // part[(c * nslice + s) * 2 + {0,1}] = {sum x, sum x^2}
 // Shifted sums: with a pivot p[c] (the layer's running mean: the same value on every rank, and close to the batch
@@ -75,14 +56,11 @@ __device__ __forceinline__ void bn_stats_body(const float *__restrict__ x, int N
                                               const float *__restrict__ pivot_src,
                                               float *__restrict__ pivot_out, const int c, const int s)
 {
-    __shared__ double sh[8];
+    __shared__ float sh[8];
     const float pv = pivot_src ? pivot_src[c] : 0.f;
     if (pivot_out && s == 0 && threadIdx.x == 0)
         pivot_out[c] = pv;
-    // sixteen values at a time are summed pairwise in float; the running sums of a thread are doubles (two conversions and two
-    // double additions per sixteen elements: nothing beside the loads) -- with float running sums the variance of a channel whose
-    // pivot is far from the batch mean lost 2-3e-5 of its value on 32 768-element planes (E[d^2] - E[d]^2 cancels)
-    double a = 0.0, b = 0.0;
+    float a = 0.f, b = 0.f;
     const int hw4 = (HW & 3) ? 0 : (HW >> 2);      // 16-B loads only when every plane base is 16-B aligned
     for (int n = s; n < N; n += nslice) {
         const float *p = x + ((size_t)n * C + c) * HW;
@@ -94,29 +72,29 @@ __device__ __forceinline__ void bn_stats_body(const float *__restrict__ x, int N
             v1.x -= pv; v1.y -= pv; v1.z -= pv; v1.w -= pv;
             v2.x -= pv; v2.y -= pv; v2.z -= pv; v2.w -= pv;
             v3.x -= pv; v3.y -= pv; v3.z -= pv; v3.w -= pv;
-            a += (double)(((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)) +
-                          (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w))));
-            b += (double)(((v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w)) +
-                          ((v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w)) +
-                          (((v2.x * v2.x + v2.y * v2.y) + (v2.z * v2.z + v2.w * v2.w)) +
-                           ((v3.x * v3.x + v3.y * v3.y) + (v3.z * v3.z + v3.w * v3.w))));
+            a += ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)) +
+                 (((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w)));
+            b += ((v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w)) +
+                 ((v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w)) +
+                 (((v2.x * v2.x + v2.y * v2.y) + (v2.z * v2.z + v2.w * v2.w)) +
+                  ((v3.x * v3.x + v3.y * v3.y) + (v3.z * v3.z + v3.w * v3.w)));
         }
         for (; i < hw4; i += BN_THREADS) {
             f32x4 v = p4[i];
             v.x -= pv; v.y -= pv; v.z -= pv; v.w -= pv;
-            a += (double)((v.x + v.y) + (v.z + v.w));
-            b += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+            a += (v.x + v.y) + (v.z + v.w);
+            b += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
         for (int i = (hw4 << 2) + threadIdx.x; i < HW; i += BN_THREADS) {
             const float v = p[i] - pv;
-            a += (double)v;
-            b += (double)(v * v);
+            a += v;
+            b += v * v;
         }
     }
     block_reduce2(a, b, sh);
     if (threadIdx.x == 0) {
-        part[((size_t)c * nslice + s) * 2 + 0] = (float)a;
-        part[((size_t)c * nslice + s) * 2 + 1] = (float)b;
+        part[((size_t)c * nslice + s) * 2 + 0] = a;
+        part[((size_t)c * nslice + s) * 2 + 1] = b;
     }
 }
 

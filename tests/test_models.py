@@ -438,7 +438,7 @@ def test_building_blocks_train_mode_pinned_against_fp64_on_gpu(name):
     if name.endswith("upernet_fpn"):
         assert r["pgrad_wo1_where"].startswith("conv_last"), r         # the flipped activation is the fusion convolution's
     # ReLU decisions at activations within fp32 round-off of zero go either way in ANY fp32 implementation, and every change of
-    # rounding moves them to other pixels (round 5: the norm kernels without packed FP32, statistics accumulated in double).  The
+    # rounding moves them to other pixels (round 5: the norm kernels without packed FP32).  The
     # stock ATen / MIOpen kernels on the same GPU, same fixtures, against the same fp64 record (tools: _module_under_test built for
     # the CPU, moved to the GPU): layer1 dx 2.2e-5 / pgrad 1.2e-2 (7.3e-3 without the worst channel), stage4 dx 6.4e-3 / pgrad
     # 2.4e-2 (5.5e-3), fuse_chain pgrad 5.9e-3 (4.7e-3).  The bars therefore hold for everything but ONE pixel neighbourhood per
