@@ -41,7 +41,17 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #ifndef DCL_CONV_PROBE
 #define DCL_CONV_PROBE 0
 #endif
-#define DCL_MFMA(A, B, C) ((DCL_CONV_PROBE & 1) ? (C) : __builtin_amdgcn_mfma_f32_32x32x16_f16((A), (B), (C), 0, 0, 0))
+// (bit 16, tools/probes/pk_mix.py: no matrix instruction, but operands A and B stay in use -- the LDS reads, weight loads and splits
+// that feed the MFMAs are all still there)
+__device__ __forceinline__ f32x16 dcl_fake_mfma(half8 a, half8 b, f32x16 c)
+{
+    c[0] += (float)a[0] * (float)b[0];
+    c[1] += (float)a[7] * (float)b[7];
+    return c;
+}
+#define DCL_MFMA(A, B, C)                                                                              \
+    ((DCL_CONV_PROBE & 1) ? (C) : (DCL_CONV_PROBE & 16) ? dcl_fake_mfma((A), (B), (C))                 \
+                                                         : __builtin_amdgcn_mfma_f32_32x32x16_f16((A), (B), (C), 0, 0, 0))
 
 constexpr int TW = 32;          // tile width in pixels (one MFMA pixel tile = 1 row x 32 columns)
 constexpr int PIXB = 80;        // bytes per LDS pixel record

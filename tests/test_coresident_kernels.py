@@ -1,10 +1,12 @@
 """Element-wise kernels must return the same bits whatever runs beside them.
 
-On MI355X a wave's packed-FP32 instructions (v_pk_fma_f32 ...) return wrong values in single quarter-waves while another wave on
-the same SIMD issues MFMAs: with the library built WITH packed FP32, 15-25 % of the norm backwards below differed from the one
-computed alone (up to 1e-2 of max) as soon as a matrix kernel of another HIP stream shared the compute units -- the situation of
-every HRNet exchange module (one stream per branch, reference models/HRNet.py:263-267).  The library is therefore built without
-packed FP32 (csrc/Makefile NOPK); this file holds the reproducer as a regression test and checks the build."""
+On MI355X a packed-FP32 instruction whose op_sel takes the high half of src1 for the low result (v_pk_fma_f32 ... op_sel:[0,1,0]:
+the compiler's broadcast of the second of two packed scalars) returns a wrong low result in lanes 48-63 while another wave on the
+same SIMD issues MFMAs with operands still arriving in its registers (stand-alone reproducer: tools/probes/pk_mfma_hazard.hip).  With
+the library built WITH packed FP32, 15-25 % of the norm backwards below differed from the one computed alone (up to 1e-2 of max) as
+soon as a matrix kernel of another HIP stream shared the compute units -- the situation of every HRNet exchange module (one stream
+per branch, reference models/HRNet.py:263-267).  The library is therefore built without packed FP32 (csrc/Makefile NOPK); this file
+holds the library-level reproducer as a regression test and checks the build."""
 import os
 import re
 import subprocess
