@@ -18,18 +18,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "eccv2022-multi-scale-and-cross-scale-contrastive-segmentation_amd", "csrc")
 
 
-def test_library_is_built_without_packed_fp32():
-    """Device assembly of the norm kernels (the ones the finding was made on) and of the resize kernels (explicit two-float vector
-    arithmetic in the source) with the Makefile's own flags: no v_pk_*_f32 instruction."""
+FAULTY_FORM = re.compile(r"\bv_pk_[a-z0-9_]+ .*op_sel:\[[01],1")      # a packed instruction whose LOW result takes src1's HIGH half
+
+
+def test_library_is_built_without_the_faulty_packed_form():
+    """Device assembly with the Makefile's own flags: the norm kernels (the ones the finding was made on) and the resize kernels
+    (explicit two-float vector arithmetic in the source) hold no packed-FP32 instruction at all; the two translation units that
+    keep packed FP32 (csrc/Makefile PACKED: the sweeps, the GEMM) hold none with op_sel[1] set -- the build itself fails otherwise."""
     mk = open(os.path.join(CSRC, "Makefile")).read()
     assert "-packed-fp32-ops" in mk and "$(NOPK)" in mk
+    packed = re.search(r"^PACKED = (.*)$", mk, re.M).group(1).split()
+    assert set(packed) <= {"dcl_sweep", "dcl_gemm"} and "op_sel:" in mk, "new PACKED members need the evidence of DESIGN.md section 7"
     for src in ("dcl_bn", "dcl_resize"):
+        assert src not in packed
         out = subprocess.run(["make", "-C", CSRC, "-B", f"{src}.s"], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr[-2000:]
         asm = open(os.path.join(CSRC, f"{src}.s")).read()
         os.remove(os.path.join(CSRC, f"{src}.s"))
         assert "s_endpgm" in asm
         assert not re.search(r"\bv_pk_(fma|mul|add)_f32\b", asm), f"{src}: packed FP32 instructions in the device code"
+    # the guard's pattern finds the form in a packed build of the norm kernels (8 instructions: the broadcasts of mean_gx)
+    out = subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-S", "--cuda-device-only",
+                          os.path.join(CSRC, "dcl_bn.hip"), "-o", "-"], capture_output=True, text=True)
+    assert out.returncode == 0 and FAULTY_FORM.search(out.stdout), "the packed build of dcl_bn.hip no longer shows the faulty form?"
+    # ... and not in what the build wrote for the PACKED units (present after `make`; the build stops if it ever does)
+    for src in packed:
+        path = os.path.join(CSRC, "build", f"{src}.pk.s")
+        if os.path.exists(path):
+            asm = open(path).read()
+            assert "v_pk_" in asm and not FAULTY_FORM.search(asm), src
 
 
 @pytest.mark.gpu

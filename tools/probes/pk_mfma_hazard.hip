@@ -255,10 +255,30 @@ __global__ __launch_bounds__(256) void k_pk_form(const float *__restrict__ in, u
             asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(p) : "v"(t), "v"(mm));
             asm volatile("v_add_f32 %0, %1, %2" : "=v"(q0) : "v"(t.x), "v"(mm.y));
             asm volatile("v_add_f32 %0, %1, %2" : "=v"(q1) : "v"(t.y), "v"(mm.y));
-        } else {
+        } else if (F == 8) {
             asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(p) : "v"(t), "v"(mm), "v"(w));
             asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q0) : "v"(t.x), "v"(mm.x), "v"(w.y));
             asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q1) : "v"(t.y), "v"(mm.y), "v"(w.y));
+        } else if (F == 9) {            // the op_sel_hi forms the packed builds of dcl_gemm.hip / dcl_sweep.hip contain
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(p) : "v"(t), "v"(mm), "v"(w));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q0) : "v"(t.x), "v"(mm.x), "v"(w.x));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q1) : "v"(t.x), "v"(mm.y), "v"(w.y));
+        } else if (F == 10) {
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(p) : "v"(t), "v"(mm), "v"(w));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q0) : "v"(t.x), "v"(mm.x), "v"(w.x));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q1) : "v"(t.y), "v"(mm.y), "v"(w.x));
+        } else if (F == 11) {
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(p) : "v"(t), "v"(mm), "v"(w));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q0) : "v"(t.x), "v"(mm.x), "v"(w.x));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q1) : "v"(t.y), "v"(mm.x), "v"(w.x));
+        } else if (F == 12) {
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(t), "v"(mm));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q0) : "v"(t.x), "v"(mm.x));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q1) : "v"(t.x), "v"(mm.y));
+        } else {
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(t), "v"(mm));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(q0) : "v"(t.x), "v"(mm.x));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(q1) : "v"(t.y), "v"(mm.x));
         }
         nlo += __float_as_uint(p.x) != __float_as_uint(q0);
         nhi += __float_as_uint(p.y) != __float_as_uint(q1);
@@ -372,7 +392,12 @@ extern "C" int pkh_launch_victim(int op, int blocks, int iters, const float *in,
     else if (op == 15) hipLaunchKernelGGL(k_pk_form<5>, dim3(blocks), dim3(256), 0, st, in, bad, iters);
     else if (op == 16) hipLaunchKernelGGL(k_pk_form<6>, dim3(blocks), dim3(256), 0, st, in, bad, iters);
     else if (op == 17) hipLaunchKernelGGL(k_pk_form<7>, dim3(blocks), dim3(256), 0, st, in, bad, iters);
-    else hipLaunchKernelGGL(k_pk_form<8>, dim3(blocks), dim3(256), 0, st, in, bad, iters);
+    else if (op == 18) hipLaunchKernelGGL(k_pk_form<8>, dim3(blocks), dim3(256), 0, st, in, bad, iters);
+    else if (op == 19) hipLaunchKernelGGL(k_pk_form<9>, dim3(blocks), dim3(256), 0, st, in, bad, iters);
+    else if (op == 20) hipLaunchKernelGGL(k_pk_form<10>, dim3(blocks), dim3(256), 0, st, in, bad, iters);
+    else if (op == 21) hipLaunchKernelGGL(k_pk_form<11>, dim3(blocks), dim3(256), 0, st, in, bad, iters);
+    else if (op == 22) hipLaunchKernelGGL(k_pk_form<12>, dim3(blocks), dim3(256), 0, st, in, bad, iters);
+    else hipLaunchKernelGGL(k_pk_form<13>, dim3(blocks), dim3(256), 0, st, in, bad, iters);
     return (int)hipGetLastError();
 }
 
@@ -544,11 +569,14 @@ int main(int argc, char **argv)
     CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
     const char *aggr[] = {"nothing", "MFMA loop, operands resident in registers (14 tiles)", "MFMA loop, B fragments arriving from LDS",
                           "MFMA loop, B fragments arriving from global memory", "the LDS arrivals with vector FMAs instead of MFMAs"};
-    const int forms[] = {0, 1, 6, 7, 5, 8};
+    const int forms[] = {0, 1, 6, 7, 5, 8, 4, 9, 10, 11, 12, 13};
     const char *fname[] = {"v_pk_fma_f32 (plain)", "v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_mul_f32 op_sel:[0,1]", "v_pk_add_f32 op_sel:[0,1]",
-                           "v_pk_fma_f32 op_sel:[1,0,0]", "v_pk_fma_f32 op_sel:[0,0,1]"};
-    for (int ag = 0; ag < 5; ++ag)
-        for (int f = 0; f < 6; ++f) {
+                           "v_pk_fma_f32 op_sel:[1,0,0]", "v_pk_fma_f32 op_sel:[0,0,1]", "v_pk_fma_f32 op_sel_hi:[1,0,1]",
+                           "v_pk_fma_f32 op_sel_hi:[0,1,1]", "v_pk_fma_f32 op_sel_hi:[1,1,0]", "v_pk_fma_f32 op_sel_hi:[1,0,0]",
+                           "v_pk_mul_f32 op_sel_hi:[0,1]", "v_pk_add_f32 op_sel_hi:[1,0]"};
+    const int nag = argc > 2 ? atoi(argv[2]) : 5;              // (2nd argument: only the first n neighbours)
+    for (int ag = (argc > 3 ? atoi(argv[3]) : 0); ag < nag; ++ag)
+        for (int f = 0; f < 12; ++f) {
             CHECK(hipMemset(bad, 0, 128 * 4));
             CHECK(hipDeviceSynchronize());
             for (int r = 0; r < rounds; ++r) {
