@@ -1,5 +1,5 @@
 """Is a whole training step (HRNet-W48 + LossWrapper(CE + DenseContrastiveLossV2_ms), manager path, all streams) reproducible
-BITWISE from run to run?    python tools/probes/step_repro.py [steps=3] [runs=4] [H=128 W=256 batch=2] [config=2|4|5]
+BITWISE from run to run?    python tools/probes/step_repro.py [steps=3] [runs=4] [H=128 W=256 batch=2] [config=2|4|5] [flags=--plain-config,...]
 
 Builds the manager `runs` times from the same seed, takes `steps` optimizer steps on the same resident batch, and compares the
 losses of every step and every parameter / buffer after the last one with the first run."""
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 kv = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 sys.argv = [sys.argv[0], "--height", kv.get("H", "128"), "--width", kv.get("W", "256"), "--batch", kv.get("batch", "2"),
-            "--config", kv.get("config", "2"), "--labels", kv.get("labels", "iid")]
+            "--config", kv.get("config", "2"), "--labels", kv.get("labels", "iid")] + [f for f in kv.get("flags", "").split(",") if f]
 import bench  # noqa: E402
 import mscs_amd  # noqa: F401,E402
 from mscs_amd.managers import HRNetManager, OCRNetManager  # noqa: E402
