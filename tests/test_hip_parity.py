@@ -1851,3 +1851,24 @@ def test_stride2_weight_gradient_lds_dma_form_is_bitwise_the_load_form(dev, shap
                                               [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
     assert ((new.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(5, 32, 1, 12, 24), (5, 32, 2, 12, 32), (12, 48, 1, 9, 16), (3, 32, 1, 10, 16)])
+def test_narrow_input_convolution_weight_gradient_is_deterministic_and_right(dev, cfg):
+    """DirectConv2d with fewer than 16 input channels that is NOT the stem's case (stride 1, or more than 3 channels): the weight
+    gradient takes the split-f16 kernel on channels zero-padded to 16 (models/ops_conv.py) instead of aten::convolution_backward --
+    2e-6 of max from float64, bitwise equal from call to call."""
+    from mscs_amd.models.ops import DirectConv2d
+    ci, co, st, h, w = cfg
+    torch.manual_seed(ci * 10 + st)
+    conv = DirectConv2d(ci, co, 3, st, 1, bias=False).to(dev)
+    x = torch.randn(2, ci, h, w, device=dev, requires_grad=True)
+    assert conv.eligible(x)
+    y = conv(x)
+    gy = torch.randn_like(y)
+    gw = [torch.autograd.grad(y, conv.weight, gy, retain_graph=True)[0] for _ in range(3)]
+    assert torch.equal(gw[0], gw[1]) and torch.equal(gw[0], gw[2])
+    ref = torch.ops.aten.convolution_backward(gy.double(), x.detach().double(), conv.weight.detach().double(), None, [st, st], [1, 1], [1, 1],
+                                              False, [0, 0], 1, [False, True, False])[1]
+    assert ((gw[0].double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+
