@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void k_mfma_pipe(float *__restrict__ out, int 
     bq[0][1] = frag[256 + threadIdx.x];
     for (int i = 0; i < iters; ++i) {
         const int nb = (i + 1) & 1, cb = i & 1;
-        if (MODE == 0 || MODE == 2 || MODE == 3) {
+        if (MODE == 0 || MODE == 2 || MODE >= 3) {
             bq[nb][0] = frag[(threadIdx.x + 7 * i) & 1023];
             bq[nb][1] = frag[(threadIdx.x + 13 * i + 512) & 1023];
         }
@@ -516,6 +516,14 @@ __global__ __launch_bounds__(256) void k_mfma_pipe(float *__restrict__ out, int 
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     acc[t][e] = __builtin_fmaf((float)a8[e], (float)bq[cb][0][e], acc[t][e]) + (float)bq[cb][1][e];
+            } else if (MODE == 4) {                 // LDS arrivals, v_mfma_f32_16x16x32_f16 (the weight gradients' shape)
+                f32x4 c = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, bq[cb][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, bq[cb][1], c, 0, 0, 0);
+                acc[t][0] = c[0]; acc[t][1] = c[1]; acc[t][2] = c[2]; acc[t][3] = c[3];
+            } else if (MODE == 5) {                 // LDS arrivals, v_mfma_f32_32x32x2f32 (fp32 matrix instructions)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)a8[0], (float)bq[cb][0][0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)a8[1], (float)bq[cb][1][0], acc[t], 0, 0, 0);
             } else {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, bq[cb][0], acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, bq[cb][1], acc[t], 0, 0, 0);
@@ -535,7 +543,9 @@ extern "C" int pkh_launch_pipe(int mode, int blocks, int iters, float *out, cons
     if (mode == 0) hipLaunchKernelGGL(k_mfma_pipe<0>, dim3(blocks), dim3(256), 0, st, out, iters, rnd);
     else if (mode == 1) hipLaunchKernelGGL(k_mfma_pipe<1>, dim3(blocks), dim3(256), 0, st, out, iters, rnd);
     else if (mode == 2) hipLaunchKernelGGL(k_mfma_pipe<2>, dim3(blocks), dim3(256), 0, st, out, iters, rnd);
-    else hipLaunchKernelGGL(k_mfma_pipe<3>, dim3(blocks), dim3(256), 0, st, out, iters, rnd);
+    else if (mode == 3) hipLaunchKernelGGL(k_mfma_pipe<3>, dim3(blocks), dim3(256), 0, st, out, iters, rnd);
+    else if (mode == 4) hipLaunchKernelGGL(k_mfma_pipe<4>, dim3(blocks), dim3(256), 0, st, out, iters, rnd);
+    else hipLaunchKernelGGL(k_mfma_pipe<5>, dim3(blocks), dim3(256), 0, st, out, iters, rnd);
     return (int)hipGetLastError();
 }
 
@@ -568,7 +578,8 @@ int main(int argc, char **argv)
     CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
     const char *aggr[] = {"nothing", "MFMA loop, operands resident in registers (14 tiles)", "MFMA loop, B fragments arriving from LDS",
-                          "MFMA loop, B fragments arriving from global memory", "the LDS arrivals with vector FMAs instead of MFMAs"};
+                          "MFMA loop, B fragments arriving from global memory", "the LDS arrivals with vector FMAs instead of MFMAs",
+                          "v_mfma_f32_16x16x32_f16 loop, LDS arrivals", "v_mfma_f32_32x32x2f32 loop, LDS arrivals"};
     const int forms[] = {0, 1, 6, 7, 5, 8, 4, 9, 10, 11, 12, 13};
     const char *fname[] = {"v_pk_fma_f32 (plain)", "v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_mul_f32 op_sel:[0,1]", "v_pk_add_f32 op_sel:[0,1]",
                            "v_pk_fma_f32 op_sel:[1,0,0]", "v_pk_fma_f32 op_sel:[0,0,1]", "v_pk_fma_f32 op_sel_hi:[1,0,1]",
@@ -585,6 +596,8 @@ int main(int argc, char **argv)
                     if (ag == 2) pkh_launch_pipe(0, blocks, 6000, out, rnd, sb);
                     if (ag == 3) pkh_launch_pipe(1, blocks, 6000, out, rnd, sb);
                     if (ag == 4) pkh_launch_pipe(3, blocks, 6000, out, rnd, sb);
+                    if (ag == 5) pkh_launch_pipe(4, blocks, 6000, out, rnd, sb);
+                    if (ag == 6) pkh_launch_pipe(5, blocks, 6000, out, rnd, sb);
                 }
                 for (int k = 0; k < 6; ++k)
                     pkh_launch_victim(10 + forms[f], blocks, 2000, in, bad, sa);
