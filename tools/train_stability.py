@@ -11,9 +11,10 @@ from mscs_amd.utils import set_verbosity  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 set_verbosity(40)
-class A:  # the benchmark's defaults at a smaller batch so that 40 steps finish quickly
-    batch, height, width, scales, no_cross, channels_last, branch_conv = 4, 512, 1024, 3, False, False, "f16x3"
-    materialize_logits, head_conv, conv1x1, config, classes = False, "direct", "f16x3", 2, 20
+_argv = sys.argv
+sys.argv = [sys.argv[0], "--batch", "4"]       # the benchmark's defaults at a smaller batch so that the run finishes quickly
+A = bench.parse()
+sys.argv = _argv
 cfg = bench.step_config(A, 1)
 cfg["train"]["learning_rate"] = 0.02
 mgr = HRNetManager(cfg, autostart=False)
