@@ -51,16 +51,27 @@ __device__ inline void block_reduce2(float &a, float &b, float *sh)
 // E[x-p]^2 does not cancel catastrophically when |mean| >> std (plain sums: 25 % error in var at mean 50, std 0.1
 // over 393k elements).  The pivot actually used is copied to pivot_out for the apply kernel (the running mean itself
 // is updated there, concurrently with other workgroups' prologues).
+// MM: the slice's extrema of the RAW values as well, mm[(c * nslice + s) * 2 + {0,1}] = {min x, max x} -- for consumers that
+// apply the norm's map on the fly (dcl_conv3x3_pre.hip) and need max|relu(sc x + sh)| without the mapped tensor: the map is
+// monotone per channel, so the channel's extrema give it exactly (k_bn_finalize_pre).
+// TAIL (with MM): the workgroup's four results leave as agent-scope stores and the workgroup reports to the caller (thread 0:
+// {sum, sum of squares, min, max} in res) instead of writing them plainly -- k_bn_stats_pre, below.
+template <bool MM = false, bool TAIL = false>
 __device__ __forceinline__ void bn_stats_body(const float *__restrict__ x, int N, int C,
                                               int HW, int nslice, float *__restrict__ part,
                                               const float *__restrict__ pivot_src,
-                                              float *__restrict__ pivot_out, const int c, const int s)
+                                              float *__restrict__ pivot_out, const int c, const int s,
+                                              float *__restrict__ mm = nullptr, float *pv_out = nullptr)
 {
+    static_assert(!TAIL || MM, "tail form: with extrema");
     __shared__ float sh[8];
     const float pv = pivot_src ? pivot_src[c] : 0.f;
     if (pivot_out && s == 0 && threadIdx.x == 0)
         pivot_out[c] = pv;
+    if (TAIL)
+        *pv_out = pv;
     float a = 0.f, b = 0.f;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
     const int hw4 = (HW & 3) ? 0 : (HW >> 2);      // 16-B loads only when every plane base is 16-B aligned
     for (int n = s; n < N; n += nslice) {
         const float *p = x + ((size_t)n * C + c) * HW;
@@ -68,6 +79,12 @@ __device__ __forceinline__ void bn_stats_body(const float *__restrict__ x, int N
         int i = threadIdx.x;
         for (; i + 3 * BN_THREADS < hw4; i += 4 * BN_THREADS) {       // four independent 16-byte loads in flight
             f32x4 v0 = p4[i], v1 = p4[i + BN_THREADS], v2 = p4[i + 2 * BN_THREADS], v3 = p4[i + 3 * BN_THREADS];
+            if (MM) {
+                lo = fminf(fminf(fminf(lo, fminf(v0.x, v0.y)), fminf(fminf(v0.z, v0.w), fminf(v1.x, v1.y))),
+                           fminf(fminf(fminf(v1.z, v1.w), fminf(v2.x, v2.y)), fminf(fminf(v2.z, v2.w), fminf(fminf(v3.x, v3.y), fminf(v3.z, v3.w)))));
+                hi = fmaxf(fmaxf(fmaxf(hi, fmaxf(v0.x, v0.y)), fmaxf(fmaxf(v0.z, v0.w), fmaxf(v1.x, v1.y))),
+                           fmaxf(fmaxf(fmaxf(v1.z, v1.w), fmaxf(v2.x, v2.y)), fmaxf(fmaxf(v2.z, v2.w), fmaxf(fmaxf(v3.x, v3.y), fmaxf(v3.z, v3.w)))));
+            }
             v0.x -= pv; v0.y -= pv; v0.z -= pv; v0.w -= pv;
             v1.x -= pv; v1.y -= pv; v1.z -= pv; v1.w -= pv;
             v2.x -= pv; v2.y -= pv; v2.z -= pv; v2.w -= pv;
@@ -81,11 +98,19 @@ __device__ __forceinline__ void bn_stats_body(const float *__restrict__ x, int N
         }
         for (; i < hw4; i += BN_THREADS) {
             f32x4 v = p4[i];
+            if (MM) {
+                lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+                hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            }
             v.x -= pv; v.y -= pv; v.z -= pv; v.w -= pv;
             a += (v.x + v.y) + (v.z + v.w);
             b += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
         for (int i = (hw4 << 2) + threadIdx.x; i < HW; i += BN_THREADS) {
+            if (MM) {
+                lo = fminf(lo, p[i]);
+                hi = fmaxf(hi, p[i]);
+            }
             const float v = p[i] - pv;
             a += v;
             b += v * v;
@@ -93,9 +118,44 @@ __device__ __forceinline__ void bn_stats_body(const float *__restrict__ x, int N
     }
     block_reduce2(a, b, sh);
     if (threadIdx.x == 0) {
-        part[((size_t)c * nslice + s) * 2 + 0] = a;
-        part[((size_t)c * nslice + s) * 2 + 1] = b;
+        if (TAIL) {
+            __hip_atomic_store(part + ((size_t)c * nslice + s) * 2 + 0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part + ((size_t)c * nslice + s) * 2 + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            part[((size_t)c * nslice + s) * 2 + 0] = a;
+            part[((size_t)c * nslice + s) * 2 + 1] = b;
+        }
     }
+    if (MM) {
+        __shared__ float shm[8];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            shm[threadIdx.x >> 6] = lo;
+            shm[4 + (threadIdx.x >> 6)] = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float l = fminf(fminf(shm[0], shm[1]), fminf(shm[2], shm[3])), h = fmaxf(fmaxf(shm[4], shm[5]), fmaxf(shm[6], shm[7]));
+            if (TAIL) {
+                __hip_atomic_store(mm + ((size_t)c * nslice + s) * 2 + 0, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mm + ((size_t)c * nslice + s) * 2 + 1, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                mm[((size_t)c * nslice + s) * 2 + 0] = l;
+                mm[((size_t)c * nslice + s) * 2 + 1] = h;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void k_bn_stats_mm(const float *__restrict__ x, int N, int C, int HW, int nslice,
+                                                           float *__restrict__ part, const float *__restrict__ pivot_src,
+                                                           float *__restrict__ pivot_out, float *__restrict__ mm)
+{
+    bn_stats_body<true>(x, N, C, HW, nslice, part, pivot_src, pivot_out, blockIdx.x, blockIdx.y, mm);
 }
 
 __global__ __launch_bounds__(BN_THREADS) void k_bn_stats(const float *__restrict__ x, int N, int C,
@@ -229,6 +289,7 @@ struct BnFused {
 // norm + residual + ReLU reads it instead of y (whose values it needs only for the sign).
 __device__ __forceinline__ size_t relu_mask_word(size_t plane, int hw4, int iv) { return (plane * (hw4 >> 6) + (iv >> 6)) * 4; }
 
+template <bool AGENT = false>
 __device__ __forceinline__ void part_sums(const float *part, int c, int ns, float &a, float &b)
 {
     // eight slices per trip, their loads issued together (clamped: no branch around a load), added in slice order -- the same
@@ -240,7 +301,7 @@ __device__ __forceinline__ void part_sums(const float *part, int c, int ns, floa
         float2 v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (DCL_BN_PROBE & 1) {
+            if (AGENT || (DCL_BN_PROBE & 1)) {
                 const float *q = (const float *)(p + min(s + i, ns - 1));
                 v[i] = float2{ld_agent(q), ld_agent(q + 1)};
             } else {
@@ -405,6 +466,105 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_apply(const float *__restrict
                                                         BnFused f, int N, unsigned nchunk)
 {
     bn_apply_body<RELU, RES>(x, res, mean, invstd, gamma, beta, C, HW, y, amax, f, N, nchunk, blockIdx.x);
+}
+
+// The statistics' finalisation WITHOUT the apply pass, for a consumer that forms relu(x sc + sh) itself while it stages x
+// (dcl_conv3x3_pre.hip, the weight-gradient kernels' PRE forms): thread = channel.  mean / invstd / running statistics / sc / sh are
+// the apply kernel's prologue, operation for operation (part_sums, the double-precision mean and variance, bn_shift), so that the
+// consumer's fma reproduces the values k_bn_apply<true,false> would have written bit for bit, and so does the backward kernels'
+// recomputed ReLU mask.  amax: max over this rank's values of relu(x sc + sh) per channel -- the map is monotone in x, so it is
+// the map of one of the channel's two extrema -- max-ed into slot c % DCL_AMAX_SLOTS (integer atomicMax on non-negative floats:
+// order-independent), the same side channel the apply kernel feeds.
+struct BnPre {
+    const float *gamma, *beta;
+    double count;
+    float eps, momentum;
+    float *mean, *invstd, *running_mean, *running_var;
+    long long *batches_tracked;
+    float *sc, *sh, *amax;
+};
+
+// AGENT: the partial results were written by OTHER workgroups of the running launch (k_bn_stats_pre): agent-scope loads
+template <bool AGENT>
+__device__ __forceinline__ void bn_finalize_pre_channel(const float *part, const float *mm, int ns, int c, float pv, const BnPre &f)
+{
+    const double count = f.count;
+    const float eps = f.eps, momentum = f.momentum;
+    const float *gamma = f.gamma, *beta = f.beta;
+    float *mean = f.mean, *invstd = f.invstd, *running_mean = f.running_mean, *running_var = f.running_var;
+    long long *batches_tracked = f.batches_tracked;
+    float *sc_out = f.sc, *sh_out = f.sh, *amax = f.amax;
+    float a, b;
+    part_sums<AGENT>(part, c, ns, a, b);
+    const double ms = (double)a / count;
+    double var = (double)b / count - ms * ms;
+    var = var > 0.0 ? var : 0.0;
+    const double m = ms + (double)pv;
+    const float mean_f = (float)m, invstd_f = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = mean_f;
+    invstd[c] = invstd_f;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+    if (c == 0 && batches_tracked)
+        batches_tracked[0] += 1;
+    const float sc = invstd_f * (gamma ? gamma[c] : 1.f);
+    const float sh = bn_shift(beta ? beta[c] : 0.f, mean_f, sc);
+    sc_out[c] = sc;
+    sh_out[c] = sh;
+    if (amax) {
+        float lo = __builtin_inff(), hi = -__builtin_inff();
+        for (int i0 = 0; i0 < ns; i0 += 8) {
+            float l[8], h[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float *q = mm + ((size_t)c * ns + min(i0 + i, ns - 1)) * 2;
+                l[i] = AGENT ? ld_agent(q) : q[0];
+                h[i] = AGENT ? ld_agent(q + 1) : q[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                lo = fminf(lo, l[i]);
+                hi = fmaxf(hi, h[i]);
+            }
+        }
+        const float y = fmaxf(fmaxf(bn_eval(lo, sc, sh), bn_eval(hi, sc, sh)), 0.f);
+        atomicMax((unsigned int *)(amax + (c & (DCL_AMAX_SLOTS - 1))), __float_as_uint(y));
+    }
+}
+
+__global__ __launch_bounds__(64) void k_bn_finalize_pre(const float *__restrict__ part, const float *__restrict__ mm, int ns, int C,
+                                                       const float *__restrict__ pivot, BnPre f)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C)
+        return;
+    bn_finalize_pre_channel<false>(part, mm, ns, c, pivot ? pivot[c] : 0.f, f);
+}
+
+// Statistics AND their finalisation in one launch (one rank: nothing to exchange in between): workgroup (c, s) publishes its four
+// partial results with agent-scope stores, waits for them to be acknowledged, and takes a ticket of channel c (an agent-scope
+// counter that starts at zero); the workgroup that draws the LAST ticket of the channel finalises it (bn_finalize_pre_channel
+// on agent-scope loads: the other workgroups' results come from memory, not from this XCD's L2) -- same sums in the same order
+// as k_bn_finalize_pre, bitwise the same outputs, without the ~5 us of a 64-thread launch between the statistics and the
+// convolution that waits for the map.  The pivot (the running mean) is read by every workgroup of the channel before it takes
+// its ticket, so the last one may update it.
+__global__ __launch_bounds__(BN_THREADS) void k_bn_stats_pre(const float *__restrict__ x, int N, int C, int HW, int nslice,
+                                                            float *__restrict__ part, float *__restrict__ mm,
+                                                            const float *__restrict__ pivot_src, unsigned *__restrict__ tickets,
+                                                            BnPre f)
+{
+    const int c = blockIdx.x, s = blockIdx.y;
+    float pv;
+    bn_stats_body<true, true>(x, N, C, HW, nslice, part, pivot_src, nullptr, c, s, mm, &pv);
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(tickets + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned)nslice - 1u)
+            bn_finalize_pre_channel<true>(part, mm, nslice, c, pv, f);
+    }
 }
 
 // part[(c*nslice + s)*2 + {0,1}] = {sum g, sum g * xhat},  g = dy * (y > 0 if RELU)
@@ -890,6 +1050,55 @@ extern "C" int dcl_bn_stats_part(const float *x, int N, int C, int HW, float *pa
     const int ns = pick_slices(N, C);
     hipLaunchKernelGGL(k_bn_stats, dim3(C, ns), dim3(BN_THREADS), 0, (hipStream_t)stream, x, N, C, HW, ns, part, pivot_src,
                        pivot_out);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// Statistics pass for a norm whose normalised output is NOT written (its consumer applies the map while staging the input):
+// dcl_bn_stats_part plus the per-slice extrema of x, mm f32 [C * dcl_bn_num_slices(N, C) * 2] = {min, max}.
+extern "C" int dcl_bn_stats_minmax_part(const float *x, int N, int C, int HW, float *part, float *mm, const float *pivot_src,
+                                        float *pivot_out, void *stream)
+{
+    DCL_CHECK_ARG(x && part && mm && N > 0 && C > 0 && HW > 0, "bad arguments");
+    DCL_CHECK_ARG((pivot_src == nullptr) == (pivot_out == nullptr), "pivot_src and pivot_out go together");
+    const int ns = pick_slices(N, C);
+    hipLaunchKernelGGL(k_bn_stats_mm, dim3(C, ns), dim3(BN_THREADS), 0, (hipStream_t)stream, x, N, C, HW, ns, part, pivot_src,
+                       pivot_out, mm);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ... and its finalisation: what dcl_bn_apply_parts does apart from writing y (see k_bn_finalize_pre).
+extern "C" int dcl_bn_finalize_pre(const float *part, const float *mm, int ns, double count, float eps, float momentum,
+                                   const float *gamma, const float *beta, int C, float *mean, float *invstd,
+                                   float *running_mean, float *running_var, int64_t *batches_tracked, const float *pivot,
+                                   float *pre_sc, float *pre_sh, float *amax, void *stream)
+{
+    DCL_CHECK_ARG(part && mean && invstd && pre_sc && pre_sh && C > 0 && ns >= 1 && ns <= 64 && count > 0.0, "bad arguments");
+    DCL_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var go together");
+    DCL_CHECK_ARG(amax == nullptr || mm != nullptr, "amax needs the extrema");
+    const BnPre f{gamma, beta, count, eps, momentum, mean, invstd, running_mean, running_var, (long long *)batches_tracked,
+                  pre_sc, pre_sh, amax};
+    hipLaunchKernelGGL(k_bn_finalize_pre, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, mm, ns, C, pivot, f);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// dcl_bn_stats_minmax_part + dcl_bn_finalize_pre in ONE launch, for one rank (no exchange between the two): see k_bn_stats_pre.
+// tickets: C zero-initialised 32-bit words (left at dcl_bn_num_slices(N, C) each); the pivot of the sums is running_mean (NULL: 0).
+extern "C" int dcl_bn_stats_pre(const float *x, int N, int C, int HW, float *part, float *mm, void *tickets, double count, float eps,
+                                float momentum, const float *gamma, const float *beta, float *mean, float *invstd,
+                                float *running_mean, float *running_var, int64_t *batches_tracked, float *pre_sc, float *pre_sh,
+                                float *amax, void *stream)
+{
+    DCL_CHECK_ARG(x && part && mm && tickets && mean && invstd && pre_sc && pre_sh && N > 0 && C > 0 && HW > 0 && count > 0.0,
+                  "bad arguments");
+    DCL_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running_mean and running_var go together");
+    const int ns = pick_slices(N, C);
+    const BnPre f{gamma, beta, count, eps, momentum, mean, invstd, running_mean, running_var, (long long *)batches_tracked,
+                  pre_sc, pre_sh, amax};
+    hipLaunchKernelGGL(k_bn_stats_pre, dim3(C, ns), dim3(BN_THREADS), 0, (hipStream_t)stream, x, N, C, HW, ns, part, mm,
+                       running_mean, (unsigned *)tickets, f);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -14,6 +14,7 @@ struct WgradArgs {
     int wave_mode;               // 1: S pixel splits per pair dealt out to WAVES (k_wgrad3x3d<.., true>), one slab per split
     int band;                    // rows per column of the traversal (H, or a divisor of H: wave form, see k_wgrad3x3d)
     int grp;                     // 1 | 2 | 4: the waves of a workgroup walk `grp` ADJACENT strips over the same rows (k_wgrad3x3d)
+    const float *pre_sc, *pre_sh;   // k_wgrad3x3d PRE forms: the operand is relu(x * pre_sc[ci] + pre_sh[ci]); NULL otherwise
 };
 
 // dcl_wgrad3x3d.hip: the stride-1 kernel with LDS-DMA operand staging; same grid, slabs and arguments as k_wgrad3x3

@@ -622,9 +622,44 @@ extern "C" int dcl_wgrad3x3_splits(int N, int Cin, int Cout, int H, int W, int s
     return nco * nci <= 4 ? (S + 3) / 4 : S;      // one slab per workgroup (4 splits), or per wave (6-tile variant)
 }
 
+static int wgrad3x3_impl(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax, int xcount,
+                         const float *gamax, int gcount, int stride, float *part, float *dw, void *stream, const float *pre_sc,
+                         const float *pre_sh);
+
 extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W,
                                   const float *xamax, int xcount, const float *gamax, int gcount, int stride,
                                   float *part, float *dw, void *stream)
+{
+    return wgrad3x3_impl(x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, stride, part, dw, stream, nullptr, nullptr);
+}
+
+// 1 when dcl_wgrad3x3_pre_f16x3 serves the shape: stride 1 on the LDS-DMA kernel (the slab count is dcl_wgrad3x3_splits(..., 1))
+extern "C" int dcl_wgrad3x3_pre_supported(int N, int Cin, int Cout, int H, int W)
+{
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cin & 15) || (Cout & 15) || (W & 7))
+        return 0;
+    int nco, nci, S, units;
+    wgrad_plan(N, Cin, Cout, H, W, nco, nci, S, units);
+    return use_dma(Cin > Cout ? Cin : Cout, H, W) && dcl_wgrad_dma_supported(nco, nci) ? 1 : 0;
+}
+
+// The weight gradient of conv2d(relu(x * pre_sc[ci] + pre_sh[ci]), w, padding = 1) for the output gradient dy: x is the RAW
+// tensor in front of the norm, xamax the absmax slots of the mapped tensor (dcl_bn_finalize_pre); see k_wgrad3x3d, PRE.
+extern "C" int dcl_wgrad3x3_pre_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W,
+                                      const float *xamax, int xcount, const float *gamax, int gcount, const float *pre_sc,
+                                      const float *pre_sh, float *part, float *dw, void *stream)
+{
+    DCL_CHECK_ARG(pre_sc && pre_sh, "null pointer");
+    if (!dcl_wgrad3x3_pre_supported(N, Cin, Cout, H, W)) {
+        dcl_set_error("dcl_wgrad3x3_pre_f16x3: shape not served by the LDS-DMA kernel");
+        return DCL_EUNSUPPORTED;
+    }
+    return wgrad3x3_impl(x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, 1, part, dw, stream, pre_sc, pre_sh);
+}
+
+static int wgrad3x3_impl(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax, int xcount,
+                         const float *gamax, int gcount, int stride, float *part, float *dw, void *stream, const float *pre_sc,
+                         const float *pre_sh)
 {
     DCL_CHECK_ARG(stride == 1 || stride == 2, "stride must be 1 or 2");
     DCL_CHECK_ARG(x && dy && xamax && gamax && part && dw, "null pointer");
@@ -660,6 +695,8 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     a.Wd = stride == 2 ? W / 2 : W;
     a.strips = (W + 31) / 32;
     a.nseg = 1;
+    a.pre_sc = pre_sc;
+    a.pre_sh = pre_sh;
     int nco, nci;
     bool wm = false;
     wgrad_plan(N, Cin, Cout, H, W, nco, nci, a.S, a.units,

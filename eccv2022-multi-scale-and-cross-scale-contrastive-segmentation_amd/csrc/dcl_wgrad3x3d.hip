@@ -94,7 +94,13 @@ constexpr bool g_wgrad_spread = DCL_WG_SPREAD != 0;      // LDS-DMA instructions
 // wave_mode 2: pair fastest, so the four waves of a workgroup walk the same pixels for four neighbouring pairs (shared dY rows
 // hit in the CU's L1: 1.89 ms against 1.99 with split fastest, 2.83 with a workgroup per pair on 12 x (144 -> 720) x 128 x 256) --
 // and a wave writes its own slab (no LDS reduction: the four waves of a workgroup belong to different pairs).
-template <int NCO, int NCI, bool WAVE = false>
+//
+// PRE: x is the RAW output z of the convolution in front of a training-mode norm and the operand is relu(z sc[ci] + sh[ci]) --
+// the weight gradient of the BasicBlock's conv2 (reference models/HRNet.py:77-93) without the normalised tensor in memory
+// (dcl_conv3x3_pre.hip has the forward).  A lane converts values of ONE input channel per ci tile (row j of the tile), so the
+// map costs two registers per tile and one fma + one max per value in front of the split; the halo values and the pixels past
+// the row end are masked through the operand scale, i.e. after the map.
+template <int NCO, int NCI, bool WAVE = false, bool PRE = false>
 __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
 {
     constexpr int NIA = (NCO * 16 * APIECES + 63) / 64, NIB = (NCI * 16 * BPIECES + 63) / 64, NI = NIA + NIB;
@@ -179,6 +185,14 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
 #pragma unroll
     for (int u = 0; u < NCI; ++u)
         ci_ok[u] = ci0 + 16 * u < a.Cin;
+    float psc[NCI], psh[NCI];               // PRE: the norm's map of this lane's channel of ci tile u
+#pragma unroll
+    for (int u = 0; u < NCI; ++u) {
+        const int ch = ci_ok[u] ? ci0 + 16 * u + j : ci0 + j;
+        psc[u] = PRE ? a.pre_sc[ch] : 1.f;
+        psh[u] = PRE ? a.pre_sh[ch] : 0.f;
+    }
+    auto pre = [&](float v, int u) { return PRE ? fmaxf(__builtin_fmaf(v, psc[u], psh[u]), 0.f) : v; };
 
     // staging geometry of this lane, per DMA instruction m: which (tile, row, piece) of the slot image it carries
     // (piece = 64 m + lane in [tile][row][piece] order; the tail of the last instruction repeats piece 0)
@@ -310,15 +324,15 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3d(WgradArgs a)
                 const float sc = ci_ok[u] ? sx_c : 0.f, sl = ci_ok[u] ? sx_l : 0.f, sr = ci_ok[u] ? sx_r : 0.f;
                 unsigned h[5], q[5];
                 unsigned hl, ql, hr, qr, hm, qm;
-                split1(l[u], sl, hl, ql);
-                split1(src[u][0].x, sc, hm, qm);
+                split1(pre(l[u], u), sl, hl, ql);
+                split1(pre(src[u][0].x, u), sc, hm, qm);
                 h[0] = __builtin_amdgcn_perm(hm, hl, 0x05040100u);
                 q[0] = __builtin_amdgcn_perm(qm, ql, 0x05040100u);
-                split2(src[u][0].y, src[u][0].z, sc, h[1], q[1]);
-                split2(src[u][0].w, src[u][1].x, sc, h[2], q[2]);
-                split2(src[u][1].y, src[u][1].z, sc, h[3], q[3]);
-                split1(src[u][1].w, sc, hm, qm);
-                split1(rr[u], sr, hr, qr);
+                split2(pre(src[u][0].y, u), pre(src[u][0].z, u), sc, h[1], q[1]);
+                split2(pre(src[u][0].w, u), pre(src[u][1].x, u), sc, h[2], q[2]);
+                split2(pre(src[u][1].y, u), pre(src[u][1].z, u), sc, h[3], q[3]);
+                split1(pre(src[u][1].w, u), sc, hm, qm);
+                split1(pre(rr[u], u), sr, hr, qr);
                 h[4] = __builtin_amdgcn_perm(hr, hm, 0x05040100u);
                 q[4] = __builtin_amdgcn_perm(qr, qm, 0x05040100u);
                 unsigned a1h[4], a1l[4];
@@ -843,6 +857,24 @@ bool dcl_wgrad_dma_wave_mode_supported(int nco, int nci) { return nco == 3 && nc
 
 void dcl_wgrad_dma_launch(const WgradArgs &a, int nco, int nci, dim3 grid, hipStream_t s)
 {
+    if (a.pre_sc) {             // the input operand through the producer norm's map + ReLU (k_wgrad3x3d, PRE)
+        if (a.wave_mode) {
+            hipLaunchKernelGGL((k_wgrad3x3d<3, 1, true, true>), dim3(256), dim3(256), 0, s, a);
+            dcl_note_kernel("k_wgrad3x3d_pre<3,1,true>");
+            return;
+        }
+#define DCL_WGD_CASE(o, i)       \
+    if (nco == o && nci == i)    \
+        hipLaunchKernelGGL((k_wgrad3x3d<o, i, false, true>), grid, dim3(256), 0, s, a);
+        DCL_WGD_CASE(2, 2)
+        DCL_WGD_CASE(1, 2)
+        DCL_WGD_CASE(3, 1)
+        DCL_WGD_CASE(2, 1)
+        DCL_WGD_CASE(1, 1)
+#undef DCL_WGD_CASE
+        dcl_note_kernel("k_wgrad3x3d_pre<%d,%d,false>", nco, nci);
+        return;
+    }
     if (a.wave_mode) {
         hipLaunchKernelGGL((k_wgrad3x3d<3, 1, true>), dim3(256), dim3(256), 0, s, a);
         dcl_note_kernel("k_wgrad3x3d<3,1,true>");

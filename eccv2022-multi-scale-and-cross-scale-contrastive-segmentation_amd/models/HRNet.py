@@ -97,6 +97,13 @@ def _side_streams(device, n):
     return have[:n]
 
 
+def _defers(bn, z, conv):
+    """conv(relu(bn(z))) without the normalised tensor: the norm is a fused one on its training path and the convolution
+    says it applies the map itself (DirectConv2d.fuses_input_norm)."""
+    return (isinstance(bn, FusedBatchNorm2d) and isinstance(conv, DirectConv2d) and bn._fusable(z, None)
+            and conv.fuses_input_norm(z))
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -119,9 +126,11 @@ class BasicBlock(nn.Module):
         if _FUSE_RESIDUAL_GRAD and self.downsample is None and isinstance(self.conv1, DirectConv2d) \
                 and isinstance(self.bn2, FusedBatchNorm2d) and self.conv1.fuses_residual_grad(x):
             tok = GradToken()
-            out = bn_act(self.bn1, self.conv1(x, grad_token=tok))
+            out = self.conv1(x, grad_token=tok)
         else:
-            out = bn_act(self.bn1, self.conv1(x))
+            out = self.conv1(x)
+        # bn1 + ReLU inside conv2's operand staging when conv2 takes it: the normalised tensor is never written
+        out = bn_act(self.bn1, out, defer=_defers(self.bn1, out, self.conv2))
         return bn_act(self.bn2, self.conv2(out), residual=identity, grad_token=tok)
 
 
@@ -149,9 +158,10 @@ class Bottleneck(nn.Module):
         if _FUSE_RESIDUAL_GRAD and self.downsample is None and isinstance(self.conv1, DirectConv2d) \
                 and isinstance(self.bn3, FusedBatchNorm2d) and self.conv1.fuses_residual_grad(x):
             tok = GradToken()
-            out = bn_act(self.bn1, self.conv1(x, grad_token=tok))
+            out = self.conv1(x, grad_token=tok)
         else:
-            out = bn_act(self.bn1, self.conv1(x))
+            out = self.conv1(x)
+        out = bn_act(self.bn1, out, defer=_defers(self.bn1, out, self.conv2))
         out = bn_act(self.bn2, self.conv2(out))
         return bn_act(self.bn3, self.conv3(out), residual=identity, grad_token=tok)
 
@@ -276,7 +286,8 @@ class HighResolutionModule(nn.Module):
                     else:
                         z.append(blk.conv1(cur[b]))
                     toks.append(tok)
-            a = bn_act_group([blk.bn1 for blk in blocks], z, relu=True, streams=streams)
+            a = bn_act_group([blk.bn1 for blk in blocks], z, relu=True, streams=streams,
+                             defers=[_defers(blk.bn1, z[b], blk.conv2) for b, blk in enumerate(blocks)])
             z2 = []
             for b, blk in enumerate(blocks):
                 with on(b):

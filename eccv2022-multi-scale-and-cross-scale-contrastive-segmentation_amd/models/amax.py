@@ -64,6 +64,33 @@ def amax_of(t: torch.Tensor) -> torch.Tensor:
     return buf
 
 
+class PreAct:
+    """Marks a tensor whose STORAGE holds the raw input z of a training-mode norm while its VALUE -- for the one consumer that
+    understands the mark, ``DirectConv2d`` -- is ``relu(z * sc[c] + sh[c])``: the normalised tensor of conv1 -> bn1 -> relu ->
+    conv2 (reference models/HRNet.py:77-93) is never written; conv2's forward and weight-gradient kernels apply the map while
+    they stage their operand (csrc/dcl_conv3x3_pre.hip, k_wgrad3x3d PRE).  Only ``FusedBatchNorm2d(..., defer=True)`` creates one,
+    and only after the consumer said it takes it (``DirectConv2d.fuses_input_norm``); anything else that is handed such a tensor
+    must refuse it (``refuse_pre``).  ``amax``: the absmax slots of the mapped tensor."""
+    __slots__ = ("sc", "sh", "amax", "version")
+
+    def __init__(self, sc, sh, amax, version):
+        self.sc, self.sh, self.amax, self.version = sc, sh, amax, version
+
+
+def pre_of(t: torch.Tensor):
+    """The valid PreAct mark of t, or None."""
+    got = getattr(t, "_dcl_pre", None)
+    if got is not None and got.version == t._version:
+        return got
+    return None
+
+
+def refuse_pre(t: torch.Tensor, who: str):
+    if getattr(t, "_dcl_pre", None) is not None:
+        raise RuntimeError(f"{who}: the input is a deferred norm output (its storage holds the norm's INPUT); only a DirectConv2d "
+                           "that answered fuses_input_norm() may consume it")
+
+
 def record_stream(t: torch.Tensor, stream) -> torch.Tensor:
     """``t.record_stream(stream)`` for a tensor that is handed to another HIP stream, including the absmax buffer
     it is tagged with (separate storage, same lifetime hazard with the caching allocator)."""

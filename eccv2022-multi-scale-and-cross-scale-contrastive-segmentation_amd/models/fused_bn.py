@@ -53,7 +53,9 @@ def _check_equal_batch(n, device):
 class _FusedBNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, nbt, eps, momentum, relu, sync, amax,
-                token=None, xmask=False):
+                token=None, xmask=False, pre=None):
+        """``pre`` (a list, filled with [sc, sh]): deferred mode -- statistics and their finalisation only; the output is an alias
+        of x that the caller marks with amax.PreAct (relu, no residual)."""
         ctx.token = token
         ctx.xmask = bool(xmask)     # x is a ReLU output whose backward this norm's backward performs (relu_then_bn)
         L = _lib.lib()
@@ -71,6 +73,34 @@ class _FusedBNFunction(torch.autograd.Function):
         ws = torch.empty((C * ns * 2 + 3 * C,), dtype=torch.float32, device=dev)
         part, mean, invstd = ws[:C * ns * 2], ws[C * ns * 2:C * ns * 2 + C], ws[C * ns * 2 + C:C * ns * 2 + 2 * C]
         pivot = ws[C * ns * 2 + 2 * C:]
+        if pre is not None:
+            assert relu and res is None and not xmask and amax is not None
+            # [mm C*ns*2 | sc C | sh C]: the slices' extrema of x; the map the consumer applies
+            ws2 = torch.empty((C * ns * 2 + 2 * C,), dtype=torch.float32, device=dev)
+            mm, sc, sh = ws2[:C * ns * 2], ws2[C * ns * 2:C * ns * 2 + C], ws2[C * ns * 2 + C:]
+            if world == 1:
+                # one launch: the last workgroup of a channel's statistics finalises the channel (csrc/dcl_bn.hip k_bn_stats_pre)
+                _lib.check(L.dcl_bn_stats_pre(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(mm), _lib.ptr(_amax.zeros(C, dev)),
+                                              count, eps, momentum, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(mean),
+                                              _lib.ptr(invstd), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(nbt),
+                                              _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(amax), st), "dcl_bn_stats_pre")
+            else:
+                _lib.check(L.dcl_bn_stats_minmax_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(mm), _lib.ptr(running_mean),
+                                                      _lib.ptr(pivot), st), "dcl_bn_stats_minmax_part")
+                _check_equal_batch(N, dev)
+                exch = _all_reduce_async(part)
+                exch.wait()
+                _lib.check(L.dcl_bn_finalize_pre(_lib.ptr(part), _lib.ptr(mm), ns, count, eps, momentum, _lib.ptr(weight),
+                                                 _lib.ptr(bias), C, _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(running_mean),
+                                                 _lib.ptr(running_var), _lib.ptr(nbt), _lib.ptr(pivot), _lib.ptr(sc), _lib.ptr(sh),
+                                                 _lib.ptr(amax), st), "dcl_bn_finalize_pre")
+            pre += [sc, sh]
+            ctx.save_for_backward(x, None, weight, bias, mean, invstd)
+            ctx.packed_mask = False
+            ctx.relu, ctx.world, ctx.count = True, world, count
+            ctx.has_res = False
+            ctx.emit_amax = True
+            return x.detach()           # same storage: the consumer maps it on the fly (amax.PreAct)
         _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, HW, _lib.ptr(part), _lib.ptr(running_mean), _lib.ptr(pivot),
                                        st), "dcl_bn_stats_part")
         if world > 1:
@@ -135,13 +165,14 @@ class _FusedBNFunction(torch.autograd.Function):
         if ctx.token is not None:
             # the residual's gradient travels through the token to the convolution that shares the input
             ctx.token.dres, dres = dres, None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 # SyncBatchNorm exchanges issued by this process, and how many of them made the HOST wait (tests / tools read it): on RCCL the
 # wait of an all-reduce orders the calling STREAM behind the collective and returns at once -- 0 host waits; gloo (the CPU
 # stand-in of the two-rank tests) completes on the host
 COLLECTIVES = {"count": 0, "host_waits": 0}
+DEFERRED = {"count": 0}           # norms whose output was not written (defer=True): tests / tools read it
 FORCE_GROUP = False               # tests: take the grouped schedule on ONE rank too (the exchange itself is skipped)
 
 
@@ -206,9 +237,17 @@ class _FusedBNGroupFunction(torch.autograd.Function):
                     stack.record_stream(st)
                 wsb = torch.empty((3 * C,), dtype=torch.float32, device=dev)
                 m['ws'] = wsb
-                _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, H * W, _lib.ptr(stack[offs[k]:]),
-                                               _lib.ptr(m['running_mean']), _lib.ptr(wsb[2 * C:]), _lib.stream_ptr(dev)),
-                           "dcl_bn_stats_part")
+                if m.get('defer'):
+                    # the member's output is not written (see _FusedBNFunction, ``pre``): statistics with the slices' extrema
+                    ns = L.dcl_bn_num_slices(N, C)
+                    m['ws2'] = torch.empty((C * ns * 2 + 2 * C,), dtype=torch.float32, device=dev)
+                    _lib.check(L.dcl_bn_stats_minmax_part(_lib.ptr(x), N, C, H * W, _lib.ptr(stack[offs[k]:]), _lib.ptr(m['ws2']),
+                                                          _lib.ptr(m['running_mean']), _lib.ptr(wsb[2 * C:]), _lib.stream_ptr(dev)),
+                               "dcl_bn_stats_minmax_part")
+                else:
+                    _lib.check(L.dcl_bn_stats_part(_lib.ptr(x), N, C, H * W, _lib.ptr(stack[offs[k]:]),
+                                                   _lib.ptr(m['running_mean']), _lib.ptr(wsb[2 * C:]), _lib.stream_ptr(dev)),
+                               "dcl_bn_stats_part")
         for m in meta:
             if m['stream'] is not None and m['stream'] is not main:
                 main.wait_stream(m['stream'])
@@ -222,6 +261,21 @@ class _FusedBNGroupFunction(torch.autograd.Function):
             relu = m['relu']
             if st is not main:
                 st.wait_stream(main)
+            if m.get('defer'):
+                with torch.cuda.stream(st):
+                    wsb, ws2 = m['ws'], m['ws2']
+                    ns = L.dcl_bn_num_slices(N, C)
+                    sc, sh = ws2[C * ns * 2:C * ns * 2 + C], ws2[C * ns * 2 + C:]
+                    _lib.check(L.dcl_bn_finalize_pre(_lib.ptr(stack[offs[k]:]), _lib.ptr(ws2), ns, float(N * HW * world), m['eps'],
+                                                     m['momentum'], _lib.ptr(ws[k]), _lib.ptr(bs[k]), C, _lib.ptr(wsb[:C]),
+                                                     _lib.ptr(wsb[C:2 * C]), _lib.ptr(m['running_mean']), _lib.ptr(m['running_var']),
+                                                     _lib.ptr(m['nbt']), _lib.ptr(wsb[2 * C:]), _lib.ptr(sc), _lib.ptr(sh),
+                                                     _lib.ptr(m['amax']), _lib.stream_ptr(dev)), "dcl_bn_finalize_pre")
+                    m['pre'] = (sc, sh)
+                ys.append(x.detach())
+                saved += [x, None, ws[k], bs[k], wsb]
+                masks.append(False)
+                continue
             with torch.cuda.stream(st):
                 wsb = m['ws']
                 y = torch.empty_like(x)
@@ -316,18 +370,20 @@ class _FusedBNGroupFunction(torch.autograd.Function):
         return (None, *grads)
 
 
-def bn_act_group(bns, xs, residuals=None, relu=True, tokens=None, streams=None):
+def bn_act_group(bns, xs, residuals=None, relu=True, tokens=None, streams=None, defers=None):
     """``[bn_act(bn_k, x_k, residual_k, relu, token_k)]`` for independent FusedBatchNorm2d layers in SyncBatchNorm mode
     with one stacked statistics exchange per direction instead of one per layer (see _FusedBNGroupFunction); member k's
-    kernels run on ``streams[k]`` (None: the current stream), its input must have been produced there."""
+    kernels run on ``streams[k]`` (None: the current stream), its input must have been produced there.  ``defers[k]``: member k's
+    output is not written (FusedBatchNorm2d.forward, ``defer``)."""
     n = len(bns)
+    defers = defers or [False] * n
     residuals = residuals or [None] * n
     tokens = tokens or [None] * n
     streams = streams or [None] * n
     meta, tensors = [], []
     for k, bn in enumerate(bns):
         amax = None
-        if bn.emit_amax:
+        if bn.emit_amax or defers[k]:
             st = streams[k]
             if st is not None:
                 with torch.cuda.stream(st):
@@ -336,12 +392,18 @@ def bn_act_group(bns, xs, residuals=None, relu=True, tokens=None, streams=None):
                 amax = _amax.zeros(_amax.SLOTS, xs[k].device)
         meta.append(dict(stream=streams[k], sync=bool(bn.sync), running_mean=bn.running_mean, running_var=bn.running_var,
                          nbt=bn.num_batches_tracked, eps=float(bn.eps), momentum=float(bn.momentum), relu=bool(relu),
-                         amax=amax, token=tokens[k] if residuals[k] is not None else None))
+                         amax=amax, token=tokens[k] if residuals[k] is not None else None,
+                         defer=bool(defers[k]) and relu and residuals[k] is None))
         tensors += [xs[k], residuals[k], bn.weight, bn.bias]
     ys = _FusedBNGroupFunction.apply(meta, *tensors)
     out = []
     for k, y in enumerate(ys):
-        out.append(_amax.tag(y, meta[k]['amax']) if meta[k]['amax'] is not None else y)
+        if meta[k]['amax'] is not None:
+            _amax.tag(y, meta[k]['amax'])
+        if meta[k].get('pre') is not None:
+            DEFERRED["count"] += 1
+            y._dcl_pre = _amax.PreAct(meta[k]['pre'][0], meta[k]['pre'][1], meta[k]['amax'], y._version)
+        out.append(y)
     return out
 
 
@@ -384,8 +446,22 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
                 and (residual is None or (residual.shape == x.shape and residual.is_contiguous()
                                           and residual.dtype == torch.float32)))
 
-    def forward(self, x, residual=None, relu=False, grad_token=None, input_relu=False):
-        """``input_relu`` (relu_then_bn only): x is the output of a ReLU whose backward is left to this norm's backward kernel."""
+    def forward(self, x, residual=None, relu=False, grad_token=None, input_relu=False, defer=False):
+        """``input_relu`` (relu_then_bn only): x is the output of a ReLU whose backward is left to this norm's backward kernel.
+        ``defer`` (relu, no residual; the caller has asked the consuming convolution, DirectConv2d.fuses_input_norm): the
+        normalised tensor is not written -- the result aliases x and carries the map as an amax.PreAct mark."""
+        if defer:
+            if not (relu and residual is None and not input_relu and self._fusable(x, None)):
+                raise RuntimeError("FusedBatchNorm2d(defer=True): needs relu, no residual and an input of the fused path")
+            amax = _amax.zeros(_amax.SLOTS, x.device)
+            DEFERRED["count"] += 1
+            pre = []
+            y = _FusedBNFunction.apply(x, None, self.weight, self.bias, self.running_mean, self.running_var,
+                                       self.num_batches_tracked, float(self.eps), float(self.momentum), True, bool(self.sync),
+                                       amax, None, False, pre)
+            _amax.tag(y, amax)
+            y._dcl_pre = _amax.PreAct(pre[0], pre[1], amax, y._version)
+            return y
         if self._fusable(x, residual):
             # partial max|y| side output (64 slots) for the f16x3 convolutions that consume y (models/amax.py)
             amax = _amax.zeros(_amax.SLOTS, x.device) if self.emit_amax else None
@@ -431,11 +507,13 @@ def relu_then_bn(bn, t):
     return bn(F.relu(t, inplace=True))
 
 
-def bn_act(bn, x, residual=None, relu=True, grad_token=None):
+def bn_act(bn, x, residual=None, relu=True, grad_token=None, defer=False):
     """norm (+ residual) (+ ReLU) for any norm layer; one fused call when ``bn`` supports it.  ``grad_token``
-    (models/ops.py GradToken): hand the residual's gradient to the convolution that shares the residual tensor."""
+    (models/ops.py GradToken): hand the residual's gradient to the convolution that shares the residual tensor.
+    ``defer``: see FusedBatchNorm2d.forward."""
     if isinstance(bn, FusedBatchNorm2d):
-        return bn(x, residual=residual, relu=relu, grad_token=grad_token)
+        return bn(x, residual=residual, relu=relu, grad_token=grad_token, defer=defer)
+    assert not defer
     y = bn(x)
     if residual is not None:
         y = y + residual

@@ -189,6 +189,26 @@ def conv3x3_wgrad(x, gy, stride=1):
     return dw
 
 
+def conv3x3_wgrad_pre(x, gy, pre_sc, pre_sh, pre_amax):
+    """dw of conv2d(relu(x * sc[c] + sh[c]), w, padding=1) for the output gradient gy (stride 1), x the RAW tensor in front of the
+    norm: csrc/dcl_wgrad3x3d.hip, PRE forms."""
+    from .. import _lib
+    from .amax import amax_of
+    n, ci, h, w = x.shape
+    co = gy.shape[1]
+    L = _lib.lib()
+    splits = L.dcl_wgrad3x3_splits(n, ci, co, h, w, 1)
+    if splits <= 0:
+        raise RuntimeError("conv3x3_wgrad_pre: unsupported shape")
+    part = torch.empty(splits * 9 * co * ci, dtype=torch.float32, device=x.device)
+    dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)
+    ga = amax_of(gy)
+    _lib.check(L.dcl_wgrad3x3_pre_f16x3(_lib.ptr(x), _lib.ptr(gy), n, ci, co, h, w, _lib.ptr(pre_amax), pre_amax.numel(),
+                                        _lib.ptr(ga), ga.numel(), _lib.ptr(pre_sc), _lib.ptr(pre_sh), _lib.ptr(part),
+                                        _lib.ptr(dw), _stream(x)), "dcl_wgrad3x3_pre_f16x3")
+    return dw
+
+
 def stem_wgrad_supported(x, cout, stride):
     return stride == 2 and x.shape[1] * 9 <= 32 and cout <= 64 and x.is_contiguous() and x.dtype == torch.float32
 
@@ -214,7 +234,7 @@ class _Conv3x3Direct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, mod, token=None, bias=None):
-        from .amax import amax_of
+        from .amax import amax_of, pre_of
         ctx.token = token
         ctx.has_bias = bias is not None
         ctx.stride = st = mod.stride[0]
@@ -222,6 +242,22 @@ class _Conv3x3Direct(torch.autograd.Function):
         wamax, wp, _ = mod.packed_weights()
         out = torch.empty((x.shape[0], weight.shape[0], (x.shape[2] - 1) // st + 1, (x.shape[3] - 1) // st + 1),
                           dtype=torch.float32, device=x.device)
+        pre = pre_of(x)
+        ctx.pre = pre is not None
+        if pre is not None:
+            # x's storage holds the raw input z of the norm in front of this convolution; the operand is relu(z sc + sh), formed
+            # in the kernel's patch staging (csrc/dcl_conv3x3_pre.hip).  The caller asked fuses_input_norm() first.
+            from .. import _lib
+            if not mod.fuses_input_norm(x):
+                raise RuntimeError("DirectConv2d: handed a deferred norm output it does not take (fuses_input_norm() is False)")
+            n, ci, h, w = x.shape
+            _lib.check(_lib.lib().dcl_conv3x3_pre_f16x3(_lib.ptr(x), n, ci, h, w, _lib.ptr(wp), weight.shape[0],
+                                                        _lib.ptr(pre.amax), pre.amax.numel(), _lib.ptr(wamax), _lib.ptr(pre.sc),
+                                                        _lib.ptr(pre.sh), _lib.ptr(bias), _lib.ptr(out), st, 0, 0, _stream(x)),
+                       "dcl_conv3x3_pre_f16x3")
+            ctx.save_for_backward(x, weight, pre.sc, pre.sh, pre.amax)
+            ctx.mod = mod
+            return out
         if k1 and _conv1x1_by_gemm(weight.shape[0], weight.shape[1], x, False):
             conv1x1_gemm(x, weight.view(weight.shape[0], -1), out, amax_of(x), wamax)
             if bias is not None:
@@ -249,7 +285,10 @@ class _Conv3x3Direct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         from .amax import amax_of
-        x, weight = ctx.saved_tensors
+        if ctx.pre:
+            x, weight, pre_sc, pre_sh, pre_amax = ctx.saved_tensors
+        else:
+            x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
@@ -287,7 +326,9 @@ class _Conv3x3Direct(torch.autograd.Function):
                 conv1x1_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend)
             else:
                 conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend, in_up=ctx.stride)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.pre:
+            gw = conv3x3_wgrad_pre(x, gy, pre_sc, pre_sh, pre_amax)
+        elif ctx.needs_input_grad[1]:
             if ctx.k1:
                 if conv1x1_wgrad_supported(x, weight.shape[0]):
                     gw = conv1x1_wgrad(x, gy)
@@ -344,7 +385,24 @@ class DirectConv2d(torch.nn.Conv2d):
     def forward(self, x, grad_token=None):
         if self.eligible(x):
             return _Conv3x3Direct.apply(x, self.weight, self, grad_token, self.bias)
+        from .amax import refuse_pre
+        refuse_pre(x, "DirectConv2d (library path)")
         return super().forward(x)
+
+    def fuses_input_norm(self, z):
+        """True when this convolution takes ``relu(bn(z))`` as a deferred norm output (amax.PreAct): the norm's map + ReLU run in
+        the operand staging of its forward and weight-gradient kernels and the normalised tensor is never written.  3x3 / stride
+        1 / pad 1 on the direct kernels, channel counts in sixteens, rows in octets (the weight gradient's row padding would
+        pad the RAW tensor, whose zeros do not map to zeros)."""
+        from .. import _lib
+        if not (_dbg.fuse_bn_apply and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.eligible(z)):
+            return False
+        n, ci, h, w = z.shape
+        co = self.weight.shape[0]
+        if ci % 16 or co % 16 or w % 8:
+            return False
+        L = _lib.lib()
+        return bool(L.dcl_conv3x3_pre_supported(n, ci, co, h, w, 1)) and bool(L.dcl_wgrad3x3_pre_supported(n, ci, co, h, w))
 
     def fuses_residual_grad(self, x):
         """True when a GradToken may be used for x: the direct path runs and x needs a gradient."""

@@ -297,6 +297,28 @@ int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const float *y, cons
                            const float *gamma, const float *beta, const float *part, const float *part_local,
                            double count, int N, int C, int HW, int relu, float *dx, float *dres, float *dbeta,
                            float *dgamma, float *amax, void *stream);
+/* A norm whose normalised output is never written: conv1 -> bn1 -> relu -> conv2 of the reference's residual blocks
+ * (models/HRNet.py:77-93 BasicBlock, :117-137 Bottleneck conv1 -> bn1 -> relu -> conv2) with bn1's apply pass folded into the
+ * operand staging of conv2's forward (dcl_conv3x3_pre_f16x3) and weight gradient (dcl_wgrad3x3_pre_f16x3).
+ *   dcl_bn_stats_minmax_part : dcl_bn_stats_part + mm f32 [C * ns * 2], the per-slice {min, max} of x
+ *   [SyncBatchNorm: all-reduce of part, as before; mm stays local]
+ *   dcl_bn_finalize_pre      : mean / invstd / running statistics / num_batches_tracked exactly as dcl_bn_apply_parts computes
+ *                              them, pre_sc[c] = invstd gamma, pre_sh[c] = beta - mean pre_sc (the consumer forms
+ *                              relu(fma(x, pre_sc, pre_sh)): bitwise what dcl_bn_apply_parts(relu = 1) would have written), and
+ *                              amax [DCL_AMAX_SLOTS] (zero-initialised; or NULL) = max of that tensor, from the extrema.
+ * The backward is the unchanged pair dcl_bn_bwd_reduce_part / dcl_bn_bwd_apply_fused with y = NULL, relu = 1 (mask from x). */
+int dcl_bn_stats_minmax_part(const float *x, int N, int C, int HW, float *part, float *mm, const float *pivot_src,
+                             float *pivot_out, void *stream);
+int dcl_bn_finalize_pre(const float *part, const float *mm, int ns, double count, float eps, float momentum,
+                        const float *gamma, const float *beta, int C, float *mean, float *invstd, float *running_mean,
+                        float *running_var, int64_t *batches_tracked, const float *pivot, float *pre_sc, float *pre_sh,
+                        float *amax, void *stream);
+/* The two calls above in ONE launch for one rank (nothing to exchange in between): the workgroup that finishes a channel's
+ * statistics last finalises the channel (agent-scope hand-over of the partial results, same sums in the same order: bitwise the
+ * outputs of the two-call form).  tickets: C zero-initialised 32-bit words; the pivot of the sums is running_mean (NULL: 0). */
+int dcl_bn_stats_pre(const float *x, int N, int C, int HW, float *part, float *mm, void *tickets, double count, float eps,
+                     float momentum, const float *gamma, const float *beta, float *mean, float *invstd, float *running_mean,
+                     float *running_var, int64_t *batches_tracked, float *pre_sc, float *pre_sh, float *amax, void *stream);
 /* Several INDEPENDENT norm layers in one launch per kernel stage: the bn1 (or bn2) layers of the branches of an HRNet exchange
  * module at one block depth (reference models/HRNet.py:263-287 runs the branches one after the other; :77-93 the BasicBlock's
  * conv -> bn -> relu -> conv -> bn -> += -> relu).  One job record serves all four stages of a layer; every stage is bitwise the
@@ -544,6 +566,20 @@ int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout
                        const float *xamax, int xcount, const float *gamax, int gcount,
                        int stride /* 1 | 2: dy is [N, Cout, (H - 1) / 2 + 1, W / 2] for 2 */, float *part, float *dw,
                        void *stream);
+/* The same two directions of conv2d(relu(x * pre_sc[c] + pre_sh[c]), w, padding = 1) where x is the RAW tensor in front of a
+ * training-mode norm (reference models/HRNet.py:77-93: conv2 of a BasicBlock reads relu(bn1(conv1(x)))), the map applied while
+ * the operand is staged; xamax = the absmax slots dcl_bn_finalize_pre wrote.  Bitwise dcl_bn_apply_parts (relu) followed by
+ * dcl_conv3x3_f16x3 / dcl_wgrad3x3_f16x3.  Forward: stride 1 | 2, Cin % 16 == 0; weight gradient: stride 1, slabs as
+ * dcl_wgrad3x3_splits(.., 1).  *_supported: 1 when the automatic tile has the form (else the caller writes the tensor). */
+int dcl_conv3x3_pre_supported(int N, int Cin, int Cout, int H, int W, int stride);
+int dcl_conv3x3_pre_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout, const float *xamax,
+                          int xcount, const float *wamax, const float *pre_sc, const float *pre_sh,
+                          const float *bias /* [Cout] or NULL */, float *y, int stride,
+                          int tile_r, int tile_p /* 0, 0 = automatic (what *_supported answers for) */, void *stream);
+int dcl_wgrad3x3_pre_supported(int N, int Cin, int Cout, int H, int W);
+int dcl_wgrad3x3_pre_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax,
+                           int xcount, const float *gamax, int gcount, const float *pre_sc, const float *pre_sh, float *part,
+                           float *dw, void *stream);
 
 /* ---- 1x1 convolution on the same kernels ----------------------------------------------------------------------------
  * Replaces nn.Conv2d(C_in, C_out, 1) forward / data gradient / weight gradient (reference models/HRNet.py:63-100
