@@ -786,8 +786,8 @@ def compact_line(full):
         line["roofline_sweep"] = _slim_roofline(sweep[0])
     cb = full.get("cpu_baseline")
     if cb:
-        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample_seconds", "model_seconds", "loss_seconds")
-                                if k in cb}
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample_count", "sample_seconds", "model_seconds",
+                                                   "loss_seconds") if k in cb}
         line["cpu_baseline"]["sample"] = str(cb.get("sample_short") or cb.get("sample", ""))[:200]
     drop = ["peak_mem_gb", "config_keys_beyond_reference", "fused_optimizer", "lazy_projector", "lazy_logits", "metrics_in_step",
             "eager_gpu_step_ms_miopen_find", "detail", "roofline_sweep", "timed_batch"]
@@ -905,12 +905,15 @@ def main():
             if workload == "loss":
                 out["cpu_baseline"] = {"value": round(1.0 / lsec, 5), "unit": unit, "cores": cores,
                                        "kind": "port", "sample": lsample, "sample_seconds": round(lsec, 2),
+                                       "sample_count": 1,      # ONE evaluation (tens of seconds), not the median of three
                                        "sample_short": f"one whole DCV2_ms evaluation fwd+bwd ({args.scales} scales + cross-scale, batch "
                                                        f"{args.batch}, {args.height}x{args.width}), eager torch fp32, measured once"}
             else:
                 msec, msample = cpu_baseline_model(args)
                 out["cpu_baseline"] = {"value": round(args.batch / (msec + lsec), 5), "unit": unit, "cores": cores,
                                        "kind": "port", "sample": msample + "; " + lsample,
+                                       "sample_count": 1,      # ONE whole step (~70 s of host time), not the median of three: SURVEY
+                                                               # section 8d's three would take the default run past its few minutes
                                        "model_seconds": round(msec, 2), "loss_seconds": round(lsec, 2),
                                        "sample_seconds": round(msec + lsec, 2),
                                        "sample_short": f"one whole step: HRNet-W48 fwd+bwd over all {args.batch} images (micro-batches "

@@ -62,8 +62,8 @@ SIGNATURES = {
     "dcl_bn_stats_pre": [_vp, _i, _i, _i, _vp, _vp, _vp, ctypes.c_double, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_conv3x3_pre_supported": [_i, _i, _i, _i, _i, _i],
     "dcl_conv3x3_pre_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "dcl_wgrad3x3_pre_supported": [_i, _i, _i, _i, _i],
-    "dcl_wgrad3x3_pre_f16x3": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "dcl_wgrad3x3_pre_supported": [_i, _i, _i, _i, _i, _i],
+    "dcl_wgrad3x3_pre_f16x3": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "dcl_conv3x3_f16x3_multi": [_vp, _i, _vp],
     "dcl_conv3x3_s2_smallcin": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "dcl_wgrad3x3_s2_smallcin_workspace": [_i],

@@ -78,8 +78,9 @@ struct SweepArgs {
     // stream-K backward (SK): gridDim.x persistent workgroups share the (row block, chunk) sequence
     int N1pad;             // rows of the padded anchor bank
     float *sk_ws;          // [gridDim.x][BM][CP] partial tiles of the workgroups whose range ends inside a row block
-    int *sk_flags;         // [gridDim.x + 1]: flags[g] == sk_seq: workgroup g's partial tile of THIS launch is in sk_ws (any other
-                           // value = not yet: stale values of earlier or aborted launches never match); flags[gridDim.x] = error
+    int *sk_err;           // the error word (hand-overs that timed out): word 0 of the caller's flags buffer, whatever the grid size
+    int *sk_flags;         // [gridDim.x] (the caller's buffer from word 1): flags[g] == sk_seq: workgroup g's partial tile of THIS launch
+                           // is in sk_ws (any other value = not yet: stale values of earlier or aborted launches never match)
                            // word (number of hand-overs that timed out, ever; never reset by the kernel)
     int sk_nslice;         // 1 | 4 | 8 column slices (see k_sweep, SK): slice s writes its own finished slab dpart[s][N1pad][CP]
     int sk_seq;            // launch number of this (flags, workspace) pair, never 0 (host: dcl_infonce_bwd_streamk)
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                     // each time: with the owners spinning on acquire loads the launch took 10 ms instead of 0.3.
                     // The wait is BOUNDED: deadlock-freedom rests on every contributor (a lower workgroup id) being or becoming
                     // resident, which other streams' persistent kernels, CU masks or several ranks on one device can break.
-                    // After sk_timeout ticks without the flag the owner counts an error in flags[gridDim.x] (the caller reads that word:
+                    // After sk_timeout ticks without the flag the owner counts an error in *sk_err (the caller reads that word:
                     // the launch's gradient is then invalid and it falls back to the column-split form) and goes on.
                     if (tid == 0 && p.sk_probe == 0) {
                         const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(256, MODE == MODE_BWD ? 1 : 2) void k_sweep(SweepAr
                                 }
                             }
                         if (late)
-                            __hip_atomic_fetch_add(p.sk_flags + gridDim.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(p.sk_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     __syncthreads();
                     for (int gp = gf; gp < sk_j; ++gp) {
@@ -1291,7 +1292,8 @@ extern "C" int dcl_infonce_bwd_streamk(const float *A, int N1, int V1, const flo
     p.dpart = dout;
     p.N1pad = dcl_round_up(N1, BM);
     p.sk_ws = ws;
-    p.sk_flags = flags;
+    p.sk_err = flags;              // word 0: a FIXED place, so that launches of different grid sizes that share the buffer (a short
+    p.sk_flags = flags + 1;        // cross-scale term has fewer units than CUs) all count into the word the caller reads
     p.sk_nslice = sk_slices_for(G, N2);
     p.sk_seq = sk_next_seq(flags);
     p.sk_timeout = g_sk_timeout_ticks;

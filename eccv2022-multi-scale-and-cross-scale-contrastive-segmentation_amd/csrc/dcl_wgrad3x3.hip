@@ -501,7 +501,7 @@ void dcl_wgrad_s2_set_dma(int on);
 int dcl_wgrad_s2_slabs(int N, int Cin, int Cout, int H, int W, int force_nco, int force_nci);
 void dcl_wgrad_s2_launch(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax,
                          int xcount, const float *gamax, int gcount, float *part, int force_nco, int force_nci,
-                         hipStream_t s, int *nslab);
+                         hipStream_t s, int *nslab, const float *pre_sc = nullptr, const float *pre_sh = nullptr);
 static int g_s2_native = 1;     // stride 2: 1 = output-pixel formulation (dcl_wgrad3x3_s2.hip), 0 = zero-inserted dy
 
 static int g_wave_band = 0;     // wave form: rows per column of the traversal (0 = whole strips: the default -- 32-row bands
@@ -633,10 +633,15 @@ extern "C" int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Ci
     return wgrad3x3_impl(x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, stride, part, dw, stream, nullptr, nullptr);
 }
 
-// 1 when dcl_wgrad3x3_pre_f16x3 serves the shape: stride 1 on the LDS-DMA kernel (the slab count is dcl_wgrad3x3_splits(..., 1))
-extern "C" int dcl_wgrad3x3_pre_supported(int N, int Cin, int Cout, int H, int W)
+// 1 when dcl_wgrad3x3_pre_f16x3 serves the shape: stride 1 on the LDS-DMA kernel, stride 2 on the output-pixel formulation
+// (the slab count is dcl_wgrad3x3_splits(..., stride))
+extern "C" int dcl_wgrad3x3_pre_supported(int N, int Cin, int Cout, int H, int W, int stride)
 {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cin & 15) || (Cout & 15) || (W & 7))
+        return 0;
+    if (stride == 2)
+        return g_s2_native && dcl_wgrad_s2_supported(H, W) ? 1 : 0;
+    if (stride != 1)
         return 0;
     int nco, nci, S, units;
     wgrad_plan(N, Cin, Cout, H, W, nco, nci, S, units);
@@ -647,14 +652,14 @@ extern "C" int dcl_wgrad3x3_pre_supported(int N, int Cin, int Cout, int H, int W
 // tensor in front of the norm, xamax the absmax slots of the mapped tensor (dcl_bn_finalize_pre); see k_wgrad3x3d, PRE.
 extern "C" int dcl_wgrad3x3_pre_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W,
                                       const float *xamax, int xcount, const float *gamax, int gcount, const float *pre_sc,
-                                      const float *pre_sh, float *part, float *dw, void *stream)
+                                      const float *pre_sh, int stride, float *part, float *dw, void *stream)
 {
     DCL_CHECK_ARG(pre_sc && pre_sh, "null pointer");
-    if (!dcl_wgrad3x3_pre_supported(N, Cin, Cout, H, W)) {
-        dcl_set_error("dcl_wgrad3x3_pre_f16x3: shape not served by the LDS-DMA kernel");
+    if (!dcl_wgrad3x3_pre_supported(N, Cin, Cout, H, W, stride)) {
+        dcl_set_error("dcl_wgrad3x3_pre_f16x3: no kernel with the map for this shape / stride");
         return DCL_EUNSUPPORTED;
     }
-    return wgrad3x3_impl(x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, 1, part, dw, stream, pre_sc, pre_sh);
+    return wgrad3x3_impl(x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, stride, part, dw, stream, pre_sc, pre_sh);
 }
 
 static int wgrad3x3_impl(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax, int xcount,
@@ -670,7 +675,7 @@ static int wgrad3x3_impl(const float *x, const float *dy, int N, int Cin, int Co
     if (stride == 2 && g_s2_native && dcl_wgrad_s2_supported(H, W)) {
         int nslab = 0;
         dcl_wgrad_s2_launch(x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, part, g_tile_nco, g_tile_nci,
-                            (hipStream_t)stream, &nslab);
+                            (hipStream_t)stream, &nslab, pre_sc, pre_sh);
         DCL_LAUNCH_CHECK();
         const int total = 9 * Cout * Cin;
         (void)total;

@@ -41,6 +41,7 @@ struct WgradS2Args {
     int N, Cin, Cout, H, W;      // x is [N, Cin, H, W]
     int Hd, Wd;                  // dy is [N, Cout, Hd, Wd]
     int strips, units, S, ncig, npairs, nx;
+    const float *pre_sc, *pre_sh;   // PRE forms: the input operand is relu(x * pre_sc[ci] + pre_sh[ci]) (see k_wgrad3x3d, PRE); else NULL
 };
 
 __device__ __forceinline__ void split2(float v0, float v1, float s, unsigned &hi, unsigned &lo)
@@ -60,7 +61,11 @@ __device__ __forceinline__ void split1(float v0, float s, unsigned &hi, unsigned
 __device__ __forceinline__ half8 as_half8(u32x4 v) { return __builtin_bit_cast(half8, v); }
 
 // DEEP: operands are loaded two steps ahead of their use instead of one (second set of raw registers)
-template <int NCO, int NCI, bool DEEP>
+// PRE: x is the RAW output of the convolution in front of a training-mode norm, the operand relu(x sc[ci] + sh[ci]) -- the second
+// convolution of a two-step down-sampling chain (reference models/HRNet.py:236-258: conv s2 -> bn -> relu -> conv s2) and the stem's
+// conv2 (:333-338) without the normalised tensor in memory; a lane converts values of one input channel per ci tile, rows outside
+// the image and halo values are masked through the operand scale, i.e. after the map (as in dcl_wgrad3x3d.hip).
+template <int NCO, int NCI, bool DEEP, bool PRE = false>
 __global__ __launch_bounds__(256, 1) void k_wgrad3x3_s2(WgradS2Args a)
 {
     __shared__ float wm[8];
@@ -108,6 +113,14 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_s2(WgradS2Args a)
 #pragma unroll
     for (int u = 0; u < NCI; ++u)
         ci_ok[u] = ci0 + 16 * u < a.Cin;
+    float psc[NCI], psh[NCI];               // PRE: the norm's map of this lane's channel of ci tile u
+#pragma unroll
+    for (int u = 0; u < NCI; ++u) {
+        const int ch = ci_ok[u] ? ci0 + 16 * u + j : ci0 + j;
+        psc[u] = PRE ? a.pre_sc[ch] : 1.f;
+        psh[u] = PRE ? a.pre_sh[ch] : 0.f;
+    }
+    auto pre = [&](float v, int u) { return PRE ? fmaxf(__builtin_fmaf(v, psc[u], psh[u]), 0.f) : v; };
 
     f32x4 acc[NCO][NCI][9];
 #pragma unroll
@@ -180,11 +193,11 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_s2(WgradS2Args a)
                 unsigned eh[4], el[4], oh[4], ol[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    split2(src[u][e].x, src[u][e].z, sc, eh[e], el[e]);          // (V[4e], V[4e + 2])
-                    split2(src[u][e].y, src[u][e].w, sc, oh[e], ol[e]);          // (V[4e + 1], V[4e + 3])
+                    split2(pre(src[u][e].x, u), pre(src[u][e].z, u), sc, eh[e], el[e]);          // (V[4e], V[4e + 2])
+                    split2(pre(src[u][e].y, u), pre(src[u][e].w, u), sc, oh[e], ol[e]);          // (V[4e + 1], V[4e + 3])
                 }
                 unsigned hl, ql;
-                split1(l[u], sl, hl, ql);                                        // V[-1]
+                split1(pre(l[u], u), sl, hl, ql);                                        // V[-1]
                 unsigned zh[4], zl[4];                                           // (V[-1], V[1]), (V[3], V[5]), ..
                 zh[0] = __builtin_amdgcn_perm(oh[0], hl, 0x05040100u);
                 zl[0] = __builtin_amdgcn_perm(ol[0], ql, 0x05040100u);
@@ -356,7 +369,7 @@ __device__ __forceinline__ void vm_wait()
 
 constexpr int S2_BP = 17;                                 // pieces per staged x row: left-halo piece + 16 pieces of 4 pixels
 
-template <int NCO, int NCI>
+template <int NCO, int NCI, bool PRE = false>
 __global__ __launch_bounds__(256, 1) void k_wgrad3x3_s2d(WgradS2Args a)
 {
     constexpr int NIR = (NCI * 16 * S2_BP + 63) / 64;      // DMA instructions per row set (5 | 9)
@@ -413,6 +426,14 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_s2d(WgradS2Args a)
 #pragma unroll
     for (int u = 0; u < NCI; ++u)
         ci_ok[u] = ci0 + 16 * u < a.Cin;
+    float psc[NCI], psh[NCI];               // PRE: the norm's map of this lane's channel of ci tile u
+#pragma unroll
+    for (int u = 0; u < NCI; ++u) {
+        const int ch = ci_ok[u] ? ci0 + 16 * u + j : ci0 + j;
+        psc[u] = PRE ? a.pre_sc[ch] : 1.f;
+        psh[u] = PRE ? a.pre_sh[ch] : 0.f;
+    }
+    auto pre = [&](float v, int u) { return PRE ? fmaxf(__builtin_fmaf(v, psc[u], psh[u]), 0.f) : v; };
 
     // DMA geometry of this lane, per instruction m of a row set: piece P = 64 m + lane in [row][piece] order (the tail repeats piece 0)
     unsigned chanB[NIR];
@@ -516,11 +537,11 @@ __global__ __launch_bounds__(256, 1) void k_wgrad3x3_s2d(WgradS2Args a)
                 unsigned eh[4], el[4], oh[4], ol[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    split2(src[u][e].x, src[u][e].z, sc, eh[e], el[e]);
-                    split2(src[u][e].y, src[u][e].w, sc, oh[e], ol[e]);
+                    split2(pre(src[u][e].x, u), pre(src[u][e].z, u), sc, eh[e], el[e]);
+                    split2(pre(src[u][e].y, u), pre(src[u][e].w, u), sc, oh[e], ol[e]);
                 }
                 unsigned hl, ql;
-                split1(l[u], sl, hl, ql);
+                split1(pre(l[u], u), sl, hl, ql);
                 unsigned zh[4], zl[4];
                 zh[0] = __builtin_amdgcn_perm(oh[0], hl, 0x05040100u);
                 zl[0] = __builtin_amdgcn_perm(ol[0], ql, 0x05040100u);
@@ -752,10 +773,12 @@ int dcl_wgrad_s2_slabs(int N, int Cin, int Cout, int H, int W, int force_nco, in
 // kernel only; the caller sums the *nslab slabs (k_wgrad_reduce)
 void dcl_wgrad_s2_launch(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax,
                          int xcount, const float *gamax, int gcount, float *part, int force_nco, int force_nci,
-                         hipStream_t s, int *nslab)
+                         hipStream_t s, int *nslab, const float *pre_sc, const float *pre_sh)
 {
     const S2Plan p = s2_plan(N, Cin, Cout, H, W, force_nco, force_nci);
     WgradS2Args a;
+    a.pre_sc = pre_sc;
+    a.pre_sh = pre_sh;
     a.x = x; a.dy = dy; a.part = part; a.xamax = xamax; a.gamax = gamax; a.xcount = xcount; a.gcount = gcount;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.Hd = (H - 1) / 2 + 1;
@@ -769,23 +792,31 @@ void dcl_wgrad_s2_launch(const float *x, const float *dy, int N, int Cin, int Co
     // (one ci tile per wave only: with two, three ring slots of four waves do not fit the 160 KB of LDS)
     if (g_s2_dma && p.nci == 1 && (size_t)Cin * H * W * 4 < ((size_t)1 << 32)) {
 #define DCL_S2D_CASE(o, i)                                                      \
-    if (p.nco == o && p.nci == i)                                               \
-        hipLaunchKernelGGL((k_wgrad3x3_s2d<o, i>), grid, dim3(256), 0, s, a);
+    if (p.nco == o && p.nci == i) {                                             \
+        if (pre_sc)                                                             \
+            hipLaunchKernelGGL((k_wgrad3x3_s2d<o, i, true>), grid, dim3(256), 0, s, a);  \
+        else                                                                    \
+            hipLaunchKernelGGL((k_wgrad3x3_s2d<o, i>), grid, dim3(256), 0, s, a);        \
+    }
         DCL_S2D_CASE(3, 1)
         DCL_S2D_CASE(2, 1)
         DCL_S2D_CASE(1, 1)
 #undef DCL_S2D_CASE
-        dcl_note_kernel("k_wgrad3x3_s2d<%d,%d>", p.nco, p.nci);
+        dcl_note_kernel(pre_sc ? "k_wgrad3x3_s2d_pre<%d,%d>" : "k_wgrad3x3_s2d<%d,%d>", p.nco, p.nci);
         return;
     }
 #define DCL_S2_CASE(o, i, deep)                                                 \
-    if (p.nco == o && p.nci == i)                                               \
-        hipLaunchKernelGGL((k_wgrad3x3_s2<o, i, deep>), grid, dim3(256), 0, s, a);
+    if (p.nco == o && p.nci == i) {                                             \
+        if (pre_sc)                                                             \
+            hipLaunchKernelGGL((k_wgrad3x3_s2<o, i, deep, true>), grid, dim3(256), 0, s, a);  \
+        else                                                                    \
+            hipLaunchKernelGGL((k_wgrad3x3_s2<o, i, deep>), grid, dim3(256), 0, s, a);        \
+    }
     DCL_S2_CASE(3, 1, true)
     DCL_S2_CASE(2, 2, false)
     DCL_S2_CASE(2, 1, true)
     DCL_S2_CASE(1, 2, true)
     DCL_S2_CASE(1, 1, true)
 #undef DCL_S2_CASE
-    dcl_note_kernel("k_wgrad3x3_s2<%d,%d>", p.nco, p.nci);
+    dcl_note_kernel(pre_sc ? "k_wgrad3x3_s2_pre<%d,%d>" : "k_wgrad3x3_s2<%d,%d>", p.nco, p.nci);
 }

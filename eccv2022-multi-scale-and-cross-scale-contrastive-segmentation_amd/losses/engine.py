@@ -781,14 +781,17 @@ class StreamKTimeout(RuntimeError):
 def _streamk_workspace(dev, G: int):
     """(partial-tile workspace f32 [G, 128, 256], flags int32 [G + 1]) of the stream-K backward for the CURRENT stream of
     ``dev``.  One persistent pair per (device, stream) serves every term of every step: the launches of one stream run one
-    after the other and a flag is only valid for the launch whose number it carries (nothing has to be reset).  flags[G] is
-    the error word (hand-overs that timed out): a copy of it travels to a pinned host word after every backward pass
-    (``_streamk_note_launches``) and is looked at -- without waiting -- when the workspace is asked for the next time; a
-    non-zero value switches stream-K off for the process (column-split ``dcl_infonce_bwd`` from then on) and raises, because
-    the gradients of that earlier step were wrong."""
+    after the other and a flag is only valid for the launch whose number it carries (nothing has to be reset).  flags[0] is
+    the error word (hand-overs that timed out; a FIXED word, whatever the grid size of the launch that counts into it): a copy
+    of it travels to a pinned host word after every backward pass (``_streamk_note_launches``).  ``streamk_check`` -- the
+    managers' optimizer pre-step hook -- is what acts on it.  On ONE rank the word is also looked at, without waiting, when the
+    workspace is asked for the next time (for callers without the hook): a non-zero value switches stream-K off for the
+    process and raises, because the gradients of that earlier step were wrong.  On several ranks that second look is left out:
+    it depends on this rank's timing, and a rank that raises out of its backward pass while its peers go on leaves them in
+    a collective without a partner -- there the all-rank maximum and the pre-step hook decide for everybody."""
     key = (dev.index, _lib.stream_ptr(dev))
     got = _SK_WS.get(key)
-    if got is not None:
+    if got is not None and _dist_world() == 1:
         ev, host = got[2], got[3]
         if ev is not None and ev.query() and int(host[0]) != 0:
             _lib.lib().dcl_infonce_set_streamk(0)
@@ -800,8 +803,8 @@ def _streamk_workspace(dev, G: int):
                 "(dcl_infonce_set_streamk(0)): later steps use the column-split backward; set DCL_SWEEP_STREAMK=0 to start that way.")
     if got is None or got[1].numel() < G + 1:
         got = [torch.empty((G, _lib.ROW_TILE, _lib.CP), dtype=torch.float32, device=dev),
-               torch.zeros((G + 1,), dtype=torch.int32, device=dev), None,
-               torch.zeros((1,), dtype=torch.int32).pin_memory(), G]
+               torch.zeros((G + 1,), dtype=torch.int32, device=dev), None if got is None else got[2],
+               torch.zeros((1,), dtype=torch.int32).pin_memory() if got is None else got[3], G]
         _SK_WS[key] = got
     return got[0], got[1]
 
@@ -811,12 +814,19 @@ def _streamk_note_launches(dev):
     ranks the word is first all-reduced (MAX, 4 bytes, asynchronous): one rank's invalid gradient reaches every rank through the
     gradient all-reduce, so every rank has to see the error (``streamk_check`` then raises on all of them, not on one whose
     peers would hang in their next collective)."""
-    got = _SK_WS.get((dev.index, _lib.stream_ptr(dev)))
+    key = (dev.index, _lib.stream_ptr(dev))
+    got = _SK_WS.get(key)
+    world = _dist_world()
     if got is None:
-        return
-    G = got[4]
-    word = got[1][G:G + 1]
-    if _dist_world() > 1:
+        if world == 1:
+            return
+        # several ranks: EVERY rank takes part in the exchange of the word in EVERY backward pass, also one that launched no
+        # stream-K kernel (switched off on it, no term with a gradient) -- a collective that only some ranks issue pairs up
+        # with the peers' next gradient bucket (ADVICE r05).  Its word is zero.
+        got = [None, torch.zeros((1,), dtype=torch.int32, device=dev), None, torch.zeros((1,), dtype=torch.int32).pin_memory(), 0]
+        _SK_WS[key] = got
+    word = got[1][0:1]
+    if world > 1:
         import torch.distributed as dist
         word = word.clone()
         work = dist.all_reduce(word, op=dist.ReduceOp.MAX, async_op=True)
@@ -930,7 +940,7 @@ def _backward_with_term_grads(st: StepState, grad_terms: torch.Tensor, feats_met
                                          _lib.ptr(A.bank_h if B.bank_h is not None else None), stream),
                        "dcl_infonce_bwd")
             slabs[t.b] += [dpart[i] for i in range(ns)]
-    if used_streamk:
+    if used_streamk or _dist_world() > 1:
         _streamk_note_launches(dev)
     grads = []
     for s, sc in enumerate(st.scales):

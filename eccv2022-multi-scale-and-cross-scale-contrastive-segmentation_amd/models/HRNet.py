@@ -61,8 +61,13 @@ class _ConvBN(nn.Sequential):
     """Sequential(conv, norm[, ReLU]) -- same indices / state_dict keys as the reference's Sequentials --
     whose forward hands the ReLU (and an optional residual) to the norm layer when it can fuse them."""
 
-    def forward(self, x, residual=None, relu=False):
-        return bn_act(self[1], self[0](x), residual=residual, relu=relu or len(self) == 3)
+    def forward(self, x, residual=None, relu=False, consumer=None):
+        """``consumer``: the convolution that is the ONLY reader of the result -- when it applies norm + ReLU itself while staging its
+        operand (DirectConv2d.fuses_input_norm), the normalised tensor is not written (FusedBatchNorm2d, ``defer``)."""
+        z = self[0](x)
+        relu = relu or len(self) == 3
+        defer = consumer is not None and residual is None and relu and _defers(self[1], z, consumer)
+        return bn_act(self[1], z, residual=residual, relu=relu, defer=defer)
 
 
 def _conv_bn(cin, cout, k, stride=1, relu=False, norm=nn.BatchNorm2d):
@@ -489,10 +494,10 @@ class HighResolutionModule(nn.Module):
                 elif j > i:
                     y = upsample_bilinear(row[j](x[j]), x[i].shape[-2:], self.align_corners, add=y)
                 else:
-                    chain = row[j]
+                    chain = list(row[j])
                     t = x[j]
-                    for step in list(chain)[:-1]:
-                        t = step(t)
+                    for k, step in enumerate(chain[:-1]):
+                        t = step(t, consumer=chain[k + 1][0])
                     y = chain[-1](t, residual=y)
             return self.relu(y)
         # coarser branches (up-sampling kernels) first, finer ones (stride-2 chains) last: the closing ReLU then rides on a
@@ -507,10 +512,10 @@ class HighResolutionModule(nn.Module):
             if j > i:
                 y = upsample_bilinear(row[j](x[j]), x[i].shape[-2:], self.align_corners, add=y, relu=last)
             else:
-                chain = row[j]                  # stride-2 conv chain; its last norm absorbs "+ y" (and the ReLU)
+                chain = list(row[j])            # stride-2 conv chain; its last norm absorbs "+ y" (and the ReLU)
                 t = x[j]
-                for step in list(chain)[:-1]:
-                    t = step(t)
+                for k, step in enumerate(chain[:-1]):
+                    t = step(t, consumer=chain[k + 1][0])       # (its norm + ReLU inside the next convolution when that one takes it)
                 y = chain[-1](t, residual=y, relu=last)
         return y if others else self.relu(y)
 
@@ -621,7 +626,9 @@ class HighResolutionNet(nn.Module):
         return out
 
     def forward(self, x):
-        x = bn_act(self.bn1, self.conv1(x))
+        x = self.conv1(x)
+        # the stem's first norm + ReLU (403 MB at 12 x 512 x 1024) inside conv2's operand staging when conv2 takes it
+        x = bn_act(self.bn1, x, defer=_defers(self.bn1, x, self.conv2))
         x = bn_act(self.bn2, self.conv2(x))
         x = self.layer1(x)
         y = self.stage2(self._enter_stage(self.transition1, [x], 1))

@@ -189,22 +189,22 @@ def conv3x3_wgrad(x, gy, stride=1):
     return dw
 
 
-def conv3x3_wgrad_pre(x, gy, pre_sc, pre_sh, pre_amax):
-    """dw of conv2d(relu(x * sc[c] + sh[c]), w, padding=1) for the output gradient gy (stride 1), x the RAW tensor in front of the
-    norm: csrc/dcl_wgrad3x3d.hip, PRE forms."""
+def conv3x3_wgrad_pre(x, gy, pre_sc, pre_sh, pre_amax, stride=1):
+    """dw of conv2d(relu(x * sc[c] + sh[c]), w, stride=stride, padding=1) for the output gradient gy, x the RAW tensor in front of
+    the norm: csrc/dcl_wgrad3x3d.hip (stride 1), csrc/dcl_wgrad3x3_s2.hip (stride 2), PRE forms."""
     from .. import _lib
     from .amax import amax_of
     n, ci, h, w = x.shape
     co = gy.shape[1]
     L = _lib.lib()
-    splits = L.dcl_wgrad3x3_splits(n, ci, co, h, w, 1)
+    splits = L.dcl_wgrad3x3_splits(n, ci, co, h, w, stride)
     if splits <= 0:
         raise RuntimeError("conv3x3_wgrad_pre: unsupported shape")
     part = torch.empty(splits * 9 * co * ci, dtype=torch.float32, device=x.device)
     dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=x.device)
     ga = amax_of(gy)
     _lib.check(L.dcl_wgrad3x3_pre_f16x3(_lib.ptr(x), _lib.ptr(gy), n, ci, co, h, w, _lib.ptr(pre_amax), pre_amax.numel(),
-                                        _lib.ptr(ga), ga.numel(), _lib.ptr(pre_sc), _lib.ptr(pre_sh), _lib.ptr(part),
+                                        _lib.ptr(ga), ga.numel(), _lib.ptr(pre_sc), _lib.ptr(pre_sh), stride, _lib.ptr(part),
                                         _lib.ptr(dw), _stream(x)), "dcl_wgrad3x3_pre_f16x3")
     return dw
 
@@ -327,7 +327,7 @@ class _Conv3x3Direct(torch.autograd.Function):
             else:
                 conv3x3_launch(gy, wpt, weight.shape[1], amax_of(gy), wamax, gx, addend=addend, in_up=ctx.stride)
         if ctx.needs_input_grad[1] and ctx.pre:
-            gw = conv3x3_wgrad_pre(x, gy, pre_sc, pre_sh, pre_amax)
+            gw = conv3x3_wgrad_pre(x, gy, pre_sc, pre_sh, pre_amax, ctx.stride)
         elif ctx.needs_input_grad[1]:
             if ctx.k1:
                 if conv1x1_wgrad_supported(x, weight.shape[0]):
@@ -392,17 +392,17 @@ class DirectConv2d(torch.nn.Conv2d):
     def fuses_input_norm(self, z):
         """True when this convolution takes ``relu(bn(z))`` as a deferred norm output (amax.PreAct): the norm's map + ReLU run in
         the operand staging of its forward and weight-gradient kernels and the normalised tensor is never written.  3x3 / stride
-        1 / pad 1 on the direct kernels, channel counts in sixteens, rows in octets (the weight gradient's row padding would
-        pad the RAW tensor, whose zeros do not map to zeros)."""
+        1 or 2 / pad 1 on the direct kernels, channel counts in sixteens, rows in octets (stride 2: sixteens; the weight gradient's
+        row padding would pad the RAW tensor, whose zeros do not map to zeros)."""
         from .. import _lib
-        if not (_dbg.fuse_bn_apply and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.eligible(z)):
+        if not (_dbg.fuse_bn_apply and self.kernel_size == (3, 3) and self.stride in ((1, 1), (2, 2)) and self.eligible(z)):
             return False
         n, ci, h, w = z.shape
-        co = self.weight.shape[0]
-        if ci % 16 or co % 16 or w % 8:
+        co, st = self.weight.shape[0], self.stride[0]
+        if ci % 16 or co % 16 or w % (8 if st == 1 else 16):
             return False
         L = _lib.lib()
-        return bool(L.dcl_conv3x3_pre_supported(n, ci, co, h, w, 1)) and bool(L.dcl_wgrad3x3_pre_supported(n, ci, co, h, w))
+        return bool(L.dcl_conv3x3_pre_supported(n, ci, co, h, w, st)) and bool(L.dcl_wgrad3x3_pre_supported(n, ci, co, h, w, st))
 
     def fuses_residual_grad(self, x):
         """True when a GradToken may be used for x: the direct path runs and x needs a gradient."""

@@ -192,14 +192,14 @@ int dcl_infonce_bwd(const float *A, int N1, int V1, const float *B, int N2,
  * N2) persistent workgroups (one per CU; 0 = switched off with dcl_infonce_set_streamk(0), use dcl_infonce_bwd) share the
  * (row block, 32-column chunk) sequence in equal contiguous ranges; the workgroup that reaches the end of a row block
  * adds the partial tiles of the (lower-numbered) workgroups that covered its earlier chunks in ascending order --
- * bitwise reproducible -- and writes the tile.  ws f32 [G, DCL_ROW_TILE, DCL_CP] partial tiles; flags int32 [G + 1],
- * zero-initialised ONCE by the caller (one pair per stream serves every launch of it): flags[g] holds the number of the
- * launch whose partial tile g is valid (the library numbers the launches of a flags pointer), so nothing is reset between
+ * bitwise reproducible -- and writes the tile.  ws f32 [G, DCL_ROW_TILE, DCL_CP] partial tiles; flags int32 [1 + G],
+ * zero-initialised ONCE by the caller (one pair per stream serves every launch of it, also launches with a smaller G):
+ * flags[0] is the error word (below), flags[1 + g] holds the number of the launch whose partial tile g is valid (the library numbers the launches of a flags pointer), so nothing is reset between
  * launches and an aborted launch leaves nothing a later one could mistake.  G = min(units, CUs of the device).  The
  * owner's wait for a contributor is BOUNDED (dcl_infonce_set_streamk_timeout_ms, default 2000 ms per hand-over): when it
  * expires -- a contributor never became resident: CU masks, other persistent kernels, several ranks on one device --
- * flags[G] is incremented and the kernel finishes with an INVALID gradient instead of hanging; the caller must read
- * flags[G] (it only ever grows) and fall back to dcl_infonce_bwd (dcl_infonce_set_streamk(0)).
+ * flags[0] is incremented and the kernel finishes with an INVALID gradient instead of hanging; the caller must read
+ * flags[0] (it only ever grows) and fall back to dcl_infonce_bwd (dcl_infonce_set_streamk(0)).
  * Replaces the same reference lines as dcl_infonce_bwd (autograd of losses/DenseContrastiveLossV2.py:150-192 and
  * losses/DenseContrastiveLossV2_ms.py:84-161). */
 int dcl_infonce_bwd_streamk_workgroups(int N1, int N2);
@@ -569,17 +569,17 @@ int dcl_wgrad3x3_f16x3(const float *x, const float *dy, int N, int Cin, int Cout
 /* The same two directions of conv2d(relu(x * pre_sc[c] + pre_sh[c]), w, padding = 1) where x is the RAW tensor in front of a
  * training-mode norm (reference models/HRNet.py:77-93: conv2 of a BasicBlock reads relu(bn1(conv1(x)))), the map applied while
  * the operand is staged; xamax = the absmax slots dcl_bn_finalize_pre wrote.  Bitwise dcl_bn_apply_parts (relu) followed by
- * dcl_conv3x3_f16x3 / dcl_wgrad3x3_f16x3.  Forward: stride 1 | 2, Cin % 16 == 0; weight gradient: stride 1, slabs as
- * dcl_wgrad3x3_splits(.., 1).  *_supported: 1 when the automatic tile has the form (else the caller writes the tensor). */
+ * dcl_conv3x3_f16x3 / dcl_wgrad3x3_f16x3.  Forward: stride 1 | 2, Cin % 16 == 0; weight gradient: stride 1 | 2, slabs as
+ * dcl_wgrad3x3_splits(.., stride).  *_supported: 1 when the automatic tile has the form (else the caller writes the tensor). */
 int dcl_conv3x3_pre_supported(int N, int Cin, int Cout, int H, int W, int stride);
 int dcl_conv3x3_pre_f16x3(const float *x, int N, int Cin, int H, int W, const void *wp, int Cout, const float *xamax,
                           int xcount, const float *wamax, const float *pre_sc, const float *pre_sh,
                           const float *bias /* [Cout] or NULL */, float *y, int stride,
                           int tile_r, int tile_p /* 0, 0 = automatic (what *_supported answers for) */, void *stream);
-int dcl_wgrad3x3_pre_supported(int N, int Cin, int Cout, int H, int W);
+int dcl_wgrad3x3_pre_supported(int N, int Cin, int Cout, int H, int W, int stride);
 int dcl_wgrad3x3_pre_f16x3(const float *x, const float *dy, int N, int Cin, int Cout, int H, int W, const float *xamax,
-                           int xcount, const float *gamax, int gcount, const float *pre_sc, const float *pre_sh, float *part,
-                           float *dw, void *stream);
+                           int xcount, const float *gamax, int gcount, const float *pre_sc, const float *pre_sh,
+                           int stride /* 1 | 2, as dcl_wgrad3x3_f16x3 */, float *part, float *dw, void *stream);
 
 /* ---- 1x1 convolution on the same kernels ----------------------------------------------------------------------------
  * Replaces nn.Conv2d(C_in, C_out, 1) forward / data gradient / weight gradient (reference models/HRNet.py:63-100

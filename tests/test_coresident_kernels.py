@@ -9,6 +9,7 @@ per branch, reference models/HRNet.py:263-267).  The library is therefore built 
 holds the library-level reproducer as a regression test and checks the build."""
 import os
 import re
+import shutil
 import subprocess
 
 import pytest
@@ -21,20 +22,26 @@ CSRC = os.path.join(ROOT, "eccv2022-multi-scale-and-cross-scale-contrastive-segm
 FAULTY_FORM = re.compile(r"\bv_pk_[a-z0-9_]+ .*op_sel:\[[01],1")      # a packed instruction whose LOW result takes src1's HIGH half
 
 
-def test_library_is_built_without_the_faulty_packed_form():
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs the ROCm toolchain (hipcc)")
+def test_library_is_built_without_the_faulty_packed_form(tmp_path):
     """Device assembly with the Makefile's own flags: the norm kernels (the ones the finding was made on) and the resize kernels
     (explicit two-float vector arithmetic in the source) hold no packed-FP32 instruction at all; the two translation units that
     keep packed FP32 (csrc/Makefile PACKED: the sweeps, the GEMM) hold none with op_sel[1] set -- the build itself fails otherwise."""
     mk = open(os.path.join(CSRC, "Makefile")).read()
     assert "-packed-fp32-ops" in mk and "$(NOPK)" in mk
+    assert 'v_pk_(fma|mul|add)_f32' in mk, "the generic rule checks every NOPK unit's device assembly at build time"
     packed = re.search(r"^PACKED = (.*)$", mk, re.M).group(1).split()
     assert set(packed) <= {"dcl_sweep", "dcl_gemm"} and "op_sel:" in mk, "new PACKED members need the evidence of DESIGN.md section 7"
     for src in ("dcl_bn", "dcl_resize"):
         assert src not in packed
-        out = subprocess.run(["make", "-C", CSRC, "-B", f"{src}.s"], capture_output=True, text=True)
+        # (the Makefile's own flags; the assembly goes to the test's directory, nothing is written into the source tree)
+        flags = subprocess.run(["make", "-C", CSRC, "-s", "--no-print-directory", "print-cxxflags"], capture_output=True, text=True)
+        assert flags.returncode == 0 and "-packed-fp32-ops" in flags.stdout, flags.stderr[-2000:]
+        dst = os.path.join(str(tmp_path), f"{src}.s")
+        out = subprocess.run(["hipcc", *flags.stdout.split(), "-S", "--cuda-device-only", os.path.join(CSRC, f"{src}.hip"), "-o", dst],
+                             capture_output=True, text=True)
         assert out.returncode == 0, out.stderr[-2000:]
-        asm = open(os.path.join(CSRC, f"{src}.s")).read()
-        os.remove(os.path.join(CSRC, f"{src}.s"))
+        asm = open(dst).read()
         assert "s_endpgm" in asm
         assert not re.search(r"\bv_pk_(fma|mul|add)_f32\b", asm), f"{src}: packed FP32 instructions in the device code"
     # the guard's pattern finds the form in a packed build of the norm kernels (8 instructions: the broadcasts of mean_gx)

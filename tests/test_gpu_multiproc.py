@@ -144,7 +144,7 @@ def test_fused_bn_sync_two_ranks_one_gpu(tmp_path):
     assert torch.allclose((outs[0]["db"] + outs[1]["db"]).double(), ref.bias.grad, atol=2e-4)
 
 
-def _train_worker(rank, world, port, out_dir, global_negatives, backbone="hrnet18", scales=2, backend="gloo"):
+def _train_worker(rank, world, port, out_dir, global_negatives, backbone="hrnet18", scales=2, backend="gloo", no_streamk_rank=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -152,6 +152,9 @@ def _train_worker(rank, world, port, out_dir, global_negatives, backbone="hrnet1
     from mscs_amd.managers import HRNetManager
     from mscs_amd.utils import set_verbosity
     set_verbosity(40)
+    if rank == no_streamk_rank:
+        from mscs_amd import _lib
+        _lib.lib().dcl_infonce_set_streamk(0)          # this rank's loss backward launches no stream-K kernel
     cfg = {"name": "t", "mode": "training", "manager": "HRNet", "cuda": True, "parallel": True,
            "gpu_device": [_device_of(q, backend) for q in range(world)], "seed": 3, "log_every_n_steps": 1000,
            "dist_backend": backend,
@@ -193,6 +196,19 @@ def test_ddp_training_step_two_ranks_one_gpu(tmp_path, global_negatives):
     assert torch.equal(a["params"], b["params"]), "parameters diverged across ranks"
     assert np.isfinite(a["metrics"]["loss"]) and np.isfinite(b["metrics"]["loss"])
     assert a["segs"] == ([2, 2, 2] if global_negatives else [1, 1, 1])
+
+
+@pytest.mark.timeout(600)
+def test_ddp_step_when_one_rank_runs_the_loss_backward_without_streamk(tmp_path):
+    """the all-rank exchange of the stream-K error word must be issued by EVERY rank in every backward pass, also by a
+    rank whose backward launched no stream-K kernel (switched off on it) -- a collective that only some ranks issue pairs up with
+    the peers' next gradient bucket and hangs or corrupts the gradients.  Rank 1 runs column-split, rank 0 stream-K: the epoch
+    finishes and the parameters agree bit for bit across the ranks."""
+    port = _free_port()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path), False, "hrnet18", 2, _backend(), 1), nprocs=2, join=True)
+    a, b = [torch.load(os.path.join(str(tmp_path), f"train{q}.pt")) for q in range(2)]
+    assert torch.equal(a["params"], b["params"]), "parameters diverged across ranks"
+    assert np.isfinite(a["metrics"]["loss"]) and np.isfinite(b["metrics"]["loss"])
 
 
 @pytest.mark.timeout(900)

@@ -261,7 +261,7 @@ def test_deterministic_bitwise(dev):
 
 def test_streamk_error_word_is_seen_before_the_gradients_are_applied(dev):
     """a timed-out stream-K hand-over must be detected in the SAME step, before optimizer.step().  The error word
-    (flags[G], counted up by the kernel, never reset) is planted by hand; the backward pass copies it to the host right behind
+    (flags[0], counted up by the kernel, never reset) is planted by hand; the backward pass copies it to the host right behind
     its sweeps, `streamk_check()` -- the managers' optimizer pre-step hook -- raises StreamKTimeout and switches the process to
     the column-split backward, whose gradients equal the stream-K ones (2e-6 of max); a clean pass raises nothing."""
     from mscs_amd import _lib
@@ -286,7 +286,7 @@ def test_streamk_error_word_is_seen_before_the_gradients_are_applied(dev):
         engine.streamk_check()                                  # clean pass: nothing to report
         assert engine._SK_WS, "the stream-K backward did not run (workspace missing)"
         for got in engine._SK_WS.values():
-            got[1][got[4]:got[4] + 1].fill_(3)                  # "three hand-overs timed out"
+            got[1][0:1].fill_(3)                                # "three hand-overs timed out"
         run()
         with pytest.raises(engine.StreamKTimeout):
             engine.streamk_check()
@@ -303,7 +303,7 @@ def test_streamk_error_word_is_seen_before_the_gradients_are_applied(dev):
         opt.register_step_pre_hook(lambda *_a, **_k: engine.streamk_check())
         run()
         for got in engine._SK_WS.values():
-            got[1][got[4]:got[4] + 1].fill_(1)
+            got[1][0:1].fill_(1)
         run()
         w.grad = torch.ones_like(w)
         with pytest.raises(engine.StreamKTimeout):
@@ -321,7 +321,7 @@ def test_streamk_backward_equals_column_split_backward(dev, n, H, W, cap):
     cross-scale dF1 (rows) and dF2 (columns, rectangular, other bank's statistics); ragged row blocks, fewer units than
     workgroups, ranges that span several row blocks.  Same products, different summation order: 2e-6 of max.  Bitwise
     reproducible on a flags buffer that is never reset (a flag is valid for the launch whose number it carries), also
-    when it starts out with garbage from an aborted launch; no hand-over timed out (error word flags[G] stays 0)."""
+    when it starts out with garbage from an aborted launch; no hand-over timed out (error word flags[0] stays 0)."""
     from mscs_amd import _lib
     from mscs_amd.losses import DenseContrastiveLossV2_ms
     L = _lib.lib()
@@ -362,7 +362,7 @@ def test_streamk_backward_equals_column_split_backward(dev, n, H, W, cap):
             outs = []
             for k in range(3):
                 if k == 1:                 # what an aborted launch leaves behind: every "tile present" mark of the last launch
-                    flags[:G] = flags[:G].max()
+                    flags[1:] = flags[1:].max()
                     ws.fill_(float("nan"))
                 dout = torch.full((nsl, n1pad, 256), float("nan"), device=dev)
                 _lib.check(L.dcl_infonce_bwd_streamk(p(X.bank), n1, X.plan.V, p(Y.bank), n2, p(lo), p(hi), 1.0 / t.tau,
@@ -370,7 +370,7 @@ def test_streamk_backward_equals_column_split_backward(dev, n, H, W, cap):
                                                      p(X.bank_h), p(Y.bank_h), stream), "bwd_streamk")
                 outs.append(dout.sum(0) if nsl > 1 else dout[0])
                 assert torch.isfinite(dout[:, :n1]).all()
-                assert int(flags[G].item()) == 0
+                assert int(flags[0].item()) == 0
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
             scale = want[:n1].abs().max().item()
             assert torch.isfinite(outs[0][:n1]).all()

@@ -189,7 +189,8 @@ def test_pre_convolution_with_its_tables_on_either_side_of_a_2_gib_boundary(dev)
     assert seen == {0, 1}
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 32, 64), (2, 96, 16, 32), (1, 192, 8, 32), (12, 384, 16, 32), (3, 64, 20, 40), (2, 32, 7, 24)])
+@pytest.mark.parametrize("shape", [(2, 48, 32, 64), (2, 96, 16, 32), (1, 192, 8, 32), (12, 384, 16, 32), (3, 64, 20, 40), (2, 32, 7, 24),
+                                   (2, 64, 21, 48), (1, 48, 9, 16)])
 def test_pre_weight_gradient_is_bitwise_the_weight_gradient_on_the_written_tensor(dev, shape):
     """dcl_wgrad3x3_pre_f16x3 on (z, sc, sh) == dcl_wgrad3x3_f16x3 on the written tensor (workgroup form, wave form at 192 tile pairs)."""
     from mscs_amd import _lib as P
@@ -201,11 +202,19 @@ def test_pre_weight_gradient_is_bitwise_the_weight_gradient_on_the_written_tenso
     y, amax_w, *_ = _written(L, P, z, gamma, beta, rmean, rvar)
     sc, sh, amax_d, *_ = _deferred(L, P, z, gamma, beta, rmean, rvar)
     gy = torch.randn(n, c, h, w, device=dev) * 1e-4
-    assert L.dcl_wgrad3x3_pre_supported(n, c, c, h, w) == 1
+    assert L.dcl_wgrad3x3_pre_supported(n, c, c, h, w, 1) == 1
     tag(y, amax_w)
     want = ops.conv3x3_wgrad(y, gy)
     got = ops.conv3x3_wgrad_pre(z, gy, sc, sh, amax_d)
     assert torch.equal(got, want)
+    if w % 16 == 0:
+        # stride 2 (csrc/dcl_wgrad3x3_s2.hip: the LDS-DMA form for one ci tile per wave, the direct-load form for 64 channels)
+        for co in (c, 2 * c):
+            gy2 = torch.randn(n, co, (h - 1) // 2 + 1, w // 2, device=dev) * 1e-4
+            assert L.dcl_wgrad3x3_pre_supported(n, c, co, h, w, 2) == 1
+            want = ops.conv3x3_wgrad(y, gy2, stride=2)
+            got = ops.conv3x3_wgrad_pre(z, gy2, sc, sh, amax_d, stride=2)
+            assert torch.equal(got, want), (shape, co)
 
 
 def _block_run(dev, block_cls, cin, planes, shape, fuse):
@@ -248,6 +257,50 @@ def test_residual_block_with_deferred_norm_is_bitwise_the_block_that_writes_it(d
     assert fused_bn.DEFERRED["count"] == n0 + 1
     b = _block_run(dev, getattr(H, name), cin, planes, shape, False)
     assert fused_bn.DEFERRED["count"] == n0 + 1
+    assert len(a) == len(b)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def _module_run(dev, fuse):
+    """One HighResolutionModule (three branches: two-step stride-2 chains in its fuse layers) and the stem of an HRNet, forward + backward."""
+    import importlib
+    from mscs_amd.debug import cfg
+    from mscs_amd.models.fused_bn import FusedBatchNorm2d
+    from mscs_amd.models.ops import use_direct_conv3x3, use_direct_conv1x1
+    H = importlib.import_module("mscs_amd.models.HRNet")
+    old = cfg.fuse_bn_apply
+    cfg.fuse_bn_apply = fuse
+    try:
+        torch.manual_seed(9)
+        mod = H.HighResolutionModule(3, H.BasicBlock, [1, 1, 1], [48, 96, 192], [48, 96, 192], "SUM", norm_layer=FusedBatchNorm2d).to(dev)
+        stem = torch.nn.ModuleDict({"conv1": torch.nn.Conv2d(3, 64, 3, 2, 1, bias=False), "bn1": FusedBatchNorm2d(64),
+                                    "conv2": torch.nn.Conv2d(64, 64, 3, 2, 1, bias=False), "bn2": FusedBatchNorm2d(64)}).to(dev)
+        for m in (mod, stem):
+            use_direct_conv3x3(m)
+            use_direct_conv1x1(m)
+        xs = [torch.randn(2, c, 64 >> k, 128 >> k, device=dev).relu_().requires_grad_(True) for k, c in enumerate((48, 96, 192))]
+        ys = mod(list(xs))
+        img = torch.randn(2, 3, 64, 128, device=dev)
+        t = stem["conv1"](img)
+        t = H.bn_act(stem["bn1"], t, defer=H._defers(stem["bn1"], t, stem["conv2"]))
+        t = H.bn_act(stem["bn2"], stem["conv2"](t))
+        (sum((y * torch.randn_like(y)).sum() for y in ys) + (t * torch.randn_like(t)).sum()).backward()
+        torch.cuda.synchronize()
+        return [y.detach() for y in ys] + [t.detach()] + [x.grad for x in xs] + [p.grad for m in (mod, stem) for p in m.parameters()] + \
+               [b.clone() for m in (mod, stem) for b in m.buffers()]
+    finally:
+        cfg.fuse_bn_apply = old
+
+
+def test_exchange_module_and_stem_with_deferred_norms_are_bitwise_the_ones_that_write_them(dev):
+    """The stride-2 consumers: the two-step down-sampling chains of a three-branch exchange module's fuse layers (reference
+    models/HRNet.py:236-258) and the stem's conv1 -> bn1 -> relu -> conv2 (:333-338), next to the module's BasicBlocks."""
+    from mscs_amd.models import fused_bn
+    n0 = fused_bn.DEFERRED["count"]
+    a = _module_run(dev, True)
+    assert fused_bn.DEFERRED["count"] == n0 + 3 + 1 + 1          # three BasicBlocks, the chain 0 -> 2, the stem
+    b = _module_run(dev, False)
     assert len(a) == len(b)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
