@@ -610,13 +610,6 @@ def time_train_step(args, dev, rank, world):
     mgr = (OCRNetManager if args.config in (4, 5) else HRNetManager)(step_config(args, world), autostart=False)
     mgr.setup()
     mgr.model.train()
-    if os.environ.get("DCL_EXP_FREEZE"):        # diagnostic (results are NOT a benchmark): drop the weight gradients of one branch
-        pat = os.environ["DCL_EXP_FREEZE"]      # e.g. "branches.0." -> which queue bounds the step?
-        nfz = 0
-        for n_, p_ in mgr.model.named_parameters():
-            if pat in n_ and n_.endswith("weight") and p_.dim() == 4:
-                p_.requires_grad_(False); nfz += 1
-        print(f"[diagnostic] froze {nfz} convolution weights matching {pat!r}", file=sys.stderr)
     gen = torch.Generator().manual_seed(1000 * rank)
     img = torch.randn(args.batch, 3, args.height, args.width, generator=gen).to(dev)
     lbl = synth_labels(args, args.batch, args.height, args.width, gen).to(dev)  # int64
@@ -640,20 +633,14 @@ def time_train_step(args, dev, rank, world):
             mgr.step_metrics(1, ret, lbl, 0.0)
         return ret
 
-    main_ctx = contextlib.nullcontext()
-    if os.environ.get("DCL_BENCH_MAIN_PRIO"):       # experiment: the whole step on a high-priority stream
-        hp = torch.cuda.Stream(device=dev, priority=int(os.environ["DCL_BENCH_MAIN_PRIO"]))
-        hp.wait_stream(torch.cuda.current_stream())
-        main_ctx = torch.cuda.stream(hp)
-    with main_ctx:
-        for _ in range(args.warmup):
-            step()
-        sync(world)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ret = step()
-        sync(world)
-        dt = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        step()
+    sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ret = step()
+    sync(world)
+    dt = time.perf_counter() - t0
     mgr.flush_logging()
     # a timing of a run whose numbers went bad is not a measurement (a chip multiplying NaNs even clocks higher):
     # the last loss and every parameter must be finite after the timed steps

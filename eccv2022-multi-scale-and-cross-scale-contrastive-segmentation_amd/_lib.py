@@ -64,17 +64,12 @@ SIGNATURES = {
     "dcl_conv3x3_pre_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "dcl_wgrad3x3_pre_supported": [_i, _i, _i, _i, _i, _i],
     "dcl_wgrad3x3_pre_f16x3": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp],
-    "dcl_conv3x3_f16x3_multi": [_vp, _i, _vp],
     "dcl_conv3x3_s2_smallcin": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "dcl_wgrad3x3_s2_smallcin_workspace": [_i],
     "dcl_wgrad3x3_s2_smallcin": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "dcl_bn_bwd_reduce_part": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "dcl_bn_bwd_apply_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp,
                                _vp, _vp, _vp],
-    "dcl_bn_stats_part_multi": [_vp, _i, _vp],
-    "dcl_bn_apply_fused_multi": [_vp, _i, _i, _i, _vp],
-    "dcl_bn_bwd_reduce_part_multi": [_vp, _i, _vp],
-    "dcl_bn_bwd_apply_fused_multi": [_vp, _i, _i, _vp],
     "dcl_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "dcl_upsample_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],

@@ -828,89 +828,6 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                             blockIdx.x);
 }
 
-// ---- job-table forms: the norms of several branches at one block depth in ONE launch (see dcl_bn_*_multi below) ------------
-constexpr int BN_MAXJ = 4;
-struct BnStatsJob {
-    const float *x;
-    float *part;
-    const float *pivot_src;
-    float *pivot_out;
-    int N, C, HW, nslice;
-};
-struct BnApplyJob {
-    const float *x, *res, *gamma, *beta;
-    float *y, *amax;
-    BnFused f;
-    int C, HW, N;
-    unsigned nchunk;
-};
-struct BnBwdReduceJob {
-    const float *dy, *x, *y, *mean, *invstd, *gamma, *beta;
-    float *part;
-    const unsigned long long *mask;
-    int N, C, HW, nslice;
-};
-struct BnBwdApplyJob {
-    const float *dy, *x, *y, *mean, *invstd, *gamma, *beta;
-    float *dx, *dres, *amax;
-    const unsigned long long *mask;
-    BnFused f;
-    float inv_count;
-    int C, HW, N;
-    unsigned nchunk;
-};
-template <class J>
-struct BnMulti {
-    J j[BN_MAXJ];
-    unsigned start[BN_MAXJ + 1];
-    int njobs;
-};
-template <class J>
-__device__ __forceinline__ int bn_job_of(const BnMulti<J> &m, unsigned b)
-{
-    int k = 0;
-#pragma unroll
-    for (int t = 1; t < BN_MAXJ; ++t)
-        k += (t < m.njobs && b >= m.start[t]) ? 1 : 0;
-    return k;
-}
-
-__global__ __launch_bounds__(BN_THREADS) void k_bn_stats_multi(BnMulti<BnStatsJob> m)
-{
-    const int k = bn_job_of(m, blockIdx.x);
-    const BnStatsJob &j = m.j[k];
-    const unsigned id = blockIdx.x - m.start[k];
-    bn_stats_body(j.x, j.N, j.C, j.HW, j.nslice, j.part, j.pivot_src, j.pivot_out, (int)(id % (unsigned)j.C), (int)(id / (unsigned)j.C));
-}
-
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(BN_THREADS) void k_bn_apply_multi(BnMulti<BnApplyJob> m)
-{
-    const int k = bn_job_of(m, blockIdx.x);
-    const BnApplyJob &j = m.j[k];
-    bn_apply_body<RELU, RES>(j.x, j.res, nullptr, nullptr, j.gamma, j.beta, j.C, j.HW, j.y, j.amax, j.f, j.N, j.nchunk,
-                             blockIdx.x - m.start[k]);
-}
-
-template <bool RELU>
-__global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_reduce_multi(BnMulti<BnBwdReduceJob> m)
-{
-    const int k = bn_job_of(m, blockIdx.x);
-    const BnBwdReduceJob &j = m.j[k];
-    const unsigned id = blockIdx.x - m.start[k];
-    bn_bwd_reduce_body<RELU>(j.dy, j.x, j.y, j.mean, j.invstd, j.gamma, j.beta, j.N, j.C, j.HW, j.nslice, j.part, j.mask,
-                             (int)(id % (unsigned)j.C), (int)(id / (unsigned)j.C));
-}
-
-template <bool RELU>
-__global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply_multi(BnMulti<BnBwdApplyJob> m)
-{
-    const int k = bn_job_of(m, blockIdx.x);
-    const BnBwdApplyJob &j = m.j[k];
-    bn_bwd_apply_body<RELU>(j.dy, j.x, j.y, j.mean, j.invstd, j.gamma, j.beta, nullptr, j.inv_count, j.C, j.HW, j.dx, j.dres,
-                            j.amax, j.f, j.mask, j.N, j.nchunk, blockIdx.x - m.start[k]);
-}
-
 int pick_slices(int N, int C)
 {
     // enough workgroups to fill 256 CUs several times over, at most one slice per image
@@ -1228,206 +1145,6 @@ extern "C" int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const flo
         hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask, Nk, nchunk);
     else
         hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask, Nk, nchunk);
-    DCL_LAUNCH_CHECK();
-    return 0;
-}
-
-// ---- several norm layers in one launch ---------------------------------------------------------------------------------------
-// The norms of an HRNet exchange module's branches at one block depth (reference models/HRNet.py:263-287; bn1 / bn2 of the
-// BasicBlocks, :77-93) are independent of each other and small on the coarse branches (12 x 384 x 16 x 32: 9 MB): one launch per
-// kernel stage for all of them -- same bodies, same arithmetic, bitwise the results of the single-layer entry points.
-namespace {
-struct BnGeom {
-    unsigned nchunk, blocks;
-    int Nk;
-};
-bool bn_geom(int N, int C, int HW, BnGeom &g)
-{
-    if ((long long)N * HW >= (1LL << 31) - 4 * BN_THREADS * BN_UNROLL)
-        return false;
-    const bool flat = (HW + 3) / 4 < BN_THREADS * BN_UNROLL;
-    const long long nvs = flat ? ((long long)N * HW + 3) / 4 : (HW + 3) / 4;
-    g.nchunk = (unsigned)((nvs + BN_THREADS * BN_UNROLL - 1) / (BN_THREADS * BN_UNROLL));
-    const long long blocks = (long long)g.nchunk * (flat ? C : (long long)N * C);
-    if (blocks >= (1LL << 31))
-        return false;
-    g.blocks = (unsigned)blocks;
-    g.Nk = flat ? N : 0;
-    return true;
-}
-}  // namespace
-
-#define DCL_BN_MULTI_CHECK()                                                                                       \
-    DCL_CHECK_ARG(jobs && njobs >= 1 && njobs <= BN_MAXJ, "1 .. 4 jobs");                                          \
-    for (int k = 0; k < njobs; ++k)                                                                                \
-        DCL_CHECK_ARG(jobs[k].x && jobs[k].part && jobs[k].N > 0 && jobs[k].C > 0 && jobs[k].HW > 0, "bad job")
-
-extern "C" int dcl_bn_stats_part_multi(const dcl_bn_job *jobs, int njobs, void *stream)
-{
-    DCL_BN_MULTI_CHECK();
-    BnMulti<BnStatsJob> m{};
-    unsigned at = 0;
-    for (int k = 0; k < njobs; ++k) {
-        const dcl_bn_job &q = jobs[k];
-        DCL_CHECK_ARG(q.running_mean && q.pivot, "running_mean / pivot");
-        const int ns = pick_slices(q.N, q.C);
-        m.j[k] = BnStatsJob{q.x, q.part, q.running_mean, q.pivot, q.N, q.C, q.HW, ns};
-        m.start[k] = at;
-        at += (unsigned)q.C * ns;
-    }
-    for (int k = njobs; k <= BN_MAXJ; ++k)
-        m.start[k] = at;
-    m.njobs = njobs;
-    hipLaunchKernelGGL(k_bn_stats_multi, dim3(at), dim3(BN_THREADS), 0, (hipStream_t)stream, m);
-    DCL_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int dcl_bn_apply_fused_multi(const dcl_bn_job *jobs, int njobs, int world, int relu, void *stream)
-{
-    DCL_BN_MULTI_CHECK();
-    DCL_CHECK_ARG(world >= 1, "world");
-    BnMulti<BnApplyJob> m{};
-    unsigned at = 0;
-    const bool has_res = jobs[0].res != nullptr;
-    for (int k = 0; k < njobs; ++k) {
-        const dcl_bn_job &q = jobs[k];
-        DCL_CHECK_ARG(q.y && q.mean && q.invstd, "null output");
-        DCL_CHECK_ARG((q.res != nullptr) == has_res, "all jobs with or all without a residual");
-        DCL_CHECK_ARG(!q.relu_mask || (relu && q.HW % 256 == 0), "relu_mask: ReLU and HW % 256 == 0 only");
-        BnGeom g;
-        DCL_CHECK_ARG(bn_geom(q.N, q.C, q.HW, g), "tensor too large for one launch");
-        BnApplyJob &j = m.j[k];
-        j.x = q.x;
-        j.res = q.res;
-        j.gamma = q.gamma;
-        j.beta = q.beta;
-        j.y = q.y;
-        j.amax = q.amax;
-        j.f = BnFused{};
-        j.f.part = q.part_all ? q.part_all : q.part;
-        j.f.pivot = q.pivot;
-        j.f.mask_out = (unsigned long long *)q.relu_mask;
-        j.f.ns = pick_slices(q.N, q.C);
-        j.f.count = (double)q.N * q.HW * world;
-        j.f.eps = q.eps;
-        j.f.momentum = q.momentum;
-        j.f.mean = q.mean;
-        j.f.invstd = q.invstd;
-        j.f.running_mean = q.running_mean;
-        j.f.running_var = q.running_var;
-        j.f.batches_tracked = (long long *)q.batches_tracked;
-        j.C = q.C;
-        j.HW = q.HW;
-        j.N = g.Nk;
-        j.nchunk = g.nchunk;
-        m.start[k] = at;
-        at += g.blocks;
-    }
-    for (int k = njobs; k <= BN_MAXJ; ++k)
-        m.start[k] = at;
-    m.njobs = njobs;
-    hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(R, S) hipLaunchKernelGGL((k_bn_apply_multi<R, S>), dim3(at), dim3(BN_THREADS), 0, st, m)
-    if (relu && has_res) LAUNCH(true, true);
-    else if (relu) LAUNCH(true, false);
-    else if (has_res) LAUNCH(false, true);
-    else LAUNCH(false, false);
-#undef LAUNCH
-    DCL_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int dcl_bn_bwd_reduce_part_multi(const dcl_bn_job *jobs, int njobs, void *stream)
-{
-    DCL_BN_MULTI_CHECK();
-    BnMulti<BnBwdReduceJob> m{};
-    unsigned at = 0;
-    const bool relu = jobs[0].relu_mode != 0;
-    for (int k = 0; k < njobs; ++k) {
-        const dcl_bn_job &q = jobs[k];
-        DCL_CHECK_ARG(q.dy && q.mean && q.invstd, "null pointer");
-        DCL_CHECK_ARG((q.relu_mode != 0) == relu && q.relu_mode >= 0 && q.relu_mode <= 2, "relu_mode: all jobs 0 or all 1 / 2");
-        DCL_CHECK_ARG(q.relu_mode != 2 || (q.ymask && q.HW % 256 == 0), "relu_mode 2: packed mask, HW % 256 == 0");
-        const int ns = pick_slices(q.N, q.C);
-        BnBwdReduceJob &j = m.j[k];
-        j.dy = q.dy;
-        j.x = q.x;
-        j.y = q.relu_mode == 1 ? (const float *)q.ymask : nullptr;
-        j.mask = q.relu_mode == 2 ? (const unsigned long long *)q.ymask : nullptr;
-        j.mean = q.mean;
-        j.invstd = q.invstd;
-        j.gamma = q.gamma;
-        j.beta = q.beta;
-        j.part = q.part;
-        j.N = q.N;
-        j.C = q.C;
-        j.HW = q.HW;
-        j.nslice = ns;
-        m.start[k] = at;
-        at += (unsigned)q.C * ns;
-    }
-    for (int k = njobs; k <= BN_MAXJ; ++k)
-        m.start[k] = at;
-    m.njobs = njobs;
-    hipStream_t st = (hipStream_t)stream;
-    if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_reduce_multi<true>), dim3(at), dim3(BN_THREADS), 0, st, m);
-    else
-        hipLaunchKernelGGL((k_bn_bwd_reduce_multi<false>), dim3(at), dim3(BN_THREADS), 0, st, m);
-    DCL_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int dcl_bn_bwd_apply_fused_multi(const dcl_bn_job *jobs, int njobs, int world, void *stream)
-{
-    DCL_BN_MULTI_CHECK();
-    DCL_CHECK_ARG(world >= 1, "world");
-    BnMulti<BnBwdApplyJob> m{};
-    unsigned at = 0;
-    const bool relu = jobs[0].relu_mode != 0;
-    for (int k = 0; k < njobs; ++k) {
-        const dcl_bn_job &q = jobs[k];
-        DCL_CHECK_ARG(q.dy && q.mean && q.invstd && q.dx, "null pointer");
-        DCL_CHECK_ARG((q.relu_mode != 0) == relu && q.relu_mode >= 0 && q.relu_mode <= 2, "relu_mode: all jobs 0 or all 1 / 2");
-        DCL_CHECK_ARG(q.relu_mode != 2 || (q.ymask && q.HW % 256 == 0), "relu_mode 2: packed mask, HW % 256 == 0");
-        BnGeom g;
-        DCL_CHECK_ARG(bn_geom(q.N, q.C, q.HW, g), "tensor too large for one launch");
-        BnBwdApplyJob &j = m.j[k];
-        j.dy = q.dy;
-        j.x = q.x;
-        j.y = q.relu_mode == 1 ? (const float *)q.ymask : nullptr;
-        j.mask = q.relu_mode == 2 ? (const unsigned long long *)q.ymask : nullptr;
-        j.mean = q.mean;
-        j.invstd = q.invstd;
-        j.gamma = q.gamma;
-        j.beta = q.beta;
-        j.dx = q.dx;
-        j.dres = q.dres;
-        j.amax = q.amax;
-        j.f = BnFused{};
-        j.f.part = q.part_all ? q.part_all : q.part;
-        j.f.part_local = q.part;
-        j.f.ns = pick_slices(q.N, q.C);
-        j.f.count = (double)q.N * q.HW * world;
-        j.f.dbeta = q.dbeta;
-        j.f.dgamma = q.dgamma;
-        j.inv_count = (float)(1.0 / j.f.count);
-        j.C = q.C;
-        j.HW = q.HW;
-        j.N = g.Nk;
-        j.nchunk = g.nchunk;
-        m.start[k] = at;
-        at += g.blocks;
-    }
-    for (int k = njobs; k <= BN_MAXJ; ++k)
-        m.start[k] = at;
-    m.njobs = njobs;
-    hipStream_t st = (hipStream_t)stream;
-    if (relu)
-        hipLaunchKernelGGL((k_bn_bwd_apply_multi<true>), dim3(at), dim3(BN_THREADS), 0, st, m);
-    else
-        hipLaunchKernelGGL((k_bn_bwd_apply_multi<false>), dim3(at), dim3(BN_THREADS), 0, st, m);
     DCL_LAUNCH_CHECK();
     return 0;
 }

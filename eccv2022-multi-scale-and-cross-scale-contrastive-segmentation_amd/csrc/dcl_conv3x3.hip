@@ -74,39 +74,6 @@ __global__ __launch_bounds__(256, 1) void k_conv1x1(ConvArgs a)
 }
 
 
-// ---- several independent convolutions in ONE launch (job table) --------------------------------------------------------------
-// The branches of an HRNet exchange module (reference models/HRNet.py:263-287) run the same 3x3 convolution at different
-// resolutions and widths: 12 x 96 x 64 x 128, 12 x 192 x 32 x 64, 12 x 384 x 16 x 32 at W48.  Launched one by one the coarse ones
-// put 96 / 48 workgroups on 256 CUs; on one stream per branch their kernels still run mostly one after the other (r04: one kernel
-// alone on the chip for 75 of 101 busy ms).  Here the workgroups of up to MAXJ convolutions form ONE grid, heaviest workgroups
-// first (the dispatcher hands them out in order: longest-processing-time-first list scheduling over the CUs); every job's range
-// starts at a multiple of 8 so that `bid & 7` is still the XCD the workgroup runs on.  Same bodies, same tiles, same arithmetic
-// as the single launches: results are bitwise those of dcl_conv3x3_f16x3 with the same tile.
-constexpr int MAXJ = 4;
-struct ConvMulti {
-    ConvArgs a[MAXJ];
-    int start[MAXJ + 1];        // first workgroup of job j (multiples of 8), start[njobs] = grid size
-    int count[MAXJ];            // its workgroups (the rest of the range exits at once)
-    int p[MAXJ];                // rows per wave of its tile (R = 3)
-    int njobs;
-};
-
-__global__ __launch_bounds__(256, 1) void k_conv3x3_il_multi(ConvMulti m)
-{
-    const int b = blockIdx.x;
-    int j = 0;
-#pragma unroll
-    for (int t = 1; t < MAXJ; ++t)
-        j += (t < m.njobs && b >= m.start[t]) ? 1 : 0;
-    const int bid = b - m.start[j];
-    if (bid >= m.count[j])
-        return;
-    if (m.p[j] == 4)
-        conv_body<3, 4, 1, 0, true>(m.a[j], bid);
-    else
-        conv_body<3, 2, 1, 0, true>(m.a[j], bid);
-}
-
 // ---- "PM": data gradient of a stride-2 convolution, ALL FOUR output parity classes of a tile in one workgroup ----------------
 // dx = conv3x3(dy zero-inserted at the odd coordinates, w').  Output pixel (2 i + py, 2 j + px) sees the taps whose input
 // coordinate is even: patch row offset dr = 1 (stored row i) with weight row 1 for py = 0 and weight row 0 for py = 1, dr = 2
@@ -1005,75 +972,6 @@ extern "C" int dcl_conv3x3_pre_supported(int N, int Cin, int Cout, int H, int W,
     if ((ws2 && g_conv_interleave != 2) || (stride == 2 && !g_conv_s2_interleave))
         return 0;
     return dcl_conv_pre_has_tile(R, P, stride, ws2) ? 1 : 0;
-}
-
-// Several independent stride-1 3x3 convolutions (or data gradients: transposed fragments) in one launch; see k_conv3x3_il_multi.
-// Every job must be a (3, P) interleaved-tile case: Cin % 16 == 0, Cout % 96 == 0.  tile_p[j]: 4 | 2 | 0 = automatic (4 rows per
-// wave where the map has at least 16 rows).  Returns DCL_EUNSUPPORTED when a job does not qualify (the caller launches them singly).
-extern "C" int dcl_conv3x3_f16x3_multi(const dcl_conv_job *jobs, int njobs, void *stream)
-{
-    DCL_CHECK_ARG(jobs && njobs >= 1 && njobs <= MAXJ, "1 .. 4 jobs");
-    ConvMulti m;
-    std::memset(&m, 0, sizeof(m));
-    int order[MAXJ];
-    long weight[MAXJ];
-    ConvArgs tmp[MAXJ];
-    int cnt[MAXJ], pp[MAXJ];
-    for (int j = 0; j < njobs; ++j) {
-        const dcl_conv_job &q = jobs[j];
-        DCL_CHECK_ARG(q.x && q.wp && q.xamax && q.wamax && q.y, "null pointer");
-        DCL_CHECK_ARG(q.N > 0 && q.Cin > 0 && q.Cout > 0 && q.H > 0 && q.W > 0 && q.xcount > 0, "bad shape");
-        DCL_CHECK_ARG((size_t)8 * q.H * q.W + (size_t)q.H * q.W < ((size_t)1 << 31), "image plane too large");
-        if ((q.Cin & 15) || q.Cout % 96 || !g_conv_interleave)
-            return DCL_EUNSUPPORTED;
-        ConvArgs &a = tmp[j];
-        std::memset(&a, 0, sizeof(a));
-        a.x = q.x;
-        a.wp = (const uint4 *)q.wp;
-        a.y = q.y;
-        a.addend = q.addend;
-        a.bias = q.bias;
-        a.xamax = q.xamax;
-        a.wamax = q.wamax;
-        a.xcount = q.xcount;
-        a.N = q.N;
-        a.Cin = q.Cin;
-        a.Cout = q.Cout;
-        a.H = a.Hs = a.Ho = q.H;
-        a.W = a.Ws = a.Wo = q.W;
-        a.up = 1;
-        a.nchunk = q.Cin / 16;
-        const int P = q.tile_p == 4 || q.tile_p == 2 ? q.tile_p : (q.H >= 16 ? 4 : 2);
-        a.tiles_x = (a.Wo + TW - 1) / TW;
-        a.tiles_y = (a.Ho + 4 * P - 1) / (4 * P);
-        a.groups = q.Cout / 96;
-        pp[j] = P;
-        cnt[j] = a.tiles_x * a.tiles_y * a.N * a.groups;
-        weight[j] = (long)a.nchunk * P;
-        order[j] = j;
-    }
-    for (int i = 1; i < njobs; ++i)             // heaviest workgroups first (stable)
-        for (int k = i; k > 0 && weight[order[k]] > weight[order[k - 1]]; --k) {
-            const int t = order[k];
-            order[k] = order[k - 1];
-            order[k - 1] = t;
-        }
-    int at = 0;
-    for (int i = 0; i < njobs; ++i) {
-        const int j = order[i];
-        m.a[i] = tmp[j];
-        m.start[i] = at;
-        m.count[i] = cnt[j];
-        m.p[i] = pp[j];
-        at += (cnt[j] + 7) & ~7;
-    }
-    for (int i = njobs; i <= MAXJ; ++i)
-        m.start[i] = at;
-    m.njobs = njobs;
-    hipLaunchKernelGGL(k_conv3x3_il_multi, dim3((unsigned)at), dim3(256), 0, (hipStream_t)stream, m);
-    dcl_note_kernel("k_conv3x3_il_multi");
-    DCL_LAUNCH_CHECK();
-    return 0;
 }
 
 static void auto_tile(int N, int Cout, int Ho, int Wo, int nchunk, int stride, int phases, int onetap, int tile_r, int tile_p,

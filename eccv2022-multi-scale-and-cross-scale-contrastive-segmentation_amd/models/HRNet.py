@@ -32,7 +32,6 @@ from .ops import (ConvPackGroup, DirectConv2d, GradToken, LazyConcat, conv3x3_ov
                   upsample_bilinear, use_direct_conv3x3, use_direct_conv1x1, upsample_concat, fan_out)
 from .amax import record_stream as _amax_record_stream
 from .fused_bn import FusedBatchNorm2d, bn_act, bn_act_group, can_group, can_group_static
-from .merged import bn_act_merged, bn_merged_ok, conv3x3_group, conv_multi_ok
 
 __all__ = ['hrnet18', 'hrnet32', 'hrnet48', 'HRNet', 'HighResolutionNet', 'MODEL_CONFIGS']
 
@@ -86,9 +85,6 @@ _DEFER_JOIN = _dbg.defer_join
 _STAGE_CONTINUITY = _dbg.stage_continuity
 _FANOUT_ON_BRANCH_STREAM = _dbg.fanout_on_branch_stream
 _BRANCH_STREAM_MAP = list(_dbg.branch_stream_map)     # stream per branch (0 = the main stream); default: one each
-_MERGE_FROM = _dbg.merge_from
-_MERGE_BRANCHES = _dbg.merge_branches                  # branches 1.. of a module: one launch per kernel stage and depth (models/merged.py)
-_MERGE_INTERLEAVE = False       # tests / tools/probes/dbg_merged.py: branch 0's block d right behind the coarse group's depth d
 
 
 def _side_streams(device, n):
@@ -96,9 +92,7 @@ def _side_streams(device, n):
     key = (device.type, device.index)
     have = _SIDE_STREAMS.setdefault(key, [])
     while len(have) < n:
-        # (experiment switch: HIP priority of the branch streams; larger = lower priority, 0 = the default stream's)
-        prio = _dbg.side_stream_priority
-        have.append(torch.cuda.Stream(device=device) if prio is None else torch.cuda.Stream(device=device, priority=prio))
+        have.append(torch.cuda.Stream(device=device))
     return have[:n]
 
 
@@ -304,102 +298,13 @@ class HighResolutionModule(nn.Module):
                 _amax_record_stream(cur[k], main)
         return cur
 
-    def _mergeable(self, x):
-        """Branches 1 .. n-1 can run as ONE launch per kernel stage and block depth (models/merged.py): plain BasicBlock chains
-        of equal length on the fused norms and the (3, P) direct convolution tiles (W48: 96 / 192 / 384 channels), at least two
-        of them.  Decided per call from the module structure and the inputs; anything else takes the stream-per-branch path."""
-        m0 = _MERGE_FROM
-        if not (_MERGE_BRANCHES and not _BRANCH_STREAM_MAP and self.num_branches >= m0 + 2 and x[0].is_cuda and self.training):
-            return False
-        chains = [list(br) for br in self.branches[m0:]]
-        if len({len(c) for c in chains}) != 1:
-            return False
-        if not all(type(blk) is BasicBlock and blk.downsample is None and blk.stride == 1 for c in chains for blk in c):
-            return False
-        xs = list(x[m0:])
-        for d in range(len(chains[0])):
-            blocks = [c[d] for c in chains]
-            if not (conv_multi_ok([b.conv1 for b in blocks], xs) and conv_multi_ok([b.conv2 for b in blocks], xs)
-                    and bn_merged_ok([b.bn1 for b in blocks], xs) and bn_merged_ok([b.bn2 for b in blocks], xs, xs)):
-                return False
-        return True
-
-    def _run_branches_merged(self, x):
-        """Branch 0 on the current stream as ever; branches 1 .. n-1 TOGETHER on one side stream, depth-major, every kernel
-        stage of a depth one launch over all of them (convolution, norm statistics, norm apply; the same in the backward:
-        autograd sees one node per stage).  Reference models/HRNet.py:263-267 (`x[i] = self.branches[i](x[i])`)."""
-        nb = self.num_branches
-        m0 = _MERGE_FROM                # first branch of the merged group (1: all but the finest)
-        dev = x[0].device
-        main = torch.cuda.current_stream(dev)
-        chains = [list(br) for br in self.branches[m0:]]
-        cur = list(x[m0:])
-        cs = None                       # (_BRANCH_STREAMS off -- the serialised replay of bench.py's kernel table: same launches, one stream)
-        side = _side_streams(dev, nb - 1) if _BRANCH_STREAMS else None
-        if _BRANCH_STREAMS:
-            cs = side[m0 - 1]
-            need_main = False
-            for k in range(m0, nb):
-                src = getattr(x[k], '_dcl_stream', None) if _DEFER_JOIN else None
-                if src is None:
-                    need_main = True
-                elif src is not cs:
-                    cs.wait_stream(src)
-            if need_main:
-                cs.wait_stream(main)
-            with torch.cuda.stream(cs):
-                for t in cur:
-                    _amax_record_stream(t, cs)
-        on_cs = (lambda: torch.cuda.stream(cs)) if cs is not None else contextlib.nullcontext
-        inter = _MERGE_INTERLEAVE and m0 == 1 and len(self.branches[0]) == len(chains[0])
-        cur0 = x[0]
-        for d in range(len(chains[0])):
-            blocks = [c[d] for c in chains]
-            with on_cs():
-                toks = [GradToken() if (_FUSE_RESIDUAL_GRAD and blk.conv1.fuses_residual_grad(t)) else None
-                        for blk, t in zip(blocks, cur)]
-                z = conv3x3_group([blk.conv1 for blk in blocks], cur, toks)
-                a = bn_act_merged([blk.bn1 for blk in blocks], z, relu=True)
-                z2 = conv3x3_group([blk.conv2 for blk in blocks], a)
-                cur = bn_act_merged([blk.bn2 for blk in blocks], z2, residuals=cur, relu=True, tokens=toks)
-            if inter:
-                cur0 = self.branches[0][d](cur0)
-        # Branch 0 after the whole coarse chain (or, _MERGE_INTERLEAVE, block by block in between: the order in which the autograd
-        # engine alternates between the two streams node by node -- it exposed the packed-FP32-beside-MFMA fault that csrc/Makefile's
-        # NOPK now avoids, DESIGN.md section 7; kept as a test order).  The GPU queues fill either way: the host runs ahead.
-        # (branches 1 .. m0-1, if any, on their own streams as in the per-branch schedule)
-        mid = [None] * (m0 - 1)
-        for k in range(m0 - 1, 0, -1):
-            if side is None:
-                mid[k - 1] = self.branches[k](x[k])
-                continue
-            if not (_DEFER_JOIN and getattr(x[k], '_dcl_stream', None) is side[k - 1]):
-                side[k - 1].wait_stream(main)
-            with torch.cuda.stream(side[k - 1]):
-                _amax_record_stream(x[k], side[k - 1])
-                mid[k - 1] = self.branches[k](x[k])
-        out0 = cur0 if inter else self.branches[0](x[0])
-        if cs is not None:
-            main.wait_stream(cs)
-            for t in cur:
-                _amax_record_stream(t, main)
-            for k in range(1, m0):
-                main.wait_stream(side[k - 1])
-                _amax_record_stream(mid[k - 1], main)
-        self._coarse_stream = cs
-        self._coarse_from = m0
-        return [out0] + mid + cur
-
     def _run_branches(self, x):
         """The branches of a module are independent until the fuse layers: on CUDA each runs on its own HIP stream
         (the low-resolution branches launch far fewer workgroups than the chip has CUs, so their kernels overlap
         with each other and with the high-resolution branch); autograd replays the same streams in the backward.
         Tensors that cross streams are registered with the caching allocator (record_stream)."""
-        self._coarse_stream = None
         if self._groupable(x):
             return self._run_branches_grouped(x)
-        if self._mergeable(x):
-            return self._run_branches_merged(x)
         if not (_BRANCH_STREAMS and x[0].is_cuda):
             return [branch(xi) for branch, xi in zip(self.branches, x)]
         main = torch.cuda.current_stream(x[0].device)
@@ -444,9 +349,7 @@ class HighResolutionModule(nn.Module):
                 side_f = _side_streams(x[0].device, self.num_branches - 1)
                 al = [fan_out(x[0], nrow)]
                 for j in range(1, self.num_branches):
-                    # (merged coarse branches: their outputs' gradient sums run on the group's stream, in order with its backward)
-                    cs = getattr(self, '_coarse_stream', None) if j >= getattr(self, '_coarse_from', 1) else None
-                    with torch.cuda.stream(cs if cs is not None else side_f[j - 1]):
+                    with torch.cuda.stream(side_f[j - 1]):
                         al.append(fan_out(x[j], nrow))
             else:
                 al = [fan_out(t, nrow) for t in x]
@@ -504,8 +407,6 @@ class HighResolutionModule(nn.Module):
         # norm kernel whenever the row has one -- its backward reads the packed sign mask, where an up-sampling with a
         # fused ReLU needs a threshold pass over the full-resolution gradient (rows 1.. of every module: 14 passes less)
         others = [j for j in range(self.num_branches) if j > i] + [j for j in range(self.num_branches) if j < i]
-        if not _dbg.fuse_order:                                # A/B switch for the tuning tools
-            others = [j for j in range(self.num_branches) if j != i]
         y = x[i]
         for pos, j in enumerate(others):
             last = pos == len(others) - 1

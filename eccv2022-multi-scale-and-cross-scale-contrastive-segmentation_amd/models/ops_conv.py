@@ -58,7 +58,6 @@ def _conv1x1_by_gemm(rows, k, x, both_row_contiguous):
 
 GEMM_CONV1X1 = _dbg.gemm_conv1x1     # (DCL_GEMM_CONV1X1=0: the library / tile-kernel paths, for A/B runs)
 LIB_CONV1X1_ADDEND = _dbg.lib_conv1x1_addend     # ... by the library's GEMM with beta = 1 (DCL_LIB_CONV1X1_ADDEND=0: tile kernel)
-GEMM_CONV1X1_ADDEND = _dbg.gemm_conv1x1_addend   # residual gradient accumulated by the GEMM (DCL_GEMM_CONV1X1_ADDEND=0: tile kernel)
 
 
 def conv1x1_gemm(x, weight2, out, xamax, wamax, transposed=False, accumulate=False):
@@ -121,7 +120,6 @@ def conv3x3_launch(x, wp, cout, xamax, wamax, out, tile_r=0, tile_p=0, addend=No
     return out
 
 
-DETERMINISTIC_STEM_WGRAD = _dbg.deterministic_stem_wgrad     # (DCL_DETERMINISTIC_STEM_WGRAD=0: ATen / MIOpen for input-channel counts below 16)
 SMALL_CIN_STEM = _dbg.small_cin_stem     # the stem's 3 -> 64 stride-2 convolution on its own fp32 kernel (DCL_SMALL_CIN_STEM=0: tile kernel)
 
 
@@ -297,16 +295,10 @@ class _Conv3x3Direct(torch.autograd.Function):
             addend = None
             if ctx.token is not None and ctx.token.dres is not None:
                 addend, ctx.token.dres = ctx.token.dres, None        # gradient of the residual branch, fused in
-            if ctx.k1 and _conv1x1_by_gemm(weight.shape[1], weight.shape[0], gy, True) and (
-                    addend is None or (GEMM_CONV1X1_ADDEND and addend.shape == x.shape and addend.is_contiguous()
-                                       and addend.dtype == torch.float32)):
-                # with a residual gradient (experiment, off by default): accumulated INTO it by the GEMM's epilogue (C += ...).
-                # Measured on the 256-channel gradients of layer 1's Bottlenecks: 467 us against 372 for the tile kernel's
-                # fused addend -- with K = 64 the launch is all epilogue, and the epilogue now also reads 403 MB
-                if addend is not None:
-                    gx = addend
-                conv1x1_gemm(gy, weight.view(weight.shape[0], -1), gx, amax_of(gy), wamax, transposed=True,
-                             accumulate=addend is not None)
+            if ctx.k1 and _conv1x1_by_gemm(weight.shape[1], weight.shape[0], gy, True) and addend is None:
+                # (with a residual gradient the tile kernel's fused addend wins: accumulating into it in the GEMM's epilogue was
+                # measured at 467 us against 372 on the 256-channel gradients of layer 1's Bottlenecks and left the product in round 6)
+                conv1x1_gemm(gy, weight.view(weight.shape[0], -1), gx, amax_of(gy), wamax, transposed=True)
             elif ctx.k1 and _conv1x1_by_library(x, gy) and addend is None:
                 n, ci, h, w = x.shape
                 torch.matmul(weight.view(-1, ci).t(), gy.view(n, -1, h * w), out=gx.view(n, ci, h * w))
@@ -337,13 +329,13 @@ class _Conv3x3Direct(torch.autograd.Function):
                     gw = torch.bmm(gy.view(n, -1, h * w), x.view(n, ci, h * w).transpose(1, 2)).sum(0).view_as(weight)
             elif conv3x3_wgrad_supported(x, weight.shape[0], ctx.stride):
                 gw = conv3x3_wgrad(x, gy, ctx.stride)
-            elif DETERMINISTIC_STEM_WGRAD and stem_wgrad_supported(x, weight.shape[0], ctx.stride):
+            elif stem_wgrad_supported(x, weight.shape[0], ctx.stride):
                 # the stem's 3-channel input (reference models/HRNet.py:404-405): the library's kernel for this shape splits the
                 # pixels and adds the pieces with ATOMICS (igemm_wrw ... gkgs) -- the one launch of a training step whose result
                 # changed from run to run (tools/probes/step_repro.py: after one step this weight differed by 8e-8, everything else
                 # was bitwise equal; after three steps every tensor differed)
                 gw = stem_wgrad(x, gy)
-            elif DETERMINISTIC_STEM_WGRAD and weight.shape[1] < 16 and weight.shape[0] % 16 == 0 \
+            elif weight.shape[1] < 16 and weight.shape[0] % 16 == 0 \
                     and (x.shape[3] % 8 == 0 or ctx.stride == 1):
                 # other narrow inputs: channels zero-padded to 16, then the split-f16 weight-gradient kernel (fixed summation order too)
                 xp = x.new_zeros((x.shape[0], 16, x.shape[2], x.shape[3]))

@@ -142,26 +142,21 @@ def _upsample_bwd(a):       # (dy, planes, h, w, H, W, ...)
     return 0.0, 4.0 * pl * (h * w + H * W), f"{pl}x{h}x{w}<-{H}x{W}"
 
 
-def _conv_multi(a):         # (jobs, njobs, stream): job-table launch, see models/merged.py ConvJob
-    from ..models.merged import ConvJob
-    jobs = (ConvJob * a[1]).from_address(a[0])
-    flops = sum(2.0 * j.N * j.Cout * j.Cin * 9 * j.H * j.W for j in jobs)
-    byts = sum(4.0 * j.N * j.H * j.W * (j.Cin + j.Cout * (2 if j.addend else 1)) for j in jobs)
-    return flops, byts, " + ".join(f"{j.N}x({j.Cin}->{j.Cout})x{j.H}x{j.W}" for j in jobs)
+def _conv3x3_pre(a):
+    # (x, N, Cin, H, W, wp, Cout, xamax, xcount, wamax, pre_sc, pre_sh, bias, y, stride, tile_r, tile_p, stream): the convolution of
+    # relu(bn(x)) with the map applied in the operand staging -- same work as dcl_conv3x3_f16x3 on the written tensor
+    n, ci, h, w, co, stride = a[1], a[2], a[3], a[4], a[6], a[14]
+    ho, wo = ((h - 1) // 2 + 1, (w - 1) // 2 + 1) if stride == 2 else (h, w)
+    return 2.0 * n * co * ci * 9 * ho * wo, 4.0 * n * (ci * h * w + co * ho * wo), \
+        f"{n}x({ci}->{co})x{h}x{w}" + (" s2" if stride == 2 else "") + " pre"
 
 
-def _bn_multi(stage):       # (jobs, njobs, ...): models/merged.py BnJob; bytes as the single-layer entry points count them
-    def f(a):
-        from ..models.merged import BnJob
-        jobs = (BnJob * a[1]).from_address(a[0])
-        byts = 0.0
-        for j in jobs:
-            e = 4.0 * j.N * j.C * j.HW
-            extra = 1.0 / 32 if j.relu_mode == 2 else (1 if (j.relu_mode == 1 and j.ymask) else 0)
-            byts += {"stats": e, "apply": e * (3 if j.res else 2), "bwd_reduce": e * (2 + extra),
-                     "bwd_apply": e * (3 + extra + (1 if j.dres else 0))}[stage]
-        return 0.0, byts, " + ".join(f"{j.N}x{j.C}x{j.HW}" for j in jobs)
-    return f
+def _wgrad3x3_pre(a):
+    # (x, dy, N, Cin, Cout, H, W, xamax, xcount, gamax, gcount, pre_sc, pre_sh, stride, part, dw, stream)
+    n, ci, co, h, w, stride = a[2], a[3], a[4], a[5], a[6], a[13]
+    hd, wd = ((h - 1) // 2 + 1, w // 2) if stride == 2 else (h, w)
+    return 2.0 * n * co * ci * 9 * hd * wd, 4.0 * n * (ci * h * w + co * hd * wd), \
+        f"{n}x({ci}->{co})x{h}x{w}" + (" s2" if stride == 2 else "") + " pre"
 
 
 # entry point -> (work model, bound, fixed kernel symbol or None = ask dcl_last_kernel)
@@ -179,12 +174,11 @@ MODELS = {
     "dcl_infonce_zsweep_keep": (_sweep(2.0), "mfma", "k_sweep<MODE_Z>"),
     "dcl_infonce_bwd_streamk": (_sweep(4.0), "mfma", "k_sweep<MODE_BWD,stream-K>"),
     "dcl_infonce_bwd": (_sweep(4.0), "mfma", "k_sweep<MODE_BWD>"),
-    "dcl_conv3x3_f16x3_multi": (_conv_multi, "mfma", "k_conv3x3_il_multi"),
-    "dcl_bn_stats_part_multi": (_bn_multi("stats"), "hbm", "k_bn_stats_multi"),
-    "dcl_bn_apply_fused_multi": (_bn_multi("apply"), "hbm", "k_bn_apply_multi"),
-    "dcl_bn_bwd_reduce_part_multi": (_bn_multi("bwd_reduce"), "hbm", "k_bn_bwd_reduce_multi"),
-    "dcl_bn_bwd_apply_fused_multi": (_bn_multi("bwd_apply"), "hbm", "k_bn_bwd_apply_multi"),
+    "dcl_conv3x3_pre_f16x3": (_conv3x3_pre, "mfma", None),
+    "dcl_wgrad3x3_pre_f16x3": (_wgrad3x3_pre, "mfma", None),
     "dcl_bn_stats_part": (_bn_stats, "hbm", "k_bn_stats"),
+    "dcl_bn_stats_pre": (_bn_stats, "hbm", "k_bn_stats_pre"),
+    "dcl_bn_stats_minmax_part": (_bn_stats, "hbm", "k_bn_stats_mm"),
     "dcl_bn_apply_fused": (_bn_apply, "hbm", "k_bn_apply"),
     "dcl_bn_apply_parts": (_bn_apply_parts, "hbm", "k_bn_apply"),
     "dcl_bn_bwd_reduce_part": (_bn_bwd_reduce, "hbm", "k_bn_bwd_reduce"),

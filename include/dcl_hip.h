@@ -319,40 +319,6 @@ int dcl_bn_finalize_pre(const float *part, const float *mm, int ns, double count
 int dcl_bn_stats_pre(const float *x, int N, int C, int HW, float *part, float *mm, void *tickets, double count, float eps,
                      float momentum, const float *gamma, const float *beta, float *mean, float *invstd, float *running_mean,
                      float *running_var, int64_t *batches_tracked, float *pre_sc, float *pre_sh, float *amax, void *stream);
-/* Several INDEPENDENT norm layers in one launch per kernel stage: the bn1 (or bn2) layers of the branches of an HRNet exchange
- * module at one block depth (reference models/HRNet.py:263-287 runs the branches one after the other; :77-93 the BasicBlock's
- * conv -> bn -> relu -> conv -> bn -> += -> relu).  One job record serves all four stages of a layer; every stage is bitwise the
- * single-layer entry point (same kernel bodies).  1..4 jobs per call; forward: all jobs with or all without a residual and one
- * shared `relu`; backward: relu_mode 0 for all jobs, or 1 / 2 per job (1: ymask = y, or NULL = the ReLU mask is recomputed from
- * x; 2: ymask = the packed sign mask the forward wrote, HW % 256 == 0).  `world`: ranks whose partial sums were all-reduced into
- * part_all (NULL: part itself, one rank).
- *   dcl_bn_stats_part_multi      : part[C * ns * 2] (ns = dcl_bn_num_slices(N, C)), pivot <- running_mean
- *   dcl_bn_apply_fused_multi     : y, mean, invstd, running statistics, amax slots, relu_mask
- *   dcl_bn_bwd_reduce_part_multi : part <- {sum g, sum g xhat} slices (mean / invstd are inputs)
- *   dcl_bn_bwd_apply_fused_multi : dx, dres, dbeta, dgamma (this rank's sums: part), amax slots */
-typedef struct dcl_bn_job {
-    const float *x;                 /* [N, C, HW] the layer's input */
-    const float *res;               /* forward: residual added before the ReLU, or NULL */
-    const float *dy;                /* backward: gradient of the output */
-    const void *ymask;              /* backward: see relu_mode */
-    const float *gamma, *beta;
-    float *part;                    /* this rank's partial sums */
-    const float *part_all;          /* the all-reduced ones, or NULL */
-    float *mean, *invstd;           /* [C] forward: out, backward: in */
-    float *running_mean, *running_var;
-    int64_t *batches_tracked;
-    float *pivot;                   /* [C] forward: shift of the sums, written by the statistics stage */
-    float *y;
-    void *relu_mask;                /* forward: packed sign mask out, or NULL */
-    float *dx, *dres, *dbeta, *dgamma;
-    float *amax;                    /* DCL_AMAX_SLOTS partial maxima of y / dx, or NULL */
-    int N, C, HW, relu_mode;
-    float eps, momentum;
-} dcl_bn_job;
-int dcl_bn_stats_part_multi(const dcl_bn_job *jobs, int njobs, void *stream);
-int dcl_bn_apply_fused_multi(const dcl_bn_job *jobs, int njobs, int world, int relu, void *stream);
-int dcl_bn_bwd_reduce_part_multi(const dcl_bn_job *jobs, int njobs, void *stream);
-int dcl_bn_bwd_apply_fused_multi(const dcl_bn_job *jobs, int njobs, int world, void *stream);
 
 
 /* ---- bilinear up-sampling, NCHW f32 (planes = N * C), ATen index arithmetic ----------------------------
@@ -489,21 +455,6 @@ int dcl_conv3x3_f16x3(const float *x, int N, int Cin, int H, int W /* stored inp
                                    the data gradient of a stride-2 convolution (stride must be 1) */,
                       int Hout, int Wout /* output size (checked; required for in_up = 2, may be 0 otherwise) */,
                       int tile_r, int tile_p, void *stream);
-/* Several INDEPENDENT stride-1 3x3 convolutions (or data gradients: transposed fragments at wp) in ONE launch -- the branches of an
- * HRNet exchange module at one block depth (reference models/HRNet.py:263-287: `for i in range(self.num_branches): x[i] =
- * self.branches[i](x[i])`), whose coarse members fill 48-192 of the 256 CUs when launched singly.  The jobs' workgroups form one
- * grid, heaviest first; same tiles and arithmetic as dcl_conv3x3_f16x3 (bitwise the same results for the same tile).  1..4 jobs,
- * each with Cin % 16 == 0 and Cout % 96 == 0 (else DCL_EUNSUPPORTED: launch them singly); tile_p 4 | 2 | 0 = automatic. */
-typedef struct dcl_conv_job {
-    const float *x;
-    const void *wp;
-    const float *xamax, *wamax;
-    const float *addend;        /* [N, Cout, H, W] or NULL */
-    const float *bias;          /* [Cout] or NULL */
-    float *y;
-    int N, Cin, Cout, H, W, xcount, tile_p, reserved;
-} dcl_conv_job;
-int dcl_conv3x3_f16x3_multi(const dcl_conv_job *jobs, int njobs, void *stream);
 /* 3x3 / stride 2 / pad 1 convolution with 1 .. 4 input channels on plain fp32 FMAs (the stem's conv1 on the image, reference
  * models/HRNet.py:404-405): x [N, Cin, H, W], w [Cout, Cin, 3, 3] (unpacked), bias [Cout] or NULL, y [N, Cout, (H - 1) / 2 + 1,
  * (W - 1) / 2 + 1].  The tile kernels would pad the contraction to 16 channels. */

@@ -82,27 +82,6 @@ def _bn_worker(rank, world, port, out_dir, backend):
     for k in range(2):
         out[f"g{k}"] = {"y": ys[k].detach().cpu(), "dx": xs[k].grad.cpu(), "dr": rs[k].grad.cpu(),
                         "dw": bns[k].weight.grad.cpu(), "rm": bns[k].running_mean.cpu()}
-    # ... and as the two members of ONE job-table launch per kernel stage (models/merged.bn_act_merged: the merged-branch schedule),
-    # whose partial sums of all members travel in one exchange as well
-    from mscs_amd.models import merged
-    bns = []
-    for _ in range(2):
-        b2 = FusedBatchNorm2d(24).to(dev)
-        b2.sync = True
-        with torch.no_grad():
-            b2.weight.copy_(w); b2.bias.copy_(b)
-        bns.append(b2)
-    xs = [x[half].to(dev).requires_grad_(True) for _ in range(2)]
-    rs = [r[half].to(dev).requires_grad_(True) for _ in range(2)]
-    before = fused_bn.COLLECTIVES["count"]
-    assert merged.bn_merged_ok(bns, xs, rs)
-    ys = merged.bn_act_merged(bns, xs, residuals=rs, relu=True)
-    ((ys[0] * gy[half].to(dev)).sum() + (ys[1] * gy[half].to(dev)).sum()).backward()
-    torch.cuda.synchronize()
-    out["merged_collectives"] = fused_bn.COLLECTIVES["count"] - before
-    for k in range(2):
-        out[f"m{k}"] = {"y": ys[k].detach().cpu(), "dx": xs[k].grad.cpu(), "dr": rs[k].grad.cpu(),
-                        "dw": bns[k].weight.grad.cpu(), "rm": bns[k].running_mean.cpu()}
     torch.save(out, os.path.join(out_dir, f"bn{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -135,10 +114,6 @@ def test_fused_bn_sync_two_ranks_one_gpu(tmp_path):
         for k in range(2):                   # the grouped (stacked-exchange) form: identical to the single layer
             for key in ("y", "dx", "dr", "dw", "rm"):
                 assert torch.equal(outs[q][f"g{k}"][key], outs[q][key]), (k, key)
-        assert outs[q]["merged_collectives"] == 2           # the job-table form: one exchange per direction for both members
-        for k in range(2):
-            for key in ("y", "dx", "dr", "dw", "rm"):
-                assert torch.equal(outs[q][f"m{k}"][key], outs[q][key]), (k, key)
     # weight / bias grads are per-rank partial sums (DDP averages them): they add up to the full-batch grads
     assert torch.allclose((outs[0]["dw"] + outs[1]["dw"]).double(), ref.weight.grad, atol=2e-4)
     assert torch.allclose((outs[0]["db"] + outs[1]["db"]).double(), ref.bias.grad, atol=2e-4)

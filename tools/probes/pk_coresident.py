@@ -73,29 +73,9 @@ def b_wgrad192():
     ops.conv3x3_wgrad(x192, gy192)
 
 
-# the coarse branches of an exchange module, merged launches (models/merged.py): forward once, backward again and again
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from test_merged_branches import _module  # noqa: E402
-hm, mod, ch = _module(4, dev)
-hm._MERGE_BRANCHES = True
-mxs = [torch.randn(2, c, 64 >> i, 96 >> i, device=dev, requires_grad=True) for i, c in enumerate(ch)]
+# (round 5 also ran the merged coarse-block backward of models/merged.py as a neighbour; that schedule is retired:
+# tools/probes/retired/merged_branches/)
 sb = torch.cuda.Stream(dev)
-sb.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(sb):
-    from mscs_amd.models.merged import conv3x3_group, bn_act_merged
-    blocks = [br[0] for br in mod.branches[1:]]
-    z = conv3x3_group([b.conv1 for b in blocks], mxs[1:], [None] * 3)
-    a = bn_act_merged([b.bn1 for b in blocks], z, relu=True)
-    z2 = conv3x3_group([b.conv2 for b in blocks], a)
-    outm = bn_act_merged([b.bn2 for b in blocks], z2, residuals=mxs[1:], relu=True, tokens=[None] * 3)
-    gouts = [torch.randn_like(o) for o in outm]
-torch.cuda.synchronize()
-
-
-def b_merged_bwd():
-    torch.autograd.grad(outm, mxs[1:] + [p for b in blocks for p in b.parameters()], gouts, retain_graph=True)
-
-
 sa = torch.cuda.Stream(dev)
 # victim: the norm backward of this library (default) or ATen element-wise kernels (`aten`: whatever PyTorch's own build made of
 # them -- not this library's code, not built with NOPK)
@@ -123,8 +103,7 @@ else:
 ref = victim().clone()
 torch.cuda.synchronize()
 CASES = (("nothing", None), ("f16x3 convolution (MFMA)", b_conv), ("weight gradient 96 ch (LDS-DMA + MFMA)", b_wgrad96),
-         ("weight gradient 192 ch", b_wgrad192), ("merged coarse-block backward", b_merged_bwd),
-         ("norm statistics (VALU)", b_stats), ("ATen mul", b_aten), ("merged coarse-block backward", b_merged_bwd))
+         ("weight gradient 192 ch", b_wgrad192),          ("norm statistics (VALU)", b_stats), ("ATen mul", b_aten))
 c48 = torch.randn(12, 48, 128, 256, device=dev).relu_()
 w48 = torch.randn(48, 48, 3, 3, device=dev) * 0.05
 s48x, s48w = amax_of(c48), amax_of(w48)
