@@ -270,30 +270,36 @@ def roofline_conv_kernels(args, dev, iters=20):
 # (FETCH_SIZE KiB, WRITE_SIZE KiB) averaged over the symbol's launches of one step; traffic = (2 * FETCH + WRITE) KiB per the gfx950
 # correction of MI355X_MICROARCH.md.  Keys = kernel symbols of mscs_amd/utils/kernel_timer.py.
 PMC_STEP = {
-    "k_wgrad3x3d<3,1,false>": (91550.8, 6736.6),        # (+ k_wgrad_reduce_t: 3.5 MiB fetched per launch)
-    "k_wgrad3x3d<3,1,true>": (329721.0, 25949.6),
-    "k_conv3x3_il_ws2<1,4>": (47687.2, 77424.3),
-    "k_conv3x3_il<3,4>": (31238.8, 42786.9),
-    "k_conv3x3_il<3,2>": (26989.8, 9216.0),
-    "k_conv3x3_pm<2,1>": (16429.1, 76595.6),
-    "k_conv3x3_il_s2<3>": (26060.2, 19677.4),
-    "k_conv3x3_il_s2<2>": (43989.6, 21174.9),
-    "k_wgrad3x3_s2<3,1>": (62257.5, 6607.0),
-    "k_wgrad3x3_s2d<3,1>": (64579.9, 6607.6),           # (round 5: x rows by LDS-DMA; the halo pieces are whole 16-byte fetches)
-    "k_bn_bwd_apply<true>": (46719.6, 70047.6),
-    "k_bn_bwd_reduce<true>": (46581.0, 13.1),
-    "k_bn_apply<true,true>": (49313.1, 50776.2),
-    "k_bn_apply<true,false>": (21833.7, 43432.8),
-    "k_bn_stats": (22807.4, 17.3),
-    "k_bn_bwd_apply<false>": (42641.1, 46317.2),
-    "k_bn_bwd_reduce<false>": (42496.8, 13.9),
-    "k_bn_apply<false,false>": (26532.5, 52791.1),
-    "k_upsample_fwd": (37572.3, 64049.4),
-    "k_upsample_bwd_rows": (63138.8, 9767.5),
-    "k_sweep<MODE_Z>": (104508.6, 21137.7),             # (since it keeps the positives' similarities: 21 MB written per launch)
-    "k_sweep<MODE_BWD,stream-K>": (60944.6, 71687.9),
+    "k_wgrad3x3d<3,1,false>": (92674.4, 6739.6),        # (+ k_wgrad_reduce_t: 3.5 MiB fetched per launch)
+    "k_wgrad3x3d_pre<3,1,false>": (90392.0, 6733.6),    # (round 6: the x operand is the raw tensor in front of the norm)
+    "k_wgrad3x3d<3,1,true>": (578650.2, 25974.8),       # (13 launches since round 6, the head's 144 -> 720 one among them)
+    "k_conv3x3_il_ws2<1,4>": (50393.1, 77759.8),
+    "k_conv3x3_il_ws2_pre<1,4>": (39804.5, 76458.7),
+    "k_conv3x3_il<3,4>": (35730.4, 46166.0),
+    "k_conv3x3_il_pre<3,4>": (17849.5, 31795.3),
+    "k_conv3x3_il<3,2>": (27364.8, 9216.0),
+    "k_conv3x3_il_pre<3,2>": (25828.0, 9216.0),
+    "k_conv3x3_pm<2,1>": (16445.8, 76595.3),
+    "k_conv3x3_il_s2<3>": (35149.8, 22656.0),
+    "k_conv3x3_il_s2<2>": (38106.3, 18432.0),
+    "k_wgrad3x3_s2d<3,1>": (78114.6, 6565.8),
+    "k_bn_bwd_apply<true>": (46733.4, 70047.6),
+    "k_bn_bwd_reduce<true>": (46585.8, 13.0),
+    "k_bn_apply<true,true>": (49300.3, 50777.6),
+    "k_bn_apply<true,false>": (35202.8, 70116.0),       # (9 launches left: transitions, the stem's bn2, layer 1's bn2)
+    "k_bn_stats": (24206.6, 18.6),
+    "k_bn_stats_pre": (20792.4, 223.8),
+    "k_bn_bwd_apply<false>": (42656.4, 46317.2),
+    "k_bn_bwd_reduce<false>": (42497.6, 13.9),
+    "k_bn_apply<false,false>": (26526.1, 52791.2),
+    "k_upsample_fwd": (37566.6, 64049.4),
+    "k_upsample_bwd_rows": (63130.9, 9767.5),
+    "k_sweep<MODE_Z>": (104706.1, 21138.2),             # (since it keeps the positives' similarities: 21 MB written per launch)
+    "k_sweep<MODE_BWD,stream-K>": (60549.6, 71687.9),
+    "k_gather_normalize": (88338.3, 19796.3),           # K3 on the lazily projected rows (round 6: the two HBM legs of the loss
+    "k_normalize_bwd_scatter": (51025.7, 52102.1),      # that had no constant here; the counters were in the csv all along)
 }
-PMC_STEP_SOURCE = "profiles/r05_step_pmc_fetch.csv, r05_step_pmc_write.csv (round 4's passes of the same kernels: equal to 0.01 %)"
+PMC_STEP_SOURCE = "profiles/r06_step_pmc_fetch.csv, r06_step_pmc_write.csv"
 
 
 def roofline_from_rows(rows, args):

@@ -1,6 +1,6 @@
 """Stand-alone times of the deferred-norm pieces against the pieces they replace, on the BasicBlock shapes of HRNet-W48 at batch 12
 (C ABI, HIP events, alternating):   gpurun -- python tools/probes/conv_pre_time.py
-  norm:  stats + apply(relu)            vs  stats_minmax + finalize_pre
+  norm:  stats + apply(relu)            vs  stats_minmax + finalize_pre, or dcl_bn_stats_pre (one launch)
   conv2: dcl_conv3x3_f16x3 on y         vs  dcl_conv3x3_pre_f16x3 on z
   wgrad: dcl_wgrad3x3_f16x3 on y        vs  dcl_wgrad3x3_pre_f16x3 on z"""
 import os
@@ -55,6 +55,13 @@ def main():
         def stats_mm():
             L.dcl_bn_stats_minmax_part(P.ptr(z), N, c, h * w, P.ptr(part), P.ptr(mm), P.ptr(rm), P.ptr(pivot), st)
 
+        tickets = torch.zeros(c, dtype=torch.int32, device=dev)
+
+        def stats_pre():
+            tickets.zero_()
+            L.dcl_bn_stats_pre(P.ptr(z), N, c, h * w, P.ptr(part), P.ptr(mm), P.ptr(tickets), cnt, 1e-5, 0.0, P.ptr(gamma), P.ptr(beta),
+                               P.ptr(mean), P.ptr(invstd), P.ptr(rm), P.ptr(rv), P.ptr(nbt), P.ptr(sc), P.ptr(sh), P.ptr(amax_d), st)
+
         def finalize():
             L.dcl_bn_finalize_pre(P.ptr(part), P.ptr(mm), ns, cnt, 1e-5, 0.0, P.ptr(gamma), P.ptr(beta), c, P.ptr(mean), P.ptr(invstd),
                                   P.ptr(rm), P.ptr(rv), P.ptr(nbt), P.ptr(pivot), P.ptr(sc), P.ptr(sh), P.ptr(amax_d), st)
@@ -84,11 +91,12 @@ def main():
 
         def wgrad_pre():
             L.dcl_wgrad3x3_pre_f16x3(P.ptr(z), P.ptr(gy), N, c, c, h, w, P.ptr(amax_d), A.SLOTS, P.ptr(ga), ga.numel(), P.ptr(sc),
-                                     P.ptr(sh), P.ptr(wpart), P.ptr(dw), st)
+                                     P.ptr(sh), 1, P.ptr(wpart), P.ptr(dw), st)
 
         res = {}
         for rnd in range(2):
-            for name, fn in (("stats", stats), ("stats_mm", stats_mm), ("apply", apply), ("finalize", finalize), ("conv", conv),
+            for name, fn in (("stats", stats), ("stats_mm", stats_mm), ("stats_pre(+4us memset)", stats_pre), ("apply", apply),
+                             ("finalize", finalize), ("conv", conv),
                              ("conv_pre", conv_pre), ("wgrad", wgrad), ("wgrad_pre", wgrad_pre)):
                 res.setdefault(name, []).append(timeit(fn))
         print(f"{c:4d} ch {h}x{w}: " + "  ".join(f"{k} {min(v):.1f}" for k, v in res.items()), flush=True)
