@@ -68,3 +68,56 @@ def test_training_step_is_bitwise_reproducible(config, hw, labels):
             bad = [k for k in first if not torch.equal(state[k], first[k])]
             assert not bad, f"run {run}: {len(bad)} of {len(first)} tensors differ from run 0, e.g. {bad[:5]}"
         del mgr
+
+
+@pytest.mark.gpu
+def test_training_step_with_deferred_norms_is_bitwise_the_step_that_writes_them():
+    """Config 2 (HRNet-W48 + CE + multi-scale / cross-scale contrastive loss through the manager): two optimizer steps with the
+    norms of `conv -> bn -> relu -> conv` deferred into the consuming convolution (the default: 108 BasicBlocks / Bottlenecks, the
+    fuse layers' two-step chains, the stem; csrc/dcl_conv3x3_pre.hip) against the same steps with every norm writing its output
+    (DCL_FUSE_BN_APPLY=0, the round-5 path): both losses, every parameter and every buffer bitwise equal -- the deferred path is an
+    exact re-arrangement (same fma, same operand scales, same tiles), not an approximation, on the whole model as on its blocks
+    (tests/test_pre_norm_conv.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, ROOT)
+    import mscs_amd  # noqa: F401
+    from mscs_amd.debug import cfg
+    from mscs_amd.managers import HRNetManager
+    from mscs_amd.models import fused_bn
+    from mscs_amd.utils import set_verbosity
+    set_verbosity(40)
+    bench, args = _bench(["--config", "2", "--height", "128", "--width", "256", "--batch", "2"])
+    dev = torch.device("cuda:0")
+    states, deferred = [], []
+    keep = cfg.fuse_bn_apply
+    try:
+        for fuse in (True, False):
+            cfg.fuse_bn_apply = fuse
+            n0 = fused_bn.DEFERRED["count"]
+            torch.manual_seed(0)
+            mgr = HRNetManager(bench.step_config(args, 1), autostart=False)
+            mgr.setup()
+            mgr.model.train()
+            gen = torch.Generator().manual_seed(0)
+            img = torch.randn(args.batch, 3, args.height, args.width, generator=gen).to(dev)
+            lbl = bench.synth_labels(args, args.batch, args.height, args.width, gen).to(dev)
+            losses = []
+            for _ in range(2):
+                mgr.optimiser.zero_grad(set_to_none=True)
+                ret = mgr.forward_step(img, lbl)
+                ret["loss"].backward()
+                mgr.optimiser.step()
+                mgr.scheduler.step()
+                losses.append(ret["loss"].detach().clone())
+            torch.cuda.synchronize()
+            state = {k: v.detach().clone() for k, v in mgr.model.state_dict().items()}
+            state.update({f"loss{i}": l for i, l in enumerate(losses)})
+            states.append(state)
+            deferred.append(fused_bn.DEFERRED["count"] - n0)
+            del mgr
+    finally:
+        cfg.fuse_bn_apply = keep
+    assert deferred[0] >= 2 * 120 and deferred[1] == 0, deferred        # 104 BasicBlocks + 4 Bottlenecks + chains + stem, two steps
+    bad = [k for k in states[0] if not torch.equal(states[0][k], states[1][k])]
+    assert not bad, f"{len(bad)} of {len(states[0])} tensors differ between the deferred and the written path, e.g. {bad[:5]}"
