@@ -60,6 +60,7 @@ SIGNATURES = {
     "dcl_bn_stats_minmax_part": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_finalize_pre": [_vp, _vp, _i, ctypes.c_double, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "dcl_bn_stats_pre": [_vp, _i, _i, _i, _vp, _vp, _vp, ctypes.c_double, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dcl_head_norm_dz": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "dcl_conv3x3_pre_supported": [_i, _i, _i, _i, _i, _i],
     "dcl_conv3x3_pre_f16x3": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "dcl_wgrad3x3_pre_supported": [_i, _i, _i, _i, _i, _i],

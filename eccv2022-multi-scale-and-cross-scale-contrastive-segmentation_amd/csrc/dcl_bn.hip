@@ -828,6 +828,63 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float *__rest
                             blockIdx.x);
 }
 
+// ---- the head's norm folded into its classifier (reference models/HRNet.py:596-600: conv3x3 -> BatchNorm -> conv1x1, NO activation
+// between the norm and the 1x1 convolution) ------------------------------------------------------------------------------------
+// logits = W (sc z + sh) = (W diag(sc)) z + W sh: the normalised 720-channel tensor (1.13 GB at batch 12 x 128 x 256) is never formed
+// -- the forward is the statistics pass plus the classifier GEMM on z with rescaled weights (models/ops_head.py).  Backward: with
+// dy = W^T dl the gradient of the norm's output (never formed either),
+//     dz = sc dy - (sc / n) sum dy - (sc / n) xhat sum(dy xhat)  =  W'^T dl + c1 z + c0,     W' = W diag(sc),
+// where the two channel sums follow from G = dl z^T (the classifier's weight-gradient product, [K, C]) and s = sum dl: c1 = -sc
+// invstd dgamma / n, c0 = -sc dbeta / n - c1 mean.  This kernel forms dz in ONE pass (read z, read the K-channel dl, write dz) instead
+// of the classifier's data-gradient GEMM (write dy), the norm's reduce (read dy, z) and its apply (read dy, z, write dz): K <= 32
+// products per element from scalar-register weights, HBM-bound.  One thread = four consecutive pixels; a workgroup keeps its dl
+// values in registers and walks a group of channels; max|dz| leaves through the absmax slots (one atomic per workgroup).
+constexpr int HEAD_KMAX = 32;
+template <int K4>       // K rounded up to a multiple of 4, in fours
+__global__ __launch_bounds__(256) void k_head_norm_dz(const float *__restrict__ dl, const float *__restrict__ z,
+                                                     const float *__restrict__ wt /* [C][4 K4]: W' transposed, zero padded */,
+                                                     const float *__restrict__ c0, const float *__restrict__ c1, int K, int C,
+                                                     int HW, unsigned total /* N * HW / 4 */, int cper,
+                                                     float *__restrict__ dz, float *__restrict__ amax)
+{
+    constexpr int KP = 4 * K4;
+    const unsigned hw4 = (unsigned)HW >> 2;
+    const unsigned v = blockIdx.x * 256u + threadIdx.x;             // vector index over (image, pixel quad)
+    const bool live = v < total;
+    const unsigned vc = live ? v : total - 1;                       // tail threads: clamped loads, no stores
+    const unsigned n = vc / hw4, q = vc - n * hw4;
+    const size_t pl = (size_t)HW;
+    f32x4 d[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+        d[k] = *(const f32x4 *)(dl + ((size_t)n * K + min(k, K - 1)) * pl + 4 * (size_t)q);     // (k >= K meets a zero weight)
+    const int cg0 = blockIdx.y * cper, cg1 = min(C, cg0 + cper);
+    float am = 0.f;
+    const float *zp = z + (size_t)n * C * pl + 4 * (size_t)q;
+    float *op = dz + (size_t)n * C * pl + 4 * (size_t)q;
+    for (int c = cg0; c < cg1; ++c) {
+        const f32x4 zv = *(const f32x4 *)(zp + (size_t)c * pl);
+        const float a0 = c0[c], a1 = c1[c];
+        f32x4 acc{__builtin_fmaf(a1, zv.x, a0), __builtin_fmaf(a1, zv.y, a0), __builtin_fmaf(a1, zv.z, a0),
+                  __builtin_fmaf(a1, zv.w, a0)};
+        const float *w = wt + (size_t)c * KP;                       // wave-uniform: scalar loads
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const float wk = w[k];
+            acc.x = __builtin_fmaf(wk, d[k].x, acc.x);
+            acc.y = __builtin_fmaf(wk, d[k].y, acc.y);
+            acc.z = __builtin_fmaf(wk, d[k].z, acc.z);
+            acc.w = __builtin_fmaf(wk, d[k].w, acc.w);
+        }
+        if (live) {
+            *(f32x4 *)(op + (size_t)c * pl) = acc;
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
+        }
+    }
+    if (amax)
+        block_amax(am, amax + (blockIdx.x & (DCL_AMAX_SLOTS - 1)));
+}
+
 int pick_slices(int N, int C)
 {
     // enough workgroups to fill 256 CUs several times over, at most one slice per image
@@ -1145,6 +1202,37 @@ extern "C" int dcl_bn_bwd_apply_fused(const float *dy, const float *x, const flo
         hipLaunchKernelGGL((k_bn_bwd_apply<true>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask, Nk, nchunk);
     else
         hipLaunchKernelGGL((k_bn_bwd_apply<false>), grid, dim3(BN_THREADS), 0, st, dy, x, y, mean, invstd, gamma, beta, (const float *)nullptr, inv, C, HW, dx, dres, amax, f, mask, Nk, nchunk);
+    DCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// dz = W'^T dl + c1 z + c0 (see k_head_norm_dz): dl [N, K, HW] (K <= 32), z / dz [N, C, HW], wt [C][Kp] = W' transposed with the K
+// index padded with zeros to Kp = 4 ceil(K / 4), c0 / c1 [C]; HW % 4 == 0, 16-byte aligned tensors.  amax: DCL_AMAX_SLOTS
+// zero-initialised slots (max|dz|) or NULL.
+extern "C" int dcl_head_norm_dz(const float *dl, const float *z, const float *wt, const float *c0, const float *c1, int N, int K,
+                                int C, int HW, float *dz, float *amax, void *stream)
+{
+    DCL_CHECK_ARG(dl && z && wt && c0 && c1 && dz, "null pointer");
+    DCL_CHECK_ARG(N > 0 && C > 0 && HW > 0 && K >= 1 && K <= HEAD_KMAX, "bad shape (1 <= K <= 32)");
+    DCL_CHECK_ARG((HW & 3) == 0, "HW must be a multiple of 4");
+    DCL_CHECK_ARG((((uintptr_t)dl | (uintptr_t)z | (uintptr_t)dz) & 15) == 0, "tensors must be 16-byte aligned");
+    DCL_CHECK_ARG((size_t)N * (HW / 4) < ((size_t)1 << 31), "too many pixels");
+    const unsigned total = (unsigned)((size_t)N * (HW / 4));
+    const unsigned gx = (total + 255u) / 256u;
+    // enough workgroups for a few rounds of the chip: channel groups when the pixel blocks alone are few
+    int groups = 1;
+    while (groups < 16 && (size_t)gx * groups < 2048 && C / (groups * 2) >= 8)
+        groups *= 2;
+    const int cper = (C + groups - 1) / groups;
+    const dim3 grid(gx, (unsigned)((C + cper - 1) / cper));
+    const int K4 = (K + 3) / 4;
+    hipStream_t st = (hipStream_t)stream;
+#define DCL_HEAD_CASE(k4)                                                                                                   \
+    if (K4 == k4)                                                                                                           \
+        hipLaunchKernelGGL((k_head_norm_dz<k4>), grid, dim3(256), 0, st, dl, z, wt, c0, c1, K, C, HW, total, cper, dz, amax);
+    DCL_HEAD_CASE(1) DCL_HEAD_CASE(2) DCL_HEAD_CASE(3) DCL_HEAD_CASE(4) DCL_HEAD_CASE(5) DCL_HEAD_CASE(6) DCL_HEAD_CASE(7) DCL_HEAD_CASE(8)
+#undef DCL_HEAD_CASE
+    dcl_note_kernel("k_head_norm_dz<%d>", K4);
     DCL_LAUNCH_CHECK();
     return 0;
 }

@@ -23,6 +23,8 @@ def _int(name: str) -> Optional[int]:
 class DebugConfig:
     # ---- model graph (models/HRNet.py, models/ops.py, models/fused_bn.py)
     fuse_residual_grad: bool = field(default_factory=lambda: _flag('DCL_FUSE_RESIDUAL_GRAD'))   # GradToken path
+    fold_head_norm: bool = field(default_factory=lambda: _flag('DCL_FOLD_HEAD_NORM'))           # the head's norm folded into its
+    # classifier's weights (models/ops_head.py _HeadNormClassifier); 0 = the norm writes its 720-channel output (A/B runs)
     fuse_bn_apply: bool = field(default_factory=lambda: _flag('DCL_FUSE_BN_APPLY'))             # bn1 + ReLU of a residual block inside
     # conv2's operand staging (models/fused_bn.py PreAct, csrc/dcl_conv3x3_pre.hip); 0 = the norm writes its output (A/B runs)
     branch_streams: bool = field(default_factory=lambda: _flag('DCL_BRANCH_STREAMS'))           # one HIP stream per branch

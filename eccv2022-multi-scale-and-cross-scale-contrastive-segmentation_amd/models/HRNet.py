@@ -29,6 +29,7 @@ from ..debug import cfg as _dbg
 from ..utils import DATASETS_INFO, printlog
 from .Projector import Projector
 from .ops import (ConvPackGroup, DirectConv2d, GradToken, LazyConcat, conv3x3_over_upsampled, use_gemm_conv1x1,
+                  head_norm_classifier, head_norm_classifier_ok,
                   upsample_bilinear, use_direct_conv3x3, use_direct_conv1x1, upsample_concat, fan_out)
 from .amax import record_stream as _amax_record_stream
 from .fused_bn import FusedBatchNorm2d, bn_act, bn_act_group, can_group, can_group_static
@@ -675,11 +676,17 @@ class HRNet(nn.Module):
                     and t0.is_cuda and t0.dtype == torch.float32 and not torch.is_autocast_enabled()
                     and all(t.is_contiguous() for t in x.ts)):
                 y = conv3x3_over_upsampled(x.ts, x.align_corners, conv.weight, conv.bias)
-                for layer in list(self.cls_head)[1:]:
-                    y = layer(y)
-                return y
+                return self._head_tail(y)
             x = x.materialize()
-        return self.cls_head(x)
+        return self._head_tail(self.cls_head[0](x))
+
+    def _head_tail(self, z):
+        """norm -> classifier behind the head convolution (reference models/HRNet.py:596-600: no activation in between): folded
+        into one GEMM on z with rescaled weights when the norm is on its fused training path (models/ops_head.py)."""
+        bn, cls = self.cls_head[1], self.cls_head[2]
+        if len(self.cls_head) == 3 and head_norm_classifier_ok(z, bn, cls):
+            return head_norm_classifier(z, bn, cls)
+        return cls(bn(z))
 
     def forward(self, x):
         size = x.shape[-2:]

@@ -358,3 +358,104 @@ def conv3x3_over_upsampled(ts, align_corners, weight, bias, min_scale=None):
     if not coarse:
         return _Conv3x3Addend.apply(hi, weight, bias, None)
     return _HeadSplit.apply(bool(align_corners), H, W, (fine_ranges, coarse_offs), hi, weight, bias, *coarse)
+
+
+# ---- the head's norm folded into its classifier -------------------------------------------------------------------------------
+
+class _HeadNormClassifier(torch.autograd.Function):
+    """``conv1x1(bn(z), W)`` of the HRNet head (reference models/HRNet.py:596-600: conv3x3 -> BatchNorm -> conv1x1 with NO activation
+    in between) without the normalised tensor: a training-mode norm is a per-channel affine map, a 1x1 convolution is linear, so
+    ``W (sc z + sh) = (W diag(sc)) z + W sh``.  Forward: the norm's statistics pass and its finalisation (csrc/dcl_bn.hip: mean,
+    invstd, running statistics and the map exactly as FusedBatchNorm2d computes them; the SyncBatchNorm exchange in between on several
+    ranks), then the classifier GEMM on z with rescaled weights.  Backward: G = dl z^T (the classifier's weight-gradient product) and
+    s = sum dl give dW, dgamma, dbeta and the two channel sums of the norm's backward; dz = W'^T dl + c1 z + c0 is ONE pass
+    (dcl_head_norm_dz) instead of the classifier's data-gradient GEMM, the norm's reduce and its apply.  At batch 12 x 128 x 256 x 720
+    channels: six passes over 1.13 GB less per step and two 1.13-GB tensors less in memory."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, weight, bn):
+        from .. import _lib
+        from . import amax as _amax
+        from .fused_bn import _all_reduce_async, _check_equal_batch, _world
+        L = _lib.lib()
+        n, c, h, w = z.shape
+        hw = h * w
+        k = weight.shape[0]
+        dev = z.device
+        st = _lib.stream_ptr(dev)
+        world = _world() if bn.sync else 1
+        count = float(n * hw * world)
+        ns = L.dcl_bn_num_slices(n, c)
+        ws = torch.empty((c * ns * 2 + 5 * c,), dtype=torch.float32, device=dev)
+        part = ws[:c * ns * 2]
+        mean, invstd, pivot, sc, sh = (ws[c * ns * 2 + i * c:c * ns * 2 + (i + 1) * c] for i in range(5))
+        _lib.check(L.dcl_bn_stats_part(_lib.ptr(z), n, c, hw, _lib.ptr(part), _lib.ptr(bn.running_mean), _lib.ptr(pivot), st),
+                   "dcl_bn_stats_part")
+        if world > 1:
+            _check_equal_batch(n, dev)
+            _all_reduce_async(part).wait()
+        _lib.check(L.dcl_bn_finalize_pre(_lib.ptr(part), None, ns, count, float(bn.eps), float(bn.momentum), _lib.ptr(gamma),
+                                         _lib.ptr(beta), c, _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(bn.running_mean),
+                                         _lib.ptr(bn.running_var), _lib.ptr(bn.num_batches_tracked), _lib.ptr(pivot), _lib.ptr(sc),
+                                         _lib.ptr(sh), None, st), "dcl_bn_finalize_pre")
+        w2 = weight.view(k, c)
+        out = torch.empty((n, k, h, w), dtype=torch.float32, device=dev)
+        torch.matmul(w2 * sc, z.view(n, c, hw), out=out.view(n, k, hw))
+        out += (w2 @ sh).view(1, k, 1, 1)
+        ctx.save_for_backward(z, w2, gamma, mean, invstd, sc, sh)
+        ctx.world, ctx.count = world, count
+        return out
+
+    @staticmethod
+    def backward(ctx, dl):
+        from .. import _lib
+        from . import amax as _amax
+        from .fused_bn import _all_reduce_async
+        L = _lib.lib()
+        z, w2, gamma, mean, invstd, sc, sh = ctx.saved_tensors
+        n, c, h, w = z.shape
+        hw = h * w
+        k = w2.shape[0]
+        dev = z.device
+        dl = dl.contiguous()
+        s = dl.sum((0, 2, 3))                                                          # [K]
+        g = torch.bmm(dl.view(n, k, hw), z.view(n, c, hw).transpose(1, 2)).sum(0)      # [K, C] = sum dl z^T
+        # gradient of the norm's output dy = W^T dl, never formed: its channel sums follow from G and s
+        dbeta = (w2 * s.view(k, 1)).sum(0)                                             # sum dy
+        dgamma = (w2 * (g - mean.view(1, c) * s.view(k, 1))).sum(0) * invstd           # sum dy xhat
+        dw = (g * sc.view(1, c) + s.view(k, 1) * sh.view(1, c)).view(k, c, 1, 1)
+        sums = torch.stack([dbeta, dgamma])
+        if ctx.world > 1:
+            # dz needs the sums over ALL ranks; dgamma / dbeta stay this rank's (DDP averages parameter gradients)
+            sums = sums.clone()
+            _all_reduce_async(sums).wait()
+        c1 = -sc * invstd * sums[1] / ctx.count
+        c0 = -sc * sums[0] / ctx.count - c1 * mean
+        kp = (k + 3) // 4 * 4
+        wt = torch.zeros((c, kp), dtype=torch.float32, device=dev)
+        wt[:, :k] = (w2 * sc.view(1, c)).t()
+        dz = torch.empty_like(z)
+        am = _amax.zeros(_amax.SLOTS, dev)
+        _lib.check(L.dcl_head_norm_dz(_lib.ptr(dl), _lib.ptr(z), _lib.ptr(wt), _lib.ptr(c0.contiguous()), _lib.ptr(c1.contiguous()),
+                                      n, k, c, hw, _lib.ptr(dz), _lib.ptr(am), _lib.stream_ptr(dev)), "dcl_head_norm_dz")
+        _amax.tag(dz, am)
+        return dz, dgamma if ctx.needs_input_grad[1] else None, dbeta if ctx.needs_input_grad[2] else None, \
+            dw if ctx.needs_input_grad[3] else None, None
+
+
+FOLD_HEAD_NORM = _dbg.fold_head_norm     # (DCL_FOLD_HEAD_NORM=0: the norm writes its output, the classifier reads it)
+
+
+def head_norm_classifier_ok(z, bn, conv):
+    """conv1x1(bn(z)) can run folded: a fused norm on its training path followed DIRECTLY by a bias-free 1x1 convolution with at most
+    32 outputs (the classifier), contiguous fp32 NCHW with whole pixel quads."""
+    from .fused_bn import FusedBatchNorm2d
+    return (FOLD_HEAD_NORM and isinstance(bn, FusedBatchNorm2d) and bn._fusable(z, None) and isinstance(conv, torch.nn.Conv2d)
+            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.bias is None and conv.weight.dtype == torch.float32 and 1 <= conv.weight.shape[0] <= 32
+            and (z.shape[2] * z.shape[3]) % 4 == 0 and z.data_ptr() % 16 == 0)
+
+
+def head_norm_classifier(z, bn, conv):
+    """``conv(bn(z))`` for a training-mode norm and a bias-free 1x1 convolution, see _HeadNormClassifier."""
+    return _HeadNormClassifier.apply(z, bn.weight, bn.bias, conv.weight, bn)

@@ -280,6 +280,16 @@ int dcl_bn_apply_fused(const float *x, const float *res, const float *part, doub
                        void *relu_mask /* optional (relu, HW % 256 == 0): N * C * HW / 8 bytes, the sign bits of y packed
                                           for the backward -- see below */,
                        void *stream);
+/* The HRNet head's norm folded into its classifier (reference models/HRNet.py:596-600: conv3x3 -> BatchNorm2d -> conv1x1, no
+ * activation in between): conv1x1(bn(z), W) = (W diag(sc)) z + W sh, so the forward is dcl_bn_stats_part + dcl_bn_finalize_pre (mm,
+ * amax = NULL) and a GEMM on z.  Backward: with G = dl z^T and s = sum dl (the classifier's weight-gradient products) the caller
+ * forms c1 = -sc invstd dgamma / n, c0 = -sc dbeta / n - c1 mean and this call writes
+ *     dz[n, c, p] = sum_k wt[c][k] dl[n, k, p] + c1[c] z[n, c, p] + c0[c]
+ * in one pass -- the classifier's data-gradient GEMM, the norm's backward reduce and its backward apply in one HBM-bound kernel.
+ * dl [N, K, HW] with K <= 32, wt [C][4 ceil(K / 4)] = (W diag(sc))^T zero-padded, HW % 4 == 0, 16-byte aligned tensors;
+ * amax: DCL_AMAX_SLOTS zero-initialised slots receiving max|dz|, or NULL. */
+int dcl_head_norm_dz(const float *dl, const float *z, const float *wt, const float *c0, const float *c1, int N, int K, int C,
+                     int HW, float *dz, float *amax, void *stream);
 /* relu = 2 in the two backward calls: `y` is the packed mask dcl_bn_apply_fused wrote (1/32 of y's size), not y
  * itself -- what the backward of a norm + residual + ReLU needs from y is only y > 0.
  * dcl_bn_bwd_apply_fused only, relu + 4: the norm's INPUT x is the output of a ReLU (conv -> ReLU -> norm, the projection heads,
