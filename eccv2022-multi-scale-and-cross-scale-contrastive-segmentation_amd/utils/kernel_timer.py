@@ -142,6 +142,11 @@ def _upsample_bwd(a):       # (dy, planes, h, w, H, W, ...)
     return 0.0, 4.0 * pl * (h * w + H * W), f"{pl}x{h}x{w}<-{H}x{W}"
 
 
+def _head_norm_dz(a):       # (dl, z, wt, c0, c1, N, K, C, HW, dz, amax, stream): read z and the K-channel dl, write dz
+    n, k, c, hw = a[5], a[6], a[7], a[8]
+    return 2.0 * n * k * c * hw, 4.0 * n * hw * (2 * c + k), f"{n}x({k}->{c})x{hw}"
+
+
 def _conv3x3_pre(a):
     # (x, N, Cin, H, W, wp, Cout, xamax, xcount, wamax, pre_sc, pre_sh, bias, y, stride, tile_r, tile_p, stream): the convolution of
     # relu(bn(x)) with the map applied in the operand staging -- same work as dcl_conv3x3_f16x3 on the written tensor
@@ -176,6 +181,7 @@ MODELS = {
     "dcl_infonce_bwd": (_sweep(4.0), "mfma", "k_sweep<MODE_BWD>"),
     "dcl_conv3x3_pre_f16x3": (_conv3x3_pre, "mfma", None),
     "dcl_wgrad3x3_pre_f16x3": (_wgrad3x3_pre, "mfma", None),
+    "dcl_head_norm_dz": (_head_norm_dz, "hbm", "k_head_norm_dz"),
     "dcl_bn_stats_part": (_bn_stats, "hbm", "k_bn_stats"),
     "dcl_bn_stats_pre": (_bn_stats, "hbm", "k_bn_stats_pre"),
     "dcl_bn_stats_minmax_part": (_bn_stats, "hbm", "k_bn_stats_mm"),
