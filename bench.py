@@ -270,34 +270,35 @@ def roofline_conv_kernels(args, dev, iters=20):
 # (FETCH_SIZE KiB, WRITE_SIZE KiB) averaged over the symbol's launches of one step; traffic = (2 * FETCH + WRITE) KiB per the gfx950
 # correction of MI355X_MICROARCH.md.  Keys = kernel symbols of mscs_amd/utils/kernel_timer.py.
 PMC_STEP = {
-    "k_wgrad3x3d<3,1,false>": (92674.4, 6739.6),        # (+ k_wgrad_reduce_t: 3.5 MiB fetched per launch)
-    "k_wgrad3x3d_pre<3,1,false>": (90392.0, 6733.6),    # (round 6: the x operand is the raw tensor in front of the norm)
-    "k_wgrad3x3d<3,1,true>": (578650.2, 25974.8),       # (13 launches since round 6, the head's 144 -> 720 one among them)
-    "k_conv3x3_il_ws2<1,4>": (50393.1, 77759.8),
-    "k_conv3x3_il_ws2_pre<1,4>": (39804.5, 76458.7),
-    "k_conv3x3_il<3,4>": (35730.4, 46166.0),
-    "k_conv3x3_il_pre<3,4>": (17849.5, 31795.3),
+    "k_wgrad3x3d<3,1,false>": (92674.1, 6739.6),        # (+ k_wgrad_reduce_t: 3.5 MiB fetched per launch)
+    "k_wgrad3x3d_pre<3,1,false>": (90401.9, 6733.6),    # (round 6: the x operand is the raw tensor in front of the norm)
+    "k_wgrad3x3d<3,1,true>": (577186.6, 25996.2),       # (13 launches since round 6, the head's 144 -> 720 one among them)
+    "k_conv3x3_il_ws2<1,4>": (50397.9, 77759.8),
+    "k_conv3x3_il_ws2_pre<1,4>": (39808.2, 76458.7),
+    "k_conv3x3_il<3,4>": (35729.6, 46166.0),
+    "k_conv3x3_il_pre<3,4>": (17849.4, 31795.2),
     "k_conv3x3_il<3,2>": (27364.8, 9216.0),
     "k_conv3x3_il_pre<3,2>": (25828.0, 9216.0),
-    "k_conv3x3_pm<2,1>": (16445.8, 76595.3),
-    "k_conv3x3_il_s2<3>": (35149.8, 22656.0),
-    "k_conv3x3_il_s2<2>": (38106.3, 18432.0),
-    "k_wgrad3x3_s2d<3,1>": (78114.6, 6565.8),
-    "k_bn_bwd_apply<true>": (46733.4, 70047.6),
-    "k_bn_bwd_reduce<true>": (46585.8, 13.0),
-    "k_bn_apply<true,true>": (49300.3, 50777.6),
-    "k_bn_apply<true,false>": (35202.8, 70116.0),       # (9 launches left: transitions, the stem's bn2, layer 1's bn2)
-    "k_bn_stats": (24206.6, 18.6),
-    "k_bn_stats_pre": (20792.4, 223.8),
-    "k_bn_bwd_apply<false>": (42656.4, 46317.2),
-    "k_bn_bwd_reduce<false>": (42497.6, 13.9),
-    "k_bn_apply<false,false>": (26526.1, 52791.2),
-    "k_upsample_fwd": (37566.6, 64049.4),
-    "k_upsample_bwd_rows": (63130.9, 9767.5),
-    "k_sweep<MODE_Z>": (104706.1, 21138.2),             # (since it keeps the positives' similarities: 21 MB written per launch)
-    "k_sweep<MODE_BWD,stream-K>": (60549.6, 71687.9),
-    "k_gather_normalize": (88338.3, 19796.3),           # K3 on the lazily projected rows (round 6: the two HBM legs of the loss
-    "k_normalize_bwd_scatter": (51025.7, 52102.1),      # that had no constant here; the counters were in the csv all along)
+    "k_conv3x3_pm<2,1>": (16443.0, 76595.3),
+    "k_conv3x3_il_s2<3>": (35150.1, 22656.0),
+    "k_conv3x3_il_s2<2>": (38106.8, 18432.0),
+    "k_wgrad3x3_s2d<3,1>": (78111.8, 6564.9),
+    "k_bn_bwd_apply<true>": (46739.8, 70047.6),
+    "k_bn_bwd_reduce<true>": (46585.2, 13.0),
+    "k_bn_apply<true,true>": (49305.7, 50777.2),
+    "k_bn_apply<true,false>": (35200.7, 70116.0),       # (9 launches left: transitions, the stem's bn2, layer 1's bn2)
+    "k_bn_stats": (24204.5, 18.7),
+    "k_bn_stats_pre": (20792.3, 223.8),
+    "k_bn_bwd_apply<false>": (20456.9, 24197.0),
+    "k_bn_bwd_reduce<false>": (20339.8, 12.8),
+    "k_bn_apply<false,false>": (11414.2, 22639.7),
+    "k_upsample_fwd": (37566.5, 64049.4),
+    "k_upsample_bwd_rows": (63130.8, 9767.5),
+    "k_sweep<MODE_Z>": (104674.5, 21132.7),             # (since it keeps the positives' similarities: 21 MB written per launch)
+    "k_sweep<MODE_BWD,stream-K>": (60576.3, 71687.9),
+    "k_gather_normalize": (88214.8, 19796.6),           # K3 on the lazily projected rows (round 6: the two HBM legs of the loss
+    "k_normalize_bwd_scatter": (51025.5, 52123.4),      # that had no constant here; the counters were in the csv all along)
+    "k_head_norm_dz": (644087.4, 1106016.0),
 }
 PMC_STEP_SOURCE = "profiles/r06_step_pmc_fetch.csv, r06_step_pmc_write.csv"
 
