@@ -316,7 +316,7 @@ def conv3x3_over_upsampled(ts, align_corners, weight, bias, min_scale=None):
     the gathered sum as the convolution's addend.  For HRNet-W48's head (48 + 96 + 192 + 384 channels at scales 1, 2, 4,
     8) 80 % of the multiply-adds move to 1/16 and 1/64 of the pixels; UPerNet's fusion convolution (P2, P5, P4, P3 -- the maps
     may come in any order, ts[0] is the full-resolution one) 47 %.  Equal to the reference formulation up to fp32
-    round-off (tests/test_hip_parity.py::test_head_conv_over_upsampled_matches_fp64)."""
+    round-off (tests/test_model_ops_parity.py::test_head_conv_over_upsampled_matches_fp64)."""
     t0 = ts[0]
     n, _, H, W = t0.shape
     offs, off = [], 0

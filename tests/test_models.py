@@ -250,7 +250,7 @@ def test_train_mode_matches_reference_on_gpu(name):
     nothing about a kernel; the whole-model gradients are held to the absolute cap (5e-2 of each tensor's max) and to 8x
     the stock kernels' error, and the arithmetic is pinned where it is not amplified: one block deep at fixed tolerances
     (test_building_blocks_train_mode_pinned_against_fp64_on_gpu, incl. a Swin stage) and per product against float64
-    (tests/test_window_attention.py::test_token_linear_on_split_f16_gemm, tests/test_hip_parity.py::test_gemm_*)."""
+    (tests/test_window_attention.py::test_token_linear_on_split_f16_gemm, tests/test_model_ops_parity.py::test_gemm_*)."""
     dev = torch.device("cuda:0")
     hip = _train_errors(name, dev, "f64_")
     lib = _train_errors(name, dev, "f64_", library=True)

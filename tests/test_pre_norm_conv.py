@@ -2,7 +2,7 @@
 BasicBlock, :117-137 Bottleneck): bn1's apply pass folded into the operand staging of conv2's forward (csrc/dcl_conv3x3_pre.hip) and
 weight-gradient kernels (csrc/dcl_wgrad3x3d.hip, PRE forms), the map and the operand scale coming from dcl_bn_stats_minmax_part /
 dcl_bn_finalize_pre.  The fused path must be BITWISE the path that writes the tensor (same fma, same operand scale, same tiles), and
-that path is held to float64 by tests/test_hip_parity.py and tests/test_models.py."""
+that path is held to float64 by tests/test_model_ops_parity.py and tests/test_models.py."""
 import pytest
 import torch
 
