@@ -862,23 +862,33 @@ __global__ __launch_bounds__(256) void k_head_norm_dz(const float *__restrict__ 
     float am = 0.f;
     const float *zp = z + (size_t)n * C * pl + 4 * (size_t)q;
     float *op = dz + (size_t)n * C * pl + 4 * (size_t)q;
-    for (int c = cg0; c < cg1; ++c) {
-        const f32x4 zv = *(const f32x4 *)(zp + (size_t)c * pl);
-        const float a0 = c0[c], a1 = c1[c];
-        f32x4 acc{__builtin_fmaf(a1, zv.x, a0), __builtin_fmaf(a1, zv.y, a0), __builtin_fmaf(a1, zv.z, a0),
-                  __builtin_fmaf(a1, zv.w, a0)};
-        const float *w = wt + (size_t)c * KP;                       // wave-uniform: scalar loads
+    // four channels per trip, their z vectors requested together: one channel per trip exposed a memory round trip per channel
+    // (2.1 us x 90 channels per workgroup: 0.47 ms for the benchmark's head against 0.36 at copy speed)
+    constexpr int CU4 = 4;
+    for (int c0i = cg0; c0i < cg1; c0i += CU4) {
+        f32x4 zv[CU4];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const float wk = w[k];
-            acc.x = __builtin_fmaf(wk, d[k].x, acc.x);
-            acc.y = __builtin_fmaf(wk, d[k].y, acc.y);
-            acc.z = __builtin_fmaf(wk, d[k].z, acc.z);
-            acc.w = __builtin_fmaf(wk, d[k].w, acc.w);
-        }
-        if (live) {
-            *(f32x4 *)(op + (size_t)c * pl) = acc;
-            am = fmaxf(am, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
+        for (int u = 0; u < CU4; ++u)
+            zv[u] = *(const f32x4 *)(zp + (size_t)min(c0i + u, cg1 - 1) * pl);
+#pragma unroll
+        for (int u = 0; u < CU4; ++u) {
+            const int c = min(c0i + u, cg1 - 1);
+            const float a0 = c0[c], a1 = c1[c];
+            f32x4 acc{__builtin_fmaf(a1, zv[u].x, a0), __builtin_fmaf(a1, zv[u].y, a0), __builtin_fmaf(a1, zv[u].z, a0),
+                      __builtin_fmaf(a1, zv[u].w, a0)};
+            const float *w = wt + (size_t)c * KP;                   // wave-uniform: scalar loads
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const float wk = w[k];
+                acc.x = __builtin_fmaf(wk, d[k].x, acc.x);
+                acc.y = __builtin_fmaf(wk, d[k].y, acc.y);
+                acc.z = __builtin_fmaf(wk, d[k].z, acc.z);
+                acc.w = __builtin_fmaf(wk, d[k].w, acc.w);
+            }
+            if (live && c0i + u < cg1) {
+                *(f32x4 *)(op + (size_t)c * pl) = acc;
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))));
+            }
         }
     }
     if (amax)
